@@ -1,0 +1,130 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures under ``tests/golden/`` (runs ONLY in the build container).
+
+The reference's DETR arithmetic lives in Hugging Face ``transformers`` (reference pin 4.57.3; 5.15.0 is what this
+container has — key renames only, same math).  This script builds ``DetrForObjectDetection`` from a
+LOCAL config (no hub access), loads the repo's seeded synthetic weights into it, runs it on seeded structured frames
+and stores inputs' seeds + outputs as small ``.npz`` files.  It also captures outputs of the reference's own
+``src/tracking/feature_extractor.py`` (loaded by file path; its package ``__init__`` needs cv2) and of HF's
+``post_process_object_detection`` / image processor.  Nothing here travels to the GPU box except the ``.npz`` data.
+
+Usage:  python tools/gen_golden.py            (writes tests/golden/*.npz)
+"""
+
+from __future__ import annotations
+
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from office_person_detection_vit_amd.frames import structured_frames  # noqa: E402
+from office_person_detection_vit_amd.weights import DetrArch, synth_weights  # noqa: E402
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+REFERENCE = "/root/reference"
+
+
+def build_hf(arch: DetrArch):
+    from transformers import DetrConfig, DetrForObjectDetection, ResNetConfig
+
+    cfg = DetrConfig(
+        backbone_config=ResNetConfig(depths=list(arch.depths), out_features=["stage4"]),
+        num_labels=arch.num_labels, num_queries=arch.num_queries,
+        encoder_layers=arch.encoder_layers, decoder_layers=arch.decoder_layers,
+        use_pretrained_backbone=False, use_timm_backbone=False,
+    )
+    cfg._attn_implementation = "eager"
+    return DetrForObjectDetection(cfg).eval()
+
+
+def hf_preprocess(frames_bgr):
+    """HF DetrImageProcessor with resizing disabled (frames already at model resolution)."""
+    from transformers import DetrImageProcessor
+
+    proc = DetrImageProcessor(do_resize=False)
+    rgb = [np.ascontiguousarray(f[:, :, ::-1]) for f in frames_bgr]
+    enc = proc(images=rgb, return_tensors="pt")
+    return proc, enc["pixel_values"], enc["pixel_mask"]
+
+
+def model_case(tag, arch, seed, ga, sizes, frame_seed, full_outputs=True):
+    w = synth_weights(arch, seed, ga)
+    m = build_hf(arch)
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in w.items()}, strict=True)
+    frames = [structured_frames(1, h, wd, seed=frame_seed + i)[0] for i, (h, wd) in enumerate(sizes)]
+    proc, pv, pm = hf_preprocess(frames)
+    with torch.no_grad():
+        out = m(pixel_values=pv, pixel_mask=pm)
+    target_sizes = [(f.shape[0], f.shape[1]) for f in frames]
+    post = proc.post_process_object_detection(out, threshold=0.5, target_sizes=target_sizes)
+    d = {
+        "arch_depths": np.array(arch.depths), "seed": np.array(seed), "attention_gain": np.array(ga),
+        "sizes": np.array(sizes), "frame_seed": np.array(frame_seed),
+        "logits": out.logits.numpy(), "pred_boxes": out.pred_boxes.numpy(),
+        "pixel_mask_sum": pm.sum(dim=(1, 2)).numpy(),
+    }
+    mem = out.encoder_last_hidden_state.numpy()
+    if full_outputs:
+        d["encoder_last_hidden_state"] = mem
+        d["pixel_values_sample"] = pv[:, :, ::37, ::41].numpy()
+    else:
+        d["encoder_sum"] = mem.astype(np.float64).sum(axis=(1, 2))
+        d["encoder_abs_sum"] = np.abs(mem.astype(np.float64)).sum(axis=(1, 2))
+        d["encoder_sample"] = mem[:, ::97, ::13]
+    for i, r in enumerate(post):
+        d[f"post{i}_scores"] = r["scores"].numpy()
+        d[f"post{i}_labels"] = r["labels"].numpy()
+        d[f"post{i}_boxes"] = r["boxes"].numpy()
+    np.savez_compressed(os.path.join(GOLD, f"{tag}.npz"), **d)
+    sc = torch.softmax(out.logits, -1)[..., :-1].max(-1)[0]
+    print(f"{tag}: logits {tuple(out.logits.shape)} box-std {float(out.pred_boxes.std(dim=1).mean()):.4f} "
+          f"scores>0.5 {int((sc > 0.5).sum())}/{sc.numel()}")
+
+
+def feature_extractor_case():
+    spec = importlib.util.spec_from_file_location("ref_feature_extractor",
+                                                  os.path.join(REFERENCE, "src/tracking/feature_extractor.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    fe = mod.FeatureExtractor()
+    rng = np.random.default_rng(7)
+    enc = rng.standard_normal((25, 42, 256)).astype(np.float32)
+    bboxes = [(100.0, 200.0, 50.0, 100.0), (0.0, 0.0, 1333.0, 800.0), (1300.0, 790.0, 80.0, 40.0),
+              (-20.0, -10.0, 30.0, 30.0), (640.5, 399.2, 1.0, 1.0), (10.0, 700.0, 300.0, 99.0)]
+    roi = fe.extract_roi_features(enc, bboxes, (800, 1333))
+    raw = rng.standard_normal((5, 256)).astype(np.float32)
+    raw[3] = 0.0
+    norm = fe.normalize_features(raw)
+    empty = fe.extract_roi_features(enc, [], (800, 1333))
+    # enc/raw are regenerated in the test from default_rng(7) in the same draw order (keeps the fixture small)
+    np.savez_compressed(os.path.join(GOLD, "feature_extractor.npz"), rng_seed=np.array(7), bboxes=np.array(bboxes),
+                        image_shape=np.array([800, 1333]), roi=roi, norm=norm, empty_shape=np.array(empty.shape),
+                        enc_sample=enc[::5, ::7, ::31])
+    print("feature_extractor: roi", roi.shape, "norms", np.linalg.norm(roi, axis=1)[:3])
+
+
+def main():
+    os.makedirs(GOLD, exist_ok=True)
+    r50 = DetrArch.resnet50()
+    # equal-size batches (pixel_mask all ones): the configuration the HIP path serves
+    model_case("r50_mild_256x320", r50, 0, 1.0, [(256, 320), (256, 320)], 1234)
+    model_case("r50_sharp_256x320", r50, 0, 2.0, [(256, 320), (256, 320)], 1234)
+    # ragged batch: zero padding + pixel_mask -> masked attention + cumsum position embedding (oracle only)
+    model_case("r50_mild_ragged", r50, 0, 1.0, [(256, 320), (224, 288)], 2234)
+    # odd sizes all the way down (H3), single frame
+    model_case("r50_mild_odd_203x333", r50, 0, 1.0, [(203, 333)], 3234)
+    # full benchmark resolution, one frame: logits/boxes in full, encoder output as checksums + samples
+    model_case("r50_mild_800x1333", r50, 0, 1.0, [(800, 1333)], 1234, full_outputs=False)
+    # r101 (config 4 architecture) at small size
+    model_case("r101_mild_256x320", DetrArch.resnet101(), 0, 1.0, [(256, 320)], 1234)
+    feature_extractor_case()
+
+
+if __name__ == "__main__":
+    main()
