@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""Headline benchmark: frames/sec of the Phase-2 DETR detect path (BASELINE.json: detr-resnet-50, batch 8, 800x1333).
+
+    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path over one batch of synthetic frames per rank: uint8 BGR frames already resident in
+HBM -> preprocess -> ResNet-50 -> encoder/decoder -> heads -> device post-process -> detection records; with N > 1
+every rank detects its own shard of the global batch (8 frames per rank, weak scaling) and the records are
+all-gathered over RCCL/xGMI to every rank (rank 0 = the orchestrator) inside the step.  Rank 0 prints ONE JSON line.
+"""
+
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_MFMA_TFLOPS = 2500.0  # dense fp16/bf16 MFMA, /opt/skills/guides/MI355X_MICROARCH.md §Chip-level parameters
+PEAK_HBM_GBS = 8000.0
+
+
+def cpu_baseline(path: str, H: int, W: int, batch: int = 4, iters: int = 2) -> dict:
+    """The oracle (CPU fp32 restatement, torch CPU backend) on a bounded sample of the same workload."""
+    import torch
+
+    from office_person_detection_vit_amd.frames import noise_frame
+    from office_person_detection_vit_amd.weights import load_safetensors
+    from oracle import detr_oracle as O
+
+    w = O.to_torch(load_safetensors(path))
+    frames = [noise_frame(H, W, 1234 + i) for i in range(batch)]
+    times = []
+    for it in range(iters + 1):  # first iteration is the warm-up
+        t0 = time.perf_counter()
+        pv, pm = O.preprocess(frames)
+        lg, bx, _ = O.forward(w, pv, pm)
+        O.post_process_object_detection(lg.numpy(), bx.numpy(), 0.5, [(H, W)] * batch)
+        times.append(time.perf_counter() - t0)
+    best = min(times[1:])
+    return {"value": round(batch / best, 4), "unit": "frames/s", "cores": int(torch.get_num_threads()), "kind": "port",
+            "sample": f"oracle/detr_oracle.py (torch CPU fp32), detr-resnet-50, {batch}x{H}x{W} frames, 1 warm-up + "
+                      f"{iters} timed iterations, best iteration {best:.2f} s"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
+    ap.add_argument("--height", type=int, default=800)
+    ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from office_person_detection_vit_amd import _capi
+    from office_person_detection_vit_amd.frames import noise_frame
+    from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    B, H, W = args.batch, args.height, args.width
+    cache = os.environ.get("OPD_WEIGHT_CACHE", "/tmp/opd_weights")
+    if rank == 0:
+        path = ensure_weight_file(cache, DetrArch.resnet50(), 0, 1.0, "r50")
+    if world > 1:
+        dist.barrier()
+    path = ensure_weight_file(cache, DetrArch.resnet50(), 0, 1.0, "r50")
+
+    lib = _capi.load_library()
+    cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
+    handle = C.c_void_p()
+    _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), local_rank, C.byref(handle)), "opd_detr_create")
+    info = _capi.OpdModelInfo()
+    _capi.check(lib.opd_detr_info(handle, C.byref(info)), "opd_detr_info")
+    Q = info.num_queries
+
+    # synthetic office-camera frames, resident in HBM before the timed region (torch = device memory plumbing only)
+    frames = np.stack([noise_frame(H, W, 1234 + rank * B + i) for i in range(B)])
+    d_frames = torch.from_numpy(frames).cuda()
+    d_records = torch.zeros((B, Q, 8), dtype=torch.int32, device="cuda")   # opd_det = 8 x 4 bytes
+    d_counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    g_records = torch.zeros((world, B, Q, 8), dtype=torch.int32, device="cuda") if world > 1 else None
+    g_counts = torch.zeros((world, B), dtype=torch.int32, device="cuda") if world > 1 else None
+    hw = np.asarray([[H, W]] * B, dtype=np.int32)
+
+    def step():
+        rc = lib.opd_detr_detect(handle, C.c_void_p(d_frames.data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_DEVICE,
+                                 B, H, W, 0.5, hw.ctypes.data_as(C.c_void_p),
+                                 C.cast(C.c_void_p(d_records.data_ptr()), C.POINTER(_capi.OpdDet)),
+                                 C.cast(C.c_void_p(d_counts.data_ptr()), C.POINTER(C.c_int32)))
+        _capi.check(rc, "opd_detr_detect")
+        if world > 1:  # the path's one exchange step: fixed-size detection records back to the orchestrator
+            dist.all_gather_into_tensor(g_records, d_records)
+            dist.all_gather_into_tensor(g_counts, d_counts)
+            return g_counts.cpu(), g_records.cpu() if rank == 0 else None
+        return d_counts.cpu(), d_records.cpu()
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        counts, _ = step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel: HIP event pairs around every launch on the library's stream ------------------
+    roof = None
+    stage_ms = None
+    if rank == 0:
+        _capi.check(lib.opd_detr_set_profiling(handle, 1), "opd_detr_set_profiling")
+        ms_acc = np.zeros(4)
+        fl = np.zeros(4)
+        ln = np.zeros(4, dtype=np.int64)
+        st_acc = np.zeros(8)
+        reps = 3
+        for _ in range(reps):
+            step()
+            ms4, l4, f4, s8 = (C.c_float * 4)(), (C.c_int32 * 4)(), (C.c_double * 4)(), (C.c_float * 8)()
+            _capi.check(lib.opd_detr_kernel_times(handle, ms4, l4, f4), "opd_detr_kernel_times")
+            _capi.check(lib.opd_detr_stage_times(handle, s8), "opd_detr_stage_times")
+            ms_acc += np.asarray(list(ms4)); fl = np.asarray(list(f4)); ln = np.asarray(list(l4)); st_acc += np.asarray(list(s8))
+        ms_avg = ms_acc / reps
+        stage_ms = [round(float(v), 4) for v in st_acc / reps]
+        _capi.check(lib.opd_detr_set_profiling(handle, 0), "opd_detr_set_profiling")
+        # dominant kernel = conv_gemm_kernel (backbone convolutions + transformer linears): classes 0 and 1
+        k_ms = float(ms_avg[0] + ms_avg[1])
+        k_fl = float(fl[0] + fl[1])
+        k_n = int(ln[0] + ln[1])
+        achieved = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        roof = {"bound": "mfma", "kernel": "conv_gemm_kernel", "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                "launches_per_step": k_n, "avg_launch_us": round(1e3 * k_ms / max(k_n, 1), 2),
+                "flops_per_launch": round(k_fl / max(k_n, 1)),
+                "by_class_ms": {"conv": round(float(ms_avg[0]), 4), "linear": round(float(ms_avg[1]), 4),
+                                "attention": round(float(ms_avg[2]), 4)}}
+
+    total_frames = B * world * args.steps
+    fps = total_frames / elapsed
+    if rank == 0:
+        out = {
+            "metric": "frames/sec (Phase-2 DETR detect) at 800x1333 batch 8",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": f"facebook/detr-resnet-50 architecture (seeded synthetic weights), batch {B} per GPU, "
+                                   f"{H}x{W} uint8 BGR frames resident in HBM, forward + device post-process"
+                                   + (", RCCL all-gather of detection records" if world > 1 else ""),
+                       "global_batch": B * world, "parallelism": f"frame-sharded dp{world}"},
+            "roofline": roof,
+            "stage_ms": stage_ms,
+            "detections_last_step": int(np.asarray(counts).sum()),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(path, H, W)
+            out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
+        print(json.dumps(out), flush=True)
+    lib.opd_detr_destroy(handle)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,147 @@
+/*
+ * opd_detr.h — C-ABI of the MI355X-native DETR person-detection forward pass (libopd_hip.so).
+ *
+ * The reference (Kizuna42/office-person-detection-vit) is 100 % Python and has no FFI: its Phase-2 detector is a
+ * Python class wrapping Hugging Face `DetrForObjectDetection` (deleted `src/detection/vit_detector.py`, method map
+ * in `coverage.json:1`; today's stand-in with the same surface is `src/detection/yolov8_detector.py:19-254`).  The
+ * entry points below are what a ctypes binding of that class would call; each one names the reference interface it
+ * replaces.  Plain pointers and sizes only — no torch / numpy types cross this boundary.
+ *
+ * Conventions
+ *   - every function returns 0 on success or a negative OPD_E* code; it never throws and never aborts.  The
+ *     human-readable reason of the last failure on the calling thread is `opd_last_error()`.  The Python shim turns a
+ *     non-zero code into `RuntimeError`, which preserves the reference's conventions: load failure ->
+ *     RuntimeError("Failed to load ... model: ...") (`yolov8_detector.py:86-88`), inference errors re-raised
+ *     (`:130-132`) and converted to an empty detection list by the phase (`src/pipeline/phases/detection.py:124-127`).
+ *   - output buffers are caller-allocated; the library owns only the model, its workspace and its HIP stream.
+ *   - single caller at a time per handle (the reference is strictly single-threaded).
+ *   - tensors: logits [B][Q][C+1] f32, boxes [B][Q][4] f32 (cx,cy,w,h in [0,1]), encoder features [B][h*w][D] f32
+ *     with h = ceil(H/32), w = ceil(W/32) (HF `DetrObjectDetectionOutput`: logits, pred_boxes,
+ *     encoder_last_hidden_state; HF:models/detr/modeling_detr.py:1329-1443).
+ */
+#ifndef OPD_DETR_H
+#define OPD_DETR_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define OPD_OK 0
+#define OPD_EINVAL (-1)   /* bad argument (null pointer, shape out of the configured maximum, ...) */
+#define OPD_EIO (-2)      /* weight file missing / unreadable / malformed */
+#define OPD_ESCHEMA (-3)  /* weight file lacks a tensor of the DETR state dict or has the wrong shape */
+#define OPD_EHIP (-4)     /* a HIP runtime call failed (message carries hipGetErrorString) */
+#define OPD_ENOMEM (-5)   /* device or host allocation failed */
+#define OPD_ESTATE (-6)   /* call not valid in the handle's current state */
+
+typedef struct opd_detr opd_detr; /* opaque model handle */
+
+/* Input pixel formats accepted by the forward entry points. */
+#define OPD_PIXELS_U8_BGR_HWC 0 /* the reference's frame: numpy uint8 [H][W][3], BGR (`yolov8_detector.py:90-96`) */
+#define OPD_PIXELS_F32_NCHW 1   /* HF `pixel_values`: float32 [B][3][H][W], already normalised */
+
+/* Where the caller's buffers live. */
+#define OPD_MEM_HOST 0
+#define OPD_MEM_DEVICE 1 /* pointers are HIP device pointers on the handle's device */
+
+typedef struct opd_config {
+    int32_t struct_size; /* = sizeof(opd_config), for forward compatibility */
+    int32_t max_batch;   /* workspace is sized for [max_batch][max_height][max_width] frames */
+    int32_t max_height;
+    int32_t max_width;
+    int32_t flags;       /* OPD_FLAG_* */
+    int32_t reserved[3];
+} opd_config;
+
+#define OPD_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a captured hipGraph */
+
+/* One detection record (32 bytes).  Boxes are (x1,y1,x2,y2) in pixels of the ORIGINAL frame, as produced by
+ * HF `post_process_object_detection` (HF:models/detr/image_processing_detr.py:805-856). */
+typedef struct opd_det {
+    float x1, y1, x2, y2;
+    float score;
+    int32_t label;       /* argmax over the first C classes ("no object" excluded) */
+    int32_t query_index; /* decoder query that produced it (`Detection.query_index`, src/models/data_models.py:38) */
+    int32_t frame;       /* index of the frame inside the batch */
+} opd_det;
+
+/* Architecture facts read back from a loaded model. */
+typedef struct opd_model_info {
+    int32_t depths[4];
+    int32_t d_model, heads, ffn_dim, encoder_layers, decoder_layers, num_queries, num_classes_plus1;
+    int32_t max_batch, max_height, max_width;
+    int32_t device_ordinal;
+    int64_t weight_bytes_device;
+    int64_t workspace_bytes_device;
+} opd_model_info;
+
+/* Replaces `ViTDetector.__init__` + `load_model()` (deleted vit_detector.py 36-44, 81-99; same contract as
+ * `YOLOv8Detector.load_model`, yolov8_detector.py:70-88): parse a safetensors checkpoint carrying the HF
+ * `DetrForObjectDetection` state dict (5.x or 4.x key names), fold every FrozenBN into its convolution in fp32
+ * (HF:models/detr/modeling_detr.py:179-215), convert to the device layouts and upload to GPU `device_ordinal`. */
+int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out);
+
+/* Replaces `cleanup_resources` / detector release (`src/utils/memory_utils.py:33-41`). */
+void opd_detr_destroy(opd_detr* m);
+
+int opd_detr_info(const opd_detr* m, opd_model_info* info);
+
+/* Replaces `with torch.no_grad(): outputs = model(pixel_values, pixel_mask)` in `ViTDetector.detect_batch`
+ * (deleted vit_detector.py 508-550; HF:models/detr/modeling_detr.py:1329-1443), including the BGR->RGB / 1/255 /
+ * ImageNet mean-std step of `_preprocess_batch` (562-578) when `pixel_format == OPD_PIXELS_U8_BGR_HWC`.
+ * All B frames share one size HxW (pixel_mask all ones).  `enc_features` may be NULL.
+ * `mem_kind` says whether pixels AND outputs are host or device pointers.  Synchronous: results are complete on
+ * return. */
+int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+                     float* logits, float* boxes, float* enc_features);
+
+/* Replaces `_postprocess_batch` part 1 = HF `post_process_object_detection` (deleted vit_detector.py 591-647;
+ * HF:models/detr/image_processing_detr.py:805-856): softmax over C+1, max over the first C classes, cxcywh->xyxy,
+ * scale by the ORIGINAL (height,width) of each frame, keep score > threshold.  Runs on the device on the logits and
+ * boxes of the LAST forward of this handle.  `orig_hw` = [B][2] int32 host array (height, width) or NULL (= model
+ * input size).  `out` (host) receives `counts[b]` records for frame b at out[b*Q ...]; records keep query order. */
+int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
+
+/* One call = forward + device post-process, pixels in HBM when `mem_kind == OPD_MEM_DEVICE` (the benchmark's
+ * timed region).  Equivalent to opd_detr_forward(..., NULL, NULL, NULL) followed by opd_detr_postprocess(...). */
+int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+                    float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
+/* With `mem_kind == OPD_MEM_DEVICE`, `out` ([B][Q] records) and `counts` ([B]) are DEVICE pointers too, so a sharded
+ * caller can hand them straight to an RCCL all-gather; `orig_hw` is always a host array. */
+
+/* Replaces `_postprocess_batch` part 2 (deleted vit_detector.py 591-647; `docs/plan.md:30`,
+ * `config.yaml.disabled:38`): keep `label == person_label` (pass -1 to keep every class), greedy IoU-NMS in
+ * descending score order at `nms_threshold` (pass >= 1 to disable).  Host-side, in place: compacts `dets[0..n)` and
+ * returns the new count (>= 0) or a negative error. */
+int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold);
+
+/* Replaces `FeatureExtractor.extract_roi_features` on the DETR encoder map
+ * (`src/tracking/feature_extractor.py:39-88`; deleted vit_detector.py 224-273): for each (x,y,w,h) box in original
+ * pixels, mean-pool the last forward's encoder map of frame `frame` over the int-truncated, clamped ROI and
+ * L2-normalise (x / (||x|| + 1e-8)).  `features` = host [n][D] f32.  Runs on the device. */
+int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n, int orig_h, int orig_w,
+                          float* features);
+
+/* Device time (ms) of the last forward/detect per stage, measured with HIP events on the handle's stream:
+ * [0] preprocess+stem+pool, [1] stage1, [2] stage2, [3] stage3, [4] stage4, [5] projection+encoder, [6] decoder+heads,
+ * [7] post-process.  Only filled when profiling was enabled with opd_detr_set_profiling(m, 1). */
+int opd_detr_set_profiling(opd_detr* m, int enabled);
+int opd_detr_stage_times(const opd_detr* m, float* ms8);
+/* Per-kernel-class totals of the last profiled forward, from HIP event pairs recorded around EVERY launch on the
+ * handle's stream: class 0 = conv_gemm_kernel on backbone convolutions (+ input projection), 1 = conv_gemm_kernel as
+ * transformer linear layer, 2 = attention_kernel, 3 = reserved.  ms4[c] = summed device time, launches4[c] = number of
+ * launches, flops4[c] = summed ALGORITHMIC FLOPs (2 x MAC) of those launches. */
+int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, double* flops4);
+
+/* Thread-local description of the last error returned on this thread ("" if none). */
+const char* opd_last_error(void);
+
+/* Library / kernel build identification, e.g. "opd_hip 0.1 gfx950". */
+const char* opd_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* OPD_DETR_H */

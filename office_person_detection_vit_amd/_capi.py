@@ -1,0 +1,102 @@
+"""ctypes binding of libopd_hip.so — the only way the package reaches the GPU.
+
+There is NO CPU fallback: if the shared library is missing (not built) or no HIP device is visible, the calls raise.
+The declarations mirror ``include/opd_detr.h`` one to one.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libopd_hip.so")
+
+OPD_PIXELS_U8_BGR_HWC = 0
+OPD_PIXELS_F32_NCHW = 1
+OPD_MEM_HOST = 0
+OPD_MEM_DEVICE = 1
+OPD_FLAG_NO_GRAPH = 1
+
+
+class OpdConfig(C.Structure):
+    _fields_ = [("struct_size", C.c_int32), ("max_batch", C.c_int32), ("max_height", C.c_int32),
+                ("max_width", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class OpdDet(C.Structure):
+    _fields_ = [("x1", C.c_float), ("y1", C.c_float), ("x2", C.c_float), ("y2", C.c_float), ("score", C.c_float),
+                ("label", C.c_int32), ("query_index", C.c_int32), ("frame", C.c_int32)]
+
+
+class OpdModelInfo(C.Structure):
+    _fields_ = [("depths", C.c_int32 * 4), ("d_model", C.c_int32), ("heads", C.c_int32), ("ffn_dim", C.c_int32),
+                ("encoder_layers", C.c_int32), ("decoder_layers", C.c_int32), ("num_queries", C.c_int32),
+                ("num_classes_plus1", C.c_int32), ("max_batch", C.c_int32), ("max_height", C.c_int32),
+                ("max_width", C.c_int32), ("device_ordinal", C.c_int32), ("weight_bytes_device", C.c_int64),
+                ("workspace_bytes_device", C.c_int64)]
+
+
+# name -> (restype, argtypes): every symbol include/opd_detr.h declares
+API = {
+    "opd_detr_create": (C.c_int, [C.POINTER(OpdConfig), C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "opd_detr_destroy": (None, [C.c_void_p]),
+    "opd_detr_info": (C.c_int, [C.c_void_p, C.POINTER(OpdModelInfo)]),
+    "opd_detr_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]),
+    "opd_detr_postprocess": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
+    "opd_detr_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                  C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
+    "opd_person_nms": (C.c_int, [C.POINTER(OpdDet), C.c_int, C.c_int, C.c_float]),
+    "opd_detr_roi_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_detr_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
+    "opd_detr_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "opd_last_error": (C.c_char_p, []),
+    "opd_version": (C.c_char_p, []),
+}
+
+# kernel-level test hooks (csrc/opd_test_api.cpp); not part of the boundary
+TEST_API = {
+    "opd_test_conv_gemm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 15),
+    "opd_test_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_int]),
+    "opd_test_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int]),
+    "opd_test_maxpool": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6),
+    "opd_test_preprocess_u8": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3),
+    "opd_test_f32_to_f16": (C.c_uint16, [C.c_float]),
+    "opd_test_f16_to_f32": (C.c_float, [C.c_uint16]),
+    "opd_test_normalise_key": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
+    "opd_test_inspect_checkpoint": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "opd_test_set_tr_read": (C.c_int, [C.c_void_p, C.c_int]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load_library() -> C.CDLL:
+    """dlopen libopd_hip.so (built in-tree by ``csrc/build.py``) and attach prototypes.  Raises if it is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"HIP extension not built: {LIB_PATH} is missing (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            "This package has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for table in (API, TEST_API):
+        for name, (res, args) in table.items():
+            fn = getattr(lib, name)  # AttributeError here = the library does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    return load_library().opd_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (code {rc}): {last_error()}")

@@ -1,0 +1,181 @@
+// kernels_attn.hip — flash-style multi-head attention, head_dim 32, fp16 MFMA / fp32 softmax, gfx950.
+//
+// softmax(Q K^T * 32^-1/2) V for the encoder self-attention (1050x1050), decoder
+// self-attention (100x100) and decoder cross-attention (100x1050)   (HF:models/detr/modeling_detr.py:402-427).
+// Scores are never materialised in HBM (the reference's eager path writes [B,8,1050,1050] fp32 = 282 MB).
+//
+// One workgroup = 4 waves = 64 queries of one (batch, head); each wave owns 16 queries.  Both products run
+// "swapped" so that every per-query quantity is lane-local (query index = lane & 15):
+//   S^T[key][q]  = mfma_16x16x32(A = K tile rows, B = Q rows)      -> lane holds 4 keys x its query per 16-key tile
+//   O^T[d][q]   += mfma_16x16x32(A = V^T,         B = P^T)         -> lane holds 4 head-dims x its query
+// The P accumulator tile is re-used directly as the B operand of the second product (k-slot j<4 -> S-tile 2kb,
+// j>=4 -> S-tile 2kb+1); V^T fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16
+// (hardware transpose), with a scalar-gather cross-check path selectable at run time.
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "opd_kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
+
+namespace {
+
+constexpr int KT = 64;       // keys per LDS tile
+constexpr int LDS_ROW = 80;  // bytes per key row in LDS (64 payload + 16 pad; 16-byte aligned)
+constexpr int TILE_BYTES = KT * LDS_ROW;
+
+__device__ __forceinline__ half4 lds_tr16(const unsigned char* p) {
+    short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+        (__attribute__((address_space(3))) short4v*)(const_cast<unsigned char*>(p)));
+    half4 r;
+    __builtin_memcpy(&r, &t, 8);
+    return r;
+}
+
+__global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];  // [buf][K|V]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int g = lane >> 4;
+    const int li = lane & 15;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int q = blockIdx.x * 64 + wave * 16 + li;
+    const bool q_ok = q < p.Lq;
+
+    half8 qf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qf[j] = (_Float16)0.f;
+    if (q_ok) qf = *reinterpret_cast<const half8*>(p.q + ((size_t)b * p.Lq + q) * p.ldq + h * 32 + g * 8);
+
+    const int skey = tid >> 2, schunk = tid & 3;
+    const f16_t* kbase = p.k + (size_t)b * p.Lk * p.ldk + h * 32 + schunk * 8;
+    const f16_t* vbase = p.v + (size_t)b * p.Lk * p.ldv + h * 32 + schunk * 8;
+    uint4 rk, rv;
+    auto load_tile = [&](int t) {
+        const int key = t * KT + skey;
+        rk = make_uint4(0u, 0u, 0u, 0u);
+        rv = rk;
+        if (key < p.Lk) {
+            rk = *reinterpret_cast<const uint4*>(kbase + (size_t)key * p.ldk);
+            rv = *reinterpret_cast<const uint4*>(vbase + (size_t)key * p.ldv);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        unsigned char* base = lds + buf * 2 * TILE_BYTES;
+        *reinterpret_cast<uint4*>(base + skey * LDS_ROW + schunk * 16) = rk;
+        *reinterpret_cast<uint4*>(base + TILE_BYTES + skey * LDS_ROW + schunk * 16) = rv;
+    };
+
+    float m_run = -INFINITY;  // running max of this lane's query (uniform over the 4 lanes sharing the query)
+    float l_run = 0.f;        // running sum over THIS lane's keys only (combined across the 4 lanes at the end)
+    float4v oacc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+
+    const int ntiles = (p.Lk + KT - 1) / KT;
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int t = 0; t < ntiles; ++t) {
+        const int buf = t & 1;
+        if (t + 1 < ntiles) load_tile(t + 1);
+        const unsigned char* Kl = lds + buf * 2 * TILE_BYTES;
+        const unsigned char* Vl = Kl + TILE_BYTES;
+
+        // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
+        float4v s[4];
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt) {
+            const half8 kf = *reinterpret_cast<const half8*>(Kl + (kt * 16 + li) * LDS_ROW + g * 16);
+            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        }
+        // ---- online softmax (fp32) ------------------------------------------------------------------------------
+        float mx = -INFINITY;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int key = t * KT + kt * 16 + g * 4 + r;
+                float v = s[kt][r] * p.scale;
+                v = key < p.Lk ? v : -INFINITY;
+                s[kt][r] = v;
+                mx = fmaxf(mx, v);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        const float m_new = fmaxf(m_run, mx);  // finite: tile 0 always holds key 0
+        const float alpha = expf(m_run - m_new);
+        float psum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float e = expf(s[kt][r] - m_new);
+                s[kt][r] = e;
+                psum += e;
+            }
+        l_run = l_run * alpha + psum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+
+        // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {
+            half8 pf;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                pf[r] = (_Float16)s[2 * kb][r];
+                pf[4 + r] = (_Float16)s[2 * kb + 1][r];
+            }
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                half8 vf;
+                if (p.use_tr_read) {
+                    const unsigned char* a0 = Vl + (kb * 32 + g * 4 + (li >> 2)) * LDS_ROW + (dt * 16 + (li & 3) * 4) * 2;
+                    const half4 lo = lds_tr16(a0);
+                    const half4 hi = lds_tr16(a0 + 16 * LDS_ROW);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const int key = kb * 32 + (j < 4 ? g * 4 + j : 16 + g * 4 + (j - 4));
+                        vf[j] = *reinterpret_cast<const _Float16*>(Vl + key * LDS_ROW + (dt * 16 + li) * 2);
+                    }
+                }
+                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+            }
+        }
+        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        __syncthreads();
+    }
+
+    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
+    l_tot += __shfl_xor(l_tot, 32, 64);
+    if (q_ok) {
+        const float inv = 1.0f / l_tot;
+        f16_t* orow = p.o + ((size_t)b * p.Lq + q) * p.ldo + h * 32 + g * 4;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+            half4 o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = (_Float16)(oacc[dt][r] * inv);
+            *reinterpret_cast<half4*>(orow + dt * 16) = o;
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream) {
+    if (p.B <= 0 || p.heads <= 0 || p.Lq <= 0 || p.Lk <= 0) return hipErrorInvalidValue;
+    if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;  // 16-byte row chunks
+    dim3 grid((p.Lq + 63) / 64, p.heads, p.B);
+    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, p);
+    return hipGetLastError();
+}

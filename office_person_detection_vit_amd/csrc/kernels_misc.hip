@@ -1,0 +1,296 @@
+// kernels_misc.hip — HBM-bound element-wise / small kernels of the DETR detect path (gfx950).
+//
+//   preprocess   SURVEY.md §8 a1: BGR->RGB, x*(1/255), (x-mean)/std   (HF:models/detr/image_processing_detr.py:639-668)
+//   maxpool      a3: MaxPool2d(k3,s2,p1)                              (HF:models/resnet/modeling_resnet.py:84)
+//   layernorm    a9/a12: nn.LayerNorm(256), eps 1e-5                  (HF:models/detr/modeling_detr.py:606,629-639)
+//   heads        a13: class_labels_classifier + DetrMLPPredictionHead + sigmoid (HF:...modeling_detr.py:1284-1300,1410-1411)
+//   postprocess  a14: HF post_process_object_detection               (HF:models/detr/image_processing_detr.py:805-856)
+//   roi_features a17: FeatureExtractor.extract_roi_features           (src/tracking/feature_extractor.py:39-88)
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "opd_kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+// ImageNet statistics, RGB order (HF:utils/constants.py IMAGENET_DEFAULT_MEAN/STD)
+__constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
+__constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
+
+// One thread per pixel: 3 bytes in (BGR), 8 bytes out (RGB0 fp16).  Same op order as the oracle:
+// (float(u8) * (1/255) - mean) / std.
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __restrict__ out, size_t npix) {
+#pragma clang fp contract(off)  // keep mul / sub / div separately rounded, like the reference's tensor ops
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npix) return;
+    const uint8_t* s = in + i * 3;
+    const float b = (float)s[0], g = (float)s[1], r = (float)s[2];
+    const float k = 1.0f / 255.0f;
+    half4 o;
+    o[0] = (_Float16)((r * k - c_mean[0]) / c_std[0]);
+    o[1] = (_Float16)((g * k - c_mean[1]) / c_std[1]);
+    o[2] = (_Float16)((b * k - c_mean[2]) / c_std[2]);
+    o[3] = (_Float16)0.f;
+    *reinterpret_cast<half4*>(out + i * 4) = o;
+}
+
+__global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __restrict__ out, int B, int HW) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * HW) return;
+    const size_t b = i / HW, px = i - b * HW;
+    const float* s = pv + b * 3 * (size_t)HW + px;
+    half4 o;
+    o[0] = (_Float16)s[0];
+    o[1] = (_Float16)s[(size_t)HW];
+    o[2] = (_Float16)s[2 * (size_t)HW];
+    o[3] = (_Float16)0.f;
+    *reinterpret_cast<half4*>(out + i * 4) = o;
+}
+
+// One thread per (output pixel, 8-channel group); 9 x 16-byte loads, 1 x 16-byte store.
+__global__ void maxpool_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ out, int B, int H, int W, int C, int OH,
+                               int OW) {
+    const int cg = C >> 3;
+    const size_t total = (size_t)B * OH * OW * cg;
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int c8 = (int)(i % cg);
+    size_t r = i / cg;
+    const int ow = (int)(r % OW);
+    r /= OW;
+    const int oh = (int)(r % OH);
+    const int b = (int)(r / OH);
+    half8 m;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.f);
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh) {
+        const int ih = oh * 2 - 1 + kh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            const int iw = ow * 2 - 1 + kw;
+            if ((unsigned)iw >= (unsigned)W) continue;
+            const half8 v = *reinterpret_cast<const half8*>(x + (((size_t)b * H + ih) * W + iw) * C + c8 * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+        }
+    }
+    *reinterpret_cast<half8*>(out + (((size_t)b * OH + oh) * OW + ow) * C + c8 * 8) = m;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// One wave per row of 256: lane holds 4 consecutive elements; two-pass (mean, then centred variance) in fp32.
+__global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y,
+                                                           f16_t* __restrict__ y16, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4v v = *reinterpret_cast<const float4v*>(x + (size_t)row * 256 + lane * 4);
+    const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+    const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+    const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+    const float rstd = 1.0f / sqrtf(var + 1e-5f);
+    const float4v g = *reinterpret_cast<const float4v*>(gamma + lane * 4);
+    const float4v bb = *reinterpret_cast<const float4v*>(beta + lane * 4);
+    float4v o;
+    o[0] = d0 * rstd * g[0] + bb[0];
+    o[1] = d1 * rstd * g[1] + bb[1];
+    o[2] = d2 * rstd * g[2] + bb[2];
+    o[3] = d3 * rstd * g[3] + bb[3];
+    if (y) *reinterpret_cast<float4v*>(y + (size_t)row * 256 + lane * 4) = o;
+    if (y16) {
+        half4 h;
+        h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+        *reinterpret_cast<half4*>(y16 + (size_t)row * 256 + lane * 4) = h;
+    }
+}
+
+__global__ void cast_f16_kernel(const float* __restrict__ x, f16_t* __restrict__ y, size_t n) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) reinterpret_cast<_Float16*>(y)[i] = (_Float16)x[i];
+}
+
+// Plan-build-time fp32 GEMM (pos-embedding folds): one thread per output, K-loop in order; not on the hot path.
+__global__ void gemm_f32_kernel(const float* __restrict__ A, const float* __restrict__ Wt, const float* __restrict__ bias,
+                                float* __restrict__ C, int M, int N, int K, int ldc) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    const int m = blockIdx.y;
+    if (n >= N || m >= M) return;
+    const float* a = A + (size_t)m * K;
+    const float* w = Wt + (size_t)n * K;
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) acc = fmaf(a[k], w[k], acc);
+    C[(size_t)m * ldc + n] = acc + (bias ? bias[n] : 0.f);
+}
+
+// Heads: one 256-thread block per decoder row; fp32 throughout (0.03 GFLOP/frame).
+__global__ __launch_bounds__(256) void heads_kernel(HeadParams p) {
+    __shared__ float h[256];
+    __shared__ float t1[256];
+    __shared__ float t2[256];
+    const int row = blockIdx.x;
+    const int t = threadIdx.x;
+    h[t] = p.hs[(size_t)row * 256 + t];
+    __syncthreads();
+    if (t < p.ncls) {
+        const float* w = p.wc + (size_t)t * 256;
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k) acc = fmaf(h[k], w[k], acc);
+        p.logits[(size_t)row * p.ncls + t] = acc + p.bc[t];
+    }
+    {
+        const float* w = p.w1 + (size_t)t * 256;
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k) acc = fmaf(h[k], w[k], acc);
+        acc += p.b1[t];
+        t1[t] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    {
+        const float* w = p.w2 + (size_t)t * 256;
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k) acc = fmaf(t1[k], w[k], acc);
+        acc += p.b2[t];
+        t2[t] = acc > 0.f ? acc : 0.f;
+    }
+    __syncthreads();
+    if (t < 4) {
+        const float* w = p.w3 + (size_t)t * 256;
+        float acc = 0.f;
+        for (int k = 0; k < 256; ++k) acc = fmaf(t2[k], w[k], acc);
+        acc += p.b3[t];
+        p.boxes[(size_t)row * 4 + t] = 1.0f / (1.0f + expf(-acc));
+    }
+}
+
+struct DetRec {
+    float x1, y1, x2, y2, score;
+    int32_t label, query_index, frame;
+};
+
+// One block (128 threads) per frame, one thread per query; compaction in query order via a block prefix sum.
+__global__ __launch_bounds__(128) void postprocess_kernel(PostParams p) {
+    __shared__ int flags[128];
+    const int b = blockIdx.x;
+    const int q = threadIdx.x;
+    float score = 0.f, x1 = 0.f, y1 = 0.f, x2 = 0.f, y2 = 0.f;
+    int label = 0, keep = 0;
+    if (q < p.Q) {
+        const float* lg = p.logits + ((size_t)b * p.Q + q) * p.ncls;
+        float mx = lg[0];
+        for (int c = 1; c < p.ncls; ++c) mx = fmaxf(mx, lg[c]);
+        float sum = 0.f, best = -1.f;
+        for (int c = 0; c < p.ncls; ++c) {
+            const float e = expf(lg[c] - mx);
+            sum += e;
+            if (c < p.ncls - 1 && e > best) { best = e; label = c; }
+        }
+        score = best / sum;
+        const float* bx = p.boxes + ((size_t)b * p.Q + q) * 4;
+        const float h = (float)p.orig_hw[b * 2], w = (float)p.orig_hw[b * 2 + 1];
+        x1 = (bx[0] - 0.5f * bx[2]) * w;
+        y1 = (bx[1] - 0.5f * bx[3]) * h;
+        x2 = (bx[0] + 0.5f * bx[2]) * w;
+        y2 = (bx[1] + 0.5f * bx[3]) * h;
+        keep = score > p.threshold ? 1 : 0;
+    }
+    flags[q] = keep;
+    __syncthreads();
+    int pos = 0;
+    for (int i = 0; i < q; ++i) pos += flags[i];
+    if (keep) {
+        DetRec* rec = reinterpret_cast<DetRec*>(p.records) + (size_t)b * p.Q + pos;
+        rec->x1 = x1; rec->y1 = y1; rec->x2 = x2; rec->y2 = y2; rec->score = score;
+        rec->label = label; rec->query_index = q; rec->frame = b;
+    }
+    if (q == 127) p.counts[b] = pos + keep;
+}
+
+// One block (256 threads = channels) per ROI: mean over the ROI window of the [h][w][256] map, then L2 normalise.
+__global__ __launch_bounds__(256) void roi_features_kernel(const float* __restrict__ enc, const int32_t* __restrict__ rois,
+                                                           float* __restrict__ out, int h, int w) {
+    __shared__ float red[4];
+    const int r = blockIdx.x;
+    const int c = threadIdx.x;
+    const int x0 = rois[r * 4], y0 = rois[r * 4 + 1], x1 = rois[r * 4 + 2], y1 = rois[r * 4 + 3];
+    float acc = 0.f;
+    for (int y = y0; y < y1; ++y)
+        for (int x = x0; x < x1; ++x) acc += enc[((size_t)y * w + x) * 256 + c];
+    const float mean = acc / (float)((y1 - y0) * (x1 - x0));
+    const float ss = wave_sum(mean * mean);
+    if ((c & 63) == 0) red[c >> 6] = ss;
+    __syncthreads();
+    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+    out[(size_t)r * 256 + c] = mean / (norm + 1e-8f);
+}
+
+inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
+
+}  // namespace
+
+hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, hipStream_t stream) {
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, frames, out, npix);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, hipStream_t stream) {
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H * W);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW,
+                              hipStream_t stream) {
+    if (C % 8 != 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)B * OH * OW * (C / 8);
+    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, out, B, H, W, C, OH, OW);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, f16_t* y16, int rows,
+                                hipStream_t stream) {
+    if (rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, y16, rows);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream) {
+    hipLaunchKernelGGL(cast_f16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, y, n);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K, int ldc,
+                               hipStream_t stream) {
+    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, M), dim3(64), 0, stream, A, Wt, bias, C, M, N, K, ldc);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
+    if (p.ncls > 256 || p.rows <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(heads_kernel, dim3(p.rows), dim3(256), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream) {
+    if (p.Q > 128 || p.B <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(postprocess_kernel, dim3(p.B), dim3(128), 0, stream, p);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois, float* out, int n, int h, int w,
+                                   hipStream_t stream) {
+    if (n <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(roi_features_kernel, dim3(n), dim3(256), 0, stream, enc, rois, out, h, w);
+    return hipGetLastError();
+}

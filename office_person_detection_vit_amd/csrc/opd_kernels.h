@@ -1,0 +1,75 @@
+// opd_kernels.h — host-callable launchers of the gfx950 kernels (device code lives in kernels_*.hip).
+// All launchers enqueue on `stream` and return the hipError_t of the launch; none of them synchronises.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t f16_t;  // raw IEEE half bits on the host side
+
+// ---- implicit-GEMM convolution / linear layer (kernels_gemm.hip) ---------------------------------------------------
+// out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias + residual ),  m = (b,oh,ow), k = (kh,kw,cin), NHWC fp16 input.
+struct ConvGemmParams {
+    const f16_t* x;      // [B][H][W][Cin] fp16 (Cin % 64 == 0), or NHWC4 for the stem
+    const f16_t* w;      // [N][K] fp16, K = KH*KW*Cin (stem: [N][8][8][4])
+    const float* bias;   // [N], or [bias_period][N] when bias_period > 0 (row-periodic bias, e.g. pos-embedding fold)
+    const f16_t* res16;  // optional fp16 residual [M][N]
+    const float* res32;  // optional fp32 residual [M][N]
+    void* out;           // [M][N] fp16 (out_f32 == 0) or fp32
+    f16_t* out16_aux;    // optional second fp16 copy of an fp32 output (unused when null)
+    int B, H, W, Cin, OH, OW, N, KH, KW, stride, pad;
+    int M, K;
+    int relu, bias_period, out_f32, stem;
+};
+hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
+
+// ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
+// uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order.
+hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, hipStream_t stream);
+// float32 NCHW pixel_values -> fp16 NHWC4.
+hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, hipStream_t stream);
+// 3x3 stride-2 pad-1 max-pool, NHWC fp16, C % 8 == 0.
+hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW, hipStream_t stream);
+// y = LayerNorm(x) * gamma + beta over the last dim (D == 256); writes fp32 y and optional fp16 copy.
+hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, f16_t* y16,
+                                int rows, hipStream_t stream);
+// fp32 -> fp16 cast of n elements (n % 8 == 0 not required).
+hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream);
+// naive fp32 GEMM used once at plan-build time: C[m][n] = sum_k A[m][k]*Wt[n][k] + bias[n]  (Wt fp32 [N][K])
+hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K,
+                               int ldc, hipStream_t stream);
+// heads: logits = hs*Wc^T+bc ; boxes = sigmoid(W3 relu(W2 relu(W1 hs))) ; one block per (b, query); fp32 weights.
+struct HeadParams {
+    const float* hs;  // [rows][256]
+    const float *wc, *bc, *w1, *b1, *w2, *b2, *w3, *b3;
+    float* logits;    // [rows][ncls]
+    float* boxes;     // [rows][4]
+    int rows, ncls;
+};
+hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream);
+// post-process: softmax / max over first ncls-1 / cxcywh->xyxy*scale / threshold -> fixed-slot records + counts.
+struct PostParams {
+    const float* logits;  // [B][Q][ncls]
+    const float* boxes;   // [B][Q][4]
+    const int32_t* orig_hw;  // [B][2] device, (h, w)
+    void* records;        // opd_det [B][Q] (compacted per frame, query order)
+    int32_t* counts;      // [B]
+    int B, Q, ncls;
+    float threshold;
+};
+hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream);
+// ROI mean-pool + L2 normalise on the encoder map [h][w][256] of one frame.
+hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois /*[n][4] x0,y0,x1,y1 map coords*/, float* out,
+                                   int n, int h, int w, hipStream_t stream);
+
+// ---- attention (kernels_attn.hip) -----------------------------------------------------------------------------------
+// O[b][q][h*32 + d] = softmax(Q K^T * scale) V, head_dim 32; Q/K/V are fp16 row-major with independent leading dims:
+// Q at q_ptr[(b*Lq + i)*ldq + h*32 + d] etc.  Output fp16 [B*Lq][ldo].
+struct AttnParams {
+    const f16_t *q, *k, *v;
+    f16_t* o;
+    int B, heads, Lq, Lk;
+    int ldq, ldk, ldv, ldo;
+    float scale;
+    int use_tr_read;  // 1: ds_read_b64_tr_b16 for V fragments; 0: scalar LDS gathers (cross-check path)
+};
+hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream);

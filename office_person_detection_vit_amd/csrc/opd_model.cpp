@@ -1,0 +1,869 @@
+// opd_model.cpp — device model, per-resolution plan, forward graph and the C-ABI of include/opd_detr.h.
+//
+// Host-side orchestration of the DETR detect path:
+//   preprocess -> stem 7x7 -> maxpool -> 16/33 bottlenecks -> input_projection -> 6 x encoder layer ->
+//   (memory K/V of all decoder layers in one GEMM) -> 6 x decoder layer -> final LN -> heads -> post-process.
+// Data layout in HBM: activations NHWC fp16 ([B*H*W][C] matrices), FrozenBN folded into fp16 [Cout][KH][KW][Cin]
+// kernels + fp32 bias, transformer residual stream fp32 [tokens][256] with an fp16 shadow feeding the MFMA GEMMs.
+// The sine position embedding is constant per (h, w), so pos.Wq / pos.Wk (+ biases) are folded into row-periodic
+// fp32 bias matrices at plan-build time and q/k/v become ONE GEMM over x per layer.
+#include <math.h>
+#include <string.h>
+
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/opd_detr.h"
+#include "opd_kernels.h"
+#include "opd_loader.h"
+
+namespace opd {
+
+thread_local std::string g_err;
+
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                           \
+    do {                                                                                                       \
+        hipError_t _e = (expr);                                                                                \
+        if (_e != hipSuccess)                                                                                  \
+            return fail(OPD_EHIP, std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + \
+                                      ":" + std::to_string(__LINE__) + ")");                                   \
+    } while (0)
+
+#define RCCHK(expr)            \
+    do {                       \
+        int _rc = (expr);      \
+        if (_rc != 0) return _rc; \
+    } while (0)
+
+struct Conv {
+    f16_t* w = nullptr;
+    float* bias = nullptr;
+    int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, K = 0;
+    bool stem = false;
+};
+struct Lin {
+    f16_t* w = nullptr;
+    float* b = nullptr;
+    int N = 0, K = 0;
+};
+struct LNp {
+    float* g = nullptr;
+    float* b = nullptr;
+};
+struct Block {
+    Conv c0, c1, c2, sc;
+    bool has_sc = false;
+};
+struct EncLayer {
+    f16_t* wqkv = nullptr;  // [768][256] = [Wq; Wk; Wv]
+    Lin o, fc1, fc2;
+    LNp ln1, ln2;
+};
+struct DecLayer {
+    f16_t* wqkv = nullptr;  // self-attention [768][256]
+    f16_t* wq_c = nullptr;  // cross-attention query projection [256][256]
+    Lin so, co, fc1, fc2;
+    LNp ln1, ln2, ln3;
+    float* rb_self = nullptr;  // [Q][768] = qpos.[Wq;Wk;0]^T + [bq;bk;bv]
+    float* rb_q = nullptr;     // [Q][256] = qpos.Wq_c^T + bq_c
+};
+
+struct Plan {  // everything that depends on the feature-map size (h, w)
+    int fh = 0, fw = 0;
+    std::vector<float*> rb_enc;  // per encoder layer [hw][768]
+    float* rb_kv = nullptr;      // [hw][dec_layers*512]
+};
+
+struct Dims {
+    int B, H, W, H1, W1, H2, W2;
+    int sh[4], sw[4];
+};
+
+static int down2(int n) { return (n - 1) / 2 + 1; }
+
+}  // namespace opd
+
+using namespace opd;
+
+struct opd_detr {
+    Arch arch;
+    opd_config cfg{};
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    int64_t weight_bytes = 0, workspace_bytes = 0;
+
+    Conv stem;
+    std::vector<Block> blocks;
+    std::vector<int> stage_first;  // index of first block of each stage
+    Conv proj;
+    std::vector<EncLayer> enc;
+    std::vector<DecLayer> dec;
+    f16_t* wkv_all = nullptr;  // [dec_layers*512][256] = per layer [Wk_c; Wv_c]
+    LNp dec_ln;
+    float *wc = nullptr, *bc = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
+    float* zero_bias = nullptr;  // [3072] zeros
+
+    // host copies needed to build plans for new resolutions
+    std::vector<std::vector<float>> h_enc_cat_w, h_enc_cat_b;  // per enc layer: [768*256] ([Wq;Wk;0]), [768]
+    std::vector<float> h_kv_cat_w, h_kv_cat_b;                 // [L*512*256] ([Wk;0] per layer), [L*512]
+    std::vector<std::unique_ptr<Plan>> plans;
+
+    // workspace
+    uint8_t* d_u8 = nullptr;
+    float* d_pv = nullptr;
+    f16_t *d_x4 = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_m0 = nullptr,
+          *d_m1 = nullptr, *d_sc = nullptr;
+    float *d_x32 = nullptr, *d_y32 = nullptr;
+    f16_t *d_x16 = nullptr, *d_qkv16 = nullptr, *d_attn16 = nullptr, *d_ffn16 = nullptr, *d_memkv16 = nullptr;
+    float *d_h32 = nullptr, *d_yd32 = nullptr, *d_hs32 = nullptr;
+    f16_t *d_h16 = nullptr, *d_qkvd16 = nullptr, *d_qd16 = nullptr, *d_attnd16 = nullptr, *d_ffnd16 = nullptr;
+    float *d_logits = nullptr, *d_boxes = nullptr;
+    opd_det* d_records = nullptr;
+    int32_t *d_counts = nullptr, *d_orig_hw = nullptr;
+    int32_t* d_rois = nullptr;
+    float* d_roi_out = nullptr;
+    std::vector<int32_t> h_orig_hw;
+
+    // state of the last forward
+    int last_B = 0, last_H = 0, last_W = 0, last_fh = 0, last_fw = 0;
+    bool profiling = false;
+    hipEvent_t ev[9] = {};
+    float stage_ms[8] = {};
+    int use_tr_read = 1;
+
+    // per-kernel-class timing (profiling mode only): event pairs around every launch of the last forward
+    struct Timed { int cls; hipEvent_t a, b; double flops; };
+    std::vector<Timed> timed;           // pairs used by the current forward
+    std::vector<hipEvent_t> event_pool;  // all events ever created (reused across forwards)
+    size_t pool_next = 0;
+    float class_ms[4] = {};
+    int class_launches[4] = {};
+    double class_flops[4] = {};
+};
+
+namespace opd {
+
+template <typename T>
+static int dalloc(opd_detr* m, T** p, size_t count, bool weight) {
+    void* q = nullptr;
+    const size_t bytes = count * sizeof(T);
+    hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    if (e != hipSuccess) return fail(OPD_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
+    m->allocs.push_back(q);
+    (weight ? m->weight_bytes : m->workspace_bytes) += (int64_t)bytes;
+    *p = reinterpret_cast<T*>(q);
+    return OPD_OK;
+}
+
+static int upload_f32(opd_detr* m, float** dst, const std::vector<float>& v) {
+    RCCHK(dalloc(m, dst, v.size(), true));
+    HIPCHK(hipMemcpy(*dst, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+    return OPD_OK;
+}
+static int upload_f16(opd_detr* m, f16_t** dst, const std::vector<float>& v) {
+    std::vector<f16_t> h(v.size());
+    for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_f16(v[i]);
+    RCCHK(dalloc(m, dst, h.size(), true));
+    HIPCHK(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return OPD_OK;
+}
+
+static const HostTensor& T(const StateDict& sd, const std::string& k) { return sd.at(k); }
+
+// conv + FrozenBN -> folded fp16 [Cout][KH][KW][Cin] + fp32 bias (HF:models/detr/modeling_detr.py:207-215)
+static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix, int stride, Conv* c) {
+    const HostTensor& w = T(sd, prefix + ".convolution.weight");
+    const int Cout = (int)w.shape[0], Cin = (int)w.shape[1], KH = (int)w.shape[2], KW = (int)w.shape[3];
+    const std::string n = prefix + ".normalization";
+    const auto& g = T(sd, n + ".weight").data;
+    const auto& bt = T(sd, n + ".bias").data;
+    const auto& mu = T(sd, n + ".running_mean").data;
+    const auto& var = T(sd, n + ".running_var").data;
+    std::vector<float> scale(Cout), bias(Cout);
+    for (int o = 0; o < Cout; ++o) {
+        scale[o] = g[o] * (1.0f / sqrtf(var[o] + 1e-5f));
+        bias[o] = bt[o] - mu[o] * scale[o];
+    }
+    c->Cin = Cin; c->Cout = Cout; c->KH = KH; c->KW = KW; c->stride = stride; c->pad = KH / 2;
+    std::vector<float> wt;
+    if (Cin == 3) {  // stem: [64][8][8][4], zero padded (kh = 7, kw = 7, c = 3)
+        c->stem = true;
+        c->K = 256;
+        wt.assign((size_t)Cout * 256, 0.f);
+        for (int o = 0; o < Cout; ++o)
+            for (int ci = 0; ci < 3; ++ci)
+                for (int kh = 0; kh < 7; ++kh)
+                    for (int kw = 0; kw < 7; ++kw)
+                        wt[(size_t)o * 256 + kh * 32 + kw * 4 + ci] = w.data[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * scale[o];
+    } else {
+        c->K = KH * KW * Cin;
+        wt.resize((size_t)Cout * c->K);
+        for (int o = 0; o < Cout; ++o)
+            for (int ci = 0; ci < Cin; ++ci)
+                for (int kh = 0; kh < KH; ++kh)
+                    for (int kw = 0; kw < KW; ++kw)
+                        wt[(size_t)o * c->K + (size_t)(kh * KW + kw) * Cin + ci] =
+                            w.data[(((size_t)o * Cin + ci) * KH + kh) * KW + kw] * scale[o];
+    }
+    RCCHK(upload_f16(m, &c->w, wt));
+    RCCHK(upload_f32(m, &c->bias, bias));
+    return OPD_OK;
+}
+
+static int make_lin(opd_detr* m, const StateDict& sd, const std::string& prefix, Lin* l) {
+    const HostTensor& w = T(sd, prefix + ".weight");
+    l->N = (int)w.shape[0];
+    l->K = (int)w.shape[1];
+    RCCHK(upload_f16(m, &l->w, w.data));
+    RCCHK(upload_f32(m, &l->b, T(sd, prefix + ".bias").data));
+    return OPD_OK;
+}
+static int make_ln(opd_detr* m, const StateDict& sd, const std::string& prefix, LNp* l) {
+    RCCHK(upload_f32(m, &l->g, T(sd, prefix + ".weight").data));
+    RCCHK(upload_f32(m, &l->b, T(sd, prefix + ".bias").data));
+    return OPD_OK;
+}
+static void append(std::vector<float>& dst, const std::vector<float>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
+
+static int build_weights(opd_detr* m, const StateDict& sd) {
+    const Arch& a = m->arch;
+    const std::string bb = "model.backbone.model.";
+    RCCHK(make_conv(m, sd, bb + "embedder.embedder", 2, &m->stem));
+    for (int s = 0; s < 4; ++s) {
+        m->stage_first.push_back((int)m->blocks.size());
+        for (int l = 0; l < a.depths[s]; ++l) {
+            const std::string p = bb + "encoder.stages." + std::to_string(s) + ".layers." + std::to_string(l);
+            const int stride = (l == 0 && s > 0) ? 2 : 1;
+            Block b;
+            b.has_sc = sd.count(p + ".shortcut.convolution.weight") > 0;
+            if (b.has_sc) RCCHK(make_conv(m, sd, p + ".shortcut", stride, &b.sc));
+            RCCHK(make_conv(m, sd, p + ".layer.0", 1, &b.c0));
+            RCCHK(make_conv(m, sd, p + ".layer.1", stride, &b.c1));
+            RCCHK(make_conv(m, sd, p + ".layer.2", 1, &b.c2));
+            m->blocks.push_back(b);
+        }
+    }
+    {  // input_projection: plain 1x1 conv with bias, no BN
+        const HostTensor& w = T(sd, "model.input_projection.weight");
+        m->proj.Cin = (int)w.shape[1]; m->proj.Cout = (int)w.shape[0]; m->proj.K = m->proj.Cin;
+        RCCHK(upload_f16(m, &m->proj.w, w.data));
+        RCCHK(upload_f32(m, &m->proj.bias, T(sd, "model.input_projection.bias").data));
+    }
+    const int D = a.d_model;
+    const std::vector<float> zerosW((size_t)D * D, 0.f);
+    auto cat3 = [&](const std::string& p, std::vector<float>* w_full, std::vector<float>* w_pos, std::vector<float>* b_cat) {
+        // w_full = [Wq;Wk;Wv] (GEMM weights), w_pos = [Wq;Wk;0] and b_cat = [bq;bk;bv] (row-bias fold)
+        w_full->clear(); w_pos->clear(); b_cat->clear();
+        append(*w_full, T(sd, p + ".q_proj.weight").data); append(*w_full, T(sd, p + ".k_proj.weight").data);
+        append(*w_full, T(sd, p + ".v_proj.weight").data);
+        append(*w_pos, T(sd, p + ".q_proj.weight").data); append(*w_pos, T(sd, p + ".k_proj.weight").data);
+        append(*w_pos, zerosW);
+        append(*b_cat, T(sd, p + ".q_proj.bias").data); append(*b_cat, T(sd, p + ".k_proj.bias").data);
+        append(*b_cat, T(sd, p + ".v_proj.bias").data);
+    };
+    m->enc.resize(a.enc_layers);
+    m->h_enc_cat_w.resize(a.enc_layers);
+    m->h_enc_cat_b.resize(a.enc_layers);
+    for (int i = 0; i < a.enc_layers; ++i) {
+        const std::string p = "model.encoder.layers." + std::to_string(i);
+        EncLayer& L = m->enc[i];
+        std::vector<float> wfull;
+        cat3(p + ".self_attn", &wfull, &m->h_enc_cat_w[i], &m->h_enc_cat_b[i]);
+        RCCHK(upload_f16(m, &L.wqkv, wfull));
+        RCCHK(make_lin(m, sd, p + ".self_attn.o_proj", &L.o));
+        RCCHK(make_ln(m, sd, p + ".self_attn_layer_norm", &L.ln1));
+        RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
+        RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
+        RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln2));
+    }
+    // decoder: query-position folds are resolution independent -> build them now with the fp32 plan GEMM
+    float* d_qpos = nullptr;
+    RCCHK(upload_f32(m, &d_qpos, T(sd, "model.query_position_embeddings.weight").data));
+    const int Q = a.queries;
+    m->dec.resize(a.dec_layers);
+    std::vector<float> kv_full;
+    for (int i = 0; i < a.dec_layers; ++i) {
+        const std::string p = "model.decoder.layers." + std::to_string(i);
+        DecLayer& L = m->dec[i];
+        std::vector<float> wfull, wpos, bcat;
+        cat3(p + ".self_attn", &wfull, &wpos, &bcat);
+        RCCHK(upload_f16(m, &L.wqkv, wfull));
+        float *d_w = nullptr, *d_b = nullptr;
+        RCCHK(upload_f32(m, &d_w, wpos));
+        RCCHK(upload_f32(m, &d_b, bcat));
+        RCCHK(dalloc(m, &L.rb_self, (size_t)Q * 768, true));
+        HIPCHK(opd_launch_gemm_f32(d_qpos, d_w, d_b, L.rb_self, Q, 768, D, 768, m->stream));
+        RCCHK(make_lin(m, sd, p + ".self_attn.o_proj", &L.so));
+        RCCHK(make_ln(m, sd, p + ".self_attn_layer_norm", &L.ln1));
+        // cross attention: q from the decoder state, k/v from the encoder memory
+        RCCHK(upload_f16(m, &L.wq_c, T(sd, p + ".encoder_attn.q_proj.weight").data));
+        float *d_wq = nullptr, *d_bq = nullptr;
+        RCCHK(upload_f32(m, &d_wq, T(sd, p + ".encoder_attn.q_proj.weight").data));
+        RCCHK(upload_f32(m, &d_bq, T(sd, p + ".encoder_attn.q_proj.bias").data));
+        RCCHK(dalloc(m, &L.rb_q, (size_t)Q * D, true));
+        HIPCHK(opd_launch_gemm_f32(d_qpos, d_wq, d_bq, L.rb_q, Q, D, D, D, m->stream));
+        append(kv_full, T(sd, p + ".encoder_attn.k_proj.weight").data);
+        append(kv_full, T(sd, p + ".encoder_attn.v_proj.weight").data);
+        append(m->h_kv_cat_w, T(sd, p + ".encoder_attn.k_proj.weight").data);
+        append(m->h_kv_cat_w, zerosW);
+        append(m->h_kv_cat_b, T(sd, p + ".encoder_attn.k_proj.bias").data);
+        append(m->h_kv_cat_b, T(sd, p + ".encoder_attn.v_proj.bias").data);
+        RCCHK(make_lin(m, sd, p + ".encoder_attn.o_proj", &L.co));
+        RCCHK(make_ln(m, sd, p + ".encoder_attn_layer_norm", &L.ln2));
+        RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
+        RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
+        RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln3));
+    }
+    RCCHK(upload_f16(m, &m->wkv_all, kv_full));
+    RCCHK(make_ln(m, sd, "model.decoder.layernorm", &m->dec_ln));
+    RCCHK(upload_f32(m, &m->wc, T(sd, "class_labels_classifier.weight").data));
+    RCCHK(upload_f32(m, &m->bc, T(sd, "class_labels_classifier.bias").data));
+    RCCHK(upload_f32(m, &m->w1, T(sd, "bbox_predictor.layers.0.weight").data));
+    RCCHK(upload_f32(m, &m->b1, T(sd, "bbox_predictor.layers.0.bias").data));
+    RCCHK(upload_f32(m, &m->w2, T(sd, "bbox_predictor.layers.1.weight").data));
+    RCCHK(upload_f32(m, &m->b2, T(sd, "bbox_predictor.layers.1.bias").data));
+    RCCHK(upload_f32(m, &m->w3, T(sd, "bbox_predictor.layers.2.weight").data));
+    RCCHK(upload_f32(m, &m->b3, T(sd, "bbox_predictor.layers.2.bias").data));
+    RCCHK(upload_f32(m, &m->zero_bias, std::vector<float>(4096, 0.f)));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return OPD_OK;
+}
+
+static void compute_dims(int B, int H, int W, Dims* d) {
+    d->B = B; d->H = H; d->W = W;
+    d->H1 = down2(H); d->W1 = down2(W);
+    d->H2 = down2(d->H1); d->W2 = down2(d->W1);
+    d->sh[0] = d->H2; d->sw[0] = d->W2;
+    for (int s = 1; s < 4; ++s) { d->sh[s] = down2(d->sh[s - 1]); d->sw[s] = down2(d->sw[s - 1]); }
+}
+
+static int build_workspace(opd_detr* m) {
+    const Arch& a = m->arch;
+    Dims d;
+    compute_dims(m->cfg.max_batch, m->cfg.max_height, m->cfg.max_width, &d);
+    const size_t B = d.B;
+    const size_t npix = B * d.H * d.W;
+    RCCHK(dalloc(m, &m->d_u8, npix * 3, false));
+    RCCHK(dalloc(m, &m->d_pv, npix * 3, false));
+    RCCHK(dalloc(m, &m->d_x4, npix * 4, false));
+    RCCHK(dalloc(m, &m->d_stem, B * d.H1 * d.W1 * 64, false));
+    RCCHK(dalloc(m, &m->d_pool, B * d.H2 * d.W2 * 64, false));
+    size_t trunk = 0, mid = 0;
+    for (int s = 0; s < 4; ++s) {
+        const size_t hw = (size_t)d.sh[s] * d.sw[s];
+        trunk = std::max(trunk, B * hw * a.hidden[s]);
+        // first block of a stage runs its 1x1 reduce at the INPUT resolution of the stage
+        const size_t hw_in = s == 0 ? hw : (size_t)d.sh[s - 1] * d.sw[s - 1];
+        mid = std::max(mid, B * hw_in * (a.hidden[s] / 4));
+    }
+    RCCHK(dalloc(m, &m->d_t0, trunk, false));
+    RCCHK(dalloc(m, &m->d_t1, trunk, false));
+    RCCHK(dalloc(m, &m->d_sc, trunk, false));
+    RCCHK(dalloc(m, &m->d_m0, mid, false));
+    RCCHK(dalloc(m, &m->d_m1, mid, false));
+    const size_t M = B * d.sh[3] * d.sw[3];
+    const size_t D = a.d_model, Md = B * a.queries;
+    RCCHK(dalloc(m, &m->d_x32, M * D, false));
+    RCCHK(dalloc(m, &m->d_y32, M * D, false));
+    RCCHK(dalloc(m, &m->d_x16, M * D, false));
+    RCCHK(dalloc(m, &m->d_qkv16, M * 3 * D, false));
+    RCCHK(dalloc(m, &m->d_attn16, M * D, false));
+    RCCHK(dalloc(m, &m->d_ffn16, M * a.ffn, false));
+    RCCHK(dalloc(m, &m->d_memkv16, M * 2 * D * a.dec_layers, false));
+    RCCHK(dalloc(m, &m->d_h32, Md * D, false));
+    RCCHK(dalloc(m, &m->d_yd32, Md * D, false));
+    RCCHK(dalloc(m, &m->d_hs32, Md * D, false));
+    RCCHK(dalloc(m, &m->d_h16, Md * D, false));
+    RCCHK(dalloc(m, &m->d_qkvd16, Md * 3 * D, false));
+    RCCHK(dalloc(m, &m->d_qd16, Md * D, false));
+    RCCHK(dalloc(m, &m->d_attnd16, Md * D, false));
+    RCCHK(dalloc(m, &m->d_ffnd16, Md * a.ffn, false));
+    RCCHK(dalloc(m, &m->d_logits, Md * a.ncls, false));
+    RCCHK(dalloc(m, &m->d_boxes, Md * 4, false));
+    RCCHK(dalloc(m, &m->d_records, Md, false));
+    RCCHK(dalloc(m, &m->d_counts, B, false));
+    RCCHK(dalloc(m, &m->d_orig_hw, B * 2, false));
+    RCCHK(dalloc(m, &m->d_rois, (size_t)128 * 4, false));
+    RCCHK(dalloc(m, &m->d_roi_out, (size_t)128 * D, false));
+    return OPD_OK;
+}
+
+// DetrSinePositionEmbedding with an all-ones mask (HF:models/detr/modeling_detr.py:294-368), fp32 like the reference.
+static void sine_pos_embed(int h, int w, int D, std::vector<float>* pos) {
+    const int npf = D / 2;
+    pos->assign((size_t)h * w * D, 0.f);
+    const float scale = 6.283185307179586f, eps = 1e-6f;
+    std::vector<float> dim_t(npf);
+    for (int i = 0; i < npf; ++i) dim_t[i] = powf(10000.0f, (2.0f * (float)(i / 2)) / (float)npf);
+    for (int y = 0; y < h; ++y)
+        for (int x = 0; x < w; ++x) {
+            const float ye = (float)(y + 1) / ((float)h + eps) * scale;
+            const float xe = (float)(x + 1) / ((float)w + eps) * scale;
+            float* p = pos->data() + ((size_t)y * w + x) * D;
+            for (int i = 0; i < npf; ++i) {
+                const float py = ye / dim_t[i], px = xe / dim_t[i];
+                p[i] = (i & 1) ? cosf(py) : sinf(py);
+                p[npf + i] = (i & 1) ? cosf(px) : sinf(px);
+            }
+        }
+}
+
+static int get_plan(opd_detr* m, int fh, int fw, Plan** out) {
+    for (auto& p : m->plans)
+        if (p->fh == fh && p->fw == fw) { *out = p.get(); return OPD_OK; }
+    const Arch& a = m->arch;
+    const int D = a.d_model, hw = fh * fw;
+    std::unique_ptr<Plan> p(new Plan());
+    p->fh = fh; p->fw = fw;
+    std::vector<float> pos;
+    sine_pos_embed(fh, fw, D, &pos);
+    float* d_pos = nullptr;
+    RCCHK(upload_f32(m, &d_pos, pos));
+    p->rb_enc.resize(a.enc_layers);
+    for (int i = 0; i < a.enc_layers; ++i) {
+        float *d_w = nullptr, *d_b = nullptr;
+        RCCHK(upload_f32(m, &d_w, m->h_enc_cat_w[i]));
+        RCCHK(upload_f32(m, &d_b, m->h_enc_cat_b[i]));
+        RCCHK(dalloc(m, &p->rb_enc[i], (size_t)hw * 768, true));
+        HIPCHK(opd_launch_gemm_f32(d_pos, d_w, d_b, p->rb_enc[i], hw, 768, D, 768, m->stream));
+    }
+    {
+        const int NKV = a.dec_layers * 512;
+        float *d_w = nullptr, *d_b = nullptr;
+        RCCHK(upload_f32(m, &d_w, m->h_kv_cat_w));
+        RCCHK(upload_f32(m, &d_b, m->h_kv_cat_b));
+        RCCHK(dalloc(m, &p->rb_kv, (size_t)hw * NKV, true));
+        HIPCHK(opd_launch_gemm_f32(d_pos, d_w, d_b, p->rb_kv, hw, NKV, D, NKV, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    *out = p.get();
+    m->plans.push_back(std::move(p));
+    return OPD_OK;
+}
+
+// ---- per-launch timing --------------------------------------------------------------------------------------------
+enum { CLS_CONV = 0, CLS_GEMM = 1, CLS_ATTN = 2, CLS_OTHER = 3 };
+
+static int timed_begin(opd_detr* m, int cls, double flops) {
+    if (!m->profiling) return OPD_OK;
+    hipEvent_t e[2];
+    for (int i = 0; i < 2; ++i) {
+        if (m->pool_next == m->event_pool.size()) {
+            hipEvent_t ne;
+            HIPCHK(hipEventCreate(&ne));
+            m->event_pool.push_back(ne);
+        }
+        e[i] = m->event_pool[m->pool_next++];
+    }
+    HIPCHK(hipEventRecord(e[0], m->stream));
+    m->timed.push_back({cls, e[0], e[1], flops});
+    return OPD_OK;
+}
+static int timed_end(opd_detr* m) {
+    if (!m->profiling) return OPD_OK;
+    HIPCHK(hipEventRecord(m->timed.back().b, m->stream));
+    return OPD_OK;
+}
+static void timed_reset(opd_detr* m) {
+    m->timed.clear();
+    m->pool_next = 0;
+}
+static void timed_collect(opd_detr* m) {
+    for (int c = 0; c < 4; ++c) { m->class_ms[c] = 0.f; m->class_launches[c] = 0; m->class_flops[c] = 0.0; }
+    for (const auto& t : m->timed) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
+            m->class_ms[t.cls] += ms;
+            m->class_launches[t.cls] += 1;
+            m->class_flops[t.cls] += t.flops;
+        }
+    }
+}
+
+static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, int W, int OH, int OW, void* out, bool relu,
+                    const f16_t* res16) {
+    ConvGemmParams p{};
+    p.x = x; p.w = c.w; p.bias = c.bias; p.res16 = res16; p.res32 = nullptr; p.out = out; p.out16_aux = nullptr;
+    p.B = B; p.H = H; p.W = W; p.Cin = c.Cin; p.OH = OH; p.OW = OW; p.N = c.Cout; p.KH = c.KH; p.KW = c.KW;
+    p.stride = c.stride; p.pad = c.pad; p.M = B * OH * OW; p.K = c.K; p.relu = relu ? 1 : 0; p.bias_period = 0;
+    p.out_f32 = 0; p.stem = c.stem ? 1 : 0;
+    // algorithmic FLOPs (2 x MAC over the real taps/channels; the stem's zero padding is not counted)
+    RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)c.Cout * c.KH * c.KW * c.Cin));
+    HIPCHK(opd_launch_conv_gemm(p, m->stream));
+    RCCHK(timed_end(m));
+    return OPD_OK;
+}
+
+// out[M][N] = x16[M][K] . w[N][K]^T + bias (+ res32), as a 1x1 "convolution" over M pixels
+static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
+                    void* out, bool out_f32, bool relu, const float* res32) {
+    ConvGemmParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr;
+    p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0;
+    RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
+    HIPCHK(opd_launch_conv_gemm(p, m->stream));
+    RCCHK(timed_end(m));
+    return OPD_OK;
+}
+
+static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ldk, const f16_t* v, int ldv, f16_t* o, int ldo,
+                    int B, int Lq, int Lk) {
+    AttnParams p{};
+    p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.heads = m->arch.heads; p.Lq = Lq; p.Lk = Lk;
+    p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
+    p.scale = 1.0f / sqrtf((float)(m->arch.d_model / m->arch.heads));
+    p.use_tr_read = m->use_tr_read;
+    RCCHK(timed_begin(m, CLS_ATTN, 4.0 * B * (double)m->arch.heads * Lq * Lk * 32));
+    HIPCHK(opd_launch_attention(p, m->stream));
+    RCCHK(timed_end(m));
+    return OPD_OK;
+}
+
+#define MARK(i)                                                   \
+    do {                                                          \
+        if (m->profiling) HIPCHK(hipEventRecord(m->ev[i], m->stream)); \
+    } while (0)
+
+// Enqueues the whole forward on m->stream.  `pixels` must already be on the device.
+static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W) {
+    const Arch& a = m->arch;
+    Dims d;
+    compute_dims(B, H, W, &d);
+    Plan* plan = nullptr;
+    RCCHK(get_plan(m, d.sh[3], d.sw[3], &plan));
+    timed_reset(m);
+    MARK(0);
+    if (pixel_format == OPD_PIXELS_U8_BGR_HWC)
+        HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, m->stream));
+    else
+        HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, m->stream));
+    RCCHK(run_conv(m, m->stem, m->d_x4, B, H, W, d.H1, d.W1, m->d_stem, true, nullptr));
+    HIPCHK(opd_launch_maxpool(m->d_stem, m->d_pool, B, d.H1, d.W1, 64, d.H2, d.W2, m->stream));
+    MARK(1);
+    const f16_t* cur = m->d_pool;
+    int ch = d.H2, cw = d.W2;
+    for (int s = 0; s < 4; ++s) {
+        for (int l = 0; l < a.depths[s]; ++l) {
+            const Block& b = m->blocks[m->stage_first[s] + l];
+            const int oh = (b.c1.stride == 2) ? down2(ch) : ch, ow = (b.c1.stride == 2) ? down2(cw) : cw;
+            const f16_t* res = cur;
+            if (b.has_sc) {
+                RCCHK(run_conv(m, b.sc, cur, B, ch, cw, oh, ow, m->d_sc, false, nullptr));
+                res = m->d_sc;
+            }
+            RCCHK(run_conv(m, b.c0, cur, B, ch, cw, ch, cw, m->d_m0, true, nullptr));
+            RCCHK(run_conv(m, b.c1, m->d_m0, B, ch, cw, oh, ow, m->d_m1, true, nullptr));
+            f16_t* out = (cur == m->d_t0) ? m->d_t1 : m->d_t0;
+            RCCHK(run_conv(m, b.c2, m->d_m1, B, oh, ow, oh, ow, out, true, res));
+            cur = out; ch = oh; cw = ow;
+        }
+        MARK(2 + s);
+    }
+    // ---- input projection -> encoder ------------------------------------------------------------------------------
+    const int hw = ch * cw, M = B * hw, D = a.d_model, F = a.ffn;
+    {
+        ConvGemmParams p{};
+        p.x = cur; p.w = m->proj.w; p.bias = m->proj.bias; p.out = m->d_x32; p.out16_aux = m->d_x16;
+        p.B = M; p.H = 1; p.W = 1; p.Cin = m->proj.Cin; p.OH = 1; p.OW = 1; p.N = D; p.KH = 1; p.KW = 1; p.stride = 1;
+        p.pad = 0; p.M = M; p.K = m->proj.K; p.relu = 0; p.bias_period = 0; p.out_f32 = 1; p.stem = 0;
+        RCCHK(timed_begin(m, CLS_CONV, 2.0 * M * (double)D * m->proj.K));
+        HIPCHK(opd_launch_conv_gemm(p, m->stream));
+        RCCHK(timed_end(m));
+    }
+    for (int i = 0; i < a.enc_layers; ++i) {
+        const EncLayer& L = m->enc[i];
+        RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr));
+        RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw));
+        RCCHK(run_gemm(m, m->d_attn16, L.o.w, L.o.b, 0, M, D, D, m->d_y32, true, false, m->d_x32));
+        HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
+        RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
+        RCCHK(run_gemm(m, m->d_ffn16, L.fc2.w, L.fc2.b, 0, M, D, F, m->d_y32, true, false, m->d_x32));
+        HIPCHK(opd_launch_layernorm(m->d_y32, L.ln2.g, L.ln2.b, m->d_x32, m->d_x16, M, m->stream));
+    }
+    MARK(6);
+    // ---- decoder -----------------------------------------------------------------------------------------------
+    const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
+    RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr));
+    HIPCHK(hipMemsetAsync(m->d_h32, 0, (size_t)Md * D * 4, m->stream));
+    HIPCHK(hipMemsetAsync(m->d_h16, 0, (size_t)Md * D * 2, m->stream));
+    for (int i = 0; i < a.dec_layers; ++i) {
+        const DecLayer& L = m->dec[i];
+        RCCHK(run_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false, false, nullptr));
+        RCCHK(run_attn(m, m->d_qkvd16, 3 * D, m->d_qkvd16 + D, 3 * D, m->d_qkvd16 + 2 * D, 3 * D, m->d_attnd16, D, B, Q, Q));
+        RCCHK(run_gemm(m, m->d_attnd16, L.so.w, L.so.b, 0, Md, D, D, m->d_yd32, true, false, m->d_h32));
+        HIPCHK(opd_launch_layernorm(m->d_yd32, L.ln1.g, L.ln1.b, m->d_h32, m->d_h16, Md, m->stream));
+        RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
+        RCCHK(run_attn(m, m->d_qd16, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
+                       m->d_attnd16, D, B, Q, hw));
+        RCCHK(run_gemm(m, m->d_attnd16, L.co.w, L.co.b, 0, Md, D, D, m->d_yd32, true, false, m->d_h32));
+        HIPCHK(opd_launch_layernorm(m->d_yd32, L.ln2.g, L.ln2.b, m->d_h32, m->d_h16, Md, m->stream));
+        RCCHK(run_gemm(m, m->d_h16, L.fc1.w, L.fc1.b, 0, Md, F, D, m->d_ffnd16, false, true, nullptr));
+        RCCHK(run_gemm(m, m->d_ffnd16, L.fc2.w, L.fc2.b, 0, Md, D, F, m->d_yd32, true, false, m->d_h32));
+        HIPCHK(opd_launch_layernorm(m->d_yd32, L.ln3.g, L.ln3.b, m->d_h32, m->d_h16, Md, m->stream));
+    }
+    HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream));
+    HeadParams hp{};
+    hp.hs = m->d_hs32; hp.wc = m->wc; hp.bc = m->bc; hp.w1 = m->w1; hp.b1 = m->b1; hp.w2 = m->w2; hp.b2 = m->b2;
+    hp.w3 = m->w3; hp.b3 = m->b3; hp.logits = m->d_logits; hp.boxes = m->d_boxes; hp.rows = Md; hp.ncls = a.ncls;
+    HIPCHK(opd_launch_heads(hp, m->stream));
+    MARK(7);
+    m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = ch; m->last_fw = cw;
+    return OPD_OK;
+}
+
+static int check_shape(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    if (!pixels) return fail(OPD_EINVAL, "null pixel buffer");
+    if (pixel_format != OPD_PIXELS_U8_BGR_HWC && pixel_format != OPD_PIXELS_F32_NCHW) return fail(OPD_EINVAL, "unknown pixel_format");
+    if (mem_kind != OPD_MEM_HOST && mem_kind != OPD_MEM_DEVICE) return fail(OPD_EINVAL, "unknown mem_kind");
+    if (B < 1 || B > m->cfg.max_batch || H < 32 || W < 32 || H > m->cfg.max_height || W > m->cfg.max_width ||
+        (size_t)H * W > (size_t)m->cfg.max_height * m->cfg.max_width)
+        return fail(OPD_EINVAL, "frame batch [" + std::to_string(B) + "," + std::to_string(H) + "," + std::to_string(W) +
+                                    "] outside the configured maximum [" + std::to_string(m->cfg.max_batch) + "," +
+                                    std::to_string(m->cfg.max_height) + "," + std::to_string(m->cfg.max_width) + "]");
+    return OPD_OK;
+}
+
+static int stage_pixels(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, const void** d_pixels) {
+    if (mem_kind == OPD_MEM_DEVICE) { *d_pixels = pixels; return OPD_OK; }
+    const size_t n = (size_t)B * H * W * 3;
+    if (pixel_format == OPD_PIXELS_U8_BGR_HWC) {
+        HIPCHK(hipMemcpyAsync(m->d_u8, pixels, n, hipMemcpyHostToDevice, m->stream));
+        *d_pixels = m->d_u8;
+    } else {
+        HIPCHK(hipMemcpyAsync(m->d_pv, pixels, n * 4, hipMemcpyHostToDevice, m->stream));
+        *d_pixels = m->d_pv;
+    }
+    return OPD_OK;
+}
+
+static int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw) {
+    const int B = m->last_B;
+    std::vector<int32_t>& hw = m->h_orig_hw;  // member: must outlive the async copy
+    hw.resize((size_t)B * 2);
+    for (int b = 0; b < B; ++b) {
+        hw[2 * b] = orig_hw ? orig_hw[2 * b] : m->last_H;
+        hw[2 * b + 1] = orig_hw ? orig_hw[2 * b + 1] : m->last_W;
+    }
+    HIPCHK(hipMemcpyAsync(m->d_orig_hw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, m->stream));
+    PostParams pp{};
+    pp.logits = m->d_logits; pp.boxes = m->d_boxes; pp.orig_hw = m->d_orig_hw; pp.records = m->d_records;
+    pp.counts = m->d_counts; pp.B = B; pp.Q = m->arch.queries; pp.ncls = m->arch.ncls; pp.threshold = threshold;
+    HIPCHK(opd_launch_postprocess(pp, m->stream));
+    MARK(8);
+    return OPD_OK;
+}
+
+static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kind) {
+    const int B = m->last_B, Q = m->arch.queries;
+    const hipMemcpyKind kind = mem_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    HIPCHK(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 4, kind, m->stream));
+    HIPCHK(hipMemcpyAsync(out, m->d_records, (size_t)B * Q * sizeof(opd_det), kind, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->profiling) {
+        for (int i = 0; i < 8; ++i) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) m->stage_ms[i] = ms;
+        }
+        timed_collect(m);
+    }
+    return OPD_OK;
+}
+
+}  // namespace opd
+
+// =====================================================================================================================
+// C-ABI
+// =====================================================================================================================
+extern "C" {
+
+const char* opd_last_error(void) { return opd::g_err.c_str(); }
+const char* opd_version(void) { return "opd_hip 0.1 gfx950 (fp16 MFMA, fp32 accumulate)"; }
+
+int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out) {
+    if (!cfg || !weights_path || !out) return fail(OPD_EINVAL, "opd_detr_create: null argument");
+    if (cfg->struct_size != (int32_t)sizeof(opd_config)) return fail(OPD_EINVAL, "opd_config.struct_size mismatch");
+    if (cfg->max_batch < 1 || cfg->max_height < 32 || cfg->max_width < 32) return fail(OPD_EINVAL, "opd_config maxima must be >= 1 x 32 x 32");
+    *out = nullptr;
+    StateDict sd;
+    std::string err;
+    int rc = load_safetensors(weights_path, &sd, &err);
+    if (rc) return fail(rc, err);
+    std::unique_ptr<opd_detr> m(new opd_detr());
+    rc = infer_arch(sd, &m->arch, &err);
+    if (rc) return fail(rc, err);
+    m->cfg = *cfg;
+    m->device = device_ordinal;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(OPD_EHIP, "no HIP device visible (this library has no CPU fallback)");
+    if (device_ordinal < 0 || device_ordinal >= ndev) return fail(OPD_EINVAL, "device_ordinal out of range");
+    auto cleanup = [&](int code) {
+        for (void* p : m->allocs) (void)hipFree(p);
+        if (m->stream) (void)hipStreamDestroy(m->stream);
+        return code;
+    };
+    {
+        hipError_t e = hipSetDevice(device_ordinal);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e));
+    }
+    if ((rc = build_weights(m.get(), sd))) return cleanup(rc);
+    if ((rc = build_workspace(m.get()))) return cleanup(rc);
+    for (auto& e : m->ev)
+        if (hipEventCreate(&e) != hipSuccess) return cleanup(fail(OPD_EHIP, "hipEventCreate failed"));
+    *out = m.release();
+    return OPD_OK;
+}
+
+void opd_detr_destroy(opd_detr* m) {
+    if (!m) return;
+    (void)hipSetDevice(m->device);
+    if (m->stream) (void)hipStreamSynchronize(m->stream);
+    for (void* p : m->allocs) (void)hipFree(p);
+    for (auto& e : m->ev)
+        if (e) (void)hipEventDestroy(e);
+    for (auto& e : m->event_pool) (void)hipEventDestroy(e);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    delete m;
+}
+
+int opd_detr_info(const opd_detr* m, opd_model_info* info) {
+    if (!m || !info) return fail(OPD_EINVAL, "opd_detr_info: null argument");
+    for (int i = 0; i < 4; ++i) info->depths[i] = m->arch.depths[i];
+    info->d_model = m->arch.d_model; info->heads = m->arch.heads; info->ffn_dim = m->arch.ffn;
+    info->encoder_layers = m->arch.enc_layers; info->decoder_layers = m->arch.dec_layers;
+    info->num_queries = m->arch.queries; info->num_classes_plus1 = m->arch.ncls;
+    info->max_batch = m->cfg.max_batch; info->max_height = m->cfg.max_height; info->max_width = m->cfg.max_width;
+    info->device_ordinal = m->device;
+    info->weight_bytes_device = m->weight_bytes; info->workspace_bytes_device = m->workspace_bytes;
+    return OPD_OK;
+}
+
+int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float* logits,
+                     float* boxes, float* enc_features) {
+    RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
+    HIPCHK(hipSetDevice(m->device));
+    const void* d_pixels = nullptr;
+    RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
+    RCCHK(enqueue_forward(m, d_pixels, pixel_format, B, H, W));
+    const hipMemcpyKind kind = mem_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    const size_t Md = (size_t)B * m->arch.queries;
+    if (logits) HIPCHK(hipMemcpyAsync(logits, m->d_logits, Md * m->arch.ncls * 4, kind, m->stream));
+    if (boxes) HIPCHK(hipMemcpyAsync(boxes, m->d_boxes, Md * 4 * 4, kind, m->stream));
+    if (enc_features)
+        HIPCHK(hipMemcpyAsync(enc_features, m->d_x32, (size_t)B * m->last_fh * m->last_fw * m->arch.d_model * 4, kind, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->profiling) timed_collect(m);
+    return OPD_OK;
+}
+
+int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts) {
+    if (!m || !out || !counts) return fail(OPD_EINVAL, "opd_detr_postprocess: null argument");
+    if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_postprocess called before any forward");
+    HIPCHK(hipSetDevice(m->device));
+    RCCHK(enqueue_postprocess(m, threshold, orig_hw));
+    return fetch_records(m, out, counts, OPD_MEM_HOST);
+}
+
+int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
+                    const int32_t* orig_hw, opd_det* out, int32_t* counts) {
+    RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
+    if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect: null output buffer");
+    HIPCHK(hipSetDevice(m->device));
+    const void* d_pixels = nullptr;
+    RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
+    RCCHK(enqueue_forward(m, d_pixels, pixel_format, B, H, W));
+    RCCHK(enqueue_postprocess(m, threshold, orig_hw));
+    return fetch_records(m, out, counts, mem_kind);
+}
+
+int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold) {
+    if (n < 0 || (n > 0 && !dets)) return fail(OPD_EINVAL, "opd_person_nms: bad arguments");
+    std::vector<int> idx;
+    for (int i = 0; i < n; ++i)
+        if (person_label < 0 || dets[i].label == person_label) idx.push_back(i);
+    // stable sort by descending score (ties keep query order), as the oracle's person_detections
+    for (size_t i = 1; i < idx.size(); ++i) {
+        const int v = idx[i];
+        size_t j = i;
+        while (j > 0 && dets[idx[j - 1]].score < dets[v].score) { idx[j] = idx[j - 1]; --j; }
+        idx[j] = v;
+    }
+    auto iou = [](const opd_det& a, const opd_det& b) {
+        const float ix1 = fmaxf(a.x1, b.x1), iy1 = fmaxf(a.y1, b.y1), ix2 = fminf(a.x2, b.x2), iy2 = fminf(a.y2, b.y2);
+        const float iw = fmaxf(0.f, ix2 - ix1), ih = fmaxf(0.f, iy2 - iy1), inter = iw * ih;
+        const float ua = fmaxf(0.f, a.x2 - a.x1) * fmaxf(0.f, a.y2 - a.y1) + fmaxf(0.f, b.x2 - b.x1) * fmaxf(0.f, b.y2 - b.y1) - inter;
+        return ua > 0.f ? inter / ua : 0.f;
+    };
+    std::vector<opd_det> kept;
+    for (int i : idx) {
+        bool ok = true;
+        if (nms_threshold < 1.0f)
+            for (const auto& k : kept)
+                if (iou(dets[i], k) > nms_threshold) { ok = false; break; }
+        if (ok) kept.push_back(dets[i]);
+    }
+    for (size_t i = 0; i < kept.size(); ++i) dets[i] = kept[i];
+    return (int)kept.size();
+}
+
+int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n, int orig_h, int orig_w, float* features) {
+    if (!m || (n > 0 && (!boxes_xywh || !features))) return fail(OPD_EINVAL, "opd_detr_roi_features: null argument");
+    if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_roi_features called before any forward");
+    if (frame < 0 || frame >= m->last_B || n < 0 || n > 128 || orig_h <= 0 || orig_w <= 0)
+        return fail(OPD_EINVAL, "opd_detr_roi_features: frame / n / image size out of range");
+    if (n == 0) return OPD_OK;
+    HIPCHK(hipSetDevice(m->device));
+    const int h = m->last_fh, w = m->last_fw;
+    std::vector<int32_t> rois(n * 4);
+    for (int i = 0; i < n; ++i) {  // same int-truncation and clamping as the reference (feature_extractor.py:68-78)
+        const double x = boxes_xywh[4 * i], y = boxes_xywh[4 * i + 1], bw = boxes_xywh[4 * i + 2], bh = boxes_xywh[4 * i + 3];
+        int x0 = (int)((x / orig_w) * w), y0 = (int)((y / orig_h) * h);
+        int x1 = (int)(((x + bw) / orig_w) * w), y1 = (int)(((y + bh) / orig_h) * h);
+        x0 = std::max(0, std::min(x0, w - 1)); y0 = std::max(0, std::min(y0, h - 1));
+        x1 = std::max(x0 + 1, std::min(x1, w)); y1 = std::max(y0 + 1, std::min(y1, h));
+        rois[4 * i] = x0; rois[4 * i + 1] = y0; rois[4 * i + 2] = x1; rois[4 * i + 3] = y1;
+    }
+    HIPCHK(hipMemcpyAsync(m->d_rois, rois.data(), rois.size() * 4, hipMemcpyHostToDevice, m->stream));
+    const float* enc = m->d_x32 + (size_t)frame * h * w * m->arch.d_model;
+    HIPCHK(opd_launch_roi_features(enc, m->d_rois, m->d_roi_out, n, h, w, m->stream));
+    HIPCHK(hipMemcpyAsync(features, m->d_roi_out, (size_t)n * m->arch.d_model * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return OPD_OK;
+}
+
+int opd_detr_set_profiling(opd_detr* m, int enabled) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->profiling = enabled != 0;
+    return OPD_OK;
+}
+
+int opd_detr_stage_times(const opd_detr* m, float* ms8) {
+    if (!m || !ms8) return fail(OPD_EINVAL, "opd_detr_stage_times: null argument");
+    for (int i = 0; i < 8; ++i) ms8[i] = m->stage_ms[i];
+    return OPD_OK;
+}
+
+int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, double* flops4) {
+    if (!m || !ms4 || !launches4 || !flops4) return fail(OPD_EINVAL, "opd_detr_kernel_times: null argument");
+    for (int i = 0; i < 4; ++i) { ms4[i] = m->class_ms[i]; launches4[i] = m->class_launches[i]; flops4[i] = m->class_flops[i]; }
+    return OPD_OK;
+}
+
+// ---- test / diagnostic hooks (not part of include/opd_detr.h; used by tests/test_kernels_gpu.py) ----------------------
+int opd_test_set_tr_read(opd_detr* m, int on) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->use_tr_read = on ? 1 : 0;
+    return OPD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,149 @@
+// opd_test_api.cpp — kernel-level test hooks (host buffers in, host buffers out).  NOT part of the drop-in boundary
+// (include/opd_detr.h); exported so tests/test_kernels_gpu.py can check each hand-written kernel against the oracle
+// on identical inputs.  Every hook allocates its own device buffers, runs ONE kernel on the null stream and frees.
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/opd_detr.h"
+#include "opd_kernels.h"
+#include "opd_loader.h"
+
+namespace opd {
+extern thread_local std::string g_err;
+}
+
+namespace {
+int tfail(int code, const std::string& msg) {
+    opd::g_err = msg;
+    return code;
+}
+struct DevMem {
+    std::vector<void*> ptrs;
+    ~DevMem() {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+    template <typename T>
+    T* up(const T* host, size_t count) {
+        void* d = nullptr;
+        if (hipMalloc(&d, count * sizeof(T) + 16) != hipSuccess) return nullptr;
+        ptrs.push_back(d);
+        if (host && hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        return reinterpret_cast<T*>(d);
+    }
+};
+#define TCHK(expr)                                                                                          \
+    do {                                                                                                    \
+        hipError_t _e = (expr);                                                                             \
+        if (_e != hipSuccess) return tfail(OPD_EHIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+}  // namespace
+
+extern "C" {
+
+// x: NHWC fp16 bits [B][H][W][Cin] (stem: NHWC4); w: [N][K] fp16 bits; bias fp32 [N] (or [period][N]);
+// res16/res32 optional; out fp16 bits or fp32 [M][N].
+int opd_test_conv_gemm(const uint16_t* x, const uint16_t* w, const float* bias, const uint16_t* res16, const float* res32,
+                       void* out, int B, int H, int W, int Cin, int OH, int OW, int N, int KH, int KW, int stride, int pad,
+                       int relu, int bias_period, int out_f32, int stem) {
+    DevMem dm;
+    const size_t M = (size_t)B * OH * OW;
+    const int K = stem ? 256 : KH * KW * Cin;
+    const size_t xin = (size_t)B * H * W * (stem ? 4 : Cin);
+    ConvGemmParams p{};
+    p.x = dm.up(x, xin);
+    p.w = dm.up(w, (size_t)N * K);
+    p.bias = dm.up(bias, (size_t)N * (bias_period > 0 ? bias_period : 1));
+    p.res16 = res16 ? dm.up(res16, M * N) : nullptr;
+    p.res32 = res32 ? dm.up(res32, M * N) : nullptr;
+    const size_t obytes = M * N * (out_f32 ? 4 : 2);
+    p.out = dm.up<unsigned char>(nullptr, obytes);
+    if (!p.x || !p.w || !p.bias || !p.out || (res16 && !p.res16) || (res32 && !p.res32)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+    p.M = (int)M; p.K = K; p.relu = relu; p.bias_period = bias_period; p.out_f32 = out_f32; p.stem = stem;
+    TCHK(opd_launch_conv_gemm(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out, p.out, obytes, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+int opd_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int B, int heads, int Lq, int Lk,
+                       float scale, int use_tr_read) {
+    DevMem dm;
+    const int D = heads * 32;
+    AttnParams p{};
+    p.q = dm.up(q, (size_t)B * Lq * D);
+    p.k = dm.up(k, (size_t)B * Lk * D);
+    p.v = dm.up(v, (size_t)B * Lk * D);
+    p.o = dm.up<uint16_t>(nullptr, (size_t)B * Lq * D);
+    if (!p.q || !p.k || !p.v || !p.o) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = p.ldk = p.ldv = p.ldo = D; p.scale = scale; p.use_tr_read = use_tr_read;
+    TCHK(opd_launch_attention(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(o, p.o, (size_t)B * Lq * D * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+int opd_test_layernorm(const float* x, const float* g, const float* b, float* y, uint16_t* y16, int rows) {
+    DevMem dm;
+    const float* dx = dm.up(x, (size_t)rows * 256);
+    const float* dg = dm.up(g, 256);
+    const float* db = dm.up(b, 256);
+    float* dy = dm.up<float>(nullptr, (size_t)rows * 256);
+    uint16_t* dy16 = dm.up<uint16_t>(nullptr, (size_t)rows * 256);
+    if (!dx || !dg || !db || !dy || !dy16) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_layernorm(dx, dg, db, dy, dy16, rows, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, dy, (size_t)rows * 256 * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(y16, dy16, (size_t)rows * 256 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+int opd_test_maxpool(const uint16_t* x, uint16_t* out, int B, int H, int W, int C, int OH, int OW) {
+    DevMem dm;
+    const uint16_t* dx = dm.up(x, (size_t)B * H * W * C);
+    uint16_t* dout = dm.up<uint16_t>(nullptr, (size_t)B * OH * OW * C);
+    if (!dx || !dout) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_maxpool(dx, dout, B, H, W, C, OH, OW, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out, dout, (size_t)B * OH * OW * C * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+int opd_test_preprocess_u8(const uint8_t* frames, uint16_t* out, int B, int H, int W) {
+    DevMem dm;
+    const size_t npix = (size_t)B * H * W;
+    const uint8_t* din = dm.up(frames, npix * 3);
+    uint16_t* dout = dm.up<uint16_t>(nullptr, npix * 4);
+    if (!din || !dout) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_preprocess_u8(din, dout, B, H, W, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out, dout, npix * 8, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// host-only helpers of the loader, exposed so CPU tests can exercise them without a GPU
+uint16_t opd_test_f32_to_f16(float f) { return opd::f32_to_f16(f); }
+float opd_test_f16_to_f32(uint16_t h) { return opd::f16_to_f32(h); }
+int opd_test_normalise_key(const char* in, char* out, int cap) {
+    const std::string k = opd::normalise_key(in);
+    if ((int)k.size() + 1 > cap) return OPD_EINVAL;
+    memcpy(out, k.c_str(), k.size() + 1);
+    return OPD_OK;
+}
+// parse + schema-check a checkpoint on the host (no GPU needed): returns 0 and fills depths[4], enc, dec, queries, ncls
+int opd_test_inspect_checkpoint(const char* path, int32_t* info8) {
+    opd::StateDict sd;
+    std::string err;
+    int rc = opd::load_safetensors(path, &sd, &err);
+    if (rc) return tfail(rc, err);
+    opd::Arch a;
+    rc = opd::infer_arch(sd, &a, &err);
+    if (rc) return tfail(rc, err);
+    for (int i = 0; i < 4; ++i) info8[i] = a.depths[i];
+    info8[4] = a.enc_layers; info8[5] = a.dec_layers; info8[6] = a.queries; info8[7] = a.ncls;
+    return OPD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,175 @@
+"""End-to-end parity (GPU): ``HipDetrDetector`` through the C-ABI against the committed HF golden vectors, against the
+oracle run live on the same seeded inputs, and through size-independent properties at the benchmark size.
+
+Stated tolerances (normalised cxcywh boxes / softmax probabilities), fp16 storage with fp32 accumulation:
+  * "mild" weight set (attention gain 1):  |dbox| <= 2e-3, |dprob| <= 4e-3      (north-star target 1e-3 is reported)
+  * "sharp" weight set (attention gain 2): |dbox| <= 3e-2, |dprob| <= 4e-2      (logic-error catcher: box spread is 0.075)
+The oracle's own fp16-storage emulation (``forward(..., emulate="f16")``) shows the same drift, i.e. these bounds are
+set by fp16 activation storage, not by kernel defects.
+"""
+
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from office_person_detection_vit_amd import HipDetrDetector
+from office_person_detection_vit_amd.frames import structured_frames
+from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file, load_safetensors
+from oracle import detr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL = {1.0: (2e-3, 4e-3, 3e-2), 2.0: (3e-2, 4e-2, 2e-1)}  # gain -> (box, prob, encoder abs)
+
+
+def _softmax(x):
+    return torch.softmax(torch.from_numpy(np.asarray(x)), -1).numpy()
+
+
+@pytest.fixture(scope="module")
+def detectors(weight_cache):
+    cache = {}
+
+    def get(depths=(3, 4, 6, 3), ga=1.0, max_batch=2, max_size=(800, 1333)):
+        key = (tuple(depths), ga, max_batch, tuple(max_size))
+        if key not in cache:
+            tag = "r50" if tuple(depths) == (3, 4, 6, 3) else "r" + "_".join(map(str, depths))
+            path = ensure_weight_file(weight_cache, DetrArch(depths=tuple(depths)), 0, ga, tag)
+            det = HipDetrDetector(model_path=path, confidence_threshold=0.5, max_batch=max_batch, max_size=max_size,
+                                  resize=False)
+            det.load_model()
+            cache[key] = det
+        return cache[key]
+
+    yield get
+    for d in cache.values():
+        d.close()
+
+
+def _golden_frames(g):
+    return [structured_frames(1, int(h), int(w), seed=int(g["frame_seed"]) + i)[0] for i, (h, w) in enumerate(g["sizes"])]
+
+
+@pytest.mark.parametrize("tag", ["r50_mild_256x320", "r50_sharp_256x320", "r50_mild_odd_203x333"])
+def test_forward_matches_hf_golden(detectors, golden_dir, tag):
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    ga = float(g["attention_gain"])
+    det = detectors(ga=ga)
+    logits, boxes, enc = det.forward_raw(_golden_frames(g))
+    tb, tp, te = TOL[ga]
+    dbox = float(np.abs(boxes - g["pred_boxes"]).max())
+    dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
+    denc = float(np.abs(enc - g["encoder_last_hidden_state"]).max())
+    print(f"{tag}: dbox {dbox:.2e} dprob {dprob:.2e} denc {denc:.2e}")
+    assert dbox <= tb and dprob <= tp and denc <= te
+
+
+def test_full_resolution_matches_golden(detectors, golden_dir):
+    """One 800x1333 frame (BASELINE config resolution) against the HF golden logits / boxes."""
+    g = np.load(os.path.join(golden_dir, "r50_mild_800x1333.npz"))
+    det = detectors(ga=1.0)
+    logits, boxes, enc = det.forward_raw(_golden_frames(g))
+    dbox = float(np.abs(boxes - g["pred_boxes"]).max())
+    dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
+    denc = float(np.abs(enc[:, ::97, ::13] - g["encoder_sample"]).max())
+    print(f"800x1333: dbox {dbox:.2e} dprob {dprob:.2e} denc {denc:.2e}")
+    assert dbox <= 2e-3 and dprob <= 4e-3 and denc <= 3e-2
+
+
+def test_r101_matches_golden(detectors, golden_dir):
+    g = np.load(os.path.join(golden_dir, "r101_mild_256x320.npz"))
+    det = detectors(depths=(3, 4, 23, 3), ga=1.0)
+    logits, boxes, enc = det.forward_raw(_golden_frames(g))
+    dbox = float(np.abs(boxes - g["pred_boxes"]).max())
+    dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
+    print(f"r101: dbox {dbox:.2e} dprob {dprob:.2e}")
+    assert dbox <= 3e-3 and dprob <= 6e-3
+
+
+def test_matches_live_oracle_and_postprocess(detectors, weight_cache):
+    """HIP path vs the oracle on fresh seeded frames (not in the golden set), including post-processing."""
+    det = detectors(ga=1.0)
+    w = O.to_torch(load_safetensors(det.model_path))
+    frames = structured_frames(2, 288, 352, seed=999)
+    pv, pm = O.preprocess(frames)
+    lg, bx, mem = O.forward(w, pv, pm)
+    logits, boxes, enc = det.forward_raw(frames)
+    assert float(np.abs(boxes - bx.numpy()).max()) <= 2e-3
+    want = O.post_process_object_detection(lg.numpy(), bx.numpy(), 0.5, [(288, 352)] * 2)
+    dets = det.detect_batch(frames)
+    for b in range(2):
+        ref = O.person_detections(want[b], 0.4)
+        got = dets[b]
+        # scores within 4e-3 of the threshold may flip; compare the unambiguous ones
+        ref_q = {d["query_index"]: d for d in ref if abs(d["confidence"] - 0.5) > 8e-3}
+        got_q = {d.query_index: d for d in got if abs(d.confidence - 0.5) > 8e-3}
+        assert set(ref_q) == set(got_q)
+        for qi, r in ref_q.items():
+            d = got_q[qi]
+            assert d.class_id == 1 and d.class_name == "person"
+            np.testing.assert_allclose(d.bbox, r["bbox"], atol=2e-3 * 352 * 2)
+            assert abs(d.confidence - r["confidence"]) <= 4e-3
+            assert d.camera_coords == (d.bbox[0] + d.bbox[2] / 2, d.bbox[1] + d.bbox[3])
+
+
+def test_batch8_full_size_properties(detectors):
+    """BASELINE configs[1] shape (batch 8, 800x1333): batch invariance and permutation equivariance — frame i alone
+    and inside the batch give the same boxes (the reference's frames are independent)."""
+    det = detectors(ga=1.0, max_batch=8)
+    frames = structured_frames(8, 800, 1333, seed=4242)
+    lg8, bx8, _ = det.forward_raw(frames, want_encoder=False)
+    assert np.isfinite(lg8).all() and np.isfinite(bx8).all()
+    assert (bx8 >= 0).all() and (bx8 <= 1).all()
+    lg1, bx1, _ = det.forward_raw([frames[5]], want_encoder=False)
+    np.testing.assert_allclose(bx8[5], bx1[0], atol=1e-6)   # same kernels, same order: bitwise in practice
+    perm = [3, 0, 7, 1, 6, 2, 5, 4]
+    lgp, bxp, _ = det.forward_raw([frames[i] for i in perm], want_encoder=False)
+    np.testing.assert_allclose(bxp, bx8[perm], atol=1e-6)
+    assert float(bx8.std(axis=1).mean()) > 5e-3  # queries are not collapsed
+
+
+def test_detector_surface(detectors):
+    det = detectors(ga=1.0)
+    frame = structured_frames(1, 256, 320, seed=31)[0]
+    keep = frame.copy()
+    dets, feats = det.detect_with_features(frame)
+    assert (frame == keep).all()  # caller's frame is not mutated
+    assert feats.shape == (len(dets), 256) if dets else feats.size == 0
+    for d, f in zip(dets, feats):
+        assert d.features is f or np.array_equal(d.features, f)
+        assert abs(float(np.linalg.norm(f)) - 1.0) < 1e-4
+        assert d.bbox[2] > 0 and d.bbox[3] > 0
+    assert det.extract_features(frame, []).size == 0
+    assert det._get_foot_position((100.0, 200.0, 50.0, 100.0)) == (125.0, 300.0)
+    assert det.get_attention_map(frame) is None
+    assert det.detect_batch([]) == []
+    with pytest.raises(ValueError):
+        det.detect(np.zeros((64, 64), np.uint8))
+
+
+def test_roi_features_match_reference_formula(detectors):
+    det = detectors(ga=1.0)
+    frame = structured_frames(1, 256, 320, seed=32)[0]
+    _, _, enc = det.forward_raw([frame])
+    from office_person_detection_vit_amd.data_models import Detection
+    boxes = [(10.0, 20.0, 100.0, 120.0), (0.0, 0.0, 320.0, 256.0), (300.0, 250.0, 50.0, 50.0)]
+    dets = [Detection(bbox=b, confidence=0.9, class_id=1, class_name="person", camera_coords=(0, 0)) for b in boxes]
+    got = det.extract_features(frame, dets)
+    want = O.roi_features(enc[0].reshape(8, 10, 256), boxes, (256, 320))
+    np.testing.assert_allclose(got, want, atol=1e-5)
+
+
+def test_error_conventions(weight_cache):
+    det = HipDetrDetector(model_path=os.path.join(weight_cache, "missing.safetensors"))
+    with pytest.raises(RuntimeError, match="Model not loaded"):
+        det.detect(np.zeros((64, 64, 3), np.uint8))
+    with pytest.raises(RuntimeError, match="Failed to load DETR model"):
+        det.load_model()
+    bad = os.path.join(weight_cache, "garbage.safetensors")
+    with open(bad, "wb") as f:
+        f.write(b"\x10\x00\x00\x00\x00\x00\x00\x00{not json at all}")
+    det2 = HipDetrDetector(model_path=bad)
+    with pytest.raises(RuntimeError, match="Failed to load DETR model"):
+        det2.load_model()

@@ -1,0 +1,231 @@
+"""Kernel-level parity (GPU): each hand-written HIP kernel against a torch fp32 CPU reference of the same op on the
+SAME fp16-rounded inputs, called through the exported test hooks of libopd_hip.so.
+
+Tolerances (stated per test): outputs are fp16, so one output rounding (2^-11 relative) plus fp32 accumulation-order
+noise; integer-valued cases must be bit exact.
+"""
+
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from office_person_detection_vit_amd import _capi
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    return _capi.load_library()
+
+
+def _h(a):
+    """fp32 array -> (fp16-rounded fp32 array, uint16 bit pattern)."""
+    h = np.ascontiguousarray(a, dtype=np.float32).astype(np.float16)
+    return h.astype(np.float32), np.ascontiguousarray(h.view(np.uint16))
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def run_conv(lib, x_nhwc, w_oihw, bias, stride, pad, relu, res=None, res32=None, out_f32=False, bias_period=0):
+    """x [B,H,W,Cin], w [N,Cin,KH,KW] (fp32, already fp16-representable); returns out [B,OH,OW,N] fp32."""
+    B, H, W, Cin = x_nhwc.shape
+    N, _, KH, KW = w_oihw.shape
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    xb = np.ascontiguousarray(x_nhwc.astype(np.float16).view(np.uint16))
+    wt = np.ascontiguousarray(w_oihw.transpose(0, 2, 3, 1).reshape(N, KH * KW * Cin).astype(np.float16).view(np.uint16))
+    M = B * OH * OW
+    out = np.empty((M, N), np.float32 if out_f32 else np.uint16)
+    r16 = np.ascontiguousarray(res.reshape(M, N).astype(np.float16).view(np.uint16)) if res is not None else None
+    r32 = np.ascontiguousarray(res32.reshape(M, N).astype(np.float32)) if res32 is not None else None
+    b = np.ascontiguousarray(bias.astype(np.float32))
+    rc = lib.opd_test_conv_gemm(_p(xb), _p(wt), _p(b), _p(r16), _p(r32), _p(out), B, H, W, Cin, OH, OW, N, KH, KW, stride, pad,
+                                int(relu), bias_period, int(out_f32), 0)
+    _capi.check(rc, "opd_test_conv_gemm")
+    o = out if out_f32 else out.view(np.float16).astype(np.float32)
+    return o.reshape(B, OH, OW, N)
+
+
+def ref_conv(x_nhwc, w_oihw, bias, stride, pad, relu, res=None):
+    y = F.conv2d(torch.from_numpy(x_nhwc).permute(0, 3, 1, 2), torch.from_numpy(w_oihw), torch.from_numpy(bias),
+                 stride=stride, padding=pad).permute(0, 2, 3, 1)
+    if res is not None:
+        y = y + torch.from_numpy(res)
+    if relu:
+        y = F.relu(y)
+    return y.numpy()
+
+
+CONV_CASES = [
+    # B, H, W, Cin, N, k, stride, relu, residual
+    (2, 13, 17, 64, 64, 1, 1, True, False),     # stage-1 1x1, ragged M
+    (1, 20, 23, 256, 128, 1, 1, True, False),   # stage-2 reduce
+    (2, 9, 11, 64, 256, 1, 1, True, True),      # expand + residual + ReLU
+    (2, 14, 15, 64, 64, 3, 1, True, False),     # 3x3 s1 pad 1
+    (2, 15, 13, 128, 128, 3, 2, True, False),   # 3x3 s2, odd sizes (H3)
+    (1, 17, 21, 256, 512, 1, 2, False, False),  # strided shortcut
+    (1, 7, 9, 512, 512, 3, 1, True, False),     # deep K (4608)
+    (1, 100, 128, 128, 512, 1, 1, False, False),  # 400 tiles -> the BN=128 instantiation
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_gemm_matches_torch(lib, case):
+    B, H, W, Cin, N, k, stride, relu, use_res = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    x, _ = _h(rng.standard_normal((B, H, W, Cin)))
+    w, _ = _h(rng.standard_normal((N, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k)))
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    pad = k // 2
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = _h(rng.standard_normal((B, OH, OW, N)))[0] if use_res else None
+    got = run_conv(lib, x, w, bias, stride, pad, relu, res)
+    want = ref_conv(x, w, bias, stride, pad, relu, res)
+    scale = float(np.abs(want).max())
+    # fp16 output rounding (2^-11 rel) + accumulation order: 1.5e-3 of the tensor scale is > 3 sigma
+    np.testing.assert_allclose(got, want, atol=1.5e-3 * scale, rtol=1e-3)
+
+
+def test_conv_gemm_integer_exact(lib):
+    """Small-integer operands: every product and sum is exact in fp16/fp32 -> bit-exact; asymmetric weights catch a
+    transposed fragment map (cdna_hip_programming.md §3: 'A=I-check with ASYMMETRIC B')."""
+    rng = np.random.default_rng(5)
+    B, H, W, Cin, N = 1, 12, 11, 64, 128
+    x = rng.integers(-3, 4, (B, H, W, Cin)).astype(np.float32)
+    w = np.zeros((N, Cin, 3, 3), np.float32)
+    for n in range(N):
+        w[n, (n * 7) % Cin, n % 3, (n // 3) % 3] = 1 + (n % 5)   # one tap per output channel, asymmetric
+        w[n, (n * 3 + 1) % Cin, (n + 1) % 3, n % 3] += -2
+    bias = np.arange(N, dtype=np.float32) - 60
+    got = run_conv(lib, x, w, bias, 1, 1, False)
+    want = ref_conv(x, w, bias, 1, 1, False)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_gemm_rowbias_f32_residual(lib):
+    """Transformer flavour: out_f32 = x.W^T + rowbias[m % period] + res32 (pos-embedding fold, residual stream)."""
+    rng = np.random.default_rng(11)
+    M, K, N, period = 300, 256, 768, 100
+    x, _ = _h(rng.standard_normal((M, 1, 1, K)))
+    w, _ = _h(rng.standard_normal((N, K, 1, 1)) / 16)
+    rb = rng.standard_normal((period, N)).astype(np.float32)
+    res = rng.standard_normal((M, N)).astype(np.float32)
+    got = run_conv(lib, x, w, rb, 1, 0, False, res32=res, out_f32=True, bias_period=period).reshape(M, N)
+    want = x.reshape(M, K) @ w.reshape(N, K).T + rb[np.arange(M) % period] + res
+    np.testing.assert_allclose(got, want, atol=2e-4, rtol=1e-5)
+
+
+def test_stem_conv(lib):
+    """7x7 s2 p3 stem on the NHWC4 image, odd sizes."""
+    rng = np.random.default_rng(3)
+    B, H, W, N = 2, 45, 51, 64
+    x, _ = _h(rng.standard_normal((B, H, W, 3)))
+    w, _ = _h(rng.standard_normal((N, 3, 7, 7)) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    x4 = np.zeros((B, H, W, 4), np.float16)
+    x4[..., :3] = x
+    wt = np.zeros((N, 8, 8, 4), np.float16)
+    wt[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = np.empty((B * OH * OW, N), np.uint16)
+    rc = lib.opd_test_conv_gemm(_p(np.ascontiguousarray(x4.view(np.uint16))), _p(np.ascontiguousarray(wt.view(np.uint16))),
+                                _p(bias), None, None, _p(out), B, H, W, 3, OH, OW, N, 7, 7, 2, 3, 1, 0, 0, 1)
+    _capi.check(rc, "opd_test_conv_gemm(stem)")
+    got = out.view(np.float16).astype(np.float32).reshape(B, OH, OW, N)
+    want = ref_conv(x, w, bias, 2, 3, True)
+    np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
+
+
+def _ref_attention(q, k, v, heads, scale):
+    B, Lq, D = q.shape
+    Lk = k.shape[1]
+    dh = D // heads
+    Q = torch.from_numpy(q).view(B, Lq, heads, dh).transpose(1, 2)
+    K = torch.from_numpy(k).view(B, Lk, heads, dh).transpose(1, 2)
+    V = torch.from_numpy(v).view(B, Lk, heads, dh).transpose(1, 2)
+    p = torch.softmax(Q @ K.transpose(2, 3) * scale, dim=-1)
+    return (p @ V).transpose(1, 2).reshape(B, Lq, D).numpy()
+
+
+@pytest.mark.parametrize("tr", [0, 1])
+@pytest.mark.parametrize("shape", [(2, 100, 100), (1, 130, 130), (2, 100, 150), (1, 70, 1050)])
+def test_attention_matches_torch(lib, shape, tr):
+    """Both V-fragment paths (hardware-transpose LDS read and scalar gather) against softmax(QK^T/sqrt(32))V."""
+    B, Lq, Lk = shape
+    heads, D = 8, 256
+    rng = np.random.default_rng(Lq * 1000 + Lk)
+    q, qb = _h(rng.standard_normal((B, Lq, D)) * 1.5)
+    k, kb = _h(rng.standard_normal((B, Lk, D)) * 1.5)
+    v, vb = _h(rng.standard_normal((B, Lk, D)))
+    out = np.empty((B, Lq, D), np.uint16)
+    scale = 32 ** -0.5
+    _capi.check(lib.opd_test_attention(_p(qb), _p(kb), _p(vb), _p(out), B, heads, Lq, Lk, scale, tr), "opd_test_attention")
+    got = out.view(np.float16).astype(np.float32)
+    want = _ref_attention(q, k, v, heads, scale)
+    # P is rounded to fp16 before the PV product (rel 2^-11 per weight) and the output to fp16
+    np.testing.assert_allclose(got, want, atol=2e-3, rtol=2e-3)
+
+
+def test_attention_sharp_rows(lib):
+    """A dominating key per query (forces large running-max jumps between key tiles): online-softmax rescale path."""
+    B, heads, Lq, Lk, D = 1, 8, 64, 300, 256
+    rng = np.random.default_rng(9)
+    q = rng.standard_normal((B, Lq, D)).astype(np.float32)
+    k = rng.standard_normal((B, Lk, D)).astype(np.float32)
+    for i in range(Lq):  # key (5*i + 70) % Lk aligned with query i -> score ~ +40 at a tile that varies with i
+        k[0, (5 * i + 70) % Lk] = q[0, i] * 4.0
+    q, qb = _h(q)
+    k, kb = _h(k)
+    v, vb = _h(rng.standard_normal((B, Lk, D)))
+    out = np.empty((B, Lq, D), np.uint16)
+    scale = 32 ** -0.5
+    _capi.check(lib.opd_test_attention(_p(qb), _p(kb), _p(vb), _p(out), B, heads, Lq, Lk, scale, 1), "opd_test_attention")
+    got = out.view(np.float16).astype(np.float32)
+    want = _ref_attention(q, k, v, heads, scale)
+    np.testing.assert_allclose(got, want, atol=3e-3, rtol=3e-3)
+
+
+def test_layernorm(lib):
+    rng = np.random.default_rng(2)
+    rows = 1051
+    x = (rng.standard_normal((rows, 256)) * 3 + 0.7).astype(np.float32)
+    g = rng.uniform(0.8, 1.2, 256).astype(np.float32)
+    b = rng.standard_normal(256).astype(np.float32) * 0.05
+    y = np.empty((rows, 256), np.float32)
+    y16 = np.empty((rows, 256), np.uint16)
+    _capi.check(lib.opd_test_layernorm(_p(x), _p(g), _p(b), _p(y), _p(y16), rows), "opd_test_layernorm")
+    want = F.layer_norm(torch.from_numpy(x), (256,), torch.from_numpy(g), torch.from_numpy(b), 1e-5).numpy()
+    np.testing.assert_allclose(y, want, atol=2e-6, rtol=1e-5)
+    np.testing.assert_array_equal(y16.view(np.float16), y.astype(np.float16))
+
+
+def test_maxpool_exact(lib):
+    rng = np.random.default_rng(4)
+    B, H, W, Cc = 2, 23, 31, 64
+    x, xb = _h(rng.standard_normal((B, H, W, Cc)))
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    out = np.empty((B, OH, OW, Cc), np.uint16)
+    _capi.check(lib.opd_test_maxpool(_p(xb), _p(out), B, H, W, Cc, OH, OW), "opd_test_maxpool")
+    want = F.max_pool2d(torch.from_numpy(x).permute(0, 3, 1, 2), 3, 2, 1).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_array_equal(out.view(np.float16).astype(np.float32), want)
+
+
+def test_preprocess_matches_oracle(lib):
+    from office_person_detection_vit_amd.frames import structured_frames
+    from oracle import detr_oracle as O
+
+    frames = structured_frames(2, 37, 53, seed=77)
+    pv, _ = O.preprocess(frames)
+    batch = np.ascontiguousarray(np.stack(frames))
+    out = np.empty((2, 37, 53, 4), np.uint16)
+    _capi.check(lib.opd_test_preprocess_u8(_p(batch), _p(out), 2, 37, 53), "opd_test_preprocess_u8")
+    got = out.view(np.float16)
+    want = pv.permute(0, 2, 3, 1).numpy().astype(np.float16)
+    np.testing.assert_array_equal(got[..., :3], want)  # same op order in fp32, one rounding to fp16
+    assert not got[..., 3].any()
