@@ -35,6 +35,18 @@ def cpu_baseline(path: str, H: int, W: int, batch: int = 4, iters: int = 2) -> d
     from office_person_detection_vit_amd.weights import load_safetensors
     from oracle import detr_oracle as O
 
+    # use the host cores this process may actually run on (the GPU box shares its CPUs between boxes)
+    try:
+        ncpu = len(os.sched_getaffinity(0))
+    except AttributeError:
+        ncpu = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            ncpu = max(1, min(ncpu, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    torch.set_num_threads(ncpu)
     w = O.to_torch(load_safetensors(path))
     frames = [noise_frame(H, W, 1234 + i) for i in range(batch)]
     times = []
@@ -101,8 +113,8 @@ def main() -> None:
     d_frames = torch.from_numpy(frames).cuda()
     d_records = torch.zeros((B, Q, 8), dtype=torch.int32, device="cuda")   # opd_det = 8 x 4 bytes
     d_counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
-    g_records = torch.zeros((world, B, Q, 8), dtype=torch.int32, device="cuda") if world > 1 else None
-    g_counts = torch.zeros((world, B), dtype=torch.int32, device="cuda") if world > 1 else None
+    g_records = torch.zeros((world * B, Q, 8), dtype=torch.int32, device="cuda") if world > 1 else None
+    g_counts = torch.zeros((world * B,), dtype=torch.int32, device="cuda") if world > 1 else None
     hw = np.asarray([[H, W]] * B, dtype=np.int32)
 
     def step():

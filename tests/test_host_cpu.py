@@ -1,0 +1,167 @@
+"""CPU-only tests: the C-ABI library loads and exports every symbol ``include/opd_detr.h`` declares, host-side loader
+logic (fp16 conversion, checkpoint key normalisation, native safetensors parsing + schema check), the detector's
+host pre-processing against HF golden vectors, and the reference's error conventions.  No compute calls."""
+
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from office_person_detection_vit_amd import HipDetrDetector, _capi, model_input_size
+from office_person_detection_vit_amd.detector import resize_frame
+from office_person_detection_vit_amd.frames import structured_frames
+from office_person_detection_vit_amd.weights import (DetrArch, param_specs, rename_4x_key, save_safetensors,
+                                                     synth_weights)
+from oracle import detr_oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "opd_detr.h")).read()
+    declared = set(re.findall(r"\b(opd_[a-z0-9_]+)\s*\(", header))
+    declared -= {"opd_config", "opd_det", "opd_model_info"}
+    assert len(declared) >= 12
+    lib = _capi.load_library()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"libopd_hip.so does not export {name}"
+        assert name in _capi.API, f"_capi.API lacks a prototype for {name}"
+    assert set(_capi.API) == declared
+    assert b"gfx950" in lib.opd_version()
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_capi.OpdDet) == 32
+    assert C.sizeof(_capi.OpdConfig) == 32
+    assert C.sizeof(_capi.OpdModelInfo) == 4 * 4 + 7 * 4 + 3 * 4 + 4 + 4 + 16  # incl. 4 bytes padding before int64
+
+
+def test_f16_conversion_matches_numpy():
+    lib = _capi.load_library()
+    rng = np.random.default_rng(0)
+    vals = np.concatenate([rng.standard_normal(2000).astype(np.float32) * s for s in (1e-7, 1e-4, 1.0, 300.0, 7e4)] +
+                          [np.array([0.0, -0.0, 65504.0, 65520.0, 65519.9, 6.1e-5, 5.96e-8, 2.98e-8, 2.99e-8], np.float32)])
+    with np.errstate(over="ignore"):
+        want = vals.astype(np.float16).view(np.uint16)
+    got = np.array([lib.opd_test_f32_to_f16(float(v)) for v in vals], np.uint16)
+    np.testing.assert_array_equal(got, want)
+    back = np.array([lib.opd_test_f16_to_f32(int(h)) for h in want[:3000]], np.float32)
+    np.testing.assert_array_equal(back, want[:3000].view(np.float16).astype(np.float32))
+
+
+def test_checkpoint_key_normalisation():
+    lib = _capi.load_library()
+    buf = C.create_string_buffer(512)
+    cases = {
+        "model.backbone.conv_encoder.model.conv1.weight": "model.backbone.model.embedder.embedder.convolution.weight",
+        "model.backbone.conv_encoder.model.layer3.5.bn2.running_mean":
+            "model.backbone.model.encoder.stages.2.layers.5.layer.1.normalization.running_mean",
+        "model.backbone.conv_encoder.model.layer2.0.downsample.0.weight":
+            "model.backbone.model.encoder.stages.1.layers.0.shortcut.convolution.weight",
+        "model.decoder.layers.2.encoder_attn.out_proj.bias": "model.decoder.layers.2.encoder_attn.o_proj.bias",
+        "model.encoder.layers.4.fc2.weight": "model.encoder.layers.4.mlp.fc2.weight",
+        "bbox_predictor.layers.1.weight": "bbox_predictor.layers.1.weight",
+    }
+    for k, want in cases.items():
+        assert lib.opd_test_normalise_key(k.encode(), buf, 512) == 0
+        assert buf.value.decode() == want
+    # the python mirror used by tools agrees on the 4.x transformer renames
+    assert rename_4x_key("model.decoder.layers.2.encoder_attn.out_proj.bias") == "model.decoder.layers.2.encoder_attn.o_proj.bias"
+    # 5.x names are fixed points
+    for name, _, _ in list(param_specs(DetrArch()))[::37]:
+        lib.opd_test_normalise_key(name.encode(), buf, 512)
+        assert buf.value.decode() == name
+
+
+def test_native_checkpoint_parse_and_schema(tmp_path):
+    lib = _capi.load_library()
+    arch = DetrArch(depths=(1, 2, 1, 1), encoder_layers=2, decoder_layers=1, num_queries=20)
+    w = synth_weights(arch, 3, 1.0, calibrate=False)
+    path = str(tmp_path / "tiny.safetensors")
+    save_safetensors(w, path)
+    info = (C.c_int32 * 8)()
+    assert lib.opd_test_inspect_checkpoint(path.encode(), info) == 0, _capi.last_error()
+    assert list(info) == [1, 2, 1, 1, 2, 1, 20, 92]
+    # a missing tensor is a schema error naming the tensor
+    w2 = dict(w)
+    del w2["model.decoder.layers.0.encoder_attn.k_proj.bias"]
+    bad = str(tmp_path / "bad.safetensors")
+    save_safetensors(w2, bad)
+    assert lib.opd_test_inspect_checkpoint(bad.encode(), info) == -3
+    assert "encoder_attn.k_proj.bias" in _capi.last_error()
+    # wrong shape
+    w3 = dict(w)
+    w3["model.input_projection.weight"] = np.zeros((256, 1024, 1, 1), np.float32)
+    bad3 = str(tmp_path / "bad3.safetensors")
+    save_safetensors(w3, bad3)
+    assert lib.opd_test_inspect_checkpoint(bad3.encode(), info) == -3
+    assert lib.opd_test_inspect_checkpoint(str(tmp_path / "nope.safetensors").encode(), info) == -2
+
+
+def test_size_rule_and_resize_match_hf(golden_dir):
+    """``model_input_size`` + PIL bilinear ``resize_frame`` + the oracle's normalisation reproduce HF's image processor."""
+    g = np.load(os.path.join(golden_dir, "hf_resize.npz"))
+    for tag, (h, w) in {"720x1280": (720, 1280), "480x640": (480, 640), "1080x1920": (1080, 1920), "900x700": (900, 700)}.items():
+        th, tw = model_input_size(h, w)
+        assert (th, tw) == tuple(int(v) for v in g[f"{tag}_shape"][2:])
+        frame = structured_frames(1, h, w, seed=555)[0]
+        pv, _ = O.preprocess([resize_frame(frame, th, tw)])
+        np.testing.assert_allclose(pv[:, :, ::53, ::59].numpy(), g[f"{tag}_sample"], atol=1e-6)
+    assert model_input_size(800, 1333) == (800, 1333)  # the benchmark frames need no resize
+
+
+def test_error_conventions_without_gpu(tmp_path):
+    """Reference conventions (tests/test_yolov8_detector.py:108-119): detect before load -> 'Model not loaded';
+    load failure -> RuntimeError 'Failed to load ... model'.  On a GPU-less host load_model must FAIL, not fall back."""
+    det = HipDetrDetector(model_path=str(tmp_path / "missing.safetensors"), confidence_threshold=0.5)
+    assert det.model is None and det.feature_extractor is not None and det.confidence_threshold == 0.5
+    with pytest.raises(RuntimeError, match="Model not loaded"):
+        det.detect(np.zeros((720, 1280, 3), np.uint8))
+    with pytest.raises(RuntimeError, match="Model not loaded"):
+        det.detect_with_features(np.zeros((720, 1280, 3), np.uint8))
+    with pytest.raises(RuntimeError, match="Failed to load DETR model"):
+        det.load_model()
+    assert det._get_foot_position((100.0, 200.0, 50.0, 100.0)) == (125.0, 300.0)
+    with pytest.raises(ValueError):
+        HipDetrDetector(device="cpu")
+    assert HipDetrDetector(device="cuda").device == "hip:0" and HipDetrDetector(device="hip:3").device_ordinal == 3
+
+
+def test_no_cpu_fallback_on_gpuless_host(tmp_path):
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    w = synth_weights(DetrArch(depths=(1, 1, 1, 1), encoder_layers=1, decoder_layers=1, num_queries=20), 0, 1.0, calibrate=False)
+    path = str(tmp_path / "tiny.safetensors")
+    save_safetensors(w, path)
+    det = HipDetrDetector(model_path=path)
+    with pytest.raises(RuntimeError, match="Failed to load DETR model.*(no HIP device|no CPU fallback|hip)"):
+        det.load_model()
+
+
+def test_person_nms_host_routine():
+    """``opd_person_nms`` against the oracle's ``person_detections`` on random boxes (host code, no GPU needed)."""
+    from office_person_detection_vit_amd.sharding import DET_DTYPE
+
+    lib = _capi.load_library()
+    rng = np.random.default_rng(12)
+    for trial in range(20):
+        n = int(rng.integers(0, 60))
+        xy = rng.uniform(0, 500, (n, 2)).astype(np.float32)
+        wh = rng.uniform(20, 300, (n, 2)).astype(np.float32)
+        recs = np.zeros(max(n, 1), DET_DTYPE)
+        recs["x1"][:n], recs["y1"][:n] = xy[:, 0], xy[:, 1]
+        recs["x2"][:n], recs["y2"][:n] = xy[:, 0] + wh[:, 0], xy[:, 1] + wh[:, 1]
+        recs["score"][:n] = rng.uniform(0.5, 1.0, n).astype(np.float32)
+        recs["label"][:n] = rng.choice([1, 1, 1, 3, 17], n)
+        recs["query_index"][:n] = np.arange(n)
+        res = {"scores": recs["score"][:n].copy(), "labels": recs["label"][:n].copy(),
+               "boxes": np.stack([recs["x1"][:n], recs["y1"][:n], recs["x2"][:n], recs["y2"][:n]], 1),
+               "query_index": np.arange(n)}
+        want = [d["query_index"] for d in O.person_detections(res, 0.4)]
+        kept = lib.opd_person_nms(recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), n, 1, 0.4)
+        assert kept == len(want)
+        assert list(recs["query_index"][:kept]) == want

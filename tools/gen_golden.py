@@ -109,8 +109,25 @@ def feature_extractor_case():
     print("feature_extractor: roi", roi.shape, "norms", np.linalg.norm(roi, axis=1)[:3])
 
 
+def resize_case():
+    """HF image processor with its default resize (shortest 800 / longest 1333, PIL bilinear) on camera-sized frames."""
+    from transformers import DetrImageProcessor
+
+    proc = DetrImageProcessor()
+    d = {}
+    for tag, (h, w) in {"720x1280": (720, 1280), "480x640": (480, 640), "1080x1920": (1080, 1920), "900x700": (900, 700)}.items():
+        frame = structured_frames(1, h, w, seed=555)[0]
+        enc = proc(images=[np.ascontiguousarray(frame[:, :, ::-1])], return_tensors="pt")
+        pv = enc["pixel_values"]
+        d[f"{tag}_shape"] = np.array(pv.shape)
+        d[f"{tag}_sample"] = pv[:, :, ::53, ::59].numpy()
+        print("resize", tag, "->", tuple(pv.shape))
+    np.savez_compressed(os.path.join(GOLD, "hf_resize.npz"), **d)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    resize_case()
     r50 = DetrArch.resnet50()
     # equal-size batches (pixel_mask all ones): the configuration the HIP path serves
     model_case("r50_mild_256x320", r50, 0, 1.0, [(256, 320), (256, 320)], 1234)
