@@ -60,6 +60,7 @@ API = {
 # kernel-level test hooks (csrc/opd_test_api.cpp); not part of the boundary
 TEST_API = {
     "opd_test_conv_gemm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 15),
+    "opd_test_gemm_splitk_ln": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3),
     "opd_test_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_int]),
     "opd_test_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int]),
     "opd_test_maxpool": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6),
@@ -69,6 +70,7 @@ TEST_API = {
     "opd_test_normalise_key": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "opd_test_inspect_checkpoint": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
     "opd_test_set_tr_read": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_test_set_gemm_variant": (C.c_int, [C.c_int]),
 }
 
 _lib: Optional[C.CDLL] = None

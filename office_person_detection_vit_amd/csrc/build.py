@@ -17,7 +17,7 @@ def _stale(target: str, deps) -> bool:
     if not os.path.exists(target):
         return True
     t = os.path.getmtime(target)
-    return any(os.path.getmtime(d) > t for d in deps)
+    return any(os.path.getmtime(d) >= t for d in deps)
 
 
 def build(verbose: bool = False, force: bool = False) -> str:

@@ -22,6 +22,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+static int g_gemm_variant = 1;  // 0 = v1 register-staged, 1 = v2 LDS-DMA 2-stage, 2 = v2 + v3 3-stage pipeline for deep K (default)
+
 namespace {
 
 constexpr int BM = 128;
@@ -40,6 +42,16 @@ struct Smem {
     static constexpr int TOTAL = (2 * STAGE > C_BYTES) ? 2 * STAGE : C_BYTES;
 };
 
+// XCD-aware block -> tile map (cdna_hip_programming.md T1, bijective form).  Workgroups are dealt round-robin over the 8
+// XCDs (blocks b and b+8 share an XCD and its private 4 MiB L2), so hand each XCD a CONTIGUOUS range of logical tile
+// ids: the n-tiles of one m-tile (which re-read the same activation rows) then run on one XCD, back to back, and the
+// rows are fetched from HBM / Infinity Cache once instead of once per n-tile.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint2 ldg8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
 
@@ -56,8 +68,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = p.N / BN;
-    const int tile_n = blockIdx.x % tiles_n;
-    const int tile_m = blockIdx.x / tiles_n;
+    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int tile_n = lbid % tiles_n;
+    const int tile_m = lbid / tiles_n;
     const int m_base = tile_m * BM;
     const int n_base = tile_n * BN;
 
@@ -242,6 +255,423 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v2: LDS-DMA staging (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through VGPRs or the ds_write path) and
+// a register epilogue.  Profiling of v1 (profiles/r01_first_bench_*) showed the k-loop bound by ds_write_b128
+// (~79 B/clk/CU: 32 KB of tile stores per k-step cost as much as the step's 32 MFMAs per wave) and the K=64 layers
+// bound by the fp32 LDS round trip of the epilogue.  Here:
+//   * every wave issues 1-KiB DMA pieces (8 tile rows x 128 B); the LDS image stays the v1 XOR-swizzled layout, the
+//     swizzle is applied on the per-lane SOURCE address (lane l fills physical chunk l&7 of row l>>3, so it fetches
+//     logical chunk (l&7)^(l>>3)); out-of-image taps / rows >= M fetch from a 16-byte zero page;
+//   * accumulators go bias -> (+residual) -> ReLU -> fp16 in registers; v_permlane16_swap pairs the 4-wide n-quads of
+//     two m-tiles into 8 consecutive channels per lane, so stores (and residual loads) are 16 bytes per lane.
+// ---------------------------------------------------------------------------------------------------------------------
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gsrc,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v h;
+    h[0] = (_Float16)a;
+    h[1] = (_Float16)b;
+    unsigned u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+__device__ __forceinline__ void unpack2h(unsigned u, float& a, float& b) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v h;
+    __builtin_memcpy(&h, &u, 4);
+    a = (float)h[0];
+    b = (float)h[1];
+}
+
+// Accumulators start from the bias (vector or row-periodic), so the bias loads overlap the first tile's DMA instead of
+// sitting on the epilogue's critical path.
+template <int NT>
+__device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const float* bias, float4v (&acc)[NT][4], const int m0,
+                                              const int n0, const int lane) {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nq = n0 + nt * 16 + g * 4;
+        if (p.bias_period == 0) {
+            const float4v b = *reinterpret_cast<const float4v*>(bias + nq);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b;
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m0 + mt * 16 + li;
+                acc[nt][mt] = m < p.M ? *reinterpret_cast<const float4v*>(bias + (size_t)(m % p.bias_period) * p.N + nq)
+                                      : float4v{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+    }
+}
+
+// fp16 residual in the paired 16-byte layout (see epilogue_regs), fetched BEFORE the last k-step's MFMAs.
+template <int NT>
+__device__ __forceinline__ void prefetch_res16(const ConvGemmParams& p, uint4 (&res)[NT][2], const int m0, const int n0,
+                                               const int lane) {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+            const int my_m = m0 + (mp * 2 + (g & 1)) * 16 + li;
+            const int my_n = n0 + nt * 16 + (g >> 1) * 8;
+            res[nt][mp] = make_uint4(0u, 0u, 0u, 0u);
+            if (p.res16 && my_m < p.M) res[nt][mp] = *reinterpret_cast<const uint4*>(p.res16 + (size_t)my_m * p.N + my_n);
+        }
+}
+
+// Register epilogue: (+fp32 residual) (+fp16 residual) -> ReLU -> store.  v_permlane16_swap pairs the 4-channel
+// accumulator quads of two m-tiles so each lane owns 8 consecutive channels of one row: 16-byte loads and stores.
+template <int NT>
+__device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out, float4v (&acc)[NT][4],
+                                              const uint4 (&res)[NT][2], const int m0, const int n0, const int lane) {
+    const int g = lane >> 4, li = lane & 15;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int nq = n0 + nt * 16 + g * 4;  // this lane's 4 channels in accumulator layout
+#pragma unroll
+        for (int mp = 0; mp < 2; ++mp) {
+            float4v v[2];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int m = m0 + (mp * 2 + h) * 16 + li;
+                v[h] = acc[nt][mp * 2 + h];
+                if (p.res32 && m < p.M) v[h] += *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * p.N + nq);
+            }
+            // lane's row / channels in the paired (16-byte) layout: even g -> first m-tile of the pair, odd g -> second
+            const int my_m = m0 + (mp * 2 + (g & 1)) * 16 + li;
+            const int my_n = n0 + nt * 16 + (g >> 1) * 8;
+            const size_t my_o = (size_t)my_m * p.N + my_n;
+            if (p.res16) {
+                const uint4 r = res[nt][mp];
+                const uint2v s0 = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
+                const uint2v s1 = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+                float a, b;
+                unpack2h(s0[0], a, b); v[0][0] += a; v[0][1] += b;
+                unpack2h(s1[0], a, b); v[0][2] += a; v[0][3] += b;
+                unpack2h(s0[1], a, b); v[1][0] += a; v[1][1] += b;
+                unpack2h(s1[1], a, b); v[1][2] += a; v[1][3] += b;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[h][r] = v[h][r] > 0.f ? v[h][r] : 0.f;
+            }
+            if (p.out_f32) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int m = m0 + (mp * 2 + h) * 16 + li;
+                    if (m < p.M) *reinterpret_cast<float4v*>(reinterpret_cast<float*>(out) + (size_t)m * p.N + nq) = v[h];
+                }
+            }
+            f16_t* o16 = p.out_f32 ? p.out16_aux : reinterpret_cast<f16_t*>(out);
+            if (o16) {
+                const uint2v s0 = __builtin_amdgcn_permlane16_swap(pack2h(v[0][0], v[0][1]), pack2h(v[1][0], v[1][1]), false, false);
+                const uint2v s1 = __builtin_amdgcn_permlane16_swap(pack2h(v[0][2], v[0][3]), pack2h(v[1][2], v[1][3]), false, false);
+                if (my_m < p.M) *reinterpret_cast<uint4*>(o16 + my_o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            }
+        }
+    }
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    using S = Smem<BN>;
+    constexpr int NT = BN / 32;
+    constexpr int B_PIECES = BN / 32;  // 1-KiB pieces of the B tile per wave
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = p.N / BN;
+    const int ntiles = tiles_n * ((p.M + BM - 1) / BM);
+    const int lbid_all = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int zsplit = lbid_all / ntiles;  // split-K slice (0 when split_k <= 1)
+    const int lbid = lbid_all - zsplit * ntiles;
+    const int tile_n = lbid % tiles_n;
+    const int tile_m = lbid / tiles_n;
+    const int m_base = tile_m * BM;
+    const int n_base = tile_n * BN;
+    // (kernel arguments are never written: a modified ConvGemmParams would be demoted to scratch memory)
+    void* out_ptr = p.out;
+    const float* bias_ptr = p.bias;
+    if (p.split_k > 1) {  // this slice writes its own fp32 slab; only slice 0 carries the bias
+        out_ptr = reinterpret_cast<float*>(p.out) + (size_t)zsplit * p.M * p.N;
+        if (zsplit > 0) bias_ptr = reinterpret_cast<const float*>(p.zero16);
+    }
+
+    // ---- DMA coordinates: piece q = wave*4 + i covers tile rows 8q..8q+7; lane -> (row 8q + (lane>>3), slot lane&7)
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;  // logical 16-byte chunk this lane fetches (XOR swizzle on the source side)
+    long long a_base[4];
+    int a_ih0[4], a_iw0[4];
+    bool a_ok[4];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + (wave * 4 + i) * 8 + lrow;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
+            const int b = mm / ohw;
+            const int r = mm - b * ohw;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            a_base[i] = (long long)b * p.H * p.W;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
+        }
+    }
+    const f16_t* wrow[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i)
+        wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K + lchunk * 8;
+
+    const int kpc = p.Cin / BK;
+    const int nk_all = p.K / BK;
+    const int nk = p.split_k > 1 ? nk_all / p.split_k : nk_all;  // k-steps of this slice
+    const int ks0 = zsplit * nk;
+    int tap_kh = (ks0 / kpc) / p.KW, tap_kw = (ks0 / kpc) % p.KW, tap_c = ks0 % kpc;
+
+    auto issue = [&](int ks_rel, int buf) {
+        const int ks = ks0 + ks_rel;
+        unsigned char* As = smem + buf * S::STAGE;
+        unsigned char* Bs = As + S::A_BYTES;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ih = a_ih0[i] + tap_kh;
+            const int iw = a_iw0[i] + tap_kw;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BK + lchunk * 8
+                                  : reinterpret_cast<const f16_t*>(p.zero16);
+            dma16(src, As + (wave * 4 + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BK, Bs + (wave * B_PIECES + i) * 1024);
+        if (++tap_c == kpc) {
+            tap_c = 0;
+            if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
+        }
+    };
+
+    const int wm0 = m_base + wm * 64, wn0 = n_base + wn * (BN / 2);
+    issue(0, 0);
+    float4v acc[NT][4];
+    init_acc_bias<NT>(p, bias_ptr, acc, wm0, wn0, lane);
+    uint4 res[NT][2];
+    __syncthreads();  // emits s_waitcnt vmcnt(0) for the DMA in flight, then s_barrier
+
+    const int frow = lane & 15;
+    const int fchk = lane >> 4;
+    auto compute = [&](int buf) {
+        const unsigned char* As = smem + buf * S::STAGE;
+        const unsigned char* Bs = As + S::A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[4], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * 64 + mt * 16 + frow, kk * 4 + fchk));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    };
+    for (int ks = 0; ks + 1 < nk; ++ks) {
+        issue(ks + 1, (ks & 1) ^ 1);
+        compute(ks & 1);
+        __syncthreads();
+    }
+    prefetch_res16<NT>(p, res, wm0, wn0, lane);  // in flight during the last tile's MFMAs
+    compute((nk - 1) & 1);
+    epilogue_regs<NT>(p, out_ptr, acc, res, wm0, wn0, lane);
+}
+
+template <int BN>
+hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
+    using S = Smem<BN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S::STAGE);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_n = p.N / BN;
+    const int splits = p.split_k > 1 ? p.split_k : 1;
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN>), dim3(tiles_m * tiles_n * splits), dim3(256), 2 * S::STAGE, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// v3: 3-stage LDS-DMA pipeline with counted vmcnt and ONE raw s_barrier per k-step (cdna_hip_programming.md T3/T4).
+// v2's k-step is {issue next tile; compute; vmcnt(0); barrier}: with 2 workgroups per CU at most one tile per
+// workgroup is in flight and every k-step exposes (load latency - compute time).  Here the DMA of tile ks+2 is issued
+// right after the barrier that retires tile ks, so two tiles stay in flight across barriers and the wait at the top of
+// a k-step (s_waitcnt vmcnt(PER_STAGE): "all but the newest tile's pieces have landed") normally finds the data there.
+//   order per k-step:  s_waitcnt vmcnt(N) -> s_barrier -> issue DMA(ks+2) into the buffer read at ks-1 -> MFMAs(ks)
+//   RAW: every wave waits for its own pieces of tile ks, then the barrier makes all waves' pieces visible.
+//   WAR: the buffer of tile ks+2 was last read during k-step ks-1; all waves have left it once they pass the barrier.
+// Tile = (WM*64) x BN x 64 with WM*2 waves (WM = 4: 256-row tiles, 512 threads; WM = 2: 128-row tiles).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int N_OUTSTANDING>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N_OUTSTANDING >= 0 && N_OUTSTANDING <= 63, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_OUTSTANDING) : "memory");
+}
+
+template <int WM, int BN>
+__global__ __launch_bounds__(WM * 128) void conv_gemm_pipe_kernel(ConvGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BMT = WM * 64;
+    constexpr int NWAVES = WM * 2;
+    constexpr int A_BYTES = BMT * ROW_BYTES;
+    constexpr int B_BYTES = BN * ROW_BYTES;
+    constexpr int STAGE = A_BYTES + B_BYTES;
+    constexpr int NT = BN / 32;
+    constexpr int A_PIECES = (BMT / 8) / NWAVES;  // = 4
+    constexpr int B_PIECES = (BN / 8) / NWAVES;
+    constexpr int PER_STAGE = A_PIECES + B_PIECES;
+    static_assert(A_PIECES == 4 && B_PIECES >= 1, "piece split");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int tiles_n = p.N / BN;
+    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int tile_n = lbid % tiles_n;
+    const int tile_m = lbid / tiles_n;
+    const int m_base = tile_m * BMT;
+    const int n_base = tile_n * BN;
+
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    long long a_base[A_PIECES];
+    int a_ih0[A_PIECES], a_iw0[A_PIECES];
+    bool a_ok[A_PIECES];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const int m = m_base + (wave * A_PIECES + i) * 8 + lrow;
+            a_ok[i] = m < p.M;
+            const int mm = a_ok[i] ? m : 0;
+            const int b = mm / ohw;
+            const int r = mm - b * ohw;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            a_base[i] = (long long)b * p.H * p.W;
+            a_ih0[i] = oh * p.stride - p.pad;
+            a_iw0[i] = ow * p.stride - p.pad;
+        }
+    }
+    const f16_t* wrow[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i)
+        wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K + lchunk * 8;
+
+    const int nk = p.K / BK;
+    const int kpc = p.Cin / BK;
+    int tap_kh = 0, tap_kw = 0, tap_c = 0;
+
+    auto issue = [&](int ks, int buf) {
+        unsigned char* As = smem + buf * STAGE;
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_PIECES; ++i) {
+            const int ih = a_ih0[i] + tap_kh;
+            const int iw = a_iw0[i] + tap_kw;
+            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+            const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BK + lchunk * 8
+                                  : reinterpret_cast<const f16_t*>(p.zero16);
+            dma16(src, As + (wave * A_PIECES + i) * 1024);
+        }
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BK, Bs + (wave * B_PIECES + i) * 1024);
+        if (++tap_c == kpc) {
+            tap_c = 0;
+            if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
+        }
+    };
+
+    issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    float4v acc[NT][4];
+    init_acc_bias<NT>(p, p.bias, acc, m_base + wm * 64, n_base + wn * (BN / 2), lane);
+    uint4 res[NT][2];
+
+    const int frow = lane & 15;
+    const int fchk = lane >> 4;
+    int buf = 0, buf_next2 = 2;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) wait_vmcnt<PER_STAGE>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ks + 2 < nk) issue(ks + 2, buf_next2);
+        if (ks + 1 == nk) prefetch_res16<NT>(p, res, m_base + wm * 64, n_base + wn * (BN / 2), lane);
+        const unsigned char* As = smem + buf * STAGE;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[4], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * 64 + mt * 16 + frow, kk * 4 + fchk));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        buf = (buf == 2) ? 0 : buf + 1;
+        buf_next2 = (buf_next2 == 2) ? 0 : buf_next2 + 1;
+    }
+
+    epilogue_regs<NT>(p, p.out, acc, res, m_base + wm * 64, n_base + wn * (BN / 2), lane);
+}
+
+template <int WM, int BN>
+hipError_t launch_pipe(const ConvGemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 3 * (WM * 64 + BN) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_pipe_kernel<WM, BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_m = (p.M + WM * 64 - 1) / (WM * 64);
+    const int tiles_n = p.N / BN;
+    hipLaunchKernelGGL((conv_gemm_pipe_kernel<WM, BN>), dim3(tiles_m * tiles_n), dim3(WM * 128), LDS, stream, p);
+    return hipGetLastError();
+}
+
 template <int BN, bool STEM>
 hipError_t launch(const ConvGemmParams& p, hipStream_t stream) {
     using S = Smem<BN>;
@@ -269,8 +699,30 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
         if ((p.Cin % BK) != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
     }
     if ((long long)p.B * p.OH * p.OW != p.M) return hipErrorInvalidValue;
+    if (p.split_k > 1) {  // split-K: linear fp32 partial slabs only, reduced by opd_launch_reduce_ln
+        if (!p.out_f32 || p.relu || p.res16 || p.res32 || p.out16_aux || p.bias_period != 0 || p.stem || g_gemm_variant < 1 ||
+            ((p.K / BK) % p.split_k) != 0)
+            return hipErrorInvalidValue;
+        if (!p.zero16) return hipErrorInvalidValue;
+        return (p.N % 128 == 0 && (long long)((p.M + BM - 1) / BM) * (p.N / 128) * p.split_k >= 384) ? launch_dma<128>(p, stream)
+                                                                                                     : launch_dma<64>(p, stream);
+    }
     const int tiles_m = (p.M + BM - 1) / BM;
     const bool wide = (p.N % 128 == 0) && ((long long)tiles_m * (p.N / 128) >= 384);
     if (p.stem) return launch<64, true>(p, stream);
+    if (g_gemm_variant >= 1) {
+        if (!p.zero16) return hipErrorInvalidValue;
+        const int nk = p.K / BK;
+        if (g_gemm_variant >= 2 && nk >= 3) {  // deep K: 3-stage pipeline, one workgroup per CU
+            const bool n128 = (p.N % 128) == 0;
+            const long long blocks256 = (long long)((p.M + 255) / 256) * (p.N / (n128 ? 128 : 64));
+            if (blocks256 >= 200) return n128 ? launch_pipe<4, 128>(p, stream) : launch_pipe<4, 64>(p, stream);
+            return n128 ? launch_pipe<2, 128>(p, stream) : launch_pipe<2, 64>(p, stream);
+        }
+        return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);
+    }
     return wide ? launch<128, false>(p, stream) : launch<64, false>(p, stream);
 }
+
+void opd_set_gemm_variant(int v) { g_gemm_variant = v; }
+int opd_get_gemm_variant() { return g_gemm_variant; }

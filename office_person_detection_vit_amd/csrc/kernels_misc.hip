@@ -115,6 +115,39 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restri
     }
 }
 
+// Split-K reduction + residual + LayerNorm: one wave per row of 256, slabs summed in slice order (deterministic).
+__global__ __launch_bounds__(256) void reduce_ln256_kernel(const float* __restrict__ partials, int nsplit, size_t slab_stride,
+                                                           const float* __restrict__ residual, const float* __restrict__ gamma,
+                                                           const float* __restrict__ beta, float* __restrict__ y,
+                                                           f16_t* __restrict__ y16, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const size_t o = (size_t)row * 256 + lane * 4;
+    float4v v = *reinterpret_cast<const float4v*>(partials + o);
+    for (int z = 1; z < nsplit; ++z) v += *reinterpret_cast<const float4v*>(partials + z * slab_stride + o);
+    if (residual) v += *reinterpret_cast<const float4v*>(residual + o);
+    float4v out = v;
+    if (gamma) {
+        const float mean = wave_sum(v[0] + v[1] + v[2] + v[3]) * (1.0f / 256.0f);
+        const float d0 = v[0] - mean, d1 = v[1] - mean, d2 = v[2] - mean, d3 = v[3] - mean;
+        const float var = wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        const float4v g = *reinterpret_cast<const float4v*>(gamma + lane * 4);
+        const float4v bb = *reinterpret_cast<const float4v*>(beta + lane * 4);
+        out[0] = d0 * rstd * g[0] + bb[0];
+        out[1] = d1 * rstd * g[1] + bb[1];
+        out[2] = d2 * rstd * g[2] + bb[2];
+        out[3] = d3 * rstd * g[3] + bb[3];
+    }
+    if (y) *reinterpret_cast<float4v*>(y + o) = out;
+    if (y16) {
+        half4 h;
+        h[0] = (_Float16)out[0]; h[1] = (_Float16)out[1]; h[2] = (_Float16)out[2]; h[3] = (_Float16)out[3];
+        *reinterpret_cast<half4*>(y16 + o) = h;
+    }
+}
+
 __global__ void cast_f16_kernel(const float* __restrict__ x, f16_t* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) reinterpret_cast<_Float16*>(y)[i] = (_Float16)x[i];
@@ -262,6 +295,14 @@ hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float*
                                 hipStream_t stream) {
     if (rows <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, y16, rows);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_reduce_ln(const float* partials, int nsplit, size_t slab_stride, const float* residual,
+                                const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream) {
+    if (rows <= 0 || nsplit < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(reduce_ln256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, partials, nsplit, slab_stride, residual,
+                       gamma, beta, y, y16, rows);
     return hipGetLastError();
 }
 

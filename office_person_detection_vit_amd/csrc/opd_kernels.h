@@ -16,11 +16,15 @@ struct ConvGemmParams {
     const float* res32;  // optional fp32 residual [M][N]
     void* out;           // [M][N] fp16 (out_f32 == 0) or fp32
     f16_t* out16_aux;    // optional second fp16 copy of an fp32 output (unused when null)
+    const void* zero16;  // >= 16 bytes of zeros on the device (source of padded / out-of-range LDS-DMA rows)
     int B, H, W, Cin, OH, OW, N, KH, KW, stride, pad;
     int M, K;
     int relu, bias_period, out_f32, stem;
+    int split_k;         // > 1: K is cut into split_k slices, slice z writes fp32 partials to out + z*M*N (bias in slice 0)
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
+void opd_set_gemm_variant(int v);  // 0 = register-staged v1, 1 = LDS-DMA v2 (default)
+int opd_get_gemm_variant();
 
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
 // uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order.
@@ -32,6 +36,10 @@ hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, i
 // y = LayerNorm(x) * gamma + beta over the last dim (D == 256); writes fp32 y and optional fp16 copy.
 hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, f16_t* y16,
                                 int rows, hipStream_t stream);
+// y = LayerNorm( sum_z partial[z] + residual ) (gamma == nullptr: no normalisation, plain sum): the deterministic
+// reduction of split-K GEMM slabs fused with the residual add and the post-LN of the transformer layers.  D == 256.
+hipError_t opd_launch_reduce_ln(const float* partials, int nsplit, size_t slab_stride, const float* residual,
+                                const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream);
 // fp32 -> fp16 cast of n elements (n % 8 == 0 not required).
 hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream);
 // naive fp32 GEMM used once at plan-build time: C[m][n] = sum_k A[m][k]*Wt[n][k] + bias[n]  (Wt fp32 [N][K])

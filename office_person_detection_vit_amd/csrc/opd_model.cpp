@@ -8,6 +8,7 @@
 // The sine position embedding is constant per (h, w), so pos.Wq / pos.Wk (+ biases) are folded into row-periodic
 // fp32 bias matrices at plan-build time and q/k/v become ONE GEMM over x per layer.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <memory>
@@ -120,7 +121,7 @@ struct opd_detr {
     float* d_pv = nullptr;
     f16_t *d_x4 = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_m0 = nullptr,
           *d_m1 = nullptr, *d_sc = nullptr;
-    float *d_x32 = nullptr, *d_y32 = nullptr;
+    float *d_x32 = nullptr, *d_y32 = nullptr, *d_slab = nullptr;
     f16_t *d_x16 = nullptr, *d_qkv16 = nullptr, *d_attn16 = nullptr, *d_ffn16 = nullptr, *d_memkv16 = nullptr;
     float *d_h32 = nullptr, *d_yd32 = nullptr, *d_hs32 = nullptr;
     f16_t *d_h16 = nullptr, *d_qkvd16 = nullptr, *d_qd16 = nullptr, *d_attnd16 = nullptr, *d_ffnd16 = nullptr;
@@ -372,6 +373,7 @@ static int build_workspace(opd_detr* m) {
     const size_t D = a.d_model, Md = B * a.queries;
     RCCHK(dalloc(m, &m->d_x32, M * D, false));
     RCCHK(dalloc(m, &m->d_y32, M * D, false));
+    RCCHK(dalloc(m, &m->d_slab, std::max(M * D * 4, Md * D * 8), false));
     RCCHK(dalloc(m, &m->d_x16, M * D, false));
     RCCHK(dalloc(m, &m->d_qkv16, M * 3 * D, false));
     RCCHK(dalloc(m, &m->d_attn16, M * D, false));
@@ -490,7 +492,7 @@ static void timed_collect(opd_detr* m) {
 static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, int W, int OH, int OW, void* out, bool relu,
                     const f16_t* res16) {
     ConvGemmParams p{};
-    p.x = x; p.w = c.w; p.bias = c.bias; p.res16 = res16; p.res32 = nullptr; p.out = out; p.out16_aux = nullptr;
+    p.x = x; p.w = c.w; p.bias = c.bias; p.res16 = res16; p.res32 = nullptr; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = B; p.H = H; p.W = W; p.Cin = c.Cin; p.OH = OH; p.OW = OW; p.N = c.Cout; p.KH = c.KH; p.KW = c.KW;
     p.stride = c.stride; p.pad = c.pad; p.M = B * OH * OW; p.K = c.K; p.relu = relu ? 1 : 0; p.bias_period = 0;
     p.out_f32 = 0; p.stem = c.stem ? 1 : 0;
@@ -505,12 +507,28 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
 static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
                     void* out, bool out_f32, bool relu, const float* res32) {
     ConvGemmParams p{};
-    p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr;
+    p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0;
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
+    return OPD_OK;
+}
+
+// Split-K flavour for skinny / deep-K linears: slices write fp32 slabs, then ONE fused kernel reduces them in slice
+// order, adds the residual stream and applies the post-LayerNorm (gamma == nullptr: plain sum, e.g. input_projection).
+static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int N, int K, int splits,
+                              const float* res32, const LNp* ln, float* y32, f16_t* y16, int cls) {
+    ConvGemmParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.out = m->d_slab; p.zero16 = m->zero_bias;
+    p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.M = M; p.K = K; p.out_f32 = 1; p.split_k = splits;
+    RCCHK(timed_begin(m, cls, 2.0 * M * (double)N * K));
+    HIPCHK(opd_launch_conv_gemm(p, m->stream));
+    RCCHK(timed_end(m));
+    HIPCHK(opd_launch_reduce_ln(m->d_slab, splits, (size_t)M * N, res32, ln ? ln->g : nullptr, ln ? ln->b : nullptr, y32, y16, M,
+                                m->stream));
     return OPD_OK;
 }
 
@@ -569,15 +587,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     }
     // ---- input projection -> encoder ------------------------------------------------------------------------------
     const int hw = ch * cw, M = B * hw, D = a.d_model, F = a.ffn;
-    {
-        ConvGemmParams p{};
-        p.x = cur; p.w = m->proj.w; p.bias = m->proj.bias; p.out = m->d_x32; p.out16_aux = m->d_x16;
-        p.B = M; p.H = 1; p.W = 1; p.Cin = m->proj.Cin; p.OH = 1; p.OW = 1; p.N = D; p.KH = 1; p.KW = 1; p.stride = 1;
-        p.pad = 0; p.M = M; p.K = m->proj.K; p.relu = 0; p.bias_period = 0; p.out_f32 = 1; p.stem = 0;
-        RCCHK(timed_begin(m, CLS_CONV, 2.0 * M * (double)D * m->proj.K));
-        HIPCHK(opd_launch_conv_gemm(p, m->stream));
-        RCCHK(timed_end(m));
-    }
+    RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV));
     for (int i = 0; i < a.enc_layers; ++i) {
         const EncLayer& L = m->enc[i];
         RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr));
@@ -585,8 +595,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         RCCHK(run_gemm(m, m->d_attn16, L.o.w, L.o.b, 0, M, D, D, m->d_y32, true, false, m->d_x32));
         HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
         RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
-        RCCHK(run_gemm(m, m->d_ffn16, L.fc2.w, L.fc2.b, 0, M, D, F, m->d_y32, true, false, m->d_x32));
-        HIPCHK(opd_launch_layernorm(m->d_y32, L.ln2.g, L.ln2.b, m->d_x32, m->d_x16, M, m->stream));
+        RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM));
     }
     MARK(6);
     // ---- decoder -----------------------------------------------------------------------------------------------
@@ -598,16 +607,13 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         const DecLayer& L = m->dec[i];
         RCCHK(run_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qkvd16, 3 * D, m->d_qkvd16 + D, 3 * D, m->d_qkvd16 + 2 * D, 3 * D, m->d_attnd16, D, B, Q, Q));
-        RCCHK(run_gemm(m, m->d_attnd16, L.so.w, L.so.b, 0, Md, D, D, m->d_yd32, true, false, m->d_h32));
-        HIPCHK(opd_launch_layernorm(m->d_yd32, L.ln1.g, L.ln1.b, m->d_h32, m->d_h16, Md, m->stream));
+        RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, D, 4, m->d_h32, &L.ln1, m->d_h32, m->d_h16, CLS_GEMM));
         RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qd16, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
                        m->d_attnd16, D, B, Q, hw));
-        RCCHK(run_gemm(m, m->d_attnd16, L.co.w, L.co.b, 0, Md, D, D, m->d_yd32, true, false, m->d_h32));
-        HIPCHK(opd_launch_layernorm(m->d_yd32, L.ln2.g, L.ln2.b, m->d_h32, m->d_h16, Md, m->stream));
+        RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, D, 4, m->d_h32, &L.ln2, m->d_h32, m->d_h16, CLS_GEMM));
         RCCHK(run_gemm(m, m->d_h16, L.fc1.w, L.fc1.b, 0, Md, F, D, m->d_ffnd16, false, true, nullptr));
-        RCCHK(run_gemm(m, m->d_ffnd16, L.fc2.w, L.fc2.b, 0, Md, D, F, m->d_yd32, true, false, m->d_h32));
-        HIPCHK(opd_launch_layernorm(m->d_yd32, L.ln3.g, L.ln3.b, m->d_h32, m->d_h16, Md, m->stream));
+        RCCHK(run_gemm_splitk_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, D, F, 8, m->d_h32, &L.ln3, m->d_h32, m->d_h16, CLS_GEMM));
     }
     HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream));
     HeadParams hp{};
@@ -693,6 +699,7 @@ int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_
     if (cfg->struct_size != (int32_t)sizeof(opd_config)) return fail(OPD_EINVAL, "opd_config.struct_size mismatch");
     if (cfg->max_batch < 1 || cfg->max_height < 32 || cfg->max_width < 32) return fail(OPD_EINVAL, "opd_config maxima must be >= 1 x 32 x 32");
     *out = nullptr;
+    if (const char* v = getenv("OPD_GEMM_VARIANT")) opd_set_gemm_variant(atoi(v));  // A/B switch for benchmarking
     StateDict sd;
     std::string err;
     int rc = load_safetensors(weights_path, &sd, &err);
@@ -860,6 +867,11 @@ int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, dou
 }
 
 // ---- test / diagnostic hooks (not part of include/opd_detr.h; used by tests/test_kernels_gpu.py) ----------------------
+int opd_test_set_gemm_variant(int v) {
+    opd_set_gemm_variant(v);
+    return opd_get_gemm_variant();
+}
+
 int opd_test_set_tr_read(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->use_tr_read = on ? 1 : 0;

@@ -59,12 +59,45 @@ int opd_test_conv_gemm(const uint16_t* x, const uint16_t* w, const float* bias, 
     p.res32 = res32 ? dm.up(res32, M * N) : nullptr;
     const size_t obytes = M * N * (out_f32 ? 4 : 2);
     p.out = dm.up<unsigned char>(nullptr, obytes);
-    if (!p.x || !p.w || !p.bias || !p.out || (res16 && !p.res16) || (res32 && !p.res32)) return tfail(OPD_ENOMEM, "test alloc failed");
+    {
+        const uint32_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        p.zero16 = dm.up(zeros, 8);
+    }
+    if (!p.zero16 || !p.x || !p.w || !p.bias || !p.out || (res16 && !p.res16) || (res32 && !p.res32)) return tfail(OPD_ENOMEM, "test alloc failed");
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.K = K; p.relu = relu; p.bias_period = bias_period; p.out_f32 = out_f32; p.stem = stem;
     TCHK(opd_launch_conv_gemm(p, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(out, p.out, obytes, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// split-K linear + fused reduce / residual / LayerNorm: y = LN(x.W^T + bias + res) (gamma == null: no LN), N == 256
+int opd_test_gemm_splitk_ln(const uint16_t* x, const uint16_t* w, const float* bias, const float* res32, const float* gamma,
+                            const float* beta, float* y, uint16_t* y16, int M, int K, int splits) {
+    DevMem dm;
+    const int N = 256;
+    ConvGemmParams p{};
+    p.x = dm.up(x, (size_t)M * K);
+    p.w = dm.up(w, (size_t)N * K);
+    p.bias = dm.up(bias, N);
+    std::vector<float> zeros(N, 0.f);
+    p.zero16 = dm.up(zeros.data(), N);
+    float* slab = dm.up<float>(nullptr, (size_t)splits * M * N);
+    const float* dres = res32 ? dm.up(res32, (size_t)M * N) : nullptr;
+    const float* dg = gamma ? dm.up(gamma, N) : nullptr;
+    const float* db = beta ? dm.up(beta, N) : nullptr;
+    float* dy = dm.up<float>(nullptr, (size_t)M * N);
+    uint16_t* dy16 = dm.up<uint16_t>(nullptr, (size_t)M * N);
+    if (!p.x || !p.w || !p.bias || !p.zero16 || !slab || !dy || !dy16) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.out = slab;
+    p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+    p.M = M; p.K = K; p.out_f32 = 1; p.split_k = splits;
+    TCHK(opd_launch_conv_gemm(p, nullptr));
+    TCHK(opd_launch_reduce_ln(slab, splits, (size_t)M * N, dres, dg, db, dy, dy16, M, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, dy, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(y16, dy16, (size_t)M * N * 2, hipMemcpyDeviceToHost));
     return OPD_OK;
 }
 

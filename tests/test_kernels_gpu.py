@@ -22,6 +22,15 @@ def lib():
     return _capi.load_library()
 
 
+@pytest.fixture(params=[2, 1, 0], ids=["gemm_v3_pipe", "gemm_v2_dma", "gemm_v1_regstage"])
+def gemm_variant(request, lib):
+    """Every generation of the implicit-GEMM kernel stays under test: the default dispatch (v3 3-stage LDS-DMA pipeline
+    for deep K, v2 2-stage LDS-DMA otherwise), v2 alone, and v1 (register-staged, LDS epilogue)."""
+    lib.opd_test_set_gemm_variant(request.param)
+    yield request.param
+    lib.opd_test_set_gemm_variant(2)
+
+
 def _h(a):
     """fp32 array -> (fp16-rounded fp32 array, uint16 bit pattern)."""
     h = np.ascontiguousarray(a, dtype=np.float32).astype(np.float16)
@@ -72,11 +81,14 @@ CONV_CASES = [
     (1, 17, 21, 256, 512, 1, 2, False, False),  # strided shortcut
     (1, 7, 9, 512, 512, 3, 1, True, False),     # deep K (4608)
     (1, 100, 128, 128, 512, 1, 1, False, False),  # 400 tiles -> the BN=128 instantiation
+    (1, 160, 160, 256, 256, 1, 1, True, True),    # 200 256-row tiles, K=256 -> v3 <4,128>
+    (1, 226, 227, 256, 64, 1, 1, True, False),    # 201 256-row tiles, N=64 -> v3 <4,64>
+    (1, 30, 33, 128, 64, 3, 1, True, False),      # 3x3 N=64 deep K, few tiles -> v3 <2,64>
 ]
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_gemm_matches_torch(lib, case):
+def test_conv_gemm_matches_torch(lib, gemm_variant, case):
     B, H, W, Cin, N, k, stride, relu, use_res = case
     rng = np.random.default_rng(hash(case) % (2 ** 32))
     x, _ = _h(rng.standard_normal((B, H, W, Cin)))
@@ -92,7 +104,7 @@ def test_conv_gemm_matches_torch(lib, case):
     np.testing.assert_allclose(got, want, atol=1.5e-3 * scale, rtol=1e-3)
 
 
-def test_conv_gemm_integer_exact(lib):
+def test_conv_gemm_integer_exact(lib, gemm_variant):
     """Small-integer operands: every product and sum is exact in fp16/fp32 -> bit-exact; asymmetric weights catch a
     transposed fragment map (cdna_hip_programming.md §3: 'A=I-check with ASYMMETRIC B')."""
     rng = np.random.default_rng(5)
@@ -108,7 +120,21 @@ def test_conv_gemm_integer_exact(lib):
     np.testing.assert_array_equal(got, want)
 
 
-def test_gemm_rowbias_f32_residual(lib):
+def test_conv_residual_integer_exact(lib, gemm_variant):
+    """Residual + ReLU epilogue on integer data (exact): catches any mis-pairing in the permlane16_swap 16-byte
+    store / residual-load path of the v2 epilogue, including rows >= M of the last tile."""
+    rng = np.random.default_rng(6)
+    B, H, W, Cin, N = 1, 9, 15, 64, 256   # M = 135: one full tile + 7 rows
+    x = rng.integers(-2, 3, (B, H, W, Cin)).astype(np.float32)
+    w = rng.integers(-1, 2, (N, Cin, 1, 1)).astype(np.float32)
+    bias = (np.arange(N, dtype=np.float32) % 7) - 3
+    res = rng.integers(-20, 21, (B, H, W, N)).astype(np.float32)
+    got = run_conv(lib, x, w, bias, 1, 0, True, res)
+    want = ref_conv(x, w, bias, 1, 0, True, res)
+    np.testing.assert_array_equal(got, want)
+
+
+def test_gemm_rowbias_f32_residual(lib, gemm_variant):
     """Transformer flavour: out_f32 = x.W^T + rowbias[m % period] + res32 (pos-embedding fold, residual stream)."""
     rng = np.random.default_rng(11)
     M, K, N, period = 300, 256, 768, 100
@@ -119,6 +145,31 @@ def test_gemm_rowbias_f32_residual(lib):
     got = run_conv(lib, x, w, rb, 1, 0, False, res32=res, out_f32=True, bias_period=period).reshape(M, N)
     want = x.reshape(M, K) @ w.reshape(N, K).T + rb[np.arange(M) % period] + res
     np.testing.assert_allclose(got, want, atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,K,splits,ln", [(800, 256, 4, True), (800, 2048, 8, True), (1050, 2048, 4, True), (530, 2048, 4, False)])
+def test_gemm_splitk_reduce_ln(lib, M, K, splits, ln):
+    """Split-K slices + the fused deterministic reduce / residual / LayerNorm kernel (decoder and FFN-2 path)."""
+    rng = np.random.default_rng(M + K + splits)
+    x, xb = _h(rng.standard_normal((M, K)))
+    w, wb = _h(rng.standard_normal((256, K)) / np.sqrt(K))
+    bias = rng.standard_normal(256).astype(np.float32) * 0.1
+    res = rng.standard_normal((M, 256)).astype(np.float32)
+    g = rng.uniform(0.8, 1.2, 256).astype(np.float32)
+    b = (rng.standard_normal(256) * 0.05).astype(np.float32)
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    rc = lib.opd_test_gemm_splitk_ln(_p(xb), _p(wb), _p(bias), _p(res), _p(g) if ln else None, _p(b) if ln else None, _p(y), _p(y16),
+                                     M, K, splits)
+    _capi.check(rc, "opd_test_gemm_splitk_ln")
+    pre = torch.from_numpy(x @ w.T + bias + res)
+    want = F.layer_norm(pre, (256,), torch.from_numpy(g), torch.from_numpy(b), 1e-5).numpy() if ln else pre.numpy()
+    np.testing.assert_allclose(y, want, atol=3e-5, rtol=1e-5)
+    np.testing.assert_array_equal(y16.view(np.float16), y.astype(np.float16))
+    # deterministic: a second call gives the same bits
+    y2 = np.empty_like(y)
+    lib.opd_test_gemm_splitk_ln(_p(xb), _p(wb), _p(bias), _p(res), _p(g) if ln else None, _p(b) if ln else None, _p(y2), _p(y16), M, K, splits)
+    np.testing.assert_array_equal(y, y2)
 
 
 def test_stem_conv(lib):
