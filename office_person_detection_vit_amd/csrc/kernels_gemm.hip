@@ -22,7 +22,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-static int g_gemm_variant = 1;  // 0 = v1 register-staged, 1 = v2 LDS-DMA 2-stage, 2 = v2 + v3 3-stage pipeline for deep K (default)
+static int g_gemm_variant = 1;  // 0 = v1 register-staged, 1 = v2 LDS-DMA 2-stage (default), 2 = v2 + 3-stage 64-deep ring for deep K, 3 = v2 + 4-stage 32-deep ring
 
 namespace {
 
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         }
     };
     for (int ks = 0; ks + 1 < nk; ++ks) {
-        issue(ks + 1, (ks & 1) ^ 1);
-        compute(ks & 1);
+        if (p.dbg != 2) issue(ks + 1, (ks & 1) ^ 1);  // dbg: timing-only ablations (tools/microbench), never set by the model
+        if (p.dbg != 1) compute(ks & 1);
         __syncthreads();
     }
     prefetch_res16<NT>(p, res, wm0, wn0, lane);  // in flight during the last tile's MFMAs
@@ -541,19 +541,35 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_OUTSTANDING) : "memory");
 }
 
-template <int WM, int BN>
-__global__ __launch_bounds__(WM * 128) void conv_gemm_pipe_kernel(ConvGemmParams p) {
+// Generalised ring: tile (WM*64) x BN x BKT, NSTAGE LDS buffers, NSTAGE-1 tiles of DMA in flight across barriers.
+//   <4,128,64,3> / <4,64,64,3> / <2,128,64,3>: the 256- or 128-row 3-stage form, one workgroup per CU;
+//   <2,128,32,4> / <2,64,32,4>: 128-row tiles with 32-deep k-steps and a 4-deep ring — 64 / 48 KiB of LDS, so TWO (three)
+//   workgroups stay resident per CU and ~96 KiB of tile data is continuously in flight per CU.
+// LDS rows are BKT*2 bytes; the 16-byte-chunk XOR swizzle keeps ds_read_b128 fragment reads conflict free:
+//   128-byte rows: chunk ^= row & 7;   64-byte rows: chunk ^= (-(row >> 2)) & 3   (4 tile rows share a 256-byte bank row).
+template <int BKT>
+__device__ __forceinline__ int swz_t(int row, int chunk) {
+    if constexpr (BKT == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
+    else return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
+}
+
+template <int WM, int BN, int BKT, int NSTAGE>
+__global__ __launch_bounds__(WM * 128, (BKT == 32) ? 2 : 1) void conv_gemm_ring_kernel(ConvGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BMT = WM * 64;
     constexpr int NWAVES = WM * 2;
-    constexpr int A_BYTES = BMT * ROW_BYTES;
-    constexpr int B_BYTES = BN * ROW_BYTES;
+    constexpr int ROWB = BKT * 2;          // bytes per tile row
+    constexpr int RPP = 1024 / ROWB;       // tile rows per 1-KiB DMA piece
+    constexpr int CPR = ROWB / 16;         // 16-byte chunks per tile row
+    constexpr int A_BYTES = BMT * ROWB;
+    constexpr int B_BYTES = BN * ROWB;
     constexpr int STAGE = A_BYTES + B_BYTES;
     constexpr int NT = BN / 32;
-    constexpr int A_PIECES = (BMT / 8) / NWAVES;  // = 4
-    constexpr int B_PIECES = (BN / 8) / NWAVES;
+    constexpr int A_PIECES = (BMT / RPP) / NWAVES;
+    constexpr int B_PIECES = (BN / RPP) / NWAVES;
     constexpr int PER_STAGE = A_PIECES + B_PIECES;
-    static_assert(A_PIECES == 4 && B_PIECES >= 1, "piece split");
+    constexpr int KK = BKT / 32;
+    static_assert(A_PIECES >= 1 && B_PIECES >= 1 && NSTAGE >= 3 && NSTAGE <= 4, "ring geometry");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -567,8 +583,9 @@ __global__ __launch_bounds__(WM * 128) void conv_gemm_pipe_kernel(ConvGemmParams
     const int m_base = tile_m * BMT;
     const int n_base = tile_n * BN;
 
-    const int lrow = lane >> 3;
-    const int lchunk = (lane & 7) ^ lrow;
+    const int lrow = lane / CPR;
+    const int lslot = lane % CPR;
+    const int lchunk = (BKT == 64) ? (lslot ^ (lrow & 7)) : (lslot ^ ((0 - (lrow >> 2)) & 3));
     long long a_base[A_PIECES];
     int a_ih0[A_PIECES], a_iw0[A_PIECES];
     bool a_ok[A_PIECES];
@@ -576,7 +593,7 @@ __global__ __launch_bounds__(WM * 128) void conv_gemm_pipe_kernel(ConvGemmParams
         const int ohw = p.OH * p.OW;
 #pragma unroll
         for (int i = 0; i < A_PIECES; ++i) {
-            const int m = m_base + (wave * A_PIECES + i) * 8 + lrow;
+            const int m = m_base + (wave * A_PIECES + i) * RPP + lrow;
             a_ok[i] = m < p.M;
             const int mm = a_ok[i] ? m : 0;
             const int b = mm / ohw;
@@ -591,10 +608,10 @@ __global__ __launch_bounds__(WM * 128) void conv_gemm_pipe_kernel(ConvGemmParams
     const f16_t* wrow[B_PIECES];
 #pragma unroll
     for (int i = 0; i < B_PIECES; ++i)
-        wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K + lchunk * 8;
+        wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * RPP + lrow) * p.K + lchunk * 8;
 
-    const int nk = p.K / BK;
-    const int kpc = p.Cin / BK;
+    const int nk = p.K / BKT;
+    const int kpc = p.Cin / BKT;
     int tap_kh = 0, tap_kw = 0, tap_c = 0;
 
     auto issue = [&](int ks, int buf) {
@@ -605,70 +622,76 @@ __global__ __launch_bounds__(WM * 128) void conv_gemm_pipe_kernel(ConvGemmParams
             const int ih = a_ih0[i] + tap_kh;
             const int iw = a_iw0[i] + tap_kw;
             const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BK + lchunk * 8
+            const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BKT + lchunk * 8
                                   : reinterpret_cast<const f16_t*>(p.zero16);
             dma16(src, As + (wave * A_PIECES + i) * 1024);
         }
 #pragma unroll
-        for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BK, Bs + (wave * B_PIECES + i) * 1024);
+        for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BKT, Bs + (wave * B_PIECES + i) * 1024);
         if (++tap_c == kpc) {
             tap_c = 0;
             if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
         }
     };
 
-    issue(0, 0);
-    if (nk > 1) issue(1, 1);
+#pragma unroll
+    for (int st = 0; st < NSTAGE - 1; ++st)
+        if (st < nk) issue(st, st);
     float4v acc[NT][4];
     init_acc_bias<NT>(p, p.bias, acc, m_base + wm * 64, n_base + wn * (BN / 2), lane);
     uint4 res[NT][2];
 
     const int frow = lane & 15;
     const int fchk = lane >> 4;
-    int buf = 0, buf_next2 = 2;
+    int buf = 0, buf_issue = NSTAGE - 1;
     for (int ks = 0; ks < nk; ++ks) {
-        if (ks + 1 < nk) wait_vmcnt<PER_STAGE>(); else wait_vmcnt<0>();
+        // tiles ks+1 .. ks+NSTAGE-2 may still be in flight; tile ks must have landed
+        const int ahead = nk - 1 - ks;  // tiles issued after tile ks
+        if (ahead >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * PER_STAGE>();
+        else if (NSTAGE == 4 && ahead == 1) wait_vmcnt<PER_STAGE>();
+        else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ks + 2 < nk) issue(ks + 2, buf_next2);
+        if (ks + NSTAGE - 1 < nk && p.dbg != 2) issue(ks + NSTAGE - 1, buf_issue);
         if (ks + 1 == nk) prefetch_res16<NT>(p, res, m_base + wm * 64, n_base + wn * (BN / 2), lane);
         const unsigned char* As = smem + buf * STAGE;
         const unsigned char* Bs = As + A_BYTES;
+        if (p.dbg != 1)
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < KK; ++kk) {
             half8 xf[4], wf[NT];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * 64 + mt * 16 + frow, kk * 4 + fchk));
+                xf[mt] = *reinterpret_cast<const half8*>(As + swz_t<BKT>(wm * 64 + mt * 16 + frow, kk * 4 + fchk));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
+                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz_t<BKT>(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 4; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         }
-        buf = (buf == 2) ? 0 : buf + 1;
-        buf_next2 = (buf_next2 == 2) ? 0 : buf_next2 + 1;
+        buf = (buf == NSTAGE - 1) ? 0 : buf + 1;
+        buf_issue = (buf_issue == NSTAGE - 1) ? 0 : buf_issue + 1;
     }
 
     epilogue_regs<NT>(p, p.out, acc, res, m_base + wm * 64, n_base + wn * (BN / 2), lane);
 }
 
-template <int WM, int BN>
-hipError_t launch_pipe(const ConvGemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 3 * (WM * 64 + BN) * ROW_BYTES;
+template <int WM, int BN, int BKT, int NSTAGE>
+hipError_t launch_ring(const ConvGemmParams& p, hipStream_t stream) {
+    constexpr int LDS = NSTAGE * (WM * 64 + BN) * BKT * 2;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_pipe_kernel<WM, BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_ring_kernel<WM, BN, BKT, NSTAGE>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
     const int tiles_m = (p.M + WM * 64 - 1) / (WM * 64);
     const int tiles_n = p.N / BN;
-    hipLaunchKernelGGL((conv_gemm_pipe_kernel<WM, BN>), dim3(tiles_m * tiles_n), dim3(WM * 128), LDS, stream, p);
+    hipLaunchKernelGGL((conv_gemm_ring_kernel<WM, BN, BKT, NSTAGE>), dim3(tiles_m * tiles_n), dim3(WM * 128), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -713,11 +736,14 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     if (g_gemm_variant >= 1) {
         if (!p.zero16) return hipErrorInvalidValue;
         const int nk = p.K / BK;
-        if (g_gemm_variant >= 2 && nk >= 3) {  // deep K: 3-stage pipeline, one workgroup per CU
+        if (g_gemm_variant == 2 && nk >= 3) {  // 3-stage 64-deep ring, one workgroup per CU
             const bool n128 = (p.N % 128) == 0;
             const long long blocks256 = (long long)((p.M + 255) / 256) * (p.N / (n128 ? 128 : 64));
-            if (blocks256 >= 200) return n128 ? launch_pipe<4, 128>(p, stream) : launch_pipe<4, 64>(p, stream);
-            return n128 ? launch_pipe<2, 128>(p, stream) : launch_pipe<2, 64>(p, stream);
+            if (blocks256 >= 200) return n128 ? launch_ring<4, 128, 64, 3>(p, stream) : launch_ring<4, 64, 64, 3>(p, stream);
+            return n128 ? launch_ring<2, 128, 64, 3>(p, stream) : launch_ring<2, 64, 64, 3>(p, stream);
+        }
+        if (g_gemm_variant == 3 && nk >= 2) {  // 4-stage 32-deep ring, two / three workgroups per CU
+            return wide ? launch_ring<2, 128, 32, 4>(p, stream) : launch_ring<2, 64, 32, 4>(p, stream);
         }
         return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);
     }

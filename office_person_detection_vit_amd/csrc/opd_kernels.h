@@ -20,6 +20,7 @@ struct ConvGemmParams {
     int B, H, W, Cin, OH, OW, N, KH, KW, stride, pad;
     int M, K;
     int relu, bias_period, out_f32, stem;
+    int dbg;             // timing ablation for tools (0 = normal; 1 = skip MFMAs, 2 = skip all but the first tile DMA)
     int split_k;         // > 1: K is cut into split_k slices, slice z writes fp32 partials to out + z*M*N (bias in slice 0)
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);

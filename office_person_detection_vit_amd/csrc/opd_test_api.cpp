@@ -101,6 +101,45 @@ int opd_test_gemm_splitk_ln(const uint16_t* x, const uint16_t* w, const float* b
     return OPD_OK;
 }
 
+// Times one conv_gemm launch shape on device-resident random data (no host copies): average microseconds over `iters`.
+int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride, int with_res, int variant, int dbg, int iters,
+                        float* us_out) {
+    DevMem dm;
+    const int pad = KH / 2, OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+    const size_t M = (size_t)B * OH * OW, K = (size_t)KH * KH * Cin;
+    ConvGemmParams p{};
+    uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)B * H * W * Cin);
+    uint16_t* w = dm.up<uint16_t>(nullptr, (size_t)N * K);
+    float* bias = dm.up<float>(nullptr, N);
+    uint16_t* res = with_res ? dm.up<uint16_t>(nullptr, M * N) : nullptr;
+    uint16_t* out = dm.up<uint16_t>(nullptr, M * N);
+    float* zero = dm.up<float>(nullptr, 4096);
+    if (!x || !w || !bias || !out || !zero || (with_res && !res)) return tfail(OPD_ENOMEM, "bench alloc failed");
+    TCHK(hipMemset(x, 0x2c, (size_t)B * H * W * Cin * 2));  // fp16 0x2c2c ~ 0.065
+    TCHK(hipMemset(w, 0x1c, (size_t)N * K * 2));
+    TCHK(hipMemset(bias, 0, (size_t)N * 4));
+    TCHK(hipMemset(zero, 0, 4096 * 4));
+    if (res) TCHK(hipMemset(res, 0x2c, M * N * 2));
+    p.x = x; p.w = w; p.bias = bias; p.res16 = res; p.out = out; p.zero16 = zero;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KH; p.stride = stride; p.pad = pad;
+    p.M = (int)M; p.K = (int)K; p.relu = 1; p.dbg = dbg;
+    const int old = opd_get_gemm_variant();
+    opd_set_gemm_variant(variant);
+    hipEvent_t a, b;
+    TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
+    for (int i = 0; i < 2; ++i) TCHK(opd_launch_conv_gemm(p, nullptr));
+    TCHK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) TCHK(opd_launch_conv_gemm(p, nullptr));
+    TCHK(hipEventRecord(b, nullptr));
+    TCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    TCHK(hipEventElapsedTime(&ms, a, b));
+    opd_set_gemm_variant(old);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *us_out = ms * 1000.f / iters;
+    return OPD_OK;
+}
+
 int opd_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int B, int heads, int Lq, int Lk,
                        float scale, int use_tr_read) {
     DevMem dm;

@@ -22,13 +22,13 @@ def lib():
     return _capi.load_library()
 
 
-@pytest.fixture(params=[2, 1, 0], ids=["gemm_v3_pipe", "gemm_v2_dma", "gemm_v1_regstage"])
+@pytest.fixture(params=[3, 2, 1, 0], ids=["gemm_ring4x32", "gemm_ring3x64", "gemm_v2_dma", "gemm_v1_regstage"])
 def gemm_variant(request, lib):
     """Every generation of the implicit-GEMM kernel stays under test: the default dispatch (v3 3-stage LDS-DMA pipeline
     for deep K, v2 2-stage LDS-DMA otherwise), v2 alone, and v1 (register-staged, LDS epilogue)."""
     lib.opd_test_set_gemm_variant(request.param)
     yield request.param
-    lib.opd_test_set_gemm_variant(2)
+    lib.opd_test_set_gemm_variant(1)
 
 
 def _h(a):
