@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     float4v oacc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
 
     const int ntiles = (p.Lk + KT - 1) / KT;
+    const float scale2 = p.scale * 1.44269504088896340736f;  // scores are kept pre-multiplied by log2(e)
     load_tile(0);
     store_tile(0);
     __syncthreads();
@@ -91,28 +92,38 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             const half8 kf = *reinterpret_cast<const half8*>(Kl + (kt * 16 + li) * LDS_ROW + g * 16);
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        // ---- online softmax (fp32) ------------------------------------------------------------------------------
+        // ---- online softmax (fp32, base-2 domain: exp(x) = exp2(x * log2 e), one v_exp_f32 per score) ------------------
         float mx = -INFINITY;
+        if (t + 1 < ntiles) {  // full tile: no key masking needed
 #pragma unroll
-        for (int kt = 0; kt < 4; ++kt)
+            for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int key = t * KT + kt * 16 + g * 4 + r;
-                float v = s[kt][r] * p.scale;
-                v = key < p.Lk ? v : -INFINITY;
-                s[kt][r] = v;
-                mx = fmaxf(mx, v);
-            }
+                for (int r = 0; r < 4; ++r) {
+                    const float v = s[kt][r] * scale2;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        } else {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * KT + kt * 16 + g * 4 + r;
+                    const float v = key < p.Lk ? s[kt][r] * scale2 : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);  // finite: tile 0 always holds key 0
-        const float alpha = expf(m_run - m_new);
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = expf(s[kt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
                 s[kt][r] = e;
                 psum += e;
             }

@@ -22,6 +22,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+static int g_strip3x3 = 1;      // 3x3 stride-1 convolutions use the row-strip kernel (0: plain im2col tiles)
 static int g_gemm_variant = 1;  // 0 = v1 register-staged, 1 = v2 LDS-DMA 2-stage (default), 2 = v2 + 3-stage 64-deep ring for deep K, 3 = v2 + 4-stage 32-deep ring
 
 namespace {
@@ -695,6 +696,160 @@ hipError_t launch_ring(const ConvGemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3x3 stride-1 "row strip" kernel.  In flattened NHWC order the im2col tile of filter tap (kh, kw+1) is the tile of
+// tap (kh, kw) shifted by ONE row, so instead of staging a fresh 128-row tile per tap (v2: 9 activation tiles per 64
+// channels) a strip of 128+2 consecutive pixels is staged once per (kh, 64-channel chunk) and the three kw taps read
+// it at row offsets 0/1/2.  Pixels that wrap over an image-row or image boundary are zeroed per lane when the
+// fragment is read (the zero padding of the convolution).  Activation staging traffic drops 3x — it is the part that
+// comes from beyond L2 (DESIGN.md "what bounds the GEMM"); weight tiles still stream per tap (L2-resident).
+// k-step order: (kh, cin-chunk, kw) with kw fastest; weights keep the [n][kh][kw][cin] layout.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3s1_strip_kernel(ConvGemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int NT = BN / 32;
+    constexpr int B_PIECES = BN / 32;
+    constexpr int A_ROWS = 136;                 // 17 DMA pieces: 128 + 2 halo rows, rounded up to whole pieces
+    constexpr int A_BYTES = A_ROWS * ROW_BYTES;
+    constexpr int B_BYTES = BN * ROW_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g4 = lane >> 4, li = lane & 15;
+
+    const int tiles_n = p.N / BN;
+    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int tile_n = lbid % tiles_n;
+    const int tile_m = lbid / tiles_n;
+    const int m_base = tile_m * BM;
+    const int n_base = tile_n * BN;
+
+    unsigned char* Abuf = smem;
+    unsigned char* Bbuf = smem + 2 * A_BYTES;
+
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const long long total_px = (long long)p.B * p.H * p.W;
+    const f16_t* wrow[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i)
+        wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K + lchunk * 8;
+
+    // per-lane validity of the 9 taps for the 4 output pixels this lane feeds (bit kh*3+kw)
+    int okmask[4];
+    {
+        const int ohw = p.H * p.W;
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m_base + wm * 64 + mt * 16 + li;
+            int mask = 0;
+            if (m < p.M) {
+                const int r = m % ohw;
+                const int oh = r / p.W, ow = r - oh * p.W;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw)
+                        if ((unsigned)(oh + kh - 1) < (unsigned)p.H && (unsigned)(ow + kw - 1) < (unsigned)p.W) mask |= 1 << (kh * 3 + kw);
+            }
+            okmask[mt] = mask;
+        }
+    }
+
+    const int kpc = p.Cin / BK;
+    const int nk = 9 * kpc;
+
+    auto issue = [&](int s) {
+        const int kw = s % 3, grp = s / 3;
+        const int kh = grp / kpc, cc = grp - kh * kpc;
+        unsigned char* Bs = Bbuf + (s & 1) * B_BYTES;
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            dma16(wrow[i] + (size_t)((kh * 3 + kw) * p.Cin + cc * BK), Bs + (wave * B_PIECES + i) * 1024);
+        if (kw == 0) {  // new strip: input pixels m_base-1 .. m_base+134 shifted by (kh-1) image rows
+            unsigned char* As = Abuf + (grp & 1) * A_BYTES;
+            const long long pix0 = (long long)m_base - 1 + (long long)(kh - 1) * p.W + lrow;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int q = wave + 4 * i;
+                const long long pix = pix0 + q * 8;
+                const f16_t* src = (pix >= 0 && pix < total_px) ? p.x + pix * p.Cin + cc * BK + lchunk * 8
+                                                                : reinterpret_cast<const f16_t*>(p.zero16);
+                dma16(src, As + q * 1024);
+            }
+            if (wave == 0) {
+                const long long pix = pix0 + 16 * 8;
+                const f16_t* src = (pix >= 0 && pix < total_px) ? p.x + pix * p.Cin + cc * BK + lchunk * 8
+                                                                : reinterpret_cast<const f16_t*>(p.zero16);
+                dma16(src, As + 16 * 1024);
+            }
+        }
+    };
+
+    const int wm0 = m_base + wm * 64, wn0 = n_base + wn * (BN / 2);
+    issue(0);
+    float4v acc[NT][4];
+    init_acc_bias<NT>(p, p.bias, acc, wm0, wn0, lane);
+    uint4 res[NT][2];
+    __syncthreads();
+
+    auto compute = [&](int s) {
+        const int kw = s % 3, grp = s / 3;
+        const int tapbit = (grp / kpc) * 3 + kw;
+        const unsigned char* As = Abuf + (grp & 1) * A_BYTES;
+        const unsigned char* Bs = Bbuf + (s & 1) * B_BYTES;
+        bool ok[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) ok[mt] = (okmask[mt] >> tapbit) & 1;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[4], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const half8 v = *reinterpret_cast<const half8*>(As + swz(wm * 64 + mt * 16 + li + kw, kk * 4 + g4));
+                half8 z;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) z[j] = ok[mt] ? v[j] : (_Float16)0.f;
+                xf[mt] = z;
+            }
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + li, kk * 4 + g4));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    };
+    for (int s = 0; s + 1 < nk; ++s) {
+        issue(s + 1);
+        compute(s);
+        __syncthreads();
+    }
+    prefetch_res16<NT>(p, res, wm0, wn0, lane);
+    compute(nk - 1);
+    epilogue_regs<NT>(p, p.out, acc, res, wm0, wn0, lane);
+}
+
+template <int BN>
+hipError_t launch_strip(const ConvGemmParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * 136 * ROW_BYTES + 2 * BN * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s1_strip_kernel<BN>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    const int tiles_m = (p.M + BM - 1) / BM;
+    hipLaunchKernelGGL((conv3x3s1_strip_kernel<BN>), dim3(tiles_m * (p.N / BN)), dim3(256), LDS, stream, p);
+    return hipGetLastError();
+}
+
 template <int BN, bool STEM>
 hipError_t launch(const ConvGemmParams& p, hipStream_t stream) {
     using S = Smem<BN>;
@@ -736,6 +891,8 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     if (g_gemm_variant >= 1) {
         if (!p.zero16) return hipErrorInvalidValue;
         const int nk = p.K / BK;
+        if (g_strip3x3 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && p.dbg == 0)
+            return wide ? launch_strip<128>(p, stream) : launch_strip<64>(p, stream);
         if (g_gemm_variant == 2 && nk >= 3) {  // 3-stage 64-deep ring, one workgroup per CU
             const bool n128 = (p.N % 128) == 0;
             const long long blocks256 = (long long)((p.M + 255) / 256) * (p.N / (n128 ? 128 : 64));
@@ -750,5 +907,5 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     return wide ? launch<128, false>(p, stream) : launch<64, false>(p, stream);
 }
 
-void opd_set_gemm_variant(int v) { g_gemm_variant = v; }
-int opd_get_gemm_variant() { return g_gemm_variant; }
+void opd_set_gemm_variant(int v) { g_gemm_variant = v & 15; g_strip3x3 = (v & 16) ? 0 : 1; }
+int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 0 : 16); }

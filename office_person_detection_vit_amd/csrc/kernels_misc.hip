@@ -166,7 +166,8 @@ __global__ void gemm_f32_kernel(const float* __restrict__ A, const float* __rest
     C[(size_t)m * ldc + n] = acc + (bias ? bias[n] : 0.f);
 }
 
-// Heads: one 256-thread block per decoder row; fp32 throughout (0.03 GFLOP/frame).
+// Heads: one 256-thread block per decoder row; fp32 throughout (0.03 GFLOP/frame).  Weights are stored TRANSPOSED
+// ([in][out]) so that thread t (= output t) reads wt[k*N + t]: consecutive lanes touch consecutive addresses.
 __global__ __launch_bounds__(256) void heads_kernel(HeadParams p) {
     __shared__ float h[256];
     __shared__ float t1[256];
@@ -176,31 +177,27 @@ __global__ __launch_bounds__(256) void heads_kernel(HeadParams p) {
     h[t] = p.hs[(size_t)row * 256 + t];
     __syncthreads();
     if (t < p.ncls) {
-        const float* w = p.wc + (size_t)t * 256;
         float acc = 0.f;
-        for (int k = 0; k < 256; ++k) acc = fmaf(h[k], w[k], acc);
+        for (int k = 0; k < 256; ++k) acc = fmaf(h[k], p.wc[k * p.ncls + t], acc);
         p.logits[(size_t)row * p.ncls + t] = acc + p.bc[t];
     }
     {
-        const float* w = p.w1 + (size_t)t * 256;
         float acc = 0.f;
-        for (int k = 0; k < 256; ++k) acc = fmaf(h[k], w[k], acc);
+        for (int k = 0; k < 256; ++k) acc = fmaf(h[k], p.w1[k * 256 + t], acc);
         acc += p.b1[t];
         t1[t] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
     {
-        const float* w = p.w2 + (size_t)t * 256;
         float acc = 0.f;
-        for (int k = 0; k < 256; ++k) acc = fmaf(t1[k], w[k], acc);
+        for (int k = 0; k < 256; ++k) acc = fmaf(t1[k], p.w2[k * 256 + t], acc);
         acc += p.b2[t];
         t2[t] = acc > 0.f ? acc : 0.f;
     }
     __syncthreads();
     if (t < 4) {
-        const float* w = p.w3 + (size_t)t * 256;
         float acc = 0.f;
-        for (int k = 0; k < 256; ++k) acc = fmaf(t2[k], w[k], acc);
+        for (int k = 0; k < 256; ++k) acc = fmaf(t2[k], p.w3[k * 4 + t], acc);
         acc += p.b3[t];
         p.boxes[(size_t)row * 4 + t] = 1.0f / (1.0f + expf(-acc));
     }

@@ -24,7 +24,8 @@ struct ConvGemmParams {
     int split_k;         // > 1: K is cut into split_k slices, slice z writes fp32 partials to out + z*M*N (bias in slice 0)
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
-void opd_set_gemm_variant(int v);  // 0 = register-staged v1, 1 = LDS-DMA v2 (default)
+void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LDS-DMA v2 (default), 2/3 = ring variants;
+                                   // +16 disables the 3x3 row-strip kernel (plain im2col tiles instead)
 int opd_get_gemm_variant();
 
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
@@ -46,7 +47,8 @@ hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t s
 // naive fp32 GEMM used once at plan-build time: C[m][n] = sum_k A[m][k]*Wt[n][k] + bias[n]  (Wt fp32 [N][K])
 hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K,
                                int ldc, hipStream_t stream);
-// heads: logits = hs*Wc^T+bc ; boxes = sigmoid(W3 relu(W2 relu(W1 hs))) ; one block per (b, query); fp32 weights.
+// heads: logits = hs*Wc^T+bc ; boxes = sigmoid(W3 relu(W2 relu(W1 hs))) ; one block per (b, query); fp32 weights,
+// passed TRANSPOSED ([in = 256][out]).
 struct HeadParams {
     const float* hs;  // [rows][256]
     const float *wc, *bc, *w1, *b1, *w2, *b2, *w3, *b3;

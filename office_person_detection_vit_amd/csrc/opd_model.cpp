@@ -324,13 +324,21 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
     }
     RCCHK(upload_f16(m, &m->wkv_all, kv_full));
     RCCHK(make_ln(m, sd, "model.decoder.layernorm", &m->dec_ln));
-    RCCHK(upload_f32(m, &m->wc, T(sd, "class_labels_classifier.weight").data));
+    auto transposed = [&](const std::string& key) {  // [out][in] -> [in][out] (coalesced reads in heads_kernel)
+        const HostTensor& w = T(sd, key);
+        const int O = (int)w.shape[0], I = (int)w.shape[1];
+        std::vector<float> t((size_t)O * I);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i) t[(size_t)i * O + o] = w.data[(size_t)o * I + i];
+        return t;
+    };
+    RCCHK(upload_f32(m, &m->wc, transposed("class_labels_classifier.weight")));
     RCCHK(upload_f32(m, &m->bc, T(sd, "class_labels_classifier.bias").data));
-    RCCHK(upload_f32(m, &m->w1, T(sd, "bbox_predictor.layers.0.weight").data));
+    RCCHK(upload_f32(m, &m->w1, transposed("bbox_predictor.layers.0.weight")));
     RCCHK(upload_f32(m, &m->b1, T(sd, "bbox_predictor.layers.0.bias").data));
-    RCCHK(upload_f32(m, &m->w2, T(sd, "bbox_predictor.layers.1.weight").data));
+    RCCHK(upload_f32(m, &m->w2, transposed("bbox_predictor.layers.1.weight")));
     RCCHK(upload_f32(m, &m->b2, T(sd, "bbox_predictor.layers.1.bias").data));
-    RCCHK(upload_f32(m, &m->w3, T(sd, "bbox_predictor.layers.2.weight").data));
+    RCCHK(upload_f32(m, &m->w3, transposed("bbox_predictor.layers.2.weight")));
     RCCHK(upload_f32(m, &m->b3, T(sd, "bbox_predictor.layers.2.bias").data));
     RCCHK(upload_f32(m, &m->zero_bias, std::vector<float>(4096, 0.f)));
     HIPCHK(hipStreamSynchronize(m->stream));

@@ -22,7 +22,7 @@ def lib():
     return _capi.load_library()
 
 
-@pytest.fixture(params=[3, 2, 1, 0], ids=["gemm_ring4x32", "gemm_ring3x64", "gemm_v2_dma", "gemm_v1_regstage"])
+@pytest.fixture(params=[1, 17, 3, 2, 0], ids=["gemm_v2_dma+strip3x3", "gemm_v2_dma_im2col", "gemm_ring4x32", "gemm_ring3x64", "gemm_v1_regstage"])
 def gemm_variant(request, lib):
     """Every generation of the implicit-GEMM kernel stays under test: the default dispatch (v3 3-stage LDS-DMA pipeline
     for deep K, v2 2-stage LDS-DMA otherwise), v2 alone, and v1 (register-staged, LDS epilogue)."""
@@ -84,6 +84,9 @@ CONV_CASES = [
     (1, 160, 160, 256, 256, 1, 1, True, True),    # 200 256-row tiles, K=256 -> v3 <4,128>
     (1, 226, 227, 256, 64, 1, 1, True, False),    # 201 256-row tiles, N=64 -> v3 <4,64>
     (1, 30, 33, 128, 64, 3, 1, True, False),      # 3x3 N=64 deep K, few tiles -> v3 <2,64>
+    (3, 11, 7, 64, 128, 3, 1, True, False),       # 3x3 on images NARROWER than the 128-pixel tile: several rows and
+                                                  # image boundaries inside one strip (exercises the per-lane tap masks)
+    (2, 50, 84, 256, 256, 3, 1, True, False),     # stage-3 3x3 shape at batch 2
 ]
 
 
