@@ -22,7 +22,8 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-static int g_strip3x3 = 1;      // 3x3 stride-1 convolutions use the row-strip kernel (0: plain im2col tiles)
+static int g_buffer_staging = 1;  // tile DMA through buffer descriptors (scalar tap offsets, bounds-check zero fill)
+static int g_strip3x3 = 0;      // 3x3 stride-1 convolutions use the row-strip kernel (0: plain im2col tiles)
 static int g_gemm_variant = 1;  // 0 = v1 register-staged, 1 = v2 LDS-DMA 2-stage (default), 2 = v2 + 3-stage 64-deep ring for deep K, 3 = v2 + 4-stage 32-deep ring
 
 namespace {
@@ -387,8 +388,14 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
     }
 }
 
-template <int BN>
+// BUF = true stages through BUFFER descriptors (`buffer_load_dwordx4 ... offen lds`): the per-lane part of an address is
+// a 32-bit row offset computed ONCE, the filter-tap / channel-chunk displacement is a scalar (SGPR soffset), and padding
+// or rows >= M are expressed by an out-of-range offset, which the descriptor's bounds check turns into zeros.  The
+// flat-pointer form (BUF = false) spends ~25 VALU/SALU instructions per 1-KiB piece on 64-bit address arithmetic and
+// zero-page selects — at 8 pieces per k-step that, not the MFMAs or the memory system, paced the k-loop.
+template <int BN, bool BUF>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type and builtins exist only in the gfx950 pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     using S = Smem<BN>;
     constexpr int NT = BN / 32;
@@ -443,30 +450,88 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     for (int i = 0; i < B_PIECES; ++i)
         wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K + lchunk * 8;
 
+    // ---- BUF: descriptors + per-lane 32-bit offsets + per-row tap-validity masks ---------------------------------------
+    // activation descriptor is based `backoff` bytes BEFORE the tensor so that every in-image tap has a non-negative
+    // offset: byte(ih, iw) = rowoff (centre-less pixel (oh*s, ow*s)) + soff(tap) with soff >= 0.
+    const unsigned backoff = (unsigned)(p.pad * p.W + p.pad) * (unsigned)p.Cin * 2u;
+    __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
+    unsigned rowoff[4], rowmask[4], woff[B_PIECES];
+    if constexpr (BUF) {
+        const unsigned a_bytes = (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 2) + backoff;
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - backoff, 0, a_bytes, 0x00020000);
+        rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + (wave * 4 + i) * 8 + lrow;
+            const bool okm = m < p.M;
+            const int mm = okm ? m : 0;
+            const int b = mm / ohw;
+            const int r = mm - b * ohw;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            rowoff[i] = (unsigned)(((b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.Cin) * 2u + (unsigned)lchunk * 16u;
+            unsigned mask = 0;
+            for (int kh = 0; kh < p.KH; ++kh)
+                for (int kw = 0; kw < p.KW; ++kw)
+                    if (okm && (unsigned)(oh * p.stride - p.pad + kh) < (unsigned)p.H && (unsigned)(ow * p.stride - p.pad + kw) < (unsigned)p.W)
+                        mask |= 1u << (kh * p.KW + kw);
+            rowmask[i] = mask;
+        }
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            woff[i] = (unsigned)((n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
+    }
+
     const int kpc = p.Cin / BK;
     const int nk_all = p.K / BK;
     const int nk = p.split_k > 1 ? nk_all / p.split_k : nk_all;  // k-steps of this slice
     const int ks0 = zsplit * nk;
-    int tap_kh = (ks0 / kpc) / p.KW, tap_kw = (ks0 / kpc) % p.KW, tap_c = ks0 % kpc;
+    // k-steps are visited in a rotated order (start at `rot`, wrap inside the slice): workgroups that share weight rows
+    // then pull DIFFERENT 16-KiB weight tiles at any instant instead of all hammering the same few L2 channels.
+    const int rot = (p.dbg & 4) ? 0 : (int)((unsigned)(tile_m * 5 + tile_n * 3) % (unsigned)nk);
+    int ks_cur = ks0 + rot;
+    int tap_kh = (ks_cur / kpc) / p.KW, tap_kw = (ks_cur / kpc) % p.KW, tap_c = ks_cur % kpc;
 
-    auto issue = [&](int ks_rel, int buf) {
-        const int ks = ks0 + ks_rel;
+    auto issue = [&](int, int buf) {
+        const int ks = ks_cur;
         unsigned char* As = smem + buf * S::STAGE;
         unsigned char* Bs = As + S::A_BYTES;
+        if constexpr (BUF) {
+            const int tap = tap_kh * p.KW + tap_kw;
+            const int soff_a = ((tap_kh * p.W + tap_kw) * p.Cin + tap_c * BK) * 2;  // scalar displacement of this tap / chunk
+            if (!(p.dbg & 8))
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int ih = a_ih0[i] + tap_kh;
-            const int iw = a_iw0[i] + tap_kw;
-            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BK + lchunk * 8
-                                  : reinterpret_cast<const f16_t*>(p.zero16);
-            dma16(src, As + (wave * 4 + i) * 1024);
+            for (int i = 0; i < 4; ++i) {
+                const unsigned vo = ((rowmask[i] >> tap) & 1u) ? rowoff[i] : 0x80000000u;  // out of range -> zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * 4 + i) * 1024),
+                                                         16, vo, soff_a, 0, 0);
+            }
+            if (!(p.dbg & 16))
+#pragma unroll
+            for (int i = 0; i < B_PIECES; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (wave * B_PIECES + i) * 1024),
+                                                         16, woff[i], ks * (BK * 2), 0, 0);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int ih = a_ih0[i] + tap_kh;
+                const int iw = a_iw0[i] + tap_kw;
+                const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+                const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BK + lchunk * 8
+                                      : reinterpret_cast<const f16_t*>(p.zero16);
+                dma16(src, As + (wave * 4 + i) * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BK, Bs + (wave * B_PIECES + i) * 1024);
         }
-#pragma unroll
-        for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BK, Bs + (wave * B_PIECES + i) * 1024);
         if (++tap_c == kpc) {
             tap_c = 0;
             if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
+        }
+        if (++ks_cur == ks0 + nk) {  // wrap to the first k-step of this slice
+            ks_cur = ks0;
+            tap_kh = (ks0 / kpc) / p.KW; tap_kw = (ks0 / kpc) % p.KW; tap_c = ks0 % kpc;
         }
     };
 
@@ -499,21 +564,22 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         }
     };
     for (int ks = 0; ks + 1 < nk; ++ks) {
-        if (p.dbg != 2) issue(ks + 1, (ks & 1) ^ 1);  // dbg: timing-only ablations (tools/microbench), never set by the model
-        if (p.dbg != 1) compute(ks & 1);
+        if ((p.dbg & 3) != 2) issue(ks + 1, (ks & 1) ^ 1);  // dbg: timing-only ablations (tools/microbench), never set by the model
+        if ((p.dbg & 3) != 1) compute(ks & 1);
         __syncthreads();
     }
     prefetch_res16<NT>(p, res, wm0, wn0, lane);  // in flight during the last tile's MFMAs
     compute((nk - 1) & 1);
     epilogue_regs<NT>(p, out_ptr, acc, res, wm0, wn0, lane);
+#endif
 }
 
-template <int BN>
-hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
+template <int BN, bool BUF>
+hipError_t launch_dma_t(const ConvGemmParams& p, hipStream_t stream) {
     using S = Smem<BN>;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S::STAGE);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -521,8 +587,16 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
     const int tiles_m = (p.M + BM - 1) / BM;
     const int tiles_n = p.N / BN;
     const int splits = p.split_k > 1 ? p.split_k : 1;
-    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN>), dim3(tiles_m * tiles_n * splits), dim3(256), 2 * S::STAGE, stream, p);
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF>), dim3(tiles_m * tiles_n * splits), dim3(256), 2 * S::STAGE, stream, p);
     return hipGetLastError();
+}
+
+template <int BN>
+hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
+    // buffer-descriptor staging needs 31-bit byte offsets and <= 32 filter taps; otherwise the flat-pointer form
+    const size_t a_bytes = (size_t)p.B * p.H * p.W * p.Cin * 2 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 2;
+    const bool buf_ok = g_buffer_staging && a_bytes < 0x7fffff00ull && (size_t)p.N * p.K * 2 < 0x7fffff00ull && p.KH * p.KW <= 32;
+    return buf_ok ? launch_dma_t<BN, true>(p, stream) : launch_dma_t<BN, false>(p, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -653,11 +727,11 @@ __global__ __launch_bounds__(WM * 128, (BKT == 32) ? 2 : 1) void conv_gemm_ring_
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (ks + NSTAGE - 1 < nk && p.dbg != 2) issue(ks + NSTAGE - 1, buf_issue);
+        if (ks + NSTAGE - 1 < nk && (p.dbg & 3) != 2) issue(ks + NSTAGE - 1, buf_issue);
         if (ks + 1 == nk) prefetch_res16<NT>(p, res, m_base + wm * 64, n_base + wn * (BN / 2), lane);
         const unsigned char* As = smem + buf * STAGE;
         const unsigned char* Bs = As + A_BYTES;
-        if (p.dbg != 1)
+        if ((p.dbg & 3) != 1)
 #pragma unroll
         for (int kk = 0; kk < KK; ++kk) {
             half8 xf[4], wf[NT];
@@ -907,5 +981,5 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     return wide ? launch<128, false>(p, stream) : launch<64, false>(p, stream);
 }
 
-void opd_set_gemm_variant(int v) { g_gemm_variant = v & 15; g_strip3x3 = (v & 16) ? 0 : 1; }
-int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 0 : 16); }
+void opd_set_gemm_variant(int v) { g_gemm_variant = v & 15; g_strip3x3 = (v & 16) ? 1 : 0; g_buffer_staging = (v & 32) ? 0 : 1; }
+int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32); }

@@ -25,7 +25,7 @@ struct ConvGemmParams {
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LDS-DMA v2 (default), 2/3 = ring variants;
-                                   // +16 disables the 3x3 row-strip kernel (plain im2col tiles instead)
+                                   // +16 enables the experimental 3x3 row-strip kernel, +32 disables buffer-descriptor staging
 int opd_get_gemm_variant();
 
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
