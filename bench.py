@@ -172,8 +172,14 @@ def main() -> None:
         k_fl = float(fl[0] + fl[1])
         k_n = int(ln[0] + ln[1])
         achieved = k_fl / (k_ms * 1e-3) / 1e12 if k_ms > 0 else 0.0
+        # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
+        # in separate runs, gfx950 x2 fetch correction: tools/pmc_traffic.py) — valid for the default 8 x 800x1333 workload
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+        if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333):
+            traffic = round(json.load(open(tpath))["conv_gemm_family"]["bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": "conv_gemm_kernel", "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": k_n, "avg_launch_us": round(1e3 * k_ms / max(k_n, 1), 2),
                 "flops_per_launch": round(k_fl / max(k_n, 1)),
                 "by_class_ms": {"conv": round(float(ms_avg[0]), 4), "linear": round(float(ms_avg[1]), 4),

@@ -487,10 +487,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     const int nk_all = p.K / BK;
     const int nk = p.split_k > 1 ? nk_all / p.split_k : nk_all;  // k-steps of this slice
     const int ks0 = zsplit * nk;
-    // k-steps are visited in a rotated order (start at `rot`, wrap inside the slice): workgroups that share weight rows
-    // then pull DIFFERENT 16-KiB weight tiles at any instant instead of all hammering the same few L2 channels.
-    const int rot = (p.dbg & 4) ? 0 : (int)((unsigned)(tile_m * 5 + tile_n * 3) % (unsigned)nk);
-    int ks_cur = ks0 + rot;
+    // (a per-tile rotated k-order was tried to spread L2 channel load: no gain, and it makes a frame's result depend on
+    //  its position in the batch through the fp32 summation order — removed; k-steps run in natural order.)
+    int ks_cur = ks0;
     int tap_kh = (ks_cur / kpc) / p.KW, tap_kw = (ks_cur / kpc) % p.KW, tap_c = ks_cur % kpc;
 
     auto issue = [&](int, int buf) {
@@ -629,7 +628,7 @@ __device__ __forceinline__ int swz_t(int row, int chunk) {
 }
 
 template <int WM, int BN, int BKT, int NSTAGE>
-__global__ __launch_bounds__(WM * 128, (BKT == 32) ? 2 : 1) void conv_gemm_ring_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(WM * 128, (BKT == 32) ? (NSTAGE == 3 ? 3 : 2) : 1) void conv_gemm_ring_kernel(ConvGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BMT = WM * 64;
     constexpr int NWAVES = WM * 2;
@@ -975,6 +974,9 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
         }
         if (g_gemm_variant == 3 && nk >= 2) {  // 4-stage 32-deep ring, two / three workgroups per CU
             return wide ? launch_ring<2, 128, 32, 4>(p, stream) : launch_ring<2, 64, 32, 4>(p, stream);
+        }
+        if (g_gemm_variant == 4 && nk >= 2) {  // 3-stage 32-deep ring, three / four workgroups per CU
+            return wide ? launch_ring<2, 128, 32, 3>(p, stream) : launch_ring<2, 64, 32, 3>(p, stream);
         }
         return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);
     }

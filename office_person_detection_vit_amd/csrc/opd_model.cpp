@@ -139,6 +139,10 @@ struct opd_detr {
     float stage_ms[8] = {};
     int use_tr_read = 1;
 
+    // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
+    struct GraphEntry { int B, H, W, fmt, fh, fw; const void* pixels; int uses; hipGraphExec_t exec; };
+    std::vector<GraphEntry> graphs;
+
     // per-kernel-class timing (profiling mode only): event pairs around every launch of the last forward
     struct Timed { int cls; hipEvent_t a, b; double flops; };
     std::vector<Timed> timed;           // pairs used by the current forward
@@ -633,6 +637,46 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     return OPD_OK;
 }
 
+// Forward through the graph cache.  First call of a (shape, pixel pointer) key runs eagerly (one-time function-attribute
+// setup and plan building are not capturable); the second call captures the stream into a hipGraph; later calls replay it.
+static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W) {
+    if (m->profiling || (m->cfg.flags & OPD_FLAG_NO_GRAPH)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
+    opd_detr::GraphEntry* e = nullptr;
+    for (auto& g : m->graphs)
+        if (g.B == B && g.H == H && g.W == W && g.fmt == pixel_format && g.pixels == d_pixels) e = &g;
+    if (!e) {
+        if (m->graphs.size() >= 8) {  // bounded cache: drop the oldest entry
+            if (m->graphs.front().exec) (void)hipGraphExecDestroy(m->graphs.front().exec);
+            m->graphs.erase(m->graphs.begin());
+        }
+        m->graphs.push_back({B, H, W, pixel_format, 0, 0, d_pixels, 0, nullptr});
+        e = &m->graphs.back();
+    }
+    if (e->exec) {
+        HIPCHK(hipGraphLaunch(e->exec, m->stream));
+        m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = e->fh; m->last_fw = e->fw;
+        return OPD_OK;
+    }
+    if (e->uses++ == 0) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
+    hipGraph_t graph = nullptr;
+    HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+    const int rc = enqueue_forward(m, d_pixels, pixel_format, B, H, W);
+    const hipError_t ec = hipStreamEndCapture(m->stream, &graph);
+    if (rc != OPD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
+    if (ec != hipSuccess || !graph) {  // capture refused: stay eager for this key
+        e->uses = -1000000;
+        (void)hipGetLastError();
+        return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
+    }
+    hipGraphExec_t exec = nullptr;
+    const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { e->uses = -1000000; (void)hipGetLastError(); return enqueue_forward(m, d_pixels, pixel_format, B, H, W); }
+    e->exec = exec; e->fh = m->last_fh; e->fw = m->last_fw;
+    HIPCHK(hipGraphLaunch(exec, m->stream));
+    return OPD_OK;
+}
+
 static int check_shape(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     if (!pixels) return fail(OPD_EINVAL, "null pixel buffer");
@@ -747,6 +791,8 @@ void opd_detr_destroy(opd_detr* m) {
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : m->event_pool) (void)hipEventDestroy(e);
+    for (auto& g : m->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
 }
@@ -769,7 +815,7 @@ int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
-    RCCHK(enqueue_forward(m, d_pixels, pixel_format, B, H, W));
+    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W));
     const hipMemcpyKind kind = mem_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     const size_t Md = (size_t)B * m->arch.queries;
     if (logits) HIPCHK(hipMemcpyAsync(logits, m->d_logits, Md * m->arch.ncls * 4, kind, m->stream));
@@ -796,7 +842,7 @@ int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_k
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
-    RCCHK(enqueue_forward(m, d_pixels, pixel_format, B, H, W));
+    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W));
     RCCHK(enqueue_postprocess(m, threshold, orig_hw));
     return fetch_records(m, out, counts, mem_kind);
 }

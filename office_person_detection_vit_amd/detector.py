@@ -71,6 +71,7 @@ class HipDetrDetector:
         max_batch: int = 8,
         max_size: Tuple[int, int] = (800, 1333),
         resize: bool = True,
+        use_graph: bool = True,
     ):
         """
         Args mirror ``config.yaml.disabled:33-44`` (``model_name``, ``confidence_threshold``, ``nms_threshold``,
@@ -88,6 +89,7 @@ class HipDetrDetector:
         self.max_batch = int(max_batch)
         self.max_size = (int(max_size[0]), int(max_size[1]))
         self.resize = resize
+        self.use_graph = use_graph  # replay the forward as a captured hipGraph (False: launch every kernel eagerly)
         self.model: Optional[int] = None  # opaque opd_detr* once loaded
         self.feature_extractor = FeatureExtractor()
         self._lib = None
@@ -132,7 +134,8 @@ class HipDetrDetector:
             lib = _capi.load_library()
             path = self._resolve_weights()
             cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=self.max_batch,
-                                  max_height=self.max_size[0], max_width=self.max_size[1], flags=0)
+                                  max_height=self.max_size[0], max_width=self.max_size[1],
+                                  flags=0 if self.use_graph else _capi.OPD_FLAG_NO_GRAPH)
             handle = C.c_void_p()
             rc = lib.opd_detr_create(C.byref(cfg), path.encode("utf-8"), self.device_ordinal, C.byref(handle))
             _capi.check(rc, "opd_detr_create")

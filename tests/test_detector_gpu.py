@@ -130,6 +130,28 @@ def test_batch8_full_size_properties(detectors):
     assert float(bx8.std(axis=1).mean()) > 5e-3  # queries are not collapsed
 
 
+def test_graph_replay_matches_eager(weight_cache):
+    """The captured hipGraph (3rd call onwards) must reproduce the eager launches bit for bit, also after the input
+    frames change between replays."""
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    outs = {}
+    for use_graph in (False, True):
+        det = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=False, use_graph=use_graph)
+        det.load_model()
+        seq = []
+        for seed in (10, 10, 10, 20, 10):   # eager, capture, replay, replay (new pixels), replay
+            frames = structured_frames(2, 256, 320, seed=seed)
+            lg, bx, enc = det.forward_raw(frames)
+            seq.append((lg.copy(), bx.copy(), enc.copy()))
+        outs[use_graph] = seq
+        det.close()
+    for a, b in zip(outs[False], outs[True]):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    np.testing.assert_array_equal(outs[True][0][1], outs[True][4][1])
+    assert np.abs(outs[True][0][1] - outs[True][3][1]).max() > 0
+
+
 def test_detector_surface(detectors):
     det = detectors(ga=1.0)
     frame = structured_frames(1, 256, 320, seed=31)[0]

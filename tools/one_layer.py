@@ -1,0 +1,11 @@
+#!/usr/bin/env python3
+"""Run ONE conv_gemm layer shape a few times (for rocprofv3 --pmc runs).  usage: one_layer.py B H W Cin N k stride res [variant]"""
+import ctypes as C, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from office_person_detection_vit_amd import _capi
+a = [int(v) for v in sys.argv[1:9]]
+variant = int(sys.argv[9]) if len(sys.argv) > 9 else 1
+lib = _capi.load_library()
+us = C.c_float()
+_capi.check(lib.opd_test_bench_conv(*a, variant, 0, 6, C.byref(us)), "bench_conv")
+print("avg us", us.value)
