@@ -22,6 +22,7 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
+static int g_tile_mt = 0;         // 0: pick 128/160/192-row tiles per layer by wave quantisation; 4/5/6: force
 static int g_buffer_staging = 1;  // tile DMA through buffer descriptors (scalar tap offsets, bounds-check zero fill)
 static int g_strip3x3 = 0;      // 3x3 stride-1 convolutions use the row-strip kernel (0: plain im2col tiles)
 static int g_gemm_variant = 1;  // 0 = v1 register-staged, 1 = v2 LDS-DMA 2-stage (default), 2 = v2 + 3-stage 64-deep ring for deep K, 3 = v2 + 4-stage 32-deep ring
@@ -295,8 +296,8 @@ __device__ __forceinline__ void unpack2h(unsigned u, float& a, float& b) {
 
 // Accumulators start from the bias (vector or row-periodic), so the bias loads overlap the first tile's DMA instead of
 // sitting on the epilogue's critical path.
-template <int NT>
-__device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const float* bias, float4v (&acc)[NT][4], const int m0,
+template <int NT, int MT = 4>
+__device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const float* bias, float4v (&acc)[NT][MT], const int m0,
                                               const int n0, const int lane) {
     const int g = lane >> 4, li = lane & 15;
 #pragma unroll
@@ -305,10 +306,10 @@ __device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const flo
         if (p.bias_period == 0) {
             const float4v b = *reinterpret_cast<const float4v*>(bias + nq);
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b;
+            for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b;
         } else {
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
+            for (int mt = 0; mt < MT; ++mt) {
                 const int m = m0 + mt * 16 + li;
                 acc[nt][mt] = m < p.M ? *reinterpret_cast<const float4v*>(bias + (size_t)(m % p.bias_period) * p.N + nq)
                                       : float4v{0.f, 0.f, 0.f, 0.f};
@@ -317,33 +318,45 @@ __device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const flo
     }
 }
 
-// fp16 residual in the paired 16-byte layout (see epilogue_regs), fetched BEFORE the last k-step's MFMAs.
-template <int NT>
-__device__ __forceinline__ void prefetch_res16(const ConvGemmParams& p, uint4 (&res)[NT][2], const int m0, const int n0,
+// fp16 residual in the paired 16-byte layout (see epilogue_regs), fetched BEFORE the last k-step's MFMAs.  With an odd
+// number of m-tiles the last tile is unpaired: its residual is the lane's own 4-channel quad (8 bytes, in .x/.y).
+template <int NT, int MT = 4>
+__device__ __forceinline__ void prefetch_res16(const ConvGemmParams& p, uint4 (&res)[NT][(MT + 1) / 2], const int m0, const int n0,
                                                const int lane) {
     const int g = lane >> 4, li = lane & 15;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt) {
 #pragma unroll
-        for (int mp = 0; mp < 2; ++mp) {
+        for (int mp = 0; mp < MT / 2; ++mp) {
             const int my_m = m0 + (mp * 2 + (g & 1)) * 16 + li;
             const int my_n = n0 + nt * 16 + (g >> 1) * 8;
             res[nt][mp] = make_uint4(0u, 0u, 0u, 0u);
             if (p.res16 && my_m < p.M) res[nt][mp] = *reinterpret_cast<const uint4*>(p.res16 + (size_t)my_m * p.N + my_n);
         }
+        if constexpr (MT & 1) {
+            const int m = m0 + (MT - 1) * 16 + li;
+            res[nt][MT / 2] = make_uint4(0u, 0u, 0u, 0u);
+            if (p.res16 && m < p.M) {
+                const uint2 r = *reinterpret_cast<const uint2*>(p.res16 + (size_t)m * p.N + n0 + nt * 16 + g * 4);
+                res[nt][MT / 2].x = r.x;
+                res[nt][MT / 2].y = r.y;
+            }
+        }
+    }
 }
 
 // Register epilogue: (+fp32 residual) (+fp16 residual) -> ReLU -> store.  v_permlane16_swap pairs the 4-channel
 // accumulator quads of two m-tiles so each lane owns 8 consecutive channels of one row: 16-byte loads and stores.
-template <int NT>
-__device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out, float4v (&acc)[NT][4],
-                                              const uint4 (&res)[NT][2], const int m0, const int n0, const int lane) {
+// An unpaired last m-tile (odd MT) is stored as 8-byte quads.
+template <int NT, int MT = 4>
+__device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out, float4v (&acc)[NT][MT],
+                                              const uint4 (&res)[NT][(MT + 1) / 2], const int m0, const int n0, const int lane) {
     const int g = lane >> 4, li = lane & 15;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int nq = n0 + nt * 16 + g * 4;  // this lane's 4 channels in accumulator layout
 #pragma unroll
-        for (int mp = 0; mp < 2; ++mp) {
+        for (int mp = 0; mp < MT / 2; ++mp) {
             float4v v[2];
 #pragma unroll
             for (int h = 0; h < 2; ++h) {
@@ -385,6 +398,26 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
                 if (my_m < p.M) *reinterpret_cast<uint4*>(o16 + my_o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
             }
         }
+        if constexpr (MT & 1) {  // unpaired last m-tile: accumulator layout, 8-byte accesses
+            const int m = m0 + (MT - 1) * 16 + li;
+            const size_t o = (size_t)m * p.N + nq;
+            float4v v = acc[nt][MT - 1];
+            if (p.res32 && m < p.M) v += *reinterpret_cast<const float4v*>(p.res32 + o);
+            if (p.res16) {
+                float a, b;
+                unpack2h(res[nt][MT / 2].x, a, b); v[0] += a; v[1] += b;
+                unpack2h(res[nt][MT / 2].y, a, b); v[2] += a; v[3] += b;
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            if (m < p.M) {
+                if (p.out_f32) *reinterpret_cast<float4v*>(reinterpret_cast<float*>(out) + o) = v;
+                f16_t* o16 = p.out_f32 ? p.out16_aux : reinterpret_cast<f16_t*>(out);
+                if (o16) *reinterpret_cast<uint2*>(o16 + o) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+            }
+        }
     }
 }
 
@@ -393,11 +426,13 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
 // or rows >= M are expressed by an out-of-range offset, which the descriptor's bounds check turns into zeros.  The
 // flat-pointer form (BUF = false) spends ~25 VALU/SALU instructions per 1-KiB piece on 64-bit address arithmetic and
 // zero-page selects — at 8 pieces per k-step that, not the MFMAs or the memory system, paced the k-loop.
-template <int BN, bool BUF>
+template <int BN, bool BUF, int MT>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type and builtins exist only in the gfx950 pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using S = Smem<BN>;
+    constexpr int BMT = 32 * MT;       // tile rows: 2 waves along m, MT 16-row MFMA tiles each (128 / 160 / 192)
+    constexpr int A_BYTES = BMT * ROW_BYTES;
+    constexpr int STAGE_BYTES = A_BYTES + BN * ROW_BYTES;
     constexpr int NT = BN / 32;
     constexpr int B_PIECES = BN / 32;  // 1-KiB pieces of the B tile per wave
 
@@ -407,13 +442,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     const int wm = wave >> 1, wn = wave & 1;
 
     const int tiles_n = p.N / BN;
-    const int ntiles = tiles_n * ((p.M + BM - 1) / BM);
+    const int ntiles = tiles_n * ((p.M + BMT - 1) / BMT);
     const int lbid_all = xcd_logical_block(blockIdx.x, gridDim.x);
     const int zsplit = lbid_all / ntiles;  // split-K slice (0 when split_k <= 1)
     const int lbid = lbid_all - zsplit * ntiles;
     const int tile_n = lbid % tiles_n;
     const int tile_m = lbid / tiles_n;
-    const int m_base = tile_m * BM;
+    const int m_base = tile_m * BMT;
     const int n_base = tile_n * BN;
     // (kernel arguments are never written: a modified ConvGemmParams would be demoted to scratch memory)
     void* out_ptr = p.out;
@@ -423,17 +458,17 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         if (zsplit > 0) bias_ptr = reinterpret_cast<const float*>(p.zero16);
     }
 
-    // ---- DMA coordinates: piece q = wave*4 + i covers tile rows 8q..8q+7; lane -> (row 8q + (lane>>3), slot lane&7)
+    // ---- DMA coordinates: piece q = wave*MT + i covers tile rows 8q..8q+7; lane -> (row 8q + (lane>>3), slot lane&7)
     const int lrow = lane >> 3;
     const int lchunk = (lane & 7) ^ lrow;  // logical 16-byte chunk this lane fetches (XOR swizzle on the source side)
-    long long a_base[4];
-    int a_ih0[4], a_iw0[4];
-    bool a_ok[4];
+    long long a_base[MT];
+    int a_ih0[MT], a_iw0[MT];
+    bool a_ok[MT];
     {
         const int ohw = p.OH * p.OW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_base + (wave * 4 + i) * 8 + lrow;
+        for (int i = 0; i < MT; ++i) {
+            const int m = m_base + (wave * MT + i) * 8 + lrow;
             a_ok[i] = m < p.M;
             const int mm = a_ok[i] ? m : 0;
             const int b = mm / ohw;
@@ -455,15 +490,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     // offset: byte(ih, iw) = rowoff (centre-less pixel (oh*s, ow*s)) + soff(tap) with soff >= 0.
     const unsigned backoff = (unsigned)(p.pad * p.W + p.pad) * (unsigned)p.Cin * 2u;
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
-    unsigned rowoff[4], rowmask[4], woff[B_PIECES];
+    unsigned rowoff[MT], rowmask[MT], woff[B_PIECES];
     if constexpr (BUF) {
         const unsigned a_bytes = (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 2) + backoff;
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - backoff, 0, a_bytes, 0x00020000);
         rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
         const int ohw = p.OH * p.OW;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_base + (wave * 4 + i) * 8 + lrow;
+        for (int i = 0; i < MT; ++i) {
+            const int m = m_base + (wave * MT + i) * 8 + lrow;
             const bool okm = m < p.M;
             const int mm = okm ? m : 0;
             const int b = mm / ohw;
@@ -471,12 +506,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
             const int oh = r / p.OW;
             const int ow = r - oh * p.OW;
             rowoff[i] = (unsigned)(((b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.Cin) * 2u + (unsigned)lchunk * 16u;
-            unsigned mask = 0;
+            // separable validity: row bits (kw) replicated for every valid kh
+            unsigned kwmask = 0, mask = 0;
+            for (int kw = 0; kw < p.KW; ++kw)
+                if ((unsigned)(ow * p.stride - p.pad + kw) < (unsigned)p.W) kwmask |= 1u << kw;
             for (int kh = 0; kh < p.KH; ++kh)
-                for (int kw = 0; kw < p.KW; ++kw)
-                    if (okm && (unsigned)(oh * p.stride - p.pad + kh) < (unsigned)p.H && (unsigned)(ow * p.stride - p.pad + kw) < (unsigned)p.W)
-                        mask |= 1u << (kh * p.KW + kw);
-            rowmask[i] = mask;
+                if ((unsigned)(oh * p.stride - p.pad + kh) < (unsigned)p.H) mask |= kwmask << (kh * p.KW);
+            rowmask[i] = okm ? mask : 0u;
         }
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i)
@@ -494,16 +530,16 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
 
     auto issue = [&](int, int buf) {
         const int ks = ks_cur;
-        unsigned char* As = smem + buf * S::STAGE;
-        unsigned char* Bs = As + S::A_BYTES;
+        unsigned char* As = smem + buf * STAGE_BYTES;
+        unsigned char* Bs = As + A_BYTES;
         if constexpr (BUF) {
             const int tap = tap_kh * p.KW + tap_kw;
             const int soff_a = ((tap_kh * p.W + tap_kw) * p.Cin + tap_c * BK) * 2;  // scalar displacement of this tap / chunk
             if (!(p.dbg & 8))
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MT; ++i) {
                 const unsigned vo = ((rowmask[i] >> tap) & 1u) ? rowoff[i] : 0x80000000u;  // out of range -> zeros
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * 4 + i) * 1024),
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * MT + i) * 1024),
                                                          16, vo, soff_a, 0, 0);
             }
             if (!(p.dbg & 16))
@@ -513,13 +549,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
                                                          16, woff[i], ks * (BK * 2), 0, 0);
         } else {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < MT; ++i) {
                 const int ih = a_ih0[i] + tap_kh;
                 const int iw = a_iw0[i] + tap_kw;
                 const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
                 const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BK + lchunk * 8
                                       : reinterpret_cast<const f16_t*>(p.zero16);
-                dma16(src, As + (wave * 4 + i) * 1024);
+                dma16(src, As + (wave * MT + i) * 1024);
             }
 #pragma unroll
             for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BK, Bs + (wave * B_PIECES + i) * 1024);
@@ -534,31 +570,31 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         }
     };
 
-    const int wm0 = m_base + wm * 64, wn0 = n_base + wn * (BN / 2);
+    const int wm0 = m_base + wm * (MT * 16), wn0 = n_base + wn * (BN / 2);
     issue(0, 0);
-    float4v acc[NT][4];
-    init_acc_bias<NT>(p, bias_ptr, acc, wm0, wn0, lane);
-    uint4 res[NT][2];
+    float4v acc[NT][MT];
+    init_acc_bias<NT, MT>(p, bias_ptr, acc, wm0, wn0, lane);
+    uint4 res[NT][(MT + 1) / 2];
     __syncthreads();  // emits s_waitcnt vmcnt(0) for the DMA in flight, then s_barrier
 
     const int frow = lane & 15;
     const int fchk = lane >> 4;
     auto compute = [&](int buf) {
-        const unsigned char* As = smem + buf * S::STAGE;
-        const unsigned char* Bs = As + S::A_BYTES;
+        const unsigned char* As = smem + buf * STAGE_BYTES;
+        const unsigned char* Bs = As + A_BYTES;
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            half8 xf[4], wf[NT];
+            half8 xf[MT], wf[NT];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * 64 + mt * 16 + frow, kk * 4 + fchk));
+            for (int mt = 0; mt < MT; ++mt)
+                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * (MT * 16) + mt * 16 + frow, kk * 4 + fchk));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
                 wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
                     acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         }
     };
@@ -567,27 +603,57 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         if ((p.dbg & 3) != 1) compute(ks & 1);
         __syncthreads();
     }
-    prefetch_res16<NT>(p, res, wm0, wn0, lane);  // in flight during the last tile's MFMAs
+    prefetch_res16<NT, MT>(p, res, wm0, wn0, lane);  // in flight during the last tile's MFMAs
     compute((nk - 1) & 1);
-    epilogue_regs<NT>(p, out_ptr, acc, res, wm0, wn0, lane);
+    epilogue_regs<NT, MT>(p, out_ptr, acc, res, wm0, wn0, lane);
 #endif
 }
 
-template <int BN, bool BUF>
+template <int BN, bool BUF, int MT>
 hipError_t launch_dma_t(const ConvGemmParams& p, hipStream_t stream) {
-    using S = Smem<BN>;
+    constexpr int BMT = 32 * MT;
+    constexpr int LDS = 2 * (BMT + BN) * ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, 2 * S::STAGE);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF, MT>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    const int tiles_m = (p.M + BM - 1) / BM;
+    const int tiles_m = (p.M + BMT - 1) / BMT;
     const int tiles_n = p.N / BN;
     const int splits = p.split_k > 1 ? p.split_k : 1;
-    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF>), dim3(tiles_m * tiles_n * splits), dim3(256), 2 * S::STAGE, stream, p);
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT>), dim3(tiles_m * tiles_n * splits), dim3(256), LDS, stream, p);
     return hipGetLastError();
+}
+
+// Workgroups per CU that the LDS footprint of a <BN, MT> tile admits (160 KiB per CU), capped by the 2-waves/SIMD bound.
+static inline int dma_blocks_per_cu(int bn, int mt) {
+    const int lds = 2 * (32 * mt + bn) * ROW_BYTES;
+    const int by_lds = (160 * 1024) / lds;
+    return by_lds < 2 ? by_lds : 2;
+}
+
+// Tile height by wave quantisation: with T tiles on S = 256 CUs x blocks/CU slots the launch takes ceil(T/S) rounds, and a
+// round lasts ~ (rows + cols) of the tile (DMA-throughput bound).  E.g. M = 33 600, N = 256: 128-row tiles give 526
+// workgroups on 512 slots (2 rounds), 160-row tiles 420 (1 round).
+static inline int pick_mt(int M, int N, int bn, int splits) {
+    if (g_tile_mt) return g_tile_mt;
+    {   // many rounds: quantisation is noise, keep the 128-row tile (more workgroups per CU, measured faster)
+        const long long tiles128 = (long long)((M + 127) / 128) * (N / bn) * splits;
+        if (tiles128 > 4LL * 256 * dma_blocks_per_cu(bn, 4)) return 4;
+    }
+    int best = 4;
+    double best_cost = 1e30;
+    for (int mt = 4; mt <= 6; ++mt) {
+        const long long tiles = (long long)((M + 32 * mt - 1) / (32 * mt)) * (N / bn) * splits;
+        const int bpc = dma_blocks_per_cu(bn, mt);
+        const long long slots = 256LL * bpc;
+        const long long rounds = (tiles + slots - 1) / slots;
+        const double cost = (double)rounds * bpc * (32 * mt + bn) * (mt == 4 ? 1.0 : 1.03);  // prefer 128 rows on ties
+        if (cost < best_cost) { best_cost = cost; best = mt; }
+    }
+    return best;
 }
 
 template <int BN>
@@ -595,7 +661,12 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
     // buffer-descriptor staging needs 31-bit byte offsets and <= 32 filter taps; otherwise the flat-pointer form
     const size_t a_bytes = (size_t)p.B * p.H * p.W * p.Cin * 2 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 2;
     const bool buf_ok = g_buffer_staging && a_bytes < 0x7fffff00ull && (size_t)p.N * p.K * 2 < 0x7fffff00ull && p.KH * p.KW <= 32;
-    return buf_ok ? launch_dma_t<BN, true>(p, stream) : launch_dma_t<BN, false>(p, stream);
+    if (!buf_ok) return launch_dma_t<BN, false, 4>(p, stream);
+    switch (pick_mt(p.M, p.N, BN, p.split_k > 1 ? p.split_k : 1)) {
+        case 5: return launch_dma_t<BN, true, 5>(p, stream);
+        case 6: return launch_dma_t<BN, true, 6>(p, stream);
+        default: return launch_dma_t<BN, true, 4>(p, stream);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -628,7 +699,7 @@ __device__ __forceinline__ int swz_t(int row, int chunk) {
 }
 
 template <int WM, int BN, int BKT, int NSTAGE>
-__global__ __launch_bounds__(WM * 128, (BKT == 32) ? (NSTAGE == 3 ? 3 : 2) : 1) void conv_gemm_ring_kernel(ConvGemmParams p) {
+__global__ __launch_bounds__(WM * 128, (BKT == 32) ? ((NSTAGE == 3 && BN <= 128) ? 3 : 2) : 1) void conv_gemm_ring_kernel(ConvGemmParams p) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int BMT = WM * 64;
     constexpr int NWAVES = WM * 2;
@@ -975,6 +1046,8 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
         if (g_gemm_variant == 3 && nk >= 2) {  // 4-stage 32-deep ring, two / three workgroups per CU
             return wide ? launch_ring<2, 128, 32, 4>(p, stream) : launch_ring<2, 64, 32, 4>(p, stream);
         }
+        if (g_gemm_variant == 5 && nk >= 2 && (p.N % 256) == 0)  // 128 x 256 tiles: 25 % less L2->LDS traffic per FLOP
+            return launch_ring<2, 256, 32, 3>(p, stream);
         if (g_gemm_variant == 4 && nk >= 2) {  // 3-stage 32-deep ring, three / four workgroups per CU
             return wide ? launch_ring<2, 128, 32, 3>(p, stream) : launch_ring<2, 64, 32, 3>(p, stream);
         }
@@ -983,5 +1056,8 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     return wide ? launch<128, false>(p, stream) : launch<64, false>(p, stream);
 }
 
-void opd_set_gemm_variant(int v) { g_gemm_variant = v & 15; g_strip3x3 = (v & 16) ? 1 : 0; g_buffer_staging = (v & 32) ? 0 : 1; }
-int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32); }
+void opd_set_gemm_variant(int v) {
+    g_gemm_variant = v & 15; g_strip3x3 = (v & 16) ? 1 : 0; g_buffer_staging = (v & 32) ? 0 : 1;
+    g_tile_mt = (v >> 8) & 7;  // bits 8-10: force m-tiles per wave (4, 5, 6); 0 = automatic
+}
+int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32) | (g_tile_mt << 8); }

@@ -22,7 +22,9 @@ def lib():
     return _capi.load_library()
 
 
-@pytest.fixture(params=[1, 33, 17, 3, 2, 0], ids=["gemm_v2_bufdma", "gemm_v2_flatdma", "gemm_v2+strip3x3", "gemm_ring4x32", "gemm_ring3x64", "gemm_v1_regstage"])
+@pytest.fixture(params=[1, 0x501, 0x601, 33, 17, 3, 2, 0],
+                ids=["gemm_v2_bufdma_auto", "gemm_v2_160rows", "gemm_v2_192rows", "gemm_v2_flatdma", "gemm_v2+strip3x3", "gemm_ring4x32",
+                     "gemm_ring3x64", "gemm_v1_regstage"])
 def gemm_variant(request, lib):
     """Every generation of the implicit-GEMM kernel stays under test: the default dispatch (v3 3-stage LDS-DMA pipeline
     for deep K, v2 2-stage LDS-DMA otherwise), v2 alone, and v1 (register-staged, LDS epilogue)."""
