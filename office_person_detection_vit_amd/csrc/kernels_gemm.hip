@@ -348,10 +348,17 @@ __device__ __forceinline__ void prefetch_res16(const ConvGemmParams& p, uint4 (&
 // Register epilogue: (+fp32 residual) (+fp16 residual) -> ReLU -> store.  v_permlane16_swap pairs the 4-channel
 // accumulator quads of two m-tiles so each lane owns 8 consecutive channels of one row: 16-byte loads and stores.
 // An unpaired last m-tile (odd MT) is stored as 8-byte quads.
+// `wave_stage` (optional, MT == 4, fp16 output): a wave-private NT*16 x 64-row fp16 staging area in LDS.  The wave
+// transposes its output tile through it so that every global store instruction writes whole contiguous row segments
+// (8 lanes x 16 B = 128 B per row for BN = 128) instead of 32-byte pieces of 32 different rows: the 32-byte pattern is
+// request-rate bound at ~2.7 TB/s on the store-heavy 64->256 / 128->512 layers.
 template <int NT, int MT = 4>
 __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out, float4v (&acc)[NT][MT],
-                                              const uint4 (&res)[NT][(MT + 1) / 2], const int m0, const int n0, const int lane) {
+                                              const uint4 (&res)[NT][(MT + 1) / 2], const int m0, const int n0, const int lane,
+                                              unsigned char* wave_stage = nullptr) {
     const int g = lane >> 4, li = lane & 15;
+    constexpr int WROW = NT * 32;  // bytes per staged row (NT*16 channels fp16)
+    const bool staged = (MT == 4) && wave_stage != nullptr && !p.out_f32;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int nq = n0 + nt * 16 + g * 4;  // this lane's 4 channels in accumulator layout
@@ -392,7 +399,16 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
                 }
             }
             f16_t* o16 = p.out_f32 ? p.out16_aux : reinterpret_cast<f16_t*>(out);
-            if (o16) {
+            if (staged) {
+                // accumulator layout -> LDS [row][channel]; 16-byte chunks XOR-swizzled by row to spread the banks
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int r = (mp * 2 + h) * 16 + li;
+                    const int cb = nt * 32 + g * 8;  // byte offset of this quad inside the row
+                    const int off = r * WROW + ((((cb >> 4) ^ (r & (WROW / 16 - 1))) << 4) | (cb & 8));
+                    *reinterpret_cast<uint2*>(wave_stage + off) = make_uint2(pack2h(v[h][0], v[h][1]), pack2h(v[h][2], v[h][3]));
+                }
+            } else if (o16) {
                 const uint2v s0 = __builtin_amdgcn_permlane16_swap(pack2h(v[0][0], v[0][1]), pack2h(v[1][0], v[1][1]), false, false);
                 const uint2v s1 = __builtin_amdgcn_permlane16_swap(pack2h(v[0][2], v[0][3]), pack2h(v[1][2], v[1][3]), false, false);
                 if (my_m < p.M) *reinterpret_cast<uint4*>(o16 + my_o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
@@ -417,6 +433,20 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
                 f16_t* o16 = p.out_f32 ? p.out16_aux : reinterpret_cast<f16_t*>(out);
                 if (o16) *reinterpret_cast<uint2*>(o16 + o) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
             }
+        }
+    }
+    if (staged) {
+        // read back row-contiguous: CPRW lanes cover one staged row, 64 / CPRW rows per store instruction
+        constexpr int CPRW = WROW / 16;         // 16-byte chunks per staged row (8 for BN = 128, 4 for BN = 64)
+        constexpr int RPI = 64 / CPRW;          // rows per instruction
+        const int c = lane % CPRW, r0 = lane / CPRW;
+        f16_t* o16 = reinterpret_cast<f16_t*>(out);
+#pragma unroll
+        for (int i = 0; i < 64 / RPI; ++i) {
+            const int r = r0 + i * RPI;
+            const uint4 v = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ (r & (CPRW - 1))) << 4));
+            const int m = m0 + r;
+            if (m < p.M) *reinterpret_cast<uint4*>(o16 + (size_t)m * p.N + n0 + c * 8) = v;
         }
     }
 }
@@ -605,7 +635,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     }
     prefetch_res16<NT, MT>(p, res, wm0, wn0, lane);  // in flight during the last tile's MFMAs
     compute((nk - 1) & 1);
-    epilogue_regs<NT, MT>(p, out_ptr, acc, res, wm0, wn0, lane);
+    // the stage buffer NOT used by the last k-step is free: each wave takes a private quarter of it for the output transpose
+    unsigned char* wave_stage = nullptr;
+    if constexpr (MT == 4) {  // (single-k-step launches allocate ONE stage buffer: nothing free to stage through)
+        if (!(p.dbg & 32) && nk >= 2) wave_stage = smem + (((nk - 1) & 1) ^ 1) * STAGE_BYTES + wave * (64 * NT * 32);
+    }
+    epilogue_regs<NT, MT>(p, out_ptr, acc, res, wm0, wn0, lane, wave_stage);
 #endif
 }
 
@@ -623,7 +658,10 @@ hipError_t launch_dma_t(const ConvGemmParams& p, hipStream_t stream) {
     const int tiles_m = (p.M + BMT - 1) / BMT;
     const int tiles_n = p.N / BN;
     const int splits = p.split_k > 1 ? p.split_k : 1;
-    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT>), dim3(tiles_m * tiles_n * splits), dim3(256), LDS, stream, p);
+    // a single k-step per workgroup (K = 64 layers, split-K slices of one step) needs no second stage buffer: half the
+    // LDS -> three workgroups per CU instead of two, which is what hides the DMA / residual / store round trips there
+    const int lds = ((p.K / BK) / splits == 1) ? LDS / 2 : LDS;
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 

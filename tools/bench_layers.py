@@ -27,14 +27,14 @@ def main():
     lib = _capi.load_library()
     variants = [int(v) for v in (sys.argv[1] if len(sys.argv) > 1 else "1").split(",")]
     us = C.c_float()
-    print(f"{'layer':28s} {'var':>3s} {'full us':>9s} {'TFLOP/s':>8s} {'loads-only':>10s} {'compute-only':>12s} {'loads A only':>12s} {'loads B only':>12s}")
+    print(f"{'layer':28s} {'var':>3s} {'full us':>9s} {'TFLOP/s':>8s} {'loads-only':>10s} {'compute-only':>12s} {'no-stage full':>12s} {'loads B only':>12s}")
     for name, B, H, W, Cin, N, k, st, res in SHAPES:
         pad = k // 2
         OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
         fl = 2.0 * B * OH * OW * N * k * k * Cin
         for v in variants:
             t = []
-            for dbg in (0, 1, 2, 1 + 16, 1 + 8):
+            for dbg in (0, 1, 2, 32, 1 + 8):
                 _capi.check(lib.opd_test_bench_conv(B, H, W, Cin, N, k, st, res, v, dbg, 20, C.byref(us)), "bench_conv")
                 t.append(us.value)
             print(f"{name:28s} {v:3d} {t[0]:9.1f} {fl / t[0] / 1e6:8.1f} {t[1]:10.1f} {t[2]:12.1f} {t[3]:11.1f} {t[4]:12.1f}")
