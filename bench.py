@@ -31,7 +31,7 @@ def cpu_baseline(path: str, H: int, W: int, batch: int = 4, iters: int = 2) -> d
     """The oracle (CPU fp32 restatement, torch CPU backend) on a bounded sample of the same workload."""
     import torch
 
-    from office_person_detection_vit_amd.frames import noise_frame
+    from office_person_detection_vit_amd.frames import structured_frame
     from office_person_detection_vit_amd.weights import load_safetensors
     from oracle import detr_oracle as O
 
@@ -48,7 +48,7 @@ def cpu_baseline(path: str, H: int, W: int, batch: int = 4, iters: int = 2) -> d
         pass
     torch.set_num_threads(ncpu)
     w = O.to_torch(load_safetensors(path))
-    frames = [noise_frame(H, W, 1234 + i) for i in range(batch)]
+    frames = [structured_frame(H, W, 1234 + i) for i in range(batch)]
     times = []
     for it in range(iters + 1):  # first iteration is the warm-up
         t0 = time.perf_counter()
@@ -77,7 +77,7 @@ def main() -> None:
     import torch.distributed as dist
 
     from office_person_detection_vit_amd import _capi
-    from office_person_detection_vit_amd.frames import noise_frame
+    from office_person_detection_vit_amd.frames import structured_frame
     from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file
 
     rank = int(os.environ.get("RANK", "0"))
@@ -109,7 +109,7 @@ def main() -> None:
     Q = info.num_queries
 
     # synthetic office-camera frames, resident in HBM before the timed region (torch = device memory plumbing only)
-    frames = np.stack([noise_frame(H, W, 1234 + rank * B + i) for i in range(B)])
+    frames = np.stack([structured_frame(H, W, 1234 + rank * B + i) for i in range(B)])
     d_frames = torch.from_numpy(frames).cuda()
     d_records = torch.zeros((B, Q, 8), dtype=torch.int32, device="cuda")   # opd_det = 8 x 4 bytes
     d_counts = torch.zeros((B,), dtype=torch.int32, device="cuda")

@@ -521,8 +521,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     const unsigned backoff = (unsigned)(p.pad * p.W + p.pad) * (unsigned)p.Cin * 2u;
     __amdgpu_buffer_rsrc_t rsrc_a, rsrc_b;
     unsigned rowoff[MT], rowmask[MT], woff[B_PIECES];
+    const bool stem2 = p.stem == 2;
     if constexpr (BUF) {
-        const unsigned a_bytes = (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 2) + backoff;
+        const unsigned a_bytes = stem2 ? (unsigned)((size_t)p.B * p.H * p.W * 8) : (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 2) + backoff;
         rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - backoff, 0, a_bytes, 0x00020000);
         rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
         const int ohw = p.OH * p.OW;
@@ -535,7 +536,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
             const int r = mm - b * ohw;
             const int oh = r / p.OW;
             const int ow = r - oh * p.OW;
-            rowoff[i] = (unsigned)(((b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.Cin) * 2u + (unsigned)lchunk * 16u;
+            // stem == 2: padded NHWC4 image (8 bytes / pixel); a k-step is 2 filter rows x 8 pixels, so the lane's 16-byte
+            // chunk sits at (row lchunk>>2, pixel pair lchunk&3) of the window
+            rowoff[i] = stem2 ? (unsigned)((b * p.H + oh * 2) * p.W + ow * 2) * 8u + (unsigned)((lchunk >> 2) * p.W) * 8u + (unsigned)(lchunk & 3) * 16u
+                              : (unsigned)(((b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.Cin) * 2u + (unsigned)lchunk * 16u;
             // separable validity: row bits (kw) replicated for every valid kh
             unsigned kwmask = 0, mask = 0;
             for (int kw = 0; kw < p.KW; ++kw)
@@ -564,7 +568,8 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         unsigned char* Bs = As + A_BYTES;
         if constexpr (BUF) {
             const int tap = tap_kh * p.KW + tap_kw;
-            const int soff_a = ((tap_kh * p.W + tap_kw) * p.Cin + tap_c * BK) * 2;  // scalar displacement of this tap / chunk
+            const int soff_a = stem2 ? tap_c * 16 * p.W   // two padded image rows per k-step
+                                     : ((tap_kh * p.W + tap_kw) * p.Cin + tap_c * BK) * 2;  // scalar displacement of this tap / chunk
             if (!(p.dbg & 8))
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
@@ -1053,6 +1058,13 @@ hipError_t launch(const ConvGemmParams& p, hipStream_t stream) {
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     // host-side shape contract of the kernel (checked before every launch: a violated assumption would fault the GPU)
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.N % 64) != 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
+    if (p.stem == 2) {  // padded-NHWC4 stem through the LDS-DMA kernel: [B][H = 2*OH+6][W = 2*OW+6][4], zero borders
+        if (p.K != 256 || p.Cin != 256 || p.KH != 1 || p.KW != 1 || p.stride != 2 || p.pad != 0 || p.N != 64 || p.split_k > 1 ||
+            p.H < 2 * p.OH + 6 || p.W < 2 * p.OW + 6 || (p.W & 1) || !p.zero16 || (size_t)p.B * p.H * p.W * 8 >= 0x7fffff00ull)
+            return hipErrorInvalidValue;
+        if ((long long)p.B * p.OH * p.OW != p.M) return hipErrorInvalidValue;
+        return launch_dma_t<64, true, 4>(p, stream);
+    }
     if (p.stem) {
         if (p.K != 256 || p.KH != 7 || p.KW != 7 || p.stride != 2 || p.pad != 3) return hipErrorInvalidValue;
     } else {

@@ -20,33 +20,48 @@ namespace {
 __constant__ float c_mean[3] = {0.485f, 0.456f, 0.406f};
 __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 
-// One thread per pixel: 3 bytes in (BGR), 8 bytes out (RGB0 fp16).  Same op order as the oracle:
-// (float(u8) * (1/255) - mean) / std.
-__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __restrict__ out, size_t npix) {
+// One thread per OUTPUT pixel of the zero-bordered NHWC4 image [B][Hp][Wp][4] (image at offset (3,3)): 3 bytes in (BGR),
+// 8 bytes out (RGB0 fp16).  Same op order as the oracle: (float(u8) * (1/255) - mean) / std.  The border is the stem
+// convolution's zero padding, materialised so that the stem's LDS-DMA needs no per-tap bounds logic.
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp) {
 #pragma clang fp contract(off)  // keep mul / sub / div separately rounded, like the reference's tensor ops
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= npix) return;
-    const uint8_t* s = in + i * 3;
-    const float b = (float)s[0], g = (float)s[1], r = (float)s[2];
-    const float k = 1.0f / 255.0f;
+    if (i >= (size_t)B * Hp * Wp) return;
+    const int xp = (int)(i % Wp);
+    const size_t t = i / Wp;
+    const int yp = (int)(t % Hp);
+    const int b = (int)(t / Hp);
+    const int y = yp - 3, x = xp - 3;
     half4 o;
-    o[0] = (_Float16)((r * k - c_mean[0]) / c_std[0]);
-    o[1] = (_Float16)((g * k - c_mean[1]) / c_std[1]);
-    o[2] = (_Float16)((b * k - c_mean[2]) / c_std[2]);
-    o[3] = (_Float16)0.f;
+    o[0] = o[1] = o[2] = o[3] = (_Float16)0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+        const uint8_t* s = in + (((size_t)b * H + y) * W + x) * 3;
+        const float bl = (float)s[0], g = (float)s[1], r = (float)s[2];
+        const float k = 1.0f / 255.0f;
+        o[0] = (_Float16)((r * k - c_mean[0]) / c_std[0]);
+        o[1] = (_Float16)((g * k - c_mean[1]) / c_std[1]);
+        o[2] = (_Float16)((bl * k - c_mean[2]) / c_std[2]);
+    }
     *reinterpret_cast<half4*>(out + i * 4) = o;
 }
 
-__global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __restrict__ out, int B, int HW) {
+__global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * HW) return;
-    const size_t b = i / HW, px = i - b * HW;
-    const float* s = pv + b * 3 * (size_t)HW + px;
+    if (i >= (size_t)B * Hp * Wp) return;
+    const int xp = (int)(i % Wp);
+    const size_t t = i / Wp;
+    const int yp = (int)(t % Hp);
+    const int b = (int)(t / Hp);
+    const int y = yp - 3, x = xp - 3;
     half4 o;
-    o[0] = (_Float16)s[0];
-    o[1] = (_Float16)s[(size_t)HW];
-    o[2] = (_Float16)s[2 * (size_t)HW];
-    o[3] = (_Float16)0.f;
+    o[0] = o[1] = o[2] = o[3] = (_Float16)0.f;
+    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+        const size_t HW = (size_t)H * W;
+        const float* s = pv + (size_t)b * 3 * HW + (size_t)y * W + x;
+        o[0] = (_Float16)s[0];
+        o[1] = (_Float16)s[HW];
+        o[2] = (_Float16)s[2 * HW];
+    }
     *reinterpret_cast<half4*>(out + i * 4) = o;
 }
 
@@ -268,15 +283,17 @@ inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + 
 
 }  // namespace
 
-hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, hipStream_t stream) {
-    const size_t npix = (size_t)B * H * W;
-    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, frames, out, npix);
+hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream) {
+    if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
+    const size_t npix = (size_t)B * Hp * Wp;
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, frames, out, B, H, W, Hp, Wp);
     return hipGetLastError();
 }
 
-hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, hipStream_t stream) {
-    const size_t npix = (size_t)B * H * W;
-    hipLaunchKernelGGL(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H * W);
+hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream) {
+    if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
+    const size_t npix = (size_t)B * Hp * Wp;
+    hipLaunchKernelGGL(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H, W, Hp, Wp);
     return hipGetLastError();
 }
 

@@ -19,7 +19,8 @@ struct ConvGemmParams {
     const void* zero16;  // >= 16 bytes of zeros on the device (source of padded / out-of-range LDS-DMA rows)
     int B, H, W, Cin, OH, OW, N, KH, KW, stride, pad;
     int M, K;
-    int relu, bias_period, out_f32, stem;
+    int relu, bias_period, out_f32;
+    int stem;            // 0: NHWC conv / linear; 1: stem on a plain NHWC4 image (v1 kernel); 2: stem on the padded NHWC4 image
     int dbg;             // timing ablation for tools (0 = normal; 1 = skip MFMAs, 2 = skip all but the first tile DMA)
     int split_k;         // > 1: K is cut into split_k slices, slice z writes fp32 partials to out + z*M*N (bias in slice 0)
 };
@@ -29,10 +30,11 @@ void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LD
 int opd_get_gemm_variant();
 
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
-// uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order.
-hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, hipStream_t stream);
-// float32 NCHW pixel_values -> fp16 NHWC4.
-hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, hipStream_t stream);
+// uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order, written into a
+// zero-bordered image [B][Hp][Wp][4] with the frame at offset (3, 3) (Hp >= H + 6, Wp >= W + 6): the stem's padding.
+hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream);
+// float32 NCHW pixel_values -> the same padded fp16 NHWC4 image.
+hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream);
 // 3x3 stride-2 pad-1 max-pool, NHWC fp16, C % 8 == 0.
 hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW, hipStream_t stream);
 // y = LayerNorm(x) * gamma + beta over the last dim (D == 256); writes fp32 y and optional fp16 copy.

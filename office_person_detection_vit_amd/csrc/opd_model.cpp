@@ -365,7 +365,7 @@ static int build_workspace(opd_detr* m) {
     const size_t npix = B * d.H * d.W;
     RCCHK(dalloc(m, &m->d_u8, npix * 3, false));
     RCCHK(dalloc(m, &m->d_pv, npix * 3, false));
-    RCCHK(dalloc(m, &m->d_x4, npix * 4, false));
+    RCCHK(dalloc(m, &m->d_x4, B * (size_t)(2 * d.H1 + 6) * (2 * d.W1 + 6) * 4, false));  // zero-bordered NHWC4
     RCCHK(dalloc(m, &m->d_stem, B * d.H1 * d.W1 * 64, false));
     RCCHK(dalloc(m, &m->d_pool, B * d.H2 * d.W2 * 64, false));
     size_t trunk = 0, mid = 0;
@@ -571,11 +571,20 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     RCCHK(get_plan(m, d.sh[3], d.sw[3], &plan));
     timed_reset(m);
     MARK(0);
+    const int Hp = 2 * d.H1 + 6, Wp = 2 * d.W1 + 6;  // padded image seen by the stem: rows/cols 2*o + k, k = 0..7
     if (pixel_format == OPD_PIXELS_U8_BGR_HWC)
-        HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, m->stream));
+        HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, m->stream));
     else
-        HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, m->stream));
-    RCCHK(run_conv(m, m->stem, m->d_x4, B, H, W, d.H1, d.W1, m->d_stem, true, nullptr));
+        HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, m->stream));
+    {
+        ConvGemmParams p{};
+        p.x = m->d_x4; p.w = m->stem.w; p.bias = m->stem.bias; p.out = m->d_stem; p.zero16 = m->zero_bias;
+        p.B = B; p.H = Hp; p.W = Wp; p.Cin = 256; p.OH = d.H1; p.OW = d.W1; p.N = 64; p.KH = 1; p.KW = 1; p.stride = 2; p.pad = 0;
+        p.M = B * d.H1 * d.W1; p.K = 256; p.relu = 1; p.stem = 2;
+        RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * 64.0 * 147.0));
+        HIPCHK(opd_launch_conv_gemm(p, m->stream));
+        RCCHK(timed_end(m));
+    }
     HIPCHK(opd_launch_maxpool(m->d_stem, m->d_pool, B, d.H1, d.W1, 64, d.H2, d.W2, m->stream));
     MARK(1);
     const f16_t* cur = m->d_pool;

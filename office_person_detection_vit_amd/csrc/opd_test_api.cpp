@@ -183,15 +183,34 @@ int opd_test_maxpool(const uint16_t* x, uint16_t* out, int B, int H, int W, int 
     return OPD_OK;
 }
 
-int opd_test_preprocess_u8(const uint8_t* frames, uint16_t* out, int B, int H, int W) {
+int opd_test_preprocess_u8(const uint8_t* frames, uint16_t* out, int B, int H, int W, int Hp, int Wp) {
     DevMem dm;
-    const size_t npix = (size_t)B * H * W;
-    const uint8_t* din = dm.up(frames, npix * 3);
-    uint16_t* dout = dm.up<uint16_t>(nullptr, npix * 4);
+    const uint8_t* din = dm.up(frames, (size_t)B * H * W * 3);
+    uint16_t* dout = dm.up<uint16_t>(nullptr, (size_t)B * Hp * Wp * 4);
     if (!din || !dout) return tfail(OPD_ENOMEM, "test alloc failed");
-    TCHK(opd_launch_preprocess_u8(din, dout, B, H, W, nullptr));
+    TCHK(opd_launch_preprocess_u8(din, dout, B, H, W, Hp, Wp, nullptr));
     TCHK(hipDeviceSynchronize());
-    TCHK(hipMemcpy(out, dout, npix * 8, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(out, dout, (size_t)B * Hp * Wp * 8, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// Stem on the zero-bordered NHWC4 image through the LDS-DMA kernel (stem mode 2): x4p [B][Hp][Wp][4], w [64][8][8][4].
+int opd_test_stem2(const uint16_t* x4p, const uint16_t* w, const float* bias, uint16_t* out, int B, int Hp, int Wp, int OH, int OW) {
+    DevMem dm;
+    ConvGemmParams p{};
+    const size_t M = (size_t)B * OH * OW;
+    p.x = dm.up(x4p, (size_t)B * Hp * Wp * 4);
+    p.w = dm.up(w, (size_t)64 * 256);
+    p.bias = dm.up(bias, 64);
+    std::vector<float> zeros(64, 0.f);
+    p.zero16 = dm.up(zeros.data(), 64);
+    p.out = dm.up<uint16_t>(nullptr, M * 64);
+    if (!p.x || !p.w || !p.bias || !p.zero16 || !p.out) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.H = Hp; p.W = Wp; p.Cin = 256; p.OH = OH; p.OW = OW; p.N = 64; p.KH = 1; p.KW = 1; p.stride = 2; p.pad = 0;
+    p.M = (int)M; p.K = 256; p.relu = 1; p.stem = 2;
+    TCHK(opd_launch_conv_gemm(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out, p.out, M * 64 * 2, hipMemcpyDeviceToHost));
     return OPD_OK;
 }
 

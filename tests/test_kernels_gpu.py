@@ -276,12 +276,41 @@ def test_preprocess_matches_oracle(lib):
     from office_person_detection_vit_amd.frames import structured_frames
     from oracle import detr_oracle as O
 
-    frames = structured_frames(2, 37, 53, seed=77)
+    H, W = 37, 53
+    frames = structured_frames(2, H, W, seed=77)
     pv, _ = O.preprocess(frames)
     batch = np.ascontiguousarray(np.stack(frames))
-    out = np.empty((2, 37, 53, 4), np.uint16)
-    _capi.check(lib.opd_test_preprocess_u8(_p(batch), _p(out), 2, 37, 53), "opd_test_preprocess_u8")
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = 2 * OH + 6, 2 * OW + 6
+    out = np.empty((2, Hp, Wp, 4), np.uint16)
+    _capi.check(lib.opd_test_preprocess_u8(_p(batch), _p(out), 2, H, W, Hp, Wp), "opd_test_preprocess_u8")
     got = out.view(np.float16)
     want = pv.permute(0, 2, 3, 1).numpy().astype(np.float16)
-    np.testing.assert_array_equal(got[..., :3], want)  # same op order in fp32, one rounding to fp16
+    np.testing.assert_array_equal(got[:, 3:3 + H, 3:3 + W, :3], want)  # same op order in fp32, one rounding to fp16
     assert not got[..., 3].any()
+    border = got.copy()
+    border[:, 3:3 + H, 3:3 + W, :] = 0
+    assert not border.any()  # the zero border is the stem's padding
+
+
+@pytest.mark.parametrize("H,W", [(45, 51), (64, 96), (37, 34)])
+def test_stem_conv_padded_dma(lib, H, W):
+    """The production stem: 7x7 s2 p3 on the zero-bordered NHWC4 image through the LDS-DMA kernel (odd and even sizes)."""
+    rng = np.random.default_rng(H * 100 + W)
+    B, N = 2, 64
+    x, _ = _h(rng.standard_normal((B, H, W, 3)))
+    w, _ = _h(rng.standard_normal((N, 3, 7, 7)) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = 2 * OH + 6, 2 * OW + 6
+    x4p = np.zeros((B, Hp, Wp, 4), np.float16)
+    x4p[:, 3:3 + H, 3:3 + W, :3] = x
+    wt = np.zeros((N, 8, 8, 4), np.float16)
+    wt[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
+    out = np.empty((B * OH * OW, N), np.uint16)
+    rc = lib.opd_test_stem2(_p(np.ascontiguousarray(x4p.view(np.uint16))), _p(np.ascontiguousarray(wt.view(np.uint16))), _p(bias),
+                            _p(out), B, Hp, Wp, OH, OW)
+    _capi.check(rc, "opd_test_stem2")
+    got = out.view(np.float16).astype(np.float32).reshape(B, OH, OW, N)
+    want = ref_conv(x, w, bias, 2, 3, True)
+    np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
