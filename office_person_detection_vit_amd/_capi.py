@@ -67,6 +67,8 @@ TEST_API = {
     "opd_test_maxpool": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6),
     "opd_test_preprocess_u8": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5),
     "opd_test_stem2": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5),
+    "opd_test_stem_pool": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7),
+    "opd_test_set_fuse_stem_pool": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_f32_to_f16": (C.c_uint16, [C.c_float]),
     "opd_test_f16_to_f32": (C.c_float, [C.c_uint16]),
     "opd_test_normalise_key": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),

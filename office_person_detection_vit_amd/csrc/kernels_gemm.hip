@@ -1037,6 +1037,146 @@ hipError_t launch_strip(const ConvGemmParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused stem: 7x7 s2 convolution (+FrozenBN, ReLU) AND the 3x3 s2 p1 max-pool (HF:models/resnet/modeling_resnet.py:72-93)
+// in one kernel — the 64-channel stem activation (273 MB at batch 8 x 800x1333, written and read back by the unfused
+// pair) never reaches HBM.  One workgroup = a 5 x 32 patch of convolution outputs = 2 x 15 pooled pixels (+1 halo
+// row/column recomputed by the neighbours: 1.33x the stem FLOPs, which are 2.5 % of the model).
+//   * the implicit-GEMM part is conv_gemm_dma_kernel<64, BUF, 5> with a 2-D row map instead of the flat m index:
+//     tile row r (0..159) <-> convolution pixel (2*py0 - 1 + r / 32, 2*px0 - 1 + r % 32) of the zero-bordered NHWC4 image;
+//   * epilogue: bias + ReLU -> fp16 patch in LDS (out-of-map pixels = -65504 so the max ignores them, which is exactly
+//     MaxPool2d's implicit -inf padding) -> barrier -> 240 threads each reduce one (pooled pixel, 8-channel group).
+// ---------------------------------------------------------------------------------------------------------------------
+struct StemPoolParams {
+    const f16_t* x4p;   // [B][Hp][Wp][4] zero-bordered normalised image
+    const f16_t* w;     // [64][8][8][4]
+    const float* bias;  // [64]
+    f16_t* out;         // pooled [B][PH][PW][64]
+    int B, Hp, Wp, OH, OW, PH, PW;
+    int tiles_y, tiles_x;
+};
+
+__global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int MT = 5, NT = 2, BMT = 160;
+    constexpr int A_BYTES = BMT * ROW_BYTES, STAGE_BYTES = A_BYTES + 64 * ROW_BYTES;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int tiles_per_img = p.tiles_y * p.tiles_x;
+    const int b = blockIdx.x / tiles_per_img;
+    const int t = blockIdx.x - b * tiles_per_img;
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const int py0 = ty * 2, px0 = tx * 15;            // first pooled pixel of this tile
+    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;   // first convolution-output pixel (may be -1)
+
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x4p), 0, (unsigned)((size_t)p.B * p.Hp * p.Wp * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, 64 * 256 * 2, 0x00020000);
+    unsigned rowoff[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int r = (wave * MT + i) * 8 + lrow;
+        const int cy = cy0 + (r >> 5), cx = cx0 + (r & 31);
+        const bool ok = (unsigned)cy < (unsigned)p.OH && (unsigned)cx < (unsigned)p.OW;
+        rowoff[i] = ok ? (unsigned)((b * p.Hp + cy * 2) * p.Wp + cx * 2) * 8u + (unsigned)((lchunk >> 2) * p.Wp) * 8u + (unsigned)(lchunk & 3) * 16u
+                       : 0x80000000u;  // out of range -> the descriptor returns zeros
+    }
+    unsigned woff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((wave * 2 + i) * 8 + lrow) * 256) * 2u + (unsigned)lchunk * 16u;
+
+    auto issue = [&](int ks, int buf) {
+        unsigned char* As = smem + buf * STAGE_BYTES;
+        unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * MT + i) * 1024), 16,
+                                                     rowoff[i], ks * 16 * p.Wp, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (wave * 2 + i) * 1024), 16,
+                                                     woff[i], ks * (BK * 2), 0, 0);
+    };
+
+    issue(0, 0);
+    float4v acc[NT][MT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float4v bv = *reinterpret_cast<const float4v*>(p.bias + wn * 32 + nt * 16 + g * 4);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = bv;
+    }
+    __syncthreads();
+    for (int ks = 0; ks < 4; ++ks) {
+        if (ks + 1 < 4) issue(ks + 1, (ks & 1) ^ 1);
+        const unsigned char* As = smem + (ks & 1) * STAGE_BYTES;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * 80 + mt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * 32 + nt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    // ---- ReLU -> fp16 patch [160 pixels][64 ch] in stage buffer 0 (free: the last k-step read buffer 1) ----------------
+    unsigned char* patch = smem;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int r = wm * 80 + mt * 16 + li;
+            const int cy = cy0 + (r >> 5), cx = cx0 + (r & 31);
+            const bool ok = (unsigned)cy < (unsigned)p.OH && (unsigned)cx < (unsigned)p.OW;
+            float4v v = acc[nt][mt];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = ok ? (v[j] > 0.f ? v[j] : 0.f) : -65504.f;
+            const int cb = wn * 64 + nt * 32 + g * 8;  // byte offset of the quad in the 128-byte pixel row
+            const int off = r * 128 + ((((cb >> 4) ^ (r & 7)) << 4) | (cb & 8));
+            *reinterpret_cast<uint2*>(patch + off) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+        }
+    __syncthreads();
+    // ---- 3x3 s2 max over the patch: thread -> (pooled pixel 0..29, 8-channel group 0..7) -----------------------------------
+    if (tid < 240) {
+        const int c8 = tid & 7, pp = tid >> 3;
+        const int ly = pp / 15, lx = pp - ly * 15;
+        const int py = py0 + ly, px = px0 + lx;
+        if (py < p.PH && px < p.PW) {
+            half8 m;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.f);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    const int r = (2 * ly + dy) * 32 + 2 * lx + dx;
+                    const half8 v = *reinterpret_cast<const half8*>(patch + r * 128 + ((c8 ^ (r & 7)) << 4));
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                }
+            *reinterpret_cast<half8*>(p.out + (((size_t)b * p.PH + py) * p.PW + px) * 64 + c8 * 8) = m;
+        }
+    }
+#endif
+}
+
+
 template <int BN, bool STEM>
 hipError_t launch(const ConvGemmParams& p, hipStream_t stream) {
     using S = Smem<BN>;
@@ -1111,3 +1251,24 @@ void opd_set_gemm_variant(int v) {
     g_tile_mt = (v >> 8) & 7;  // bits 8-10: force m-tiles per wave (4, 5, 6); 0 = automatic
 }
 int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32) | (g_tile_mt << 8); }
+
+// x4p: zero-bordered NHWC4 image [B][Hp = 2*OH+6][Wp = 2*OW+6][4]; out: pooled [B][PH][PW][64]
+hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
+                                int OW, int PH, int PW, hipStream_t stream) {
+    if (Hp < 2 * OH + 6 || Wp < 2 * OW + 6 || (Wp & 1) || PH != (OH - 1) / 2 + 1 || PW != (OW - 1) / 2 + 1 ||
+        (size_t)B * Hp * Wp * 8 >= 0x7fffff00ull)
+        return hipErrorInvalidValue;
+    StemPoolParams p{};
+    p.x4p = x4p; p.w = w; p.bias = bias; p.out = out; p.B = B; p.Hp = Hp; p.Wp = Wp; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
+    p.tiles_y = (PH + 1) / 2;
+    p.tiles_x = (PW + 14) / 15;
+    constexpr int LDS = 2 * (160 + 64) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(B * p.tiles_y * p.tiles_x), dim3(256), LDS, stream, p);
+    return hipGetLastError();
+}

@@ -25,6 +25,9 @@ struct ConvGemmParams {
     int split_k;         // > 1: K is cut into split_k slices, slice z writes fp32 partials to out + z*M*N (bias in slice 0)
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
+// fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16
+hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
+                                int OW, int PH, int PW, hipStream_t stream);
 void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LDS-DMA v2 (default), 2/3 = ring variants;
                                    // +16 enables the experimental 3x3 row-strip kernel, +32 disables buffer-descriptor staging
 int opd_get_gemm_variant();

@@ -138,6 +138,7 @@ struct opd_detr {
     hipEvent_t ev[9] = {};
     float stage_ms[8] = {};
     int use_tr_read = 1;
+    int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
 
     // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
     struct GraphEntry { int B, H, W, fmt, fh, fw; const void* pixels; int uses; hipGraphExec_t exec; };
@@ -576,7 +577,11 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, m->stream));
     else
         HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, m->stream));
-    {
+    if (m->fuse_stem_pool) {
+        RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
+        HIPCHK(opd_launch_stem_pool(m->d_x4, m->stem.w, m->stem.bias, m->d_pool, B, Hp, Wp, d.H1, d.W1, d.H2, d.W2, m->stream));
+        RCCHK(timed_end(m));
+    } else {
         ConvGemmParams p{};
         p.x = m->d_x4; p.w = m->stem.w; p.bias = m->stem.bias; p.out = m->d_stem; p.zero16 = m->zero_bias;
         p.B = B; p.H = Hp; p.W = Wp; p.Cin = 256; p.OH = d.H1; p.OW = d.W1; p.N = 64; p.KH = 1; p.KW = 1; p.stride = 2; p.pad = 0;
@@ -584,8 +589,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * 64.0 * 147.0));
         HIPCHK(opd_launch_conv_gemm(p, m->stream));
         RCCHK(timed_end(m));
+        HIPCHK(opd_launch_maxpool(m->d_stem, m->d_pool, B, d.H1, d.W1, 64, d.H2, d.W2, m->stream));
     }
-    HIPCHK(opd_launch_maxpool(m->d_stem, m->d_pool, B, d.H1, d.W1, 64, d.H2, d.W2, m->stream));
     MARK(1);
     const f16_t* cur = m->d_pool;
     int ch = d.H2, cw = d.W2;
@@ -933,6 +938,15 @@ int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, dou
 int opd_test_set_gemm_variant(int v) {
     opd_set_gemm_variant(v);
     return opd_get_gemm_variant();
+}
+
+int opd_test_set_fuse_stem_pool(opd_detr* m, int on) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->fuse_stem_pool = on ? 1 : 0;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
 }
 
 int opd_test_set_tr_read(opd_detr* m, int on) {

@@ -214,6 +214,21 @@ int opd_test_stem2(const uint16_t* x4p, const uint16_t* w, const float* bias, ui
     return OPD_OK;
 }
 
+// Fused stem + max-pool on the zero-bordered NHWC4 image: out = pooled [B][PH][PW][64] fp16
+int opd_test_stem_pool(const uint16_t* x4p, const uint16_t* w, const float* bias, uint16_t* out, int B, int Hp, int Wp, int OH, int OW,
+                       int PH, int PW) {
+    DevMem dm;
+    const uint16_t* dx = dm.up(x4p, (size_t)B * Hp * Wp * 4);
+    const uint16_t* dw = dm.up(w, (size_t)64 * 256);
+    const float* db = dm.up(bias, 64);
+    uint16_t* dout = dm.up<uint16_t>(nullptr, (size_t)B * PH * PW * 64);
+    if (!dx || !dw || !db || !dout) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_stem_pool(dx, dw, db, dout, B, Hp, Wp, OH, OW, PH, PW, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out, dout, (size_t)B * PH * PW * 64 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 // host-only helpers of the loader, exposed so CPU tests can exercise them without a GPU
 uint16_t opd_test_f32_to_f16(float f) { return opd::f32_to_f16(f); }
 float opd_test_f16_to_f32(uint16_t h) { return opd::f16_to_f32(h); }

@@ -314,3 +314,30 @@ def test_stem_conv_padded_dma(lib, H, W):
     got = out.view(np.float16).astype(np.float32).reshape(B, OH, OW, N)
     want = ref_conv(x, w, bias, 2, 3, True)
     np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
+
+
+@pytest.mark.parametrize("H,W", [(45, 51), (64, 96), (37, 34), (120, 131)])
+def test_fused_stem_pool(lib, H, W):
+    """Stem conv + FrozenBN/ReLU + 3x3 s2 max-pool in ONE kernel vs conv2d -> relu -> max_pool2d (odd / even sizes, tiles
+    that overhang the map on every side)."""
+    rng = np.random.default_rng(H * 1000 + W)
+    B, N = 2, 64
+    x, _ = _h(rng.standard_normal((B, H, W, 3)))
+    w, _ = _h(rng.standard_normal((N, 3, 7, 7)) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    Hp, Wp = 2 * OH + 6, 2 * OW + 6
+    x4p = np.zeros((B, Hp, Wp, 4), np.float16)
+    x4p[:, 3:3 + H, 3:3 + W, :3] = x
+    wt = np.zeros((N, 8, 8, 4), np.float16)
+    wt[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
+    out = np.empty((B, PH, PW, N), np.uint16)
+    rc = lib.opd_test_stem_pool(_p(np.ascontiguousarray(x4p.view(np.uint16))), _p(np.ascontiguousarray(wt.view(np.uint16))), _p(bias),
+                                _p(out), B, Hp, Wp, OH, OW, PH, PW)
+    _capi.check(rc, "opd_test_stem_pool")
+    got = out.view(np.float16).astype(np.float32)
+    conv = torch.from_numpy(ref_conv(x, w, bias, 2, 3, True)).permute(0, 3, 1, 2)
+    conv = conv.to(torch.float16).to(torch.float32)  # the unfused path rounds the stem output to fp16 before pooling
+    want = F.max_pool2d(conv, 3, 2, 1).permute(0, 2, 3, 1).numpy()
+    np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
