@@ -1,0 +1,408 @@
+// kernels_btail.hip — fused ResNet bottleneck tail for gfx950:   c1 (3x3) -> c2 (1x1 expand) + residual + ReLU -> c0' (1x1)
+//
+// SURVEY.md §8(a) row a4.  Reference arithmetic: HF:models/resnet/modeling_resnet.py:139-178 (ResNetBottleNeckLayer:
+// shortcut + [1x1 reduce, 3x3, 1x1 expand] then activation), FrozenBN folded at load.
+//
+// In stages 1-2 of the trunk (C1 = 64 / 128 channels inside the block, C2 = 4*C1 outside) the unfused layers are HBM
+// bound: the 3x3 output and the expand output each make a round trip through HBM only to be re-read by a 1x1 whose whole
+// reduction dimension fits in one wave's registers.  The natural fusion boundary of a ResNet-v1.5 trunk is the INPUT of a
+// 3x3 convolution (the only operator that needs a halo), so one kernel runs
+//     x1 --3x3(C1->C1)+ReLU-->  a1  --1x1(C1->C2) + residual + ReLU-->  y  --1x1(C2->C3)+ReLU--> z
+// where z is the NEXT block's reduce output (c0' of block i+1, or the first block of the next stage).  a1 never leaves
+// registers, y is written once (it is the next residual) and never re-read for c0'.  HBM traffic per block drops from
+// 1091 MB to 682 MB (stage 1, batch 8), and three launches' latency chains become one.
+//
+// Work decomposition: a workgroup owns 128 output pixels, wave w the 32 pixels 32w..32w+31 with ALL channels, so every
+// reduction of the two 1x1s is wave-local.  MFMA orientation as in kernels_gemm.hip: weights are the A operand, pixels
+// the B operand, D[row = channel][col = pixel]: lane (g = lane>>4, i = lane&15) holds channels 4g..4g+3 of pixel i.
+// Two such 16-channel accumulator tiles, rounded to fp16, ARE a B operand of the next 16x16x32 MFMA (8 k-slots per
+// lane) under the k-permutation  slot 8g+e -> channel 4g+e, slot 8g+4+e -> channel 16+4g+e  (e < 4) of each 32-channel
+// block; the 1x1 weights are stored with that permutation applied along K at load time (`opd_permute_k32`), so their A
+// fragments are plain 16-byte LDS reads.
+//
+// Pipeline: the 3x3 main loop is the LDS-DMA loop of conv_gemm_dma_kernel (two stage buffers, buffer-descriptor
+// staging, XOR-swizzled 128-byte rows).  It continues seamlessly into C2/64 "chunk steps": chunk j stages the 64 rows of
+// W2 and the 64-column slice of W3 that chunk needs into the stage buffer the previous step has left, computes 64
+// channels of y for the wave's 32 pixels, applies bias/residual/ReLU, stores them, and feeds them straight into the z
+// accumulators.  The residual for chunk j+1 is fetched during chunk j.
+#include <hip/hip_runtime.h>
+#include "opd_kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
+typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ROW_BYTES = 128;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+
+__device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
+}
+
+__device__ __forceinline__ unsigned pack2h(float a, float b) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v h;
+    h[0] = (_Float16)a;
+    h[1] = (_Float16)b;
+    unsigned u;
+    __builtin_memcpy(&u, &h, 4);
+    return u;
+}
+__device__ __forceinline__ void unpack2h(unsigned u, float& a, float& b) {
+    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    half2v h;
+    __builtin_memcpy(&h, &u, 4);
+    a = (float)h[0];
+    b = (float)h[1];
+}
+__device__ __forceinline__ half8 as_half8(unsigned a, unsigned b, unsigned c, unsigned d) {
+    uint4v u = {a, b, c, d};
+    half8 h;
+    __builtin_memcpy(&h, &u, 16);
+    return h;
+}
+
+template <int N_OUTSTANDING>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N_OUTSTANDING >= 0 && N_OUTSTANDING <= 63, "vmcnt range");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_OUTSTANDING) : "memory");
+}
+__device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
+
+template <int C1, int C3>
+__global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int C2 = 4 * C1;
+    constexpr int NT1 = C1 / 16;               // c1 accumulator tiles per wave (all C1 channels)
+    constexpr int KK1 = C1 / 32;               // 32-channel k-blocks of a1
+    constexpr int A_BYTES = 128 * ROW_BYTES;   // 128 pixels x 64 halfs
+    constexpr int STAGE_BYTES = A_BYTES + C1 * ROW_BYTES;
+    constexpr int W1_PIECES = C1 / 32;         // 1-KiB pieces of the W1 tile per wave
+    constexpr int NCH = C2 / 64;               // 64-channel chunks of y
+    constexpr int W2C_BYTES = 64 * C1 * 2;     // chunk of W2: C1/64 sub-tiles of [64 rows][64 halfs]
+    constexpr int W2_PIECES = W2C_BYTES / 4096;
+    constexpr int W3_PIECES = C3 / 32;         // slice of W3: [C3 rows][64 halfs]
+    constexpr int NT3 = C3 / 16;
+    static_assert(W2C_BYTES + C3 * ROW_BYTES <= STAGE_BYTES, "chunk operands must fit a stage buffer");
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int m_base = xcd_logical_block(blockIdx.x, gridDim.x) * 128;
+    const int wm0 = m_base + wave * 32;        // this wave's 32 pixels
+
+    // ---- staging coordinates (see conv_gemm_dma_kernel): piece = 8 tile rows x 128 B, lane -> (row lane>>3, slot lane&7)
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const unsigned backoff = (unsigned)(p.W + 1) * (unsigned)C1 * 2u;  // pad = 1: every in-image tap gets a non-negative offset
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x1)) - backoff, 0, (unsigned)((size_t)p.B * p.H * p.W * C1 * 2) + backoff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w1), 0, (unsigned)(C1 * 9 * C1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w2p), 0, (unsigned)(C2 * C1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(C3 ? p.w3p : p.w2p), 0, (unsigned)((C3 ? C3 : 1) * C2 * 2), 0x00020000);
+    unsigned rowoff[4], rowmask[4], woff1[W1_PIECES], woff2[W2_PIECES], woff3[W3_PIECES ? W3_PIECES : 1];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + (wave * 4 + i) * 8 + lrow;
+            const bool okm = m < p.M;
+            const int mm = okm ? m : 0;
+            const int b = mm / ohw;
+            const int r = mm - b * ohw;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            rowoff[i] = (unsigned)(((b * p.H + oh * p.stride) * p.W + ow * p.stride) * C1) * 2u + (unsigned)lchunk * 16u;
+            unsigned kwmask = 0, mask = 0;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                if ((unsigned)(ow * p.stride - 1 + kw) < (unsigned)p.W) kwmask |= 1u << kw;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                if ((unsigned)(oh * p.stride - 1 + kh) < (unsigned)p.H) mask |= kwmask << (kh * 3);
+            rowmask[i] = okm ? mask : 0u;
+        }
+#pragma unroll
+        for (int i = 0; i < W1_PIECES; ++i)
+            woff1[i] = (unsigned)(((wave * W1_PIECES + i) * 8 + lrow) * (9 * C1)) * 2u + (unsigned)lchunk * 16u;
+#pragma unroll
+        for (int i = 0; i < W2_PIECES; ++i) {
+            const int q = wave * W2_PIECES + i;   // sub-tile q>>3 (64 k each), rows 8*(q&7)..+7 of the 64-row chunk
+            woff2[i] = (unsigned)(((q & 7) * 8 + lrow) * C1 + (q >> 3) * 64) * 2u + (unsigned)lchunk * 16u;
+        }
+#pragma unroll
+        for (int i = 0; i < W3_PIECES; ++i)
+            woff3[i] = (unsigned)(((wave * W3_PIECES + i) * 8 + lrow) * C2) * 2u + (unsigned)lchunk * 16u;
+    }
+
+    constexpr int kpc = C1 / 64;   // k-steps per filter tap
+    constexpr int nk = 9 * kpc;
+    int tap_kh = 0, tap_kw = 0, tap_c = 0;
+    auto issue_main = [&](int ks, int buf) {
+        unsigned char* As = smem + buf * STAGE_BYTES;
+        unsigned char* Ws = As + A_BYTES;
+        const int tap = tap_kh * 3 + tap_kw;
+        const int soff_a = ((tap_kh * p.W + tap_kw) * C1 + tap_c * 64) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned vo = ((rowmask[i] >> tap) & 1u) ? rowoff[i] : 0x80000000u;  // out of range -> zero fill
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * 4 + i) * 1024), 16, vo,
+                                                     soff_a, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < W1_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (__attribute__((address_space(3))) void*)(Ws + (wave * W1_PIECES + i) * 1024),
+                                                     16, woff1[i], ks * 128, 0, 0);
+        if (++tap_c == kpc) {
+            tap_c = 0;
+            if (++tap_kw == 3) { tap_kw = 0; ++tap_kh; }
+        }
+    };
+    auto issue_chunk = [&](int j, int buf) {
+        unsigned char* W2s = smem + buf * STAGE_BYTES;
+#pragma unroll
+        for (int i = 0; i < W2_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w2, (__attribute__((address_space(3))) void*)(W2s + (wave * W2_PIECES + i) * 1024),
+                                                     16, woff2[i], j * (64 * C1 * 2), 0, 0);
+        if constexpr (C3 > 0) {
+            unsigned char* W3s = W2s + W2C_BYTES;
+#pragma unroll
+            for (int i = 0; i < W3_PIECES; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (__attribute__((address_space(3))) void*)(W3s + (wave * W3_PIECES + i) * 1024),
+                                                         16, woff3[i], j * 128, 0, 0);
+        }
+    };
+    // fp16 residual of y-chunk j in the paired 16-byte layout: lane (g, li) -> row (g&1)*16 + li, 8 channels at (g>>1)*8
+    const int pr_m = wm0 + (g & 1) * 16 + li;
+    const bool pr_ok = pr_m < p.M;
+    const size_t pr_row = (size_t)pr_m * C2 + (g >> 1) * 8;
+    const bool has_res = p.res != nullptr;
+    // Counted waits (below) rely on every wave issuing exactly 4 residual loads and 4 stores per chunk: true on full
+    // tiles with a residual; otherwise (ragged last tile, no residual) the waits fall back to vmcnt(0).
+    const bool counted = has_res && m_base + 128 <= p.M;
+    auto load_res = [&](int j, uint4 (&r)[4]) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            r[nt] = make_uint4(0u, 0u, 0u, 0u);
+            if (has_res && pr_ok) r[nt] = *reinterpret_cast<const uint4*>(p.res + pr_row + j * 64 + nt * 16);
+        }
+    };
+
+    // ---- 3x3 main loop ------------------------------------------------------------------------------------------------
+    issue_main(0, 0);
+    float4v acc1[NT1][2];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.b1 + nt * 16 + g * 4);
+        acc1[nt][0] = b;
+        acc1[nt][1] = b;
+    }
+    __syncthreads();
+    uint4 res[3][4];  // residual of chunk j lives in res[j % 3], fetched two chunk steps ahead
+    auto compute_main = [&](int buf) {
+        const unsigned char* As = smem + buf * STAGE_BYTES;
+        const unsigned char* Ws = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[2], wf[NT1];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const half8*>(As + swz(wave * 32 + mt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + swz(nt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc1[nt][mt], 0, 0, 0);
+        }
+    };
+#pragma unroll 1
+    for (int ks = 0; ks + 1 < nk; ++ks) {
+        issue_main(ks + 1, (ks + 1) & 1);
+        compute_main(ks & 1);
+        __syncthreads();
+    }
+    // last k-step: the free stage buffer receives chunk 0's operands; residual chunks 0 and 1 start their trip
+    issue_chunk(0, nk & 1);
+    compiler_fence();
+    load_res(0, res[0]);
+    load_res(1, res[1]);
+    compiler_fence();
+    compute_main((nk - 1) & 1);
+    if (counted) wait_vmcnt<8>(); else wait_vmcnt<0>();  // chunk 0 operands landed (the 8 residual loads may still fly)
+    __builtin_amdgcn_s_barrier();
+
+    // ---- a1 = relu(c1) as fp16 B operands: k-block kk <- accumulator tiles 2kk, 2kk+1 -----------------------------------
+    half8 a1[2][KK1];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+            float4v u = acc1[2 * kk][mt], v = acc1[2 * kk + 1][mt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                u[r] = u[r] > 0.f ? u[r] : 0.f;
+                v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            a1[mt][kk] = as_half8(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+        }
+
+    float4v accz[NT3 ? NT3 : 1][2];
+    if constexpr (C3 > 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt) {
+            const float4v b = *reinterpret_cast<const float4v*>(p.b3 + nt * 16 + g * 4);
+            accz[nt][0] = b;
+            accz[nt][1] = b;
+        }
+    }
+
+    // ---- chunk steps: 64 channels of y each ------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < NCH; ++j) {
+        const int buf = (nk + j) & 1;
+        uint4 (&res_cur)[4] = res[j % 3];
+        if (j + 1 < NCH) issue_chunk(j + 1, buf ^ 1);
+        compiler_fence();
+        if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]);
+        compiler_fence();
+        const unsigned char* W2s = smem + buf * STAGE_BYTES;
+        float4v acc2[4][2];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const float4v b = *reinterpret_cast<const float4v*>(p.b2 + j * 64 + nt * 16 + g * 4);
+            acc2[nt][0] = b;
+            acc2[nt][1] = b;
+        }
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+            half8 wf[4];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+                wf[nt] = *reinterpret_cast<const half8*>(W2s + (kk >> 1) * 8192 + swz(nt * 16 + li, (kk & 1) * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], a1[mt][kk], acc2[nt][mt], 0, 0, 0);
+        }
+        // residual (paired layout -> accumulator layout), ReLU, fp16; store y; keep the fp16 values as the next B operand
+        unsigned pk[4][2][2];
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            float4v v0 = acc2[nt][0], v1 = acc2[nt][1];
+            if (has_res) {
+                const uint4 r = res_cur[nt];
+                const uint2v s0 = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
+                const uint2v s1 = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+                float a, b;
+                unpack2h(s0[0], a, b); v0[0] += a; v0[1] += b;
+                unpack2h(s1[0], a, b); v0[2] += a; v0[3] += b;
+                unpack2h(s0[1], a, b); v1[0] += a; v1[1] += b;
+                unpack2h(s1[1], a, b); v1[2] += a; v1[3] += b;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
+                v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+            }
+            pk[nt][0][0] = pack2h(v0[0], v0[1]);
+            pk[nt][0][1] = pack2h(v0[2], v0[3]);
+            pk[nt][1][0] = pack2h(v1[0], v1[1]);
+            pk[nt][1][1] = pack2h(v1[2], v1[3]);
+            const uint2v s0 = __builtin_amdgcn_permlane16_swap(pk[nt][0][0], pk[nt][1][0], false, false);
+            const uint2v s1 = __builtin_amdgcn_permlane16_swap(pk[nt][0][1], pk[nt][1][1], false, false);
+            if (pr_ok) *reinterpret_cast<uint4*>(p.y + pr_row + j * 64 + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+        if constexpr (C3 > 0) {
+            const unsigned char* W3s = W2s + W2C_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                half8 yf[2];
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+                    yf[mt] = as_half8(pk[2 * kk][mt][0], pk[2 * kk][mt][1], pk[2 * kk + 1][mt][0], pk[2 * kk + 1][mt][1]);
+#pragma unroll
+                for (int nt = 0; nt < NT3; ++nt) {
+                    const half8 wf = *reinterpret_cast<const half8*>(W3s + swz(nt * 16 + li, kk * 4 + g));
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) accz[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, yf[mt], accz[nt][mt], 0, 0, 0);
+                }
+            }
+        }
+        if (j + 1 < NCH) {
+            // chunk j+1's operands (issued at the top of this step) have landed; this step's y stores and the residual
+            // loads of chunk j+2 stay in flight across the barrier (vmcnt retires in issue order)
+            if (!counted) wait_vmcnt<0>();
+            else if (j + 2 < NCH) wait_vmcnt<8>();
+            else wait_vmcnt<4>();
+            __builtin_amdgcn_s_barrier();
+        }
+    }
+
+    // ---- z = relu(c0') -----------------------------------------------------------------------------------------------------
+    if constexpr (C3 > 0) {
+        const size_t zrow = (size_t)pr_m * C3 + (g >> 1) * 8;
+#pragma unroll
+        for (int nt = 0; nt < NT3; ++nt) {
+            float4v v0 = accz[nt][0], v1 = accz[nt][1];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
+                v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+            }
+            const uint2v s0 = __builtin_amdgcn_permlane16_swap(pack2h(v0[0], v0[1]), pack2h(v1[0], v1[1]), false, false);
+            const uint2v s1 = __builtin_amdgcn_permlane16_swap(pack2h(v0[2], v0[3]), pack2h(v1[2], v1[3]), false, false);
+            if (pr_ok) *reinterpret_cast<uint4*>(p.z + zrow + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+        }
+    }
+#endif
+}
+
+template <int C1, int C3>
+hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
+    constexpr int LDS = 2 * (128 + C1) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((btail_kernel<C1, C3>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+bool opd_btail_supported(int C1, int C3) { return (C1 == 64 && (C3 == 0 || C3 == 64 || C3 == 128)) || (C1 == 128 && (C3 == 0 || C3 == 128)); }
+
+hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream) {
+    if (!opd_btail_supported(p.C1, p.C3)) return hipErrorInvalidValue;
+    // 31-bit byte offsets in the buffer descriptors
+    if ((size_t)p.B * p.H * p.W * p.C1 * 2 + (size_t)(p.W + 1) * p.C1 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
+    if (p.C1 == 64) {
+        if (p.C3 == 0) return launch_btail_t<64, 0>(p, stream);
+        if (p.C3 == 64) return launch_btail_t<64, 64>(p, stream);
+        return launch_btail_t<64, 128>(p, stream);
+    }
+    if (p.C3 == 0) return launch_btail_t<128, 0>(p, stream);
+    return launch_btail_t<128, 128>(p, stream);
+}
+
+// K-permutation of a [rows][K] fp16 weight matrix (K % 32 == 0) that makes two fp16-rounded 16x16 accumulator tiles a
+// valid B operand: within each 32-block, slot 8g+e <- channel 4g+e, slot 8g+4+e <- channel 16+4g+e.
+void opd_permute_k32(const f16_t* w, f16_t* out, int rows, int K) {
+    for (int n = 0; n < rows; ++n)
+        for (int b = 0; b < K; b += 32)
+            for (int g = 0; g < 4; ++g)
+                for (int e = 0; e < 4; ++e) {
+                    out[(size_t)n * K + b + 8 * g + e] = w[(size_t)n * K + b + 4 * g + e];
+                    out[(size_t)n * K + b + 8 * g + 4 + e] = w[(size_t)n * K + b + 16 + 4 * g + e];
+                }
+}

@@ -28,6 +28,25 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 // fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16
 hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
                                 int OW, int PH, int PW, hipStream_t stream);
+// fused bottleneck tail (kernels_btail.hip):  a1 = relu(conv3x3(x1, w1) + b1) ; y = relu(a1*w2 + b2 + res) ; z = relu(y*w3 + b3)
+// x1 [B][H][W][C1] fp16, y/res [M][4*C1], z [M][C3]  (M = B*OH*OW, 3x3 pad 1, stride 1 or 2).  w2p / w3p are the 1x1
+// weights with opd_permute_k32 applied along K.  C3 == 0: no z.  (C1, C3) must satisfy opd_btail_supported.
+struct BtailParams {
+    const f16_t* x1;
+    const f16_t* w1;   // [C1][3][3][C1]
+    const float* b1;
+    const f16_t* w2p;  // [4*C1][C1], K-permuted
+    const float* b2;
+    const f16_t* res;  // [M][4*C1] or null
+    f16_t* y;          // [M][4*C1]
+    const f16_t* w3p;  // [C3][4*C1], K-permuted (C3 > 0)
+    const float* b3;
+    f16_t* z;          // [M][C3]
+    int B, H, W, OH, OW, stride, M, C1, C3;
+};
+bool opd_btail_supported(int C1, int C3);
+hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);
+void opd_permute_k32(const f16_t* w, f16_t* out, int rows, int K);  // host
 void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LDS-DMA v2 (default), 2/3 = ring variants;
                                    // +16 enables the experimental 3x3 row-strip kernel, +32 disables buffer-descriptor staging
 int opd_get_gemm_variant();

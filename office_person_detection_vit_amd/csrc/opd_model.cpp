@@ -44,6 +44,7 @@ static int fail(int code, const std::string& msg) {
 
 struct Conv {
     f16_t* w = nullptr;
+    f16_t* wp = nullptr;  // 1x1 only: the same weights K-permuted for the fused bottleneck tail (opd_permute_k32's order)
     float* bias = nullptr;
     int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, K = 0;
     bool stem = false;
@@ -138,6 +139,7 @@ struct opd_detr {
     hipEvent_t ev[9] = {};
     float stage_ms[8] = {};
     int use_tr_read = 1;
+    int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
 
     // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
@@ -219,6 +221,17 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
                             w.data[(((size_t)o * Cin + ci) * KH + kh) * KW + kw] * scale[o];
     }
     RCCHK(upload_f16(m, &c->w, wt));
+    if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 512) {  // operands of kernels_btail.hip (stages 1-2)
+        std::vector<float> wp(wt.size());
+        for (int o = 0; o < Cout; ++o)
+            for (int b = 0; b < Cin; b += 32)
+                for (int g = 0; g < 4; ++g)
+                    for (int e = 0; e < 4; ++e) {
+                        wp[(size_t)o * Cin + b + 8 * g + e] = wt[(size_t)o * Cin + b + 4 * g + e];
+                        wp[(size_t)o * Cin + b + 8 * g + 4 + e] = wt[(size_t)o * Cin + b + 16 + 4 * g + e];
+                    }
+        RCCHK(upload_f16(m, &c->wp, wp));
+    }
     RCCHK(upload_f32(m, &c->bias, bias));
     return OPD_OK;
 }
@@ -594,19 +607,45 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     MARK(1);
     const f16_t* cur = m->d_pool;
     int ch = d.H2, cw = d.W2;
+    const f16_t* z_ready = nullptr;  // the current block's reduce (c0) output when the previous fused tail produced it
     for (int s = 0; s < 4; ++s) {
         for (int l = 0; l < a.depths[s]; ++l) {
-            const Block& b = m->blocks[m->stage_first[s] + l];
+            const int bi = m->stage_first[s] + l;
+            const Block& b = m->blocks[bi];
+            const Block* nb = bi + 1 < (int)m->blocks.size() ? &m->blocks[bi + 1] : nullptr;
             const int oh = (b.c1.stride == 2) ? down2(ch) : ch, ow = (b.c1.stride == 2) ? down2(cw) : cw;
             const f16_t* res = cur;
             if (b.has_sc) {
                 RCCHK(run_conv(m, b.sc, cur, B, ch, cw, oh, ow, m->d_sc, false, nullptr));
                 res = m->d_sc;
             }
-            RCCHK(run_conv(m, b.c0, cur, B, ch, cw, ch, cw, m->d_m0, true, nullptr));
-            RCCHK(run_conv(m, b.c1, m->d_m0, B, ch, cw, oh, ow, m->d_m1, true, nullptr));
+            const f16_t* x1 = z_ready;
+            if (!x1) {
+                RCCHK(run_conv(m, b.c0, cur, B, ch, cw, ch, cw, m->d_m0, true, nullptr));
+                x1 = m->d_m0;
+            }
+            z_ready = nullptr;
             f16_t* out = (cur == m->d_t0) ? m->d_t1 : m->d_t0;
-            RCCHK(run_conv(m, b.c2, m->d_m1, B, oh, ow, oh, ow, out, true, res));
+            const int C1 = b.c1.Cin;
+            const bool tail_ok = m->fuse_btail && b.c1.KH == 3 && b.c1.Cout == C1 && b.c2.Cin == C1 && b.c2.Cout == 4 * C1 && b.c2.wp &&
+                                 (size_t)B * ch * cw * C1 * 2 < 0x7ff00000ull;
+            if (tail_ok && opd_btail_supported(C1, 0)) {
+                int C3 = 0;
+                if (nb && nb->c0.wp && nb->c0.Cin == 4 * C1 && opd_btail_supported(C1, nb->c0.Cout)) C3 = nb->c0.Cout;
+                BtailParams p{};
+                p.x1 = x1; p.w1 = b.c1.w; p.b1 = b.c1.bias; p.w2p = b.c2.wp; p.b2 = b.c2.bias; p.res = res; p.y = out;
+                f16_t* z = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
+                if (C3) { p.w3p = nb->c0.wp; p.b3 = nb->c0.bias; p.z = z; }
+                p.B = B; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = B * oh * ow; p.C1 = C1; p.C3 = C3;
+                RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3)));
+                HIPCHK(opd_launch_btail(p, m->stream));
+                RCCHK(timed_end(m));
+                if (C3) z_ready = z;
+            } else {
+                f16_t* a1 = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
+                RCCHK(run_conv(m, b.c1, x1, B, ch, cw, oh, ow, a1, true, nullptr));
+                RCCHK(run_conv(m, b.c2, a1, B, oh, ow, oh, ow, out, true, res));
+            }
             cur = out; ch = oh; cw = ow;
         }
         MARK(2 + s);
@@ -940,6 +979,14 @@ int opd_test_set_gemm_variant(int v) {
     return opd_get_gemm_variant();
 }
 
+int opd_test_set_fuse_btail(opd_detr* m, int on) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->fuse_btail = on ? 1 : 0;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
 int opd_test_set_fuse_stem_pool(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_stem_pool = on ? 1 : 0;

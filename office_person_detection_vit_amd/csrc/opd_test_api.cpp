@@ -140,6 +140,94 @@ int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     return OPD_OK;
 }
 
+// fused bottleneck tail vs. the caller's reference: x1 [B][H][W][C1], w1 [C1][3][3][C1], w2 [4*C1][C1], w3 [C3][4*C1]
+// (plain K order: the hook applies opd_permute_k32), res [M][4*C1] or null; outputs y [M][4*C1], z [M][C3] (C3 > 0).
+int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2,
+                   const uint16_t* res, const uint16_t* w3, const float* b3, uint16_t* y, uint16_t* z, int B, int H, int W,
+                   int C1, int C3, int stride) {
+    if (!opd_btail_supported(C1, C3)) return tfail(OPD_EINVAL, "btail: unsupported (C1, C3)");
+    DevMem dm;
+    const int C2 = 4 * C1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    const size_t M = (size_t)B * OH * OW;
+    std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)(C3 ? C3 : 1) * C2);
+    opd_permute_k32(w2, w2p.data(), C2, C1);
+    if (C3) opd_permute_k32(w3, w3p.data(), C3, C2);
+    BtailParams p{};
+    p.x1 = dm.up(x1, (size_t)B * H * W * C1);
+    p.w1 = dm.up(w1, (size_t)C1 * 9 * C1);
+    p.b1 = dm.up(b1, C1);
+    p.w2p = dm.up(w2p.data(), w2p.size());
+    p.b2 = dm.up(b2, C2);
+    p.res = res ? dm.up(res, M * C2) : nullptr;
+    p.y = dm.up<uint16_t>(nullptr, M * C2);
+    p.w3p = C3 ? dm.up(w3p.data(), w3p.size()) : nullptr;
+    p.b3 = C3 ? dm.up(b3, C3) : nullptr;
+    p.z = C3 ? dm.up<uint16_t>(nullptr, M * C3) : nullptr;
+    if (!p.x1 || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.y || (res && !p.res) || (C3 && (!p.w3p || !p.b3 || !p.z)))
+        return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.M = (int)M; p.C1 = C1; p.C3 = C3;
+    TCHK(opd_launch_btail(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, p.y, M * C2 * 2, hipMemcpyDeviceToHost));
+    if (C3) TCHK(hipMemcpy(z, p.z, M * C3 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// Times the fused tail (us_out[0]) and the three unfused launches it replaces (us_out[1..3]: c1, c2, c0') on
+// device-resident data of the given shape.
+int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int iters, float* us_out) {
+    if (!opd_btail_supported(C1, C3)) return tfail(OPD_EINVAL, "btail: unsupported (C1, C3)");
+    DevMem dm;
+    const int C2 = 4 * C1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
+    const size_t M = (size_t)B * OH * OW;
+    uint16_t* x1 = dm.up<uint16_t>(nullptr, (size_t)B * H * W * C1);
+    uint16_t* w1 = dm.up<uint16_t>(nullptr, (size_t)C1 * 9 * C1);
+    uint16_t* w2 = dm.up<uint16_t>(nullptr, (size_t)C2 * C1);
+    uint16_t* w3 = dm.up<uint16_t>(nullptr, (size_t)(C3 ? C3 : 64) * C2);
+    float* bias = dm.up<float>(nullptr, C2);
+    uint16_t* res = dm.up<uint16_t>(nullptr, M * C2);
+    uint16_t* a1 = dm.up<uint16_t>(nullptr, M * C1);
+    uint16_t* y = dm.up<uint16_t>(nullptr, M * C2);
+    uint16_t* z = dm.up<uint16_t>(nullptr, M * (C3 ? C3 : 64));
+    float* zero = dm.up<float>(nullptr, 4096);
+    if (!x1 || !w1 || !w2 || !w3 || !bias || !res || !a1 || !y || !z || !zero) return tfail(OPD_ENOMEM, "bench alloc failed");
+    TCHK(hipMemset(x1, 0x2c, (size_t)B * H * W * C1 * 2));
+    TCHK(hipMemset(w1, 0x1c, (size_t)C1 * 9 * C1 * 2));
+    TCHK(hipMemset(w2, 0x1c, (size_t)C2 * C1 * 2));
+    TCHK(hipMemset(w3, 0x1c, (size_t)(C3 ? C3 : 64) * C2 * 2));
+    TCHK(hipMemset(bias, 0, (size_t)C2 * 4));
+    TCHK(hipMemset(res, 0x2c, M * C2 * 2));
+    TCHK(hipMemset(zero, 0, 4096 * 4));
+    BtailParams p{};
+    p.x1 = x1; p.w1 = w1; p.b1 = bias; p.w2p = w2; p.b2 = bias; p.res = res; p.y = y; p.w3p = w3; p.b3 = bias; p.z = z;
+    p.B = B; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.M = (int)M; p.C1 = C1; p.C3 = C3;
+    ConvGemmParams c[3] = {};
+    c[0].x = x1; c[0].w = w1; c[0].out = a1; c[0].B = B; c[0].H = H; c[0].W = W; c[0].Cin = C1; c[0].OH = OH; c[0].OW = OW; c[0].N = C1;
+    c[0].KH = c[0].KW = 3; c[0].stride = stride; c[0].pad = 1; c[0].K = 9 * C1;
+    c[1].x = a1; c[1].w = w2; c[1].res16 = res; c[1].out = y; c[1].B = B; c[1].H = OH; c[1].W = OW; c[1].Cin = C1; c[1].OH = OH; c[1].OW = OW;
+    c[1].N = C2; c[1].KH = c[1].KW = 1; c[1].stride = 1; c[1].K = C1;
+    c[2].x = y; c[2].w = w3; c[2].out = z; c[2].B = B; c[2].H = OH; c[2].W = OW; c[2].Cin = C2; c[2].OH = OH; c[2].OW = OW; c[2].N = C3 ? C3 : 64;
+    c[2].KH = c[2].KW = 1; c[2].stride = 1; c[2].K = C2;
+    for (auto& q : c) { q.bias = bias; q.zero16 = zero; q.M = (int)M; q.relu = 1; }
+    hipEvent_t ev[2];
+    TCHK(hipEventCreate(&ev[0])); TCHK(hipEventCreate(&ev[1]));
+    for (int k = 0; k < 4; ++k) {
+        if (k == 3 && !C3) { us_out[3] = 0.f; break; }
+        for (int i = -2; i < iters; ++i) {
+            if (i == 0) TCHK(hipEventRecord(ev[0], nullptr));
+            if (k == 0) TCHK(opd_launch_btail(p, nullptr));
+            else TCHK(opd_launch_conv_gemm(c[k - 1], nullptr));
+        }
+        TCHK(hipEventRecord(ev[1], nullptr));
+        TCHK(hipEventSynchronize(ev[1]));
+        float ms = 0.f;
+        TCHK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+        us_out[k] = ms * 1000.f / iters;
+    }
+    (void)hipEventDestroy(ev[0]); (void)hipEventDestroy(ev[1]);
+    return OPD_OK;
+}
+
 int opd_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int B, int heads, int Lq, int Lk,
                        float scale, int use_tr_read) {
     DevMem dm;

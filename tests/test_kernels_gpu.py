@@ -341,3 +341,104 @@ def test_fused_stem_pool(lib, H, W):
     conv = conv.to(torch.float16).to(torch.float32)  # the unfused path rounds the stem output to fp16 before pooling
     want = F.max_pool2d(conv, 3, 2, 1).permute(0, 2, 3, 1).numpy()
     np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
+
+
+# ---- fused bottleneck tail (kernels_btail.hip): 3x3 -> 1x1 expand + residual + ReLU -> next 1x1 reduce ------------------
+def run_btail(lib, x1, w1, b1, w2, b2, res, w3, b3, stride):
+    """x1 [B,H,W,C1]; w1 [C1,C1,3,3]; w2 [C2,C1]; w3 [C3,C2] or None; returns (y [B,OH,OW,C2], z [B,OH,OW,C3] | None)."""
+    B, H, W, C1 = x1.shape
+    C2 = 4 * C1
+    C3 = 0 if w3 is None else w3.shape[0]
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    M = B * OH * OW
+    f16 = lambda a: np.ascontiguousarray(a.astype(np.float16).view(np.uint16))
+    w1t = f16(w1.transpose(0, 2, 3, 1).reshape(C1, 9 * C1))
+    y = np.empty((M, C2), np.uint16)
+    z = np.empty((M, max(C3, 1)), np.uint16)
+    f32 = lambda a: np.ascontiguousarray(a.astype(np.float32))
+    args = [f16(x1), w1t, f32(b1), f16(w2), f32(b2), f16(res.reshape(M, C2)) if res is not None else None,
+            f16(w3) if C3 else None, f32(b3) if C3 else None, y, z]
+    rc = lib.opd_test_btail(*[_p(a) for a in args], B, H, W, C1, C3, stride)
+    _capi.check(rc, "opd_test_btail")
+    yy = y.view(np.float16).astype(np.float32).reshape(B, OH, OW, C2)
+    zz = z.view(np.float16).astype(np.float32).reshape(B, OH, OW, C3) if C3 else None
+    return yy, zz
+
+
+def ref_btail(x1, w1, b1, w2, b2, res, w3, b3, stride):
+    """fp32 reference with the fp16 storage points of the UNFUSED path (a1 and y are rounded to fp16 once)."""
+    r16 = lambda a: a.astype(np.float16).astype(np.float32)
+    a1 = r16(ref_conv(x1, w1, b1, stride, 1, True))
+    y = r16(ref_conv(a1, w2[:, :, None, None], b2, 1, 0, True, res))
+    z = r16(ref_conv(y, w3[:, :, None, None], b3, 1, 0, True)) if w3 is not None else None
+    return y, z
+
+
+BTAIL_CASES = [
+    # B, H, W, C1, C3, stride, residual
+    (2, 13, 17, 64, 64, 1, True),     # stage-1 block -> next block's reduce, ragged M (442 rows)
+    (1, 24, 21, 64, 128, 1, True),    # last stage-1 block -> stage-2 first reduce
+    (2, 9, 11, 64, 0, 1, True),       # no fused reduce
+    (1, 16, 16, 64, 64, 1, False),    # no residual, M a multiple of 128
+    (2, 15, 13, 128, 128, 2, True),   # stage-2 first block: stride-2 3x3, odd sizes
+    (1, 18, 23, 128, 128, 1, True),   # stage-2 block
+    (3, 11, 7, 128, 0, 1, True),      # images narrower than the tile; no fused reduce
+]
+
+
+@pytest.mark.parametrize("case", BTAIL_CASES)
+def test_btail_matches_torch(lib, case):
+    B, H, W, C1, C3, stride, use_res = case
+    C2 = 4 * C1
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    x1, _ = _h(np.abs(rng.standard_normal((B, H, W, C1))))
+    w1, _ = _h(rng.standard_normal((C1, C1, 3, 3)) * np.sqrt(2.0 / (9 * C1)))
+    w2, _ = _h(rng.standard_normal((C2, C1)) * np.sqrt(2.0 / C1))
+    w3 = _h(rng.standard_normal((C3, C2)) * np.sqrt(2.0 / C2))[0] if C3 else None
+    b1 = rng.standard_normal(C1).astype(np.float32) * 0.1
+    b2 = rng.standard_normal(C2).astype(np.float32) * 0.1
+    b3 = rng.standard_normal(C3).astype(np.float32) * 0.1 if C3 else None
+    OH, OW = (H - 1) // stride + 1, (W - 1) // stride + 1
+    res = _h(rng.standard_normal((B, OH, OW, C2)))[0] if use_res else None
+    y, z = run_btail(lib, x1, w1, b1, w2, b2, res, w3, b3, stride)
+    yr, zr = ref_btail(x1, w1, b1, w2, b2, res, w3, b3, stride)
+    # one fp16 rounding of a1 may differ by an ulp through accumulation order and propagates: 2e-3 of the tensor scale
+    np.testing.assert_allclose(y, yr, atol=2e-3 * float(np.abs(yr).max()), rtol=2e-3)
+    if C3:
+        np.testing.assert_allclose(z, zr, atol=2e-3 * float(np.abs(zr).max()), rtol=2e-3)
+
+
+@pytest.mark.parametrize("C1,C3", [(64, 64), (64, 128), (128, 128)])
+def test_btail_integer_exact_and_equals_unfused(lib, C1, C3):
+    """Small-integer operands: all three GEMMs are exact, so the fused kernel must be BIT-identical to the torch
+    reference and to the three unfused conv_gemm launches; asymmetric one-hot-ish weights catch a wrong k-permutation."""
+    rng = np.random.default_rng(C1 + C3)
+    B, H, W, C2 = 2, 10, 9, 4 * C1
+    x1 = rng.integers(0, 3, (B, H, W, C1)).astype(np.float32)
+    w1 = np.zeros((C1, C1, 3, 3), np.float32)
+    for n in range(C1):
+        w1[n, (n * 7 + 3) % C1, n % 3, (n // 3) % 3] = 1 + (n % 3)
+        w1[n, (n * 5 + 1) % C1, (n + 1) % 3, (n // 2) % 3] = -1
+    w2 = np.zeros((C2, C1), np.float32)
+    for n in range(C2):
+        w2[n, (n * 11 + 5) % C1] = 1 + (n % 2)
+        w2[n, (n * 3 + 2) % C1] -= 1
+    w3 = np.zeros((C3, C2), np.float32)
+    for n in range(C3):
+        w3[n, (n * 13 + 7) % C2] = 1
+        w3[n, (n * 29 + 1) % C2] += 1 + (n % 2)
+        w3[n, (n * 17 + 4) % C2] -= 1
+    b1 = rng.integers(-1, 2, C1).astype(np.float32)
+    b2 = rng.integers(-1, 2, C2).astype(np.float32)
+    b3 = rng.integers(-2, 3, C3).astype(np.float32)
+    res = rng.integers(-4, 5, (B, H, W, C2)).astype(np.float32)
+    y, z = run_btail(lib, x1, w1, b1, w2, b2, res, w3, b3, 1)
+    yr, zr = ref_btail(x1, w1, b1, w2, b2, res, w3, b3, 1)
+    assert np.abs(yr).max() < 2048 and np.abs(zr).max() < 2048   # exactly representable in fp16
+    np.testing.assert_array_equal(y, yr)
+    np.testing.assert_array_equal(z, zr)
+    a1 = run_conv(lib, x1, w1, b1, 1, 1, True)
+    yu = run_conv(lib, a1, w2[:, :, None, None], b2, 1, 0, True, res)
+    zu = run_conv(lib, yu, w3[:, :, None, None], b3, 1, 0, True)
+    np.testing.assert_array_equal(y, yu)
+    np.testing.assert_array_equal(z, zu)
