@@ -63,7 +63,7 @@ TEST_API = {
     "opd_test_gemm_splitk_ln": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3),
     "opd_test_bench_conv": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
     "opd_test_btail": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 6),
-    "opd_test_bench_btail": (C.c_int, [C.c_int] * 7 + [C.POINTER(C.c_float)]),
+    "opd_test_bench_btail": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_float)]),
     "opd_test_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_int]),
     "opd_test_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int]),
     "opd_test_maxpool": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6),

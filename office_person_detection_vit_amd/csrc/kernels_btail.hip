@@ -24,7 +24,15 @@
 // staging, XOR-swizzled 128-byte rows).  It continues seamlessly into C2/64 "chunk steps": chunk j stages the 64 rows of
 // W2 and the 64-column slice of W3 that chunk needs into the stage buffer the previous step has left, computes 64
 // channels of y for the wave's 32 pixels, applies bias/residual/ReLU, stores them, and feeds them straight into the z
-// accumulators.  The residual for chunk j+1 is fetched during chunk j.
+// accumulators.  The residual for chunk j+2 is fetched during chunk j; waits are counted (`s_waitcnt vmcnt(N)`) so that
+// the y stores and the youngest residual loads stay in flight across the stage barriers.
+//
+// Measured (tools/bench_btail.py, batch 8): stage-1 tail 188 us against 287 us for the three launches it replaces,
+// stage-2 tail 135 against 170.  What does NOT move it further (each built, measured, removed):
+// the residual staged through LDS by a dedicated fifth wave (SIMD imbalance: 238 us) or by one of the four waves with the
+// operand staging split over the other three (190 us), whole-line y/z stores transposed through LDS (190 us), a
+// start-up stagger between workgroups sharing a CU (no phase locking), three instead of two workgroups per CU (185 vs
+// 189 us).  PMC: no HBM credit stalls, the vector-memory address FIFO is full 45 % of the busy cycles.
 #include <hip/hip_runtime.h>
 #include "opd_kernels.h"
 
@@ -184,10 +192,10 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const int pr_m = wm0 + (g & 1) * 16 + li;
     const bool pr_ok = pr_m < p.M;
     const size_t pr_row = (size_t)pr_m * C2 + (g >> 1) * 8;
-    const bool has_res = p.res != nullptr;
+    const bool has_res = p.res != nullptr && !(p.dbg & 4);
     // Counted waits (below) rely on every wave issuing exactly 4 residual loads and 4 stores per chunk: true on full
     // tiles with a residual; otherwise (ragged last tile, no residual) the waits fall back to vmcnt(0).
-    const bool counted = has_res && m_base + 128 <= p.M;
+    const bool counted = has_res && m_base + 128 <= p.M && !(p.dbg & 2);
     auto load_res = [&](int j, uint4 (&r)[4]) {
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -197,7 +205,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     };
 
     // ---- 3x3 main loop ------------------------------------------------------------------------------------------------
-    issue_main(0, 0);
+    const int ks_first = (p.dbg & 1) ? nk - 1 : 0;  // dbg: timing ablations (tools/bench_btail.py --ablate), never set by the model
+    if (ks_first) { tap_kh = 2; tap_kw = 2; tap_c = kpc - 1; }
+    issue_main(ks_first, ks_first & 1);
     float4v acc1[NT1][2];
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) {
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         }
     };
 #pragma unroll 1
-    for (int ks = 0; ks + 1 < nk; ++ks) {
+    for (int ks = ks_first; ks + 1 < nk; ++ks) {
         issue_main(ks + 1, (ks + 1) & 1);
         compute_main(ks & 1);
         __syncthreads();
@@ -265,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     }
 
     // ---- chunk steps: 64 channels of y each ------------------------------------------------------------------------------
+    if (p.dbg & 8) return;
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const int buf = (nk + j) & 1;
@@ -318,7 +329,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             pk[nt][1][1] = pack2h(v1[2], v1[3]);
             const uint2v s0 = __builtin_amdgcn_permlane16_swap(pk[nt][0][0], pk[nt][1][0], false, false);
             const uint2v s1 = __builtin_amdgcn_permlane16_swap(pk[nt][0][1], pk[nt][1][1], false, false);
-            if (pr_ok) *reinterpret_cast<uint4*>(p.y + pr_row + j * 64 + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (pr_ok && !(p.dbg & 2)) *reinterpret_cast<uint4*>(p.y + pr_row + j * 64 + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
         if constexpr (C3 > 0) {
             const unsigned char* W3s = W2s + W2C_BYTES;
@@ -359,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             }
             const uint2v s0 = __builtin_amdgcn_permlane16_swap(pack2h(v0[0], v0[1]), pack2h(v1[0], v1[1]), false, false);
             const uint2v s1 = __builtin_amdgcn_permlane16_swap(pack2h(v0[2], v0[3]), pack2h(v1[2], v1[3]), false, false);
-            if (pr_ok) *reinterpret_cast<uint4*>(p.z + zrow + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
+            if (pr_ok && !(p.dbg & 2)) *reinterpret_cast<uint4*>(p.z + zrow + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
     }
 #endif

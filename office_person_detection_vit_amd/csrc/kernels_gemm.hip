@@ -682,9 +682,10 @@ static inline int dma_blocks_per_cu(int bn, int mt) {
 // workgroups on 512 slots (2 rounds), 160-row tiles 420 (1 round).
 static inline int pick_mt(int M, int N, int bn, int splits) {
     if (g_tile_mt) return g_tile_mt;
-    {   // many rounds: quantisation is noise, keep the 128-row tile (more workgroups per CU, measured faster)
+    {   // many rounds: quantisation is noise, keep the 128-row tile (tools/sweep_tiles.py: up to ~8 rounds the taller
+        // tiles still win, e.g. the strided stage-2/3 shortcuts: 74 -> 65 us, 53 -> 47 us)
         const long long tiles128 = (long long)((M + 127) / 128) * (N / bn) * splits;
-        if (tiles128 > 4LL * 256 * dma_blocks_per_cu(bn, 4)) return 4;
+        if (tiles128 > 10LL * 256 * dma_blocks_per_cu(bn, 4)) return 4;
     }
     int best = 4;
     double best_cost = 1e30;

@@ -43,6 +43,7 @@ struct BtailParams {
     const float* b3;
     f16_t* z;          // [M][C3]
     int B, H, W, OH, OW, stride, M, C1, C3;
+    int dbg;           // timing ablations for tools (0 = normal): 1 skip the 3x3 loop, 2 skip stores, 4 skip residual, 8 stop after the 3x3
 };
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);

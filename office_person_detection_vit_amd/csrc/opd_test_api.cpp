@@ -175,7 +175,7 @@ int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, cons
 
 // Times the fused tail (us_out[0]) and the three unfused launches it replaces (us_out[1..3]: c1, c2, c0') on
 // device-resident data of the given shape.
-int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int iters, float* us_out) {
+int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int dbg, int iters, float* us_out) {
     if (!opd_btail_supported(C1, C3)) return tfail(OPD_EINVAL, "btail: unsupported (C1, C3)");
     DevMem dm;
     const int C2 = 4 * C1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
@@ -200,7 +200,7 @@ int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int it
     TCHK(hipMemset(zero, 0, 4096 * 4));
     BtailParams p{};
     p.x1 = x1; p.w1 = w1; p.b1 = bias; p.w2p = w2; p.b2 = bias; p.res = res; p.y = y; p.w3p = w3; p.b3 = bias; p.z = z;
-    p.B = B; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.M = (int)M; p.C1 = C1; p.C3 = C3;
+    p.B = B; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.M = (int)M; p.C1 = C1; p.C3 = C3; p.dbg = dbg;
     ConvGemmParams c[3] = {};
     c[0].x = x1; c[0].w = w1; c[0].out = a1; c[0].B = B; c[0].H = H; c[0].W = W; c[0].Cin = C1; c[0].OH = OH; c[0].OW = OW; c[0].N = C1;
     c[0].KH = c[0].KW = 3; c[0].stride = stride; c[0].pad = 1; c[0].K = 9 * C1;
@@ -213,6 +213,7 @@ int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int it
     TCHK(hipEventCreate(&ev[0])); TCHK(hipEventCreate(&ev[1]));
     for (int k = 0; k < 4; ++k) {
         if (k == 3 && !C3) { us_out[3] = 0.f; break; }
+        if (k > 0 && dbg) { us_out[k] = 0.f; continue; }
         for (int i = -2; i < iters; ++i) {
             if (i == 0) TCHK(hipEventRecord(ev[0], nullptr));
             if (k == 0) TCHK(opd_launch_btail(p, nullptr));

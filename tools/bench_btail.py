@@ -20,8 +20,20 @@ print(f"{'shape':>28s} {'fused us':>9s} {'c1':>7s} {'c2':>7s} {'c0n':>7s} {'unfu
 for s in SHAPES:
     B, H, W, C1, C3, st = s
     us = (C.c_float * 4)()
-    _capi.check(lib.opd_test_bench_btail(B, H, W, C1, C3, st, 20, us), "bench_btail")
+    _capi.check(lib.opd_test_bench_btail(B, H, W, C1, C3, st, 0, 20, us), "bench_btail")
     OH, OW = (H - 1) // st + 1, (W - 1) // st + 1
     M = B * OH * OW
     byt = (B * H * W * C1 + M * 4 * C1 * 2 + M * C3) * 2
     print(f"{str(s):>28s} {us[0]:9.1f} {us[1]:7.1f} {us[2]:7.1f} {us[3]:7.1f} {us[1] + us[2] + us[3]:8.1f} {byt / us[0] / 1e6:10.2f}", flush=True)
+
+if "--ablate" in sys.argv:
+    print("\nablations (us): full | no 3x3 loop | no stores | no residual | no stores+residual | 3x3 only | no 3x3, no stores, no residual")
+    for s in SHAPES:
+        B, H, W, C1, C3, st = s
+        t = []
+        for dbg in (0, 1, 2, 4, 6, 8, 7):
+            us = (C.c_float * 4)()
+            _capi.check(lib.opd_test_bench_btail(B, H, W, C1, C3, st, dbg, 20, us), "bench_btail")
+            t.append(us[0])
+        print(f"{str(s):>28s} " + " ".join(f"{v:8.1f}" for v in t), flush=True)
+
