@@ -61,6 +61,7 @@ API = {
 TEST_API = {
     "opd_test_conv_gemm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 15),
     "opd_test_gemm_splitk_ln": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3),
+    "opd_test_gemm_ln": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 2),
     "opd_test_bench_conv": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
     "opd_test_btail": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 6),
     "opd_test_bench_btail": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_float)]),
@@ -72,6 +73,7 @@ TEST_API = {
     "opd_test_stem_pool": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7),
     "opd_test_set_fuse_stem_pool": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_set_fuse_btail": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_test_set_fuse_gemm_ln": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_f32_to_f16": (C.c_uint16, [C.c_float]),
     "opd_test_f16_to_f32": (C.c_float, [C.c_uint16]),
     "opd_test_normalise_key": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),

@@ -1,0 +1,161 @@
+// kernels_rowln.hip — Linear(K -> 256) + bias + residual + LayerNorm in ONE kernel (gfx950, fp16 MFMA, fp32 statistics).
+//
+// the attention output projections of the transformer layers,
+//     y = LayerNorm(x . W^T + b + residual)            (HF:models/detr/modeling_detr.py:646-660, 734-775: post-LN layers)
+// The output width IS the model width (256), so a workgroup that owns whole rows can finish the LayerNorm itself: no fp32
+// pre-norm tensor, no split-K slabs, no second launch.  At batch 8 the unfused pair cost 11 + 8 us per encoder layer
+// (M = 8400) and 6 + 6 us per decoder projection (M = 800, split-K 4 + reduce); this kernel is one launch of ~6 us.
+//
+// Tile: 32 rows x 256 columns x 64 (k) per workgroup of 4 waves; wave w owns columns 64w..64w+63 for all 32 rows, as
+// 4 x 2 accumulator tiles of the 16x16x32 MFMA (weights = A operand, rows of x = B operand, as in kernels_gemm.hip).
+// Staging is the LDS-DMA scheme of conv_gemm_dma_kernel (1-KiB pieces, XOR swizzle on the source side, two stage
+// buffers); every wave stages the 8 weight pieces of its own columns plus one activation piece.  LayerNorm statistics are
+// two-pass (mean, then centred variance) in fp32 like layernorm256_kernel: lane partials -> 4 lane groups (shuffles) ->
+// 4 waves (LDS).
+#include <hip/hip_runtime.h>
+#include "opd_kernels.h"
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+namespace {
+
+constexpr int ROW_BYTES = 128;
+constexpr int TM = 32;                       // rows per workgroup
+constexpr int A_BYTES = TM * ROW_BYTES;      // 4 KiB
+constexpr int W_BYTES = 256 * ROW_BYTES;     // 32 KiB
+constexpr int STAGE_BYTES = A_BYTES + W_BYTES;
+
+__device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
+
+__global__ __launch_bounds__(256, 2) void gemm_ln256_kernel(GemmLnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[2][4][TM];          // [pass][wave][row]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int m_base = blockIdx.x * TM;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+
+    // rows >= M fall outside the activation descriptor: zero fill
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x), 0, (unsigned)((size_t)p.M * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)256 * p.K * 2), 0x00020000);
+    const unsigned xoff = (unsigned)((m_base + wave * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;   // activation piece `wave`
+    const unsigned woff = (unsigned)((wave * 64 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;           // weight rows 64w + 8i + lrow
+    const unsigned wstep = (unsigned)(8 * p.K) * 2u;
+    auto issue = [&](int ks, int buf) {
+        unsigned char* As = smem + buf * STAGE_BYTES;
+        unsigned char* Ws = As + A_BYTES;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + wave * 1024), 16, xoff, ks * 128, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Ws + (wave * 8 + i) * 1024), 16,
+                                                     woff + (unsigned)i * wstep, ks * 128, 0, 0);
+    };
+
+    issue(0, 0);
+    float4v acc[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.bias + wave * 64 + nt * 16 + g * 4);
+        acc[nt][0] = b;
+        acc[nt][1] = b;
+    }
+    __syncthreads();
+    const int nk = p.K / 64;
+    for (int ks = 0; ks < nk; ++ks) {
+        if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
+        const unsigned char* As = smem + (ks & 1) * STAGE_BYTES;
+        const unsigned char* Ws = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[2], wf[4];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const half8*>(As + swz(mt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + swz(wave * 64 + nt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- + residual, LayerNorm over the 256 columns of each row -----------------------------------------------------------
+    // lane (g, li) holds, for row mt*16 + li, the 16 columns 64*wave + nt*16 + 4g + r
+    float sum[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = m_base + mt * 16 + li;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            if (p.res32 && m < p.M) acc[nt][mt] += *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + wave * 64 + nt * 16 + g * 4);
+            sum[mt] += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
+        }
+        sum[mt] += __shfl_xor(sum[mt], 16);
+        sum[mt] += __shfl_xor(sum[mt], 32);
+        if (g == 0) red[0][wave][mt * 16 + li] = sum[mt];
+    }
+    __syncthreads();
+    float mean[2], sq[2] = {0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int r = mt * 16 + li;
+        mean[mt] = (red[0][0][r] + red[0][1][r] + red[0][2][r] + red[0][3][r]) * (1.0f / 256.0f);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[nt][mt] -= mean[mt];
+            sq[mt] += acc[nt][mt][0] * acc[nt][mt][0] + acc[nt][mt][1] * acc[nt][mt][1] + acc[nt][mt][2] * acc[nt][mt][2] +
+                      acc[nt][mt][3] * acc[nt][mt][3];
+        }
+        sq[mt] += __shfl_xor(sq[mt], 16);
+        sq[mt] += __shfl_xor(sq[mt], 32);
+        if (g == 0) red[1][wave][r] = sq[mt];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int r = mt * 16 + li;
+        const int m = m_base + r;
+        const float var = (red[1][0][r] + red[1][1][r] + red[1][2][r] + red[1][3][r]) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int c = wave * 64 + nt * 16 + g * 4;
+            const float4v gm = *reinterpret_cast<const float4v*>(p.gamma + c);
+            const float4v bt = *reinterpret_cast<const float4v*>(p.beta + c);
+            float4v o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = acc[nt][mt][q] * rstd * gm[q] + bt[q];
+            if (m < p.M) {
+                if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
+                if (p.y16) {
+                    half4 h;
+                    h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+                    *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
+                }
+            }
+        }
+    }
+#endif
+}
+
+}  // namespace
+
+hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || !p.gamma || !p.beta || !p.bias) return hipErrorInvalidValue;
+    if ((size_t)p.M * p.K * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;  // 31-bit buffer offsets
+    constexpr int LDS = 2 * STAGE_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_ln256_kernel, dim3((p.M + TM - 1) / TM), dim3(256), LDS, stream, p);
+    return hipGetLastError();
+}

@@ -52,6 +52,22 @@ void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LD
                                    // +16 enables the experimental 3x3 row-strip kernel, +32 disables buffer-descriptor staging
 int opd_get_gemm_variant();
 
+// ---- Linear(K -> 256) + bias + residual + LayerNorm in one kernel (kernels_rowln.hip) ---------------------------------
+// y = LayerNorm(x . W^T + bias + res32) * gamma + beta over rows of 256; writes fp32 y and/or an fp16 copy.  y32 may alias
+// res32 (a workgroup reads its own rows before it writes them).
+struct GemmLnParams {
+    const f16_t* x;      // [M][K] fp16, K % 64 == 0
+    const f16_t* w;      // [256][K] fp16
+    const float* bias;   // [256]
+    const float* res32;  // [M][256] or null
+    const float* gamma;  // [256]
+    const float* beta;   // [256]
+    float* y32;          // [M][256] or null
+    f16_t* y16;          // [M][256] or null
+    int M, K;
+};
+hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream);
+
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
 // uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order, written into a
 // zero-bordered image [B][Hp][Wp][4] with the frame at offset (3, 3) (Hp >= H + 6, Wp >= W + 6): the stem's padding.

@@ -139,6 +139,7 @@ struct opd_detr {
     hipEvent_t ev[9] = {};
     float stage_ms[8] = {};
     int use_tr_read = 1;
+    int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
 
@@ -558,6 +559,17 @@ static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const
     return OPD_OK;
 }
 
+// y = LayerNorm(x16 . w^T + bias + res32): one launch (kernels_rowln.hip); y32 may alias res32
+static int run_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int K, const float* res32,
+                       const LNp& ln, float* y32, f16_t* y16) {
+    GemmLnParams p{};
+    p.x = x; p.w = w; p.bias = bias; p.res32 = res32; p.gamma = ln.g; p.beta = ln.b; p.y32 = y32; p.y16 = y16; p.M = M; p.K = K;
+    RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * 256.0 * K));
+    HIPCHK(opd_launch_gemm_ln(p, m->stream));
+    RCCHK(timed_end(m));
+    return OPD_OK;
+}
+
 static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ldk, const f16_t* v, int ldv, f16_t* o, int ldo,
                     int B, int Lq, int Lk) {
     AttnParams p{};
@@ -657,8 +669,12 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         const EncLayer& L = m->enc[i];
         RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw));
-        RCCHK(run_gemm(m, m->d_attn16, L.o.w, L.o.b, 0, M, D, D, m->d_y32, true, false, m->d_x32));
-        HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
+        if (m->fuse_gemm_ln && D == 256) {
+            RCCHK(run_gemm_ln(m, m->d_attn16, L.o.w, L.o.b, M, D, m->d_x32, L.ln1, m->d_x32, m->d_x16));
+        } else {
+            RCCHK(run_gemm(m, m->d_attn16, L.o.w, L.o.b, 0, M, D, D, m->d_y32, true, false, m->d_x32));
+            HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
+        }
         RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
         RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM));
     }
@@ -672,11 +688,17 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         const DecLayer& L = m->dec[i];
         RCCHK(run_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qkvd16, 3 * D, m->d_qkvd16 + D, 3 * D, m->d_qkvd16 + 2 * D, 3 * D, m->d_attnd16, D, B, Q, Q));
-        RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, D, 4, m->d_h32, &L.ln1, m->d_h32, m->d_h16, CLS_GEMM));
+        if (m->fuse_gemm_ln && D == 256)
+            RCCHK(run_gemm_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, m->d_h32, L.ln1, m->d_h32, m->d_h16));
+        else
+            RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, D, 4, m->d_h32, &L.ln1, m->d_h32, m->d_h16, CLS_GEMM));
         RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qd16, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
                        m->d_attnd16, D, B, Q, hw));
-        RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, D, 4, m->d_h32, &L.ln2, m->d_h32, m->d_h16, CLS_GEMM));
+        if (m->fuse_gemm_ln && D == 256)
+            RCCHK(run_gemm_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, m->d_h32, L.ln2, m->d_h32, m->d_h16));
+        else
+            RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, D, 4, m->d_h32, &L.ln2, m->d_h32, m->d_h16, CLS_GEMM));
         RCCHK(run_gemm(m, m->d_h16, L.fc1.w, L.fc1.b, 0, Md, F, D, m->d_ffnd16, false, true, nullptr));
         RCCHK(run_gemm_splitk_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, D, F, 8, m->d_h32, &L.ln3, m->d_h32, m->d_h16, CLS_GEMM));
     }
@@ -979,6 +1001,14 @@ int opd_test_set_gemm_variant(int v) {
     return opd_get_gemm_variant();
 }
 
+int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->fuse_gemm_ln = on ? 1 : 0;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
 int opd_test_set_fuse_btail(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_btail = on ? 1 : 0;

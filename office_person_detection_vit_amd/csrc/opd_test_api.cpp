@@ -101,6 +101,28 @@ int opd_test_gemm_splitk_ln(const uint16_t* x, const uint16_t* w, const float* b
     return OPD_OK;
 }
 
+// fused Linear(K->256) + bias + residual + LayerNorm (kernels_rowln.hip)
+int opd_test_gemm_ln(const uint16_t* x, const uint16_t* w, const float* bias, const float* res32, const float* gamma,
+                     const float* beta, float* y, uint16_t* y16, int M, int K) {
+    DevMem dm;
+    GemmLnParams p{};
+    p.x = dm.up(x, (size_t)M * K);
+    p.w = dm.up(w, (size_t)256 * K);
+    p.bias = dm.up(bias, 256);
+    p.res32 = res32 ? dm.up(res32, (size_t)M * 256) : nullptr;
+    p.gamma = dm.up(gamma, 256);
+    p.beta = dm.up(beta, 256);
+    p.y32 = dm.up<float>(nullptr, (size_t)M * 256);
+    p.y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    if (!p.x || !p.w || !p.bias || !p.gamma || !p.beta || !p.y32 || !p.y16 || (res32 && !p.res32)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.M = M; p.K = K;
+    TCHK(opd_launch_gemm_ln(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, p.y32, (size_t)M * 256 * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(y16, p.y16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 // Times one conv_gemm launch shape on device-resident random data (no host copies): average microseconds over `iters`.
 int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride, int with_res, int variant, int dbg, int iters,
                         float* us_out) {

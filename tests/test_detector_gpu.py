@@ -172,6 +172,25 @@ def test_fused_bottleneck_tail_matches_unfused(weight_cache):
     assert np.abs(bx_f - bx_u).max() > 0   # the switch really changed the launch sequence
 
 
+def test_fused_projection_layernorm_matches_unfused(weight_cache):
+    """Attention output projections through kernels_rowln.hip (default) against GEMM -> LayerNorm (encoder) and split-K
+    GEMM -> reduce + LayerNorm (decoder): same operands, fp32 statistics; only the fp32 summation order differs."""
+    import ctypes as C
+    from office_person_detection_vit_amd import _capi
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    det = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=False, use_graph=False)
+    det.load_model()
+    frames = structured_frames(2, 256, 320, seed=78)
+    lg_f, bx_f, enc_f = det.forward_raw(frames)
+    _capi.check(_capi.load_library().opd_test_set_fuse_gemm_ln(C.c_void_p(det.model), 0), "set_fuse_gemm_ln")
+    lg_u, bx_u, enc_u = det.forward_raw(frames)
+    det.close()
+    # (an fp16 rounding flip in the x16 shadow propagates like any other fp16-storage noise: golden-vector bounds)
+    assert np.abs(bx_f - bx_u).max() < TOL[1.0][0] and np.abs(_softmax(lg_f) - _softmax(lg_u)).max() < TOL[1.0][1]
+    assert np.abs(enc_f - enc_u).max() < TOL[1.0][2]
+    assert np.abs(enc_f - enc_u).max() > 0   # the switch really changed the launch sequence
+
+
 def test_detector_surface(detectors):
     det = detectors(ga=1.0)
     frame = structured_frames(1, 256, 320, seed=31)[0]

@@ -442,3 +442,28 @@ def test_btail_integer_exact_and_equals_unfused(lib, C1, C3):
     zu = run_conv(lib, yu, w3[:, :, None, None], b3, 1, 0, True)
     np.testing.assert_array_equal(y, yu)
     np.testing.assert_array_equal(z, zu)
+
+
+# ---- Linear(K -> 256) + bias + residual + LayerNorm in one kernel (kernels_rowln.hip) ---------------------------------------
+@pytest.mark.parametrize("M,K,use_res", [(800, 256, True), (8400, 256, True), (37, 256, True), (100, 2048, False), (33, 64, True)])
+def test_gemm_ln_matches_torch(lib, M, K, use_res):
+    """y = LN(x W^T + b + res): fp16 operands, fp32 accumulate and statistics.  Tolerance: fp32 summation order only
+    (the reference is computed in fp32 from the same fp16-rounded operands): 2e-5 abs on O(1) outputs; the fp16 copy
+    one rounding (2^-11 rel)."""
+    rng = np.random.default_rng(M * 7 + K)
+    x, xb = _h(rng.standard_normal((M, K)))
+    w, wb = _h(rng.standard_normal((256, K)) / np.sqrt(K))
+    bias = rng.standard_normal(256).astype(np.float32) * 0.1
+    res = rng.standard_normal((M, 256)).astype(np.float32) if use_res else None
+    gamma = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    rc = lib.opd_test_gemm_ln(_p(xb), _p(wb), _p(bias), _p(res), _p(gamma), _p(beta), _p(y), _p(y16), M, K)
+    _capi.check(rc, "opd_test_gemm_ln")
+    pre = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
+    if use_res:
+        pre = pre + torch.from_numpy(res).double()
+    want = F.layer_norm(pre, (256,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5).float().numpy()
+    np.testing.assert_allclose(y, want, atol=3e-5, rtol=1e-5)
+    np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), want, atol=2e-3, rtol=1e-3)
