@@ -181,57 +181,67 @@ __global__ void gemm_f32_kernel(const float* __restrict__ A, const float* __rest
     C[(size_t)m * ldc + n] = acc + (bias ? bias[n] : 0.f);
 }
 
-// Heads: one 256-thread block per HEAD_ROWS decoder rows; fp32 throughout (0.03 GFLOP/frame).  Weights are stored
-// TRANSPOSED ([in][out]) so that thread t (= output t) reads wt[k*N + t]: consecutive lanes touch consecutive addresses.
-// Each weight element fetched from L2 feeds HEAD_ROWS independent FMA chains (one block per row re-read 620 KB of
-// weights per row: 43 us at batch 8; this form: 7 us).
+// Heads: one 1024-thread block per HEAD_ROWS decoder rows; fp32 throughout (0.03 GFLOP/frame).  Weights are stored
+// TRANSPOSED ([in][out]) so that thread (kg, o) reads wt[k*N + o]: consecutive lanes touch consecutive addresses.
+// The kernel is a latency chain (3 dependent layers, every weight comes from L2), so the reduction dimension is split
+// over 4 thread groups (64 k each, 16 independent loads in flight per thread) and each weight feeds HEAD_ROWS FMA chains;
+// partial sums meet in LDS in a fixed order.  (One block per row: 43 us at batch 8, re-reading 620 KB of weights per row;
+// 4 rows per 256-thread block with a 256-deep serial k-loop: 54 us, pure load latency.)
 constexpr int HEAD_ROWS = 4;
-__global__ __launch_bounds__(256) void heads_kernel(HeadParams p) {
+__global__ __launch_bounds__(1024) void heads_kernel(HeadParams p) {
     __shared__ float h[HEAD_ROWS][256];
     __shared__ float t1[HEAD_ROWS][256];
-    __shared__ float t2[HEAD_ROWS][256];
+    __shared__ float part[4][HEAD_ROWS][256];
     const int row0 = blockIdx.x * HEAD_ROWS;
-    const int t = threadIdx.x;
-#pragma unroll
-    for (int r = 0; r < HEAD_ROWS; ++r) h[r][t] = row0 + r < p.rows ? p.hs[(size_t)(row0 + r) * 256 + t] : 0.f;
+    const int kg = threadIdx.x >> 8, t = threadIdx.x & 255;
+    if (kg < HEAD_ROWS) h[kg][t] = row0 + kg < p.rows ? p.hs[(size_t)(row0 + kg) * 256 + t] : 0.f;
     __syncthreads();
-    auto layer = [&](const float (&in)[HEAD_ROWS][256], const float* wt, int ld, float (&acc)[HEAD_ROWS]) {
+    // partial[kg][r][t] = sum over k in [64 kg, 64 kg + 64) of in[r][k] * wt[k][t]
+    auto layer = [&](const float (&in)[HEAD_ROWS][256], const float* wt, int ld, bool active) {
+        float acc[HEAD_ROWS];
 #pragma unroll
         for (int r = 0; r < HEAD_ROWS; ++r) acc[r] = 0.f;
-#pragma unroll 8
-        for (int k = 0; k < 256; ++k) {
-            const float w = wt[k * ld + t];
+        if (active) {
+#pragma unroll 16
+            for (int kk = 0; kk < 64; ++kk) {
+                const int k = kg * 64 + kk;
+                const float w = wt[k * ld + t];
 #pragma unroll
-            for (int r = 0; r < HEAD_ROWS; ++r) acc[r] = fmaf(in[r][k], w, acc[r]);
+                for (int r = 0; r < HEAD_ROWS; ++r) acc[r] = fmaf(in[r][k], w, acc[r]);
+            }
         }
+#pragma unroll
+        for (int r = 0; r < HEAD_ROWS; ++r) part[kg][r][t] = acc[r];
     };
-    float acc[HEAD_ROWS];
-    if (t < p.ncls) {
-        layer(h, p.wc, p.ncls, acc);
-#pragma unroll
-        for (int r = 0; r < HEAD_ROWS; ++r)
-            if (row0 + r < p.rows) p.logits[(size_t)(row0 + r) * p.ncls + t] = acc[r] + p.bc[t];
-    }
-    layer(h, p.w1, 256, acc);
-#pragma unroll
-    for (int r = 0; r < HEAD_ROWS; ++r) {
-        const float v = acc[r] + p.b1[t];
-        t1[r][t] = v > 0.f ? v : 0.f;
+    auto total = [&](int r, int o) { return ((part[0][r][o] + part[1][r][o]) + part[2][r][o]) + part[3][r][o]; };
+    // class logits
+    layer(h, p.wc, p.ncls, t < p.ncls);
+    __syncthreads();
+    if (t < p.ncls && kg < HEAD_ROWS && row0 + kg < p.rows) p.logits[(size_t)(row0 + kg) * p.ncls + t] = total(kg, t) + p.bc[t];
+    __syncthreads();
+    // box MLP
+    layer(h, p.w1, 256, true);
+    __syncthreads();
+    if (kg < HEAD_ROWS) {
+        const float v = total(kg, t) + p.b1[t];
+        t1[kg][t] = v > 0.f ? v : 0.f;
     }
     __syncthreads();
-    layer(t1, p.w2, 256, acc);
-#pragma unroll
-    for (int r = 0; r < HEAD_ROWS; ++r) {
-        const float v = acc[r] + p.b2[t];
-        t2[r][t] = v > 0.f ? v : 0.f;
+    layer(t1, p.w2, 256, true);
+    __syncthreads();
+    if (kg < HEAD_ROWS) {
+        const float v = total(kg, t) + p.b2[t];
+        h[kg][t] = v > 0.f ? v : 0.f;   // h is free: reuse it for the second hidden layer
     }
     __syncthreads();
-    if (t < 4 * HEAD_ROWS) {  // thread -> (row t>>2, coordinate t&3)
-        const int r = t >> 2, c = t & 3;
+    if (threadIdx.x < 64 * HEAD_ROWS) {  // one wave per row: lane -> (coordinate lane&3, k-slice lane>>2 of 16)
+        const int r = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 3, ks = lane >> 2;
         float a = 0.f;
-        for (int k = 0; k < 256; ++k) a = fmaf(t2[r][k], p.w3[k * 4 + c], a);
-        a += p.b3[c];
-        if (row0 + r < p.rows) p.boxes[(size_t)(row0 + r) * 4 + c] = 1.0f / (1.0f + expf(-a));
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) a = fmaf(h[r][ks * 16 + kk], p.w3[(ks * 16 + kk) * 4 + c], a);
+#pragma unroll
+        for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o);
+        if (lane < 4 && row0 + r < p.rows) p.boxes[(size_t)(row0 + r) * 4 + c] = 1.0f / (1.0f + expf(-(a + p.b3[c])));
     }
 }
 
@@ -240,36 +250,46 @@ struct DetRec {
     int32_t label, query_index, frame;
 };
 
-// One block (256 threads) per frame.  Phase 1: each wave takes queries wave, wave+4, ...; its lanes stride the classes
-// (coalesced loads, wave-level max / sum / first-argmax reductions).  Phase 2: one thread per query converts the box and
-// compacts the kept queries in query order via a block prefix sum.
-__global__ __launch_bounds__(256) void postprocess_kernel(PostParams p) {
+// One block (1024 threads = 16 waves) per frame.  Phase 1: wave w takes queries w, w+16, ... (at most 8); it issues the
+// loads of ALL its queries first (one L2 round trip instead of one per query), then its lanes stride the classes with
+// wave-level max / sum / first-argmax reductions.  Phase 2: one thread per query converts the box and compacts the kept
+// queries in query order via a block prefix sum.  (One thread per query with serial class loops: 24 us.)
+__global__ __launch_bounds__(1024) void postprocess_kernel(PostParams p) {
     __shared__ int flags[128];
     __shared__ float s_score[128];
     __shared__ int s_label[128];
     const int b = blockIdx.x;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int qq = wave; qq < p.Q; qq += 4) {
-        const float* lg = p.logits + ((size_t)b * p.Q + qq) * p.ncls;
-        float mx = -INFINITY;
-        for (int c = lane; c < p.ncls; c += 64) mx = fmaxf(mx, lg[c]);
+    {
+        float v0[8], v1[8];
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
-        float sum = 0.f, best = -1.f;
-        int bl = 0x7fffffff;
-        for (int c = lane; c < p.ncls; c += 64) {
-            const float e = expf(lg[c] - mx);
-            sum += e;
-            if (c < p.ncls - 1 && e > best) { best = e; bl = c; }   // ascending c: first maximum of this lane
+        for (int i = 0; i < 8; ++i) {
+            const int qq = wave + i * 16;
+            const float* lg = p.logits + ((size_t)b * p.Q + (qq < p.Q ? qq : 0)) * p.ncls;
+            v0[i] = lane < p.ncls ? lg[lane] : -INFINITY;
+            v1[i] = lane + 64 < p.ncls ? lg[lane + 64] : -INFINITY;
         }
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            sum += __shfl_xor(sum, o);
-            const float ob = __shfl_xor(best, o);
-            const int ol = __shfl_xor(bl, o);
-            if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; }   // ties -> lowest class index
+        for (int i = 0; i < 8; ++i) {
+            const int qq = wave + i * 16;
+            float mx = fmaxf(v0[i], v1[i]);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+            const float e0 = lane < p.ncls ? expf(v0[i] - mx) : 0.f;
+            const float e1 = lane + 64 < p.ncls ? expf(v1[i] - mx) : 0.f;
+            float sum = e0 + e1, best = -1.f;
+            int bl = 0x7fffffff;
+            if (lane < p.ncls - 1) { best = e0; bl = lane; }
+            if (lane + 64 < p.ncls - 1 && e1 > best) { best = e1; bl = lane + 64; }   // ascending class order: first maximum
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                sum += __shfl_xor(sum, o);
+                const float ob = __shfl_xor(best, o);
+                const int ol = __shfl_xor(bl, o);
+                if (ob > best || (ob == best && ol < bl)) { best = ob; bl = ol; }   // ties -> lowest class index
+            }
+            if (lane == 0 && qq < p.Q) { s_score[qq] = best / sum; s_label[qq] = bl; }
         }
-        if (lane == 0) { s_score[qq] = best / sum; s_label[qq] = bl; }
     }
     __syncthreads();
     const int q = threadIdx.x;
@@ -371,13 +391,13 @@ hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bia
 
 hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
     if (p.ncls > 256 || p.rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(256), 0, stream, p);
+    hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 
 hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream) {
-    if (p.Q > 128 || p.B <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(postprocess_kernel, dim3(p.B), dim3(256), 0, stream, p);
+    if (p.Q > 128 || p.ncls > 128 || p.B <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(postprocess_kernel, dim3(p.B), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -13,6 +13,10 @@ import json
 import sys
 
 
+# the kernels bench.py times as the "implicit-GEMM family" (classes conv + linear of opd_detr_kernel_times)
+GEMM_FAMILY = ("conv_gemm", "btail_kernel", "gemm_ln256_kernel", "stem_pool_kernel")
+
+
 def per_kernel(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
@@ -36,7 +40,7 @@ def main():
         rd = 2.0 * kib * 1024.0
         wr = write.get(k, [0, 0.0])[1] * 1024.0
         out["kernels"][k] = {"launches": n, "read_bytes": rd, "write_bytes": wr}
-        if k.startswith("conv_gemm"):
+        if k.startswith(GEMM_FAMILY):
             gemm_launches += n
             gemm_bytes += rd + wr
     out["conv_gemm_family"] = {"launches": gemm_launches, "bytes_per_forward": gemm_bytes,
