@@ -61,6 +61,7 @@ API = {
 TEST_API = {
     "opd_test_conv_gemm": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 15),
     "opd_test_gemm_splitk_ln": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3),
+    "opd_test_gemm_k256": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5),
     "opd_test_gemm_ln": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 2),
     "opd_test_bench_conv": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),
     "opd_test_btail": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 6),

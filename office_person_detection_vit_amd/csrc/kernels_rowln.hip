@@ -159,3 +159,114 @@ hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream) {
     hipLaunchKernelGGL(gemm_ln256_kernel, dim3((p.M + TM - 1) / TM), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-M linear layers of the decoder (M = batch x 100 queries): out = act(x[:, k0:k0+256] . W[:, k0:k0+256]^T + bias).
+// At M = 800 every launch is a latency chain, not a throughput problem: the general kernel walks K = 256 as four
+// double-buffered k-steps, i.e. four dependent L2 round trips (~7 us per launch at batch 8).  Here a workgroup stages its
+// whole 64 x 256 activation tile and 64 x 256 weight tile in ONE batch of LDS-DMA (64 KiB), waits once, and runs the 32
+// MFMAs per wave back to back.  Deeper reductions (FFN-2, K = 2048) are cut into 256-wide slices along gridDim.z that write
+// fp32 slabs for reduce_ln256_kernel (bias in slice 0), like the split-K form of conv_gemm_dma_kernel.
+// Tile: 64 rows x 64 columns, 4 waves as 2 x 2, each 32 x 32 (2 x 2 accumulator tiles).  LDS: four [64][64-k] sub-tiles
+// per operand with the usual 128-byte-row XOR swizzle.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256, 2) void gemm_k256_kernel(GemmK256Params p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int SUB = 64 * ROW_BYTES;       // one [64 rows][64 k] sub-tile: 8 KiB
+    unsigned char* const As = smem;           // 4 sub-tiles
+    unsigned char* const Ws = smem + 4 * SUB; // 4 sub-tiles
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m_base = blockIdx.y * 64, n_base = blockIdx.x * 64, z = blockIdx.z;
+    const int k0 = z * 256;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x), 0, (unsigned)((size_t)p.M * p.ldx * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)p.N * p.ldw * 2), 0x00020000);
+    // wave w stages rows 16w..16w+15 of both operands: 2 row-pieces x 4 sub-tiles each; rows >= M are out of range -> zeros
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int r = wave * 16 + i * 8 + lrow;
+        const unsigned xo = (unsigned)((m_base + r) * p.ldx + k0) * 2u + (unsigned)lchunk * 16u;
+        const unsigned wo = (unsigned)((n_base + r) * p.ldw + k0) * 2u + (unsigned)lchunk * 16u;
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(As + t * SUB + (wave * 2 + i) * 1024), 16,
+                                                     m_base + r < p.M ? xo : 0x80000000u, t * 128, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Ws + t * SUB + (wave * 2 + i) * 1024), 16, wo,
+                                                     t * 128, 0, 0);
+        }
+    }
+    // accumulators start from the bias (vector or row-periodic; slices z > 0 start from zero)
+    float4v acc[2][2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int n = n_base + wn * 32 + nt * 16 + g * 4;
+            const int m = m_base + wm * 32 + mt * 16 + li;
+            acc[nt][mt] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (z == 0 && m < p.M)
+                acc[nt][mt] = *reinterpret_cast<const float4v*>(p.bias + (p.bias_period ? (size_t)(m % p.bias_period) * p.N : 0) + n);
+        }
+    __syncthreads();   // vmcnt(0) + barrier: both tiles are in LDS
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[2], wf[2];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const half8*>(As + t * SUB + swz(wm * 32 + mt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + t * SUB + swz(wn * 32 + nt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int n = n_base + wn * 32 + nt * 16 + g * 4;
+            const int m = m_base + wm * 32 + mt * 16 + li;
+            if (m >= p.M) continue;
+            float4v v = acc[nt][mt];
+            if (p.relu) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            if (p.out32) {
+                *reinterpret_cast<float4v*>(p.out32 + ((size_t)z * p.M + m) * p.N + n) = v;
+            } else {
+                half4 h;
+                h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+                *reinterpret_cast<half4*>(p.out16 + (size_t)m * p.N + n) = h;
+            }
+        }
+#endif
+}
+
+}  // namespace
+
+hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream) {
+    if (p.M <= 0 || p.N <= 0 || p.N % 64 != 0 || p.slices < 1 || !p.bias || (!p.out16 && !p.out32)) return hipErrorInvalidValue;
+    if (p.slices > 1 && (!p.out32 || p.relu)) return hipErrorInvalidValue;   // partial sums: fp32 slabs, no activation
+    if (p.ldx < 256 * p.slices || p.ldw < 256 * p.slices) return hipErrorInvalidValue;
+    if ((size_t)p.M * p.ldx * 2 >= 0x7fffff00ull || (size_t)p.N * p.ldw * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
+    constexpr int LDS = 8 * 64 * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_k256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(gemm_k256_kernel, dim3(p.N / 64, (p.M + 63) / 64, p.slices), dim3(256), LDS, stream, p);
+    return hipGetLastError();
+}

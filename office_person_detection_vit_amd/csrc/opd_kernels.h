@@ -67,6 +67,18 @@ struct GemmLnParams {
     int M, K;
 };
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream);
+// Small-M linear layer, reduction cut into 256-wide slices: slice z computes x[:, 256z : 256z+256] . w[:, 256z : 256z+256]^T.
+// slices == 1: out = act(. + bias) as fp16 (out16) or fp32 (out32).  slices > 1: fp32 slabs out32[z][M][N], bias in slab 0
+// (summed by opd_launch_reduce_ln).  bias_period > 0: row-periodic bias [period][N].
+struct GemmK256Params {
+    const f16_t* x;     // [M][ldx]
+    const f16_t* w;     // [N][ldw], N % 64 == 0
+    const float* bias;  // [N] or [bias_period][N]
+    f16_t* out16;       // [M][N] or null
+    float* out32;       // [slices][M][N] or null
+    int M, N, ldx, ldw, slices, bias_period, relu;
+};
+hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream);
 
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
 // uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order, written into a

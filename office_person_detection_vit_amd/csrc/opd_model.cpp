@@ -139,6 +139,7 @@ struct opd_detr {
     hipEvent_t ev[9] = {};
     float stage_ms[8] = {};
     int use_tr_read = 1;
+    int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
@@ -570,6 +571,29 @@ static int run_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float*
     return OPD_OK;
 }
 
+// Decoder-sized linear layer (M = B x queries, K a multiple of 256): the one-shot kernel of kernels_rowln.hip; K > 256 is
+// cut into 256-wide slices whose fp32 slabs are summed by the fused reduce + residual + LayerNorm kernel.
+static int run_small_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
+                          f16_t* out16, bool relu) {
+    GemmK256Params p{};
+    p.x = x; p.w = w; p.bias = bias; p.out16 = out16; p.M = M; p.N = N; p.ldx = K; p.ldw = K; p.slices = 1;
+    p.bias_period = bias_period; p.relu = relu ? 1 : 0;
+    RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
+    HIPCHK(opd_launch_gemm_k256(p, m->stream));
+    RCCHK(timed_end(m));
+    return OPD_OK;
+}
+static int run_small_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int K, const float* res32,
+                             const LNp& ln, float* y32, f16_t* y16) {
+    GemmK256Params p{};
+    p.x = x; p.w = w; p.bias = bias; p.out32 = m->d_slab; p.M = M; p.N = 256; p.ldx = K; p.ldw = K; p.slices = K / 256;
+    RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * 256.0 * K));
+    HIPCHK(opd_launch_gemm_k256(p, m->stream));
+    RCCHK(timed_end(m));
+    HIPCHK(opd_launch_reduce_ln(m->d_slab, p.slices, (size_t)M * 256, res32, ln.g, ln.b, y32, y16, M, m->stream));
+    return OPD_OK;
+}
+
 static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ldk, const f16_t* v, int ldv, f16_t* o, int ldo,
                     int B, int Lq, int Lk) {
     AttnParams p{};
@@ -686,21 +710,29 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     HIPCHK(hipMemsetAsync(m->d_h16, 0, (size_t)Md * D * 2, m->stream));
     for (int i = 0; i < a.dec_layers; ++i) {
         const DecLayer& L = m->dec[i];
-        RCCHK(run_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false, false, nullptr));
+        const bool small = m->small_m_gemm && D == 256 && F % 256 == 0 && F / 256 <= 8;
+        if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false));
+        else RCCHK(run_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qkvd16, 3 * D, m->d_qkvd16 + D, 3 * D, m->d_qkvd16 + 2 * D, 3 * D, m->d_attnd16, D, B, Q, Q));
         if (m->fuse_gemm_ln && D == 256)
             RCCHK(run_gemm_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, m->d_h32, L.ln1, m->d_h32, m->d_h16));
         else
             RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, D, 4, m->d_h32, &L.ln1, m->d_h32, m->d_h16, CLS_GEMM));
-        RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
+        if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false));
+        else RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qd16, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
                        m->d_attnd16, D, B, Q, hw));
         if (m->fuse_gemm_ln && D == 256)
             RCCHK(run_gemm_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, m->d_h32, L.ln2, m->d_h32, m->d_h16));
         else
             RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, D, 4, m->d_h32, &L.ln2, m->d_h32, m->d_h16, CLS_GEMM));
-        RCCHK(run_gemm(m, m->d_h16, L.fc1.w, L.fc1.b, 0, Md, F, D, m->d_ffnd16, false, true, nullptr));
-        RCCHK(run_gemm_splitk_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, D, F, 8, m->d_h32, &L.ln3, m->d_h32, m->d_h16, CLS_GEMM));
+        if (small) {
+            RCCHK(run_small_gemm(m, m->d_h16, L.fc1.w, L.fc1.b, 0, Md, F, D, m->d_ffnd16, true));
+            RCCHK(run_small_gemm_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, F, m->d_h32, L.ln3, m->d_h32, m->d_h16));
+        } else {
+            RCCHK(run_gemm(m, m->d_h16, L.fc1.w, L.fc1.b, 0, Md, F, D, m->d_ffnd16, false, true, nullptr));
+            RCCHK(run_gemm_splitk_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, D, F, 8, m->d_h32, &L.ln3, m->d_h32, m->d_h16, CLS_GEMM));
+        }
     }
     HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream));
     HeadParams hp{};
@@ -1004,6 +1036,7 @@ int opd_test_set_gemm_variant(int v) {
 int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_gemm_ln = on ? 1 : 0;
+    m->small_m_gemm = on ? 1 : 0;   // the switch covers both transformer-side specialisations
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();

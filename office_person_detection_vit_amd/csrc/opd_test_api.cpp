@@ -123,6 +123,34 @@ int opd_test_gemm_ln(const uint16_t* x, const uint16_t* w, const float* bias, co
     return OPD_OK;
 }
 
+// one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel): slices == 1 -> fp16 out; slices > 1 -> the fp32
+// slabs are summed by reduce_ln256 without LayerNorm (gamma == null) into out32
+int opd_test_gemm_k256(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* out16, float* out32, int M, int N,
+                       int K, int bias_period, int relu) {
+    DevMem dm;
+    GemmK256Params p{};
+    const int slices = K / 256;
+    p.x = dm.up(x, (size_t)M * K);
+    p.w = dm.up(w, (size_t)N * K);
+    p.bias = dm.up(bias, (size_t)N * (bias_period > 0 ? bias_period : 1));
+    p.out16 = slices == 1 ? dm.up<uint16_t>(nullptr, (size_t)M * N) : nullptr;
+    p.out32 = slices > 1 ? dm.up<float>(nullptr, (size_t)slices * M * N) : nullptr;
+    float* sum = slices > 1 ? dm.up<float>(nullptr, (size_t)M * N) : nullptr;
+    if (!p.x || !p.w || !p.bias || (!p.out16 && !p.out32)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.M = M; p.N = N; p.ldx = K; p.ldw = K; p.slices = slices; p.bias_period = bias_period; p.relu = relu;
+    TCHK(opd_launch_gemm_k256(p, nullptr));
+    if (slices > 1) {
+        if (N != 256) return tfail(OPD_EINVAL, "sliced test needs N == 256");
+        TCHK(opd_launch_reduce_ln(p.out32, slices, (size_t)M * N, nullptr, nullptr, nullptr, sum, nullptr, M, nullptr));
+        TCHK(hipDeviceSynchronize());
+        TCHK(hipMemcpy(out32, sum, (size_t)M * N * 4, hipMemcpyDeviceToHost));
+    } else {
+        TCHK(hipDeviceSynchronize());
+        TCHK(hipMemcpy(out16, p.out16, (size_t)M * N * 2, hipMemcpyDeviceToHost));
+    }
+    return OPD_OK;
+}
+
 // Times one conv_gemm launch shape on device-resident random data (no host copies): average microseconds over `iters`.
 int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride, int with_res, int variant, int dbg, int iters,
                         float* us_out) {

@@ -467,3 +467,41 @@ def test_gemm_ln_matches_torch(lib, M, K, use_res):
     want = F.layer_norm(pre, (256,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5).float().numpy()
     np.testing.assert_allclose(y, want, atol=3e-5, rtol=1e-5)
     np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), want, atol=2e-3, rtol=1e-3)
+
+
+# ---- one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel) -------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,period,relu", [(800, 768, 256, 100, False), (800, 256, 256, 100, False), (800, 2048, 256, 0, True),
+                                               (800, 256, 2048, 0, False), (37, 64, 256, 0, True), (130, 256, 512, 0, False)])
+def test_gemm_k256_matches_torch(lib, M, N, K, period, relu):
+    rng = np.random.default_rng(M + N + K)
+    x, xb = _h(rng.standard_normal((M, K)))
+    w, wb = _h(rng.standard_normal((N, K)) / np.sqrt(K))
+    bias = (rng.standard_normal((max(period, 1), N)) * 0.1).astype(np.float32)
+    want = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T
+    want = want + (torch.from_numpy(bias).double()[torch.arange(M) % period] if period else torch.from_numpy(bias[0]).double())
+    if relu:
+        want = F.relu(want)
+    want = want.float().numpy()
+    out16 = np.empty((M, N), np.uint16)
+    out32 = np.empty((M, N), np.float32)
+    rc = lib.opd_test_gemm_k256(_p(xb), _p(wb), _p(np.ascontiguousarray(bias)), _p(out16), _p(out32), M, N, K, period, int(relu))
+    _capi.check(rc, "opd_test_gemm_k256")
+    if K > 256:   # fp32 slabs summed in slice order
+        np.testing.assert_allclose(out32, want, atol=3e-5 * np.sqrt(K / 256), rtol=1e-5)
+    else:         # one fp16 output rounding
+        np.testing.assert_allclose(out16.view(np.float16).astype(np.float32), want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
+
+
+def test_gemm_k256_integer_exact(lib):
+    rng = np.random.default_rng(3)
+    M, N, K = 70, 128, 256
+    x = rng.integers(-2, 3, (M, K)).astype(np.float32)
+    w = np.zeros((N, K), np.float32)
+    for n in range(N):
+        w[n, (n * 37 + 5) % K] = 1 + (n % 3)
+        w[n, (n * 11 + 2) % K] -= 2
+    bias = rng.integers(-3, 4, (1, N)).astype(np.float32)
+    out16 = np.empty((M, N), np.uint16)
+    rc = lib.opd_test_gemm_k256(_p(_h(x)[1]), _p(_h(w)[1]), _p(bias), _p(out16), None, M, N, K, 0, 0)
+    _capi.check(rc, "opd_test_gemm_k256")
+    np.testing.assert_array_equal(out16.view(np.float16).astype(np.float32), x @ w.T + bias)
