@@ -97,6 +97,17 @@ int opd_detr_info(const opd_detr* m, opd_model_info* info);
 int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                      float* logits, float* boxes, float* enc_features);
 
+/* The same call for a RAGGED batch: `model(pixel_values, pixel_mask)` with a padding mask, i.e. what HF's
+ * `DetrImageProcessor.pad` + the mask paths of the model do when the frames of a batch differ in size
+ * (HF:models/detr/image_processing_detr.py:639-668 zero-pad after normalisation + pixel_mask;
+ * HF:models/detr/modeling_detr.py:283-289 nearest down-sampling of the mask, 294-368 position embedding from the mask's
+ * cumulative sums, 402-427 additive key mask in encoder self-attention and decoder cross-attention).
+ * `pixels` is the H x W canvas batch with every frame in its top-left corner; `valid_hw` = host [B][2] int32 (height, width)
+ * of each frame inside the canvas (NULL or all (H, W): identical to opd_detr_forward).  Canvas pixels outside a frame are
+ * ignored (written as zeros on the device).  `enc_features` covers the whole canvas map, padded positions included. */
+int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+                            const int32_t* valid_hw, float* logits, float* boxes, float* enc_features);
+
 /* Replaces `_postprocess_batch` part 1 = HF `post_process_object_detection` (deleted vit_detector.py 591-647;
  * HF:models/detr/image_processing_detr.py:805-856): softmax over C+1, max over the first C classes, cxcywh->xyxy,
  * scale by the ORIGINAL (height,width) of each frame, keep score > threshold.  Runs on the device on the logits and
@@ -110,6 +121,9 @@ int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_k
                     float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
 /* With `mem_kind == OPD_MEM_DEVICE`, `out` ([B][Q] records) and `counts` ([B]) are DEVICE pointers too, so a sharded
  * caller can hand them straight to an RCCL all-gather; `orig_hw` is always a host array. */
+/* Ragged-batch form (see opd_detr_forward_ragged); `valid_hw` and `orig_hw` are host arrays. */
+int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+                           const int32_t* valid_hw, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
 
 /* Replaces `_postprocess_batch` part 2 (deleted vit_detector.py 591-647; `docs/plan.md:30`,
  * `config.yaml.disabled:38`): keep `label == person_label` (pass -1 to keep every class), greedy IoU-NMS in

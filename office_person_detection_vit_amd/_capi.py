@@ -45,9 +45,13 @@ API = {
     "opd_detr_info": (C.c_int, [C.c_void_p, C.POINTER(OpdModelInfo)]),
     "opd_detr_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),
+    "opd_detr_forward_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
     "opd_detr_postprocess": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_detr_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
+    "opd_detr_detect_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
+                                         C.c_float, C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_person_nms": (C.c_int, [C.POINTER(OpdDet), C.c_int, C.c_int, C.c_float]),
     "opd_detr_roi_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
@@ -69,7 +73,8 @@ TEST_API = {
     "opd_test_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_int]),
     "opd_test_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int]),
     "opd_test_maxpool": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6),
-    "opd_test_preprocess_u8": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5),
+    "opd_test_preprocess_u8": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 5 + [C.c_void_p]),
+    "opd_test_attention_masked": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_int]),
     "opd_test_stem2": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5),
     "opd_test_stem_pool": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7),
     "opd_test_set_fuse_stem_pool": (C.c_int, [C.c_void_p, C.c_int]),
@@ -79,6 +84,8 @@ TEST_API = {
     "opd_test_f16_to_f32": (C.c_float, [C.c_uint16]),
     "opd_test_normalise_key": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "opd_test_inspect_checkpoint": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "opd_test_valid_prefix": (C.c_int, [C.c_int] * 3),
+    "opd_test_sine_pos_embed": (C.c_int, [C.c_int] * 5 + [C.c_void_p]),
     "opd_test_set_tr_read": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_set_gemm_variant": (C.c_int, [C.c_int]),
 }

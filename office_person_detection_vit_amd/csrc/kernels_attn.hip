@@ -73,6 +73,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     float l_run = 0.f;        // running sum over THIS lane's keys only (combined across the 4 lanes at the end)
     float4v oacc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
 
+    // ragged batch: keys outside the frame's valid (rows x cols) rectangle of the key map get -inf, like the additive
+    // attention mask of the reference (HF:models/detr/modeling_detr.py:402-427, 933-991); key 0 is always valid
+    const bool masked = p.key_valid != nullptr;
+    const int kv_rows = masked ? p.key_valid[2 * b] : 0, kv_cols = masked ? p.key_valid[2 * b + 1] : 0;
     const int ntiles = (p.Lk + KT - 1) / KT;
     const float scale2 = p.scale * 1.44269504088896340736f;  // scores are kept pre-multiplied by log2(e)
     load_tile(0);
@@ -94,7 +98,19 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         }
         // ---- online softmax (fp32, base-2 domain: exp(x) = exp2(x * log2 e), one v_exp_f32 per score) ------------------
         float mx = -INFINITY;
-        if (t + 1 < ntiles) {  // full tile: no key masking needed
+        if (masked) {
+#pragma unroll
+            for (int kt = 0; kt < 4; ++kt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = t * KT + kt * 16 + g * 4 + r;
+                    const int kr = key / p.key_row, kc = key - kr * p.key_row;
+                    const bool ok = key < p.Lk && kr < kv_rows && kc < kv_cols;
+                    const float v = ok ? s[kt][r] * scale2 : -INFINITY;
+                    s[kt][r] = v;
+                    mx = fmaxf(mx, v);
+                }
+        } else if (t + 1 < ntiles) {  // full tile: no key masking needed
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll

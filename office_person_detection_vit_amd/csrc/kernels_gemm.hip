@@ -311,7 +311,8 @@ __device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const flo
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = m0 + mt * 16 + li;
-                acc[nt][mt] = m < p.M ? *reinterpret_cast<const float4v*>(bias + (size_t)(m % p.bias_period) * p.N + nq)
+                const float* brow = p.bias_ptrs && m < p.M ? p.bias_ptrs[m / p.bias_period] : bias;  // per-frame fold (ragged batch)
+                acc[nt][mt] = m < p.M ? *reinterpret_cast<const float4v*>(brow + (size_t)(m % p.bias_period) * p.N + nq)
                                       : float4v{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -1222,6 +1223,10 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     }
     const int tiles_m = (p.M + BM - 1) / BM;
     const bool wide = (p.N % 128 == 0) && ((long long)tiles_m * (p.N / 128) >= 384);
+    if (p.bias_ptrs) {  // per-frame periodic bias: implemented by the LDS-DMA kernel's accumulator initialisation only
+        if (p.bias_period <= 0 || p.stem || !p.zero16) return hipErrorInvalidValue;
+        return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);
+    }
     if (p.stem) return launch<64, true>(p, stream);
     if (g_gemm_variant >= 1) {
         if (!p.zero16) return hipErrorInvalidValue;

@@ -23,7 +23,10 @@ __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 // One thread per OUTPUT pixel of the zero-bordered NHWC4 image [B][Hp][Wp][4] (image at offset (3,3)): 3 bytes in (BGR),
 // 8 bytes out (RGB0 fp16).  Same op order as the oracle: (float(u8) * (1/255) - mean) / std.  The border is the stem
 // convolution's zero padding, materialised so that the stem's LDS-DMA needs no per-tap bounds logic.
-__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp) {
+// valid_hw (nullable): [B][2] = (h, w) of each frame inside the H x W canvas; pixels outside are written as zeros, which
+// is what HF's pad-after-normalise produces for a ragged batch (HF:models/detr/image_processing_detr.py:639-668).
+__global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp,
+                                     const int32_t* __restrict__ valid_hw) {
 #pragma clang fp contract(off)  // keep mul / sub / div separately rounded, like the reference's tensor ops
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * Hp * Wp) return;
@@ -34,7 +37,8 @@ __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __re
     const int y = yp - 3, x = xp - 3;
     half4 o;
     o[0] = o[1] = o[2] = o[3] = (_Float16)0.f;
-    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+    const int vh = valid_hw ? valid_hw[2 * b] : H, vw = valid_hw ? valid_hw[2 * b + 1] : W;
+    if ((unsigned)y < (unsigned)vh && (unsigned)x < (unsigned)vw) {
         const uint8_t* s = in + (((size_t)b * H + y) * W + x) * 3;
         const float bl = (float)s[0], g = (float)s[1], r = (float)s[2];
         const float k = 1.0f / 255.0f;
@@ -45,7 +49,8 @@ __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __re
     *reinterpret_cast<half4*>(out + i * 4) = o;
 }
 
-__global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp) {
+__global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp,
+                                      const int32_t* __restrict__ valid_hw) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (size_t)B * Hp * Wp) return;
     const int xp = (int)(i % Wp);
@@ -55,7 +60,8 @@ __global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __res
     const int y = yp - 3, x = xp - 3;
     half4 o;
     o[0] = o[1] = o[2] = o[3] = (_Float16)0.f;
-    if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+    const int vh = valid_hw ? valid_hw[2 * b] : H, vw = valid_hw ? valid_hw[2 * b + 1] : W;
+    if ((unsigned)y < (unsigned)vh && (unsigned)x < (unsigned)vw) {
         const size_t HW = (size_t)H * W;
         const float* s = pv + (size_t)b * 3 * HW + (size_t)y * W + x;
         o[0] = (_Float16)s[0];
@@ -341,17 +347,19 @@ inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + 
 
 }  // namespace
 
-hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream) {
+hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
+                                    hipStream_t stream) {
     if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
     const size_t npix = (size_t)B * Hp * Wp;
-    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, frames, out, B, H, W, Hp, Wp);
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, frames, out, B, H, W, Hp, Wp, valid_hw);
     return hipGetLastError();
 }
 
-hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream) {
+hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
+                                     hipStream_t stream) {
     if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
     const size_t npix = (size_t)B * Hp * Wp;
-    hipLaunchKernelGGL(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H, W, Hp, Wp);
+    hipLaunchKernelGGL(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H, W, Hp, Wp, valid_hw);
     return hipGetLastError();
 }
 

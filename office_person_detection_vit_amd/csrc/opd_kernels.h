@@ -12,6 +12,8 @@ struct ConvGemmParams {
     const f16_t* x;      // [B][H][W][Cin] fp16 (Cin % 64 == 0), or NHWC4 for the stem
     const f16_t* w;      // [N][K] fp16, K = KH*KW*Cin (stem: [N][8][8][4])
     const float* bias;   // [N], or [bias_period][N] when bias_period > 0 (row-periodic bias, e.g. pos-embedding fold)
+    const float* const* bias_ptrs;  // optional (device array, bias_period > 0): row m uses bias_ptrs[m / bias_period] instead of
+                                    // `bias` — one periodic bias matrix per frame (ragged batches: the fold depends on the mask)
     const f16_t* res16;  // optional fp16 residual [M][N]
     const float* res32;  // optional fp32 residual [M][N]
     void* out;           // [M][N] fp16 (out_f32 == 0) or fp32
@@ -83,9 +85,12 @@ hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream);
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
 // uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order, written into a
 // zero-bordered image [B][Hp][Wp][4] with the frame at offset (3, 3) (Hp >= H + 6, Wp >= W + 6): the stem's padding.
-hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream);
+// valid_hw (device, nullable): [B][2] = (h, w) of each frame inside the H x W canvas (ragged batch); the rest is zero.
+hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
+                                    hipStream_t stream);
 // float32 NCHW pixel_values -> the same padded fp16 NHWC4 image.
-hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, hipStream_t stream);
+hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
+                                     hipStream_t stream);
 // 3x3 stride-2 pad-1 max-pool, NHWC fp16, C % 8 == 0.
 hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW, hipStream_t stream);
 // y = LayerNorm(x) * gamma + beta over the last dim (D == 256); writes fp32 y and optional fp16 copy.
@@ -135,5 +140,7 @@ struct AttnParams {
     int ldq, ldk, ldv, ldo;
     float scale;
     int use_tr_read;  // 1: ds_read_b64_tr_b16 for V fragments; 0: scalar LDS gathers (cross-check path)
+    const int32_t* key_valid;  // optional (device) [B][2] = (rows, cols) of the valid top-left rectangle of each frame's key map
+    int key_row;               // key map row length (key k sits at (k / key_row, k % key_row)); used with key_valid
 };
 hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream);

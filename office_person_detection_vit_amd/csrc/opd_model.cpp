@@ -78,6 +78,7 @@ struct DecLayer {
 
 struct Plan {  // everything that depends on the feature-map size (h, w)
     int fh = 0, fw = 0;
+    int vh = 0, vw = 0;          // valid (unpadded) rows / columns of the feature map this fold was built for (== fh, fw unless ragged)
     std::vector<float*> rb_enc;  // per encoder layer [hw][768]
     float* rb_kv = nullptr;      // [hw][dec_layers*512]
 };
@@ -129,6 +130,11 @@ struct opd_detr {
     float *d_logits = nullptr, *d_boxes = nullptr;
     opd_det* d_records = nullptr;
     int32_t *d_counts = nullptr, *d_orig_hw = nullptr;
+    // ragged batches (frames smaller than the canvas): per-frame valid sizes and per-frame bias-fold pointers
+    int32_t *d_valid_hw = nullptr, *d_key_valid = nullptr;
+    const float** d_bias_ptrs = nullptr;   // [(enc_layers + 1)][max_batch]
+    std::vector<int32_t> h_valid_hw, h_key_valid;
+    std::vector<const float*> h_bias_ptrs;
     int32_t* d_rois = nullptr;
     float* d_roi_out = nullptr;
     std::vector<int32_t> h_orig_hw;
@@ -420,13 +426,19 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_records, Md, false));
     RCCHK(dalloc(m, &m->d_counts, B, false));
     RCCHK(dalloc(m, &m->d_orig_hw, B * 2, false));
+    RCCHK(dalloc(m, &m->d_valid_hw, B * 2, false));
+    RCCHK(dalloc(m, &m->d_key_valid, B * 2, false));
+    RCCHK(dalloc(m, &m->d_bias_ptrs, (size_t)(a.enc_layers + 1) * B, false));
     RCCHK(dalloc(m, &m->d_rois, (size_t)128 * 4, false));
     RCCHK(dalloc(m, &m->d_roi_out, (size_t)128 * D, false));
     return OPD_OK;
 }
 
-// DetrSinePositionEmbedding with an all-ones mask (HF:models/detr/modeling_detr.py:294-368), fp32 like the reference.
-static void sine_pos_embed(int h, int w, int D, std::vector<float>* pos) {
+// DetrSinePositionEmbedding (HF:models/detr/modeling_detr.py:294-368), fp32 like the reference, for a mask that is a
+// top-left rectangle of vh x vw valid positions inside the h x w map (vh == h, vw == w: all-ones mask):
+//   y_embed = cumsum(mask, rows) = min(y+1, vh) in valid columns, 0 in padded columns; normalised by its last row (+eps);
+//   x_embed = cumsum(mask, cols) = min(x+1, vw) in valid rows, 0 in padded rows; normalised by its last column (+eps).
+static void sine_pos_embed(int h, int w, int vh, int vw, int D, std::vector<float>* pos) {
     const int npf = D / 2;
     pos->assign((size_t)h * w * D, 0.f);
     const float scale = 6.283185307179586f, eps = 1e-6f;
@@ -434,8 +446,10 @@ static void sine_pos_embed(int h, int w, int D, std::vector<float>* pos) {
     for (int i = 0; i < npf; ++i) dim_t[i] = powf(10000.0f, (2.0f * (float)(i / 2)) / (float)npf);
     for (int y = 0; y < h; ++y)
         for (int x = 0; x < w; ++x) {
-            const float ye = (float)(y + 1) / ((float)h + eps) * scale;
-            const float xe = (float)(x + 1) / ((float)w + eps) * scale;
+            const float yc = x < vw ? (float)std::min(y + 1, vh) : 0.f, ylast = x < vw ? (float)vh : 0.f;
+            const float xc = y < vh ? (float)std::min(x + 1, vw) : 0.f, xlast = y < vh ? (float)vw : 0.f;
+            const float ye = yc / (ylast + eps) * scale;
+            const float xe = xc / (xlast + eps) * scale;
             float* p = pos->data() + ((size_t)y * w + x) * D;
             for (int i = 0; i < npf; ++i) {
                 const float py = ye / dim_t[i], px = xe / dim_t[i];
@@ -445,15 +459,15 @@ static void sine_pos_embed(int h, int w, int D, std::vector<float>* pos) {
         }
 }
 
-static int get_plan(opd_detr* m, int fh, int fw, Plan** out) {
+static int get_plan(opd_detr* m, int fh, int fw, int vh, int vw, Plan** out) {
     for (auto& p : m->plans)
-        if (p->fh == fh && p->fw == fw) { *out = p.get(); return OPD_OK; }
+        if (p->fh == fh && p->fw == fw && p->vh == vh && p->vw == vw) { *out = p.get(); return OPD_OK; }
     const Arch& a = m->arch;
     const int D = a.d_model, hw = fh * fw;
     std::unique_ptr<Plan> p(new Plan());
-    p->fh = fh; p->fw = fw;
+    p->fh = fh; p->fw = fw; p->vh = vh; p->vw = vw;
     std::vector<float> pos;
-    sine_pos_embed(fh, fw, D, &pos);
+    sine_pos_embed(fh, fw, vh, vw, D, &pos);
     float* d_pos = nullptr;
     RCCHK(upload_f32(m, &d_pos, pos));
     p->rb_enc.resize(a.enc_layers);
@@ -533,8 +547,9 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
 
 // out[M][N] = x16[M][K] . w[N][K]^T + bias (+ res32), as a 1x1 "convolution" over M pixels
 static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
-                    void* out, bool out_f32, bool relu, const float* res32) {
+                    void* out, bool out_f32, bool relu, const float* res32, const float* const* bias_ptrs = nullptr) {
     ConvGemmParams p{};
+    p.bias_ptrs = bias_ptrs;
     p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0;
@@ -595,8 +610,9 @@ static int run_small_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const 
 }
 
 static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ldk, const f16_t* v, int ldv, f16_t* o, int ldo,
-                    int B, int Lq, int Lk) {
+                    int B, int Lq, int Lk, const int32_t* key_valid = nullptr, int key_row = 0) {
     AttnParams p{};
+    p.key_valid = key_valid; p.key_row = key_row;
     p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.heads = m->arch.heads; p.Lq = Lq; p.Lk = Lk;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.scale = 1.0f / sqrtf((float)(m->arch.d_model / m->arch.heads));
@@ -613,19 +629,74 @@ static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ld
     } while (0)
 
 // Enqueues the whole forward on m->stream.  `pixels` must already be on the device.
-static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W) {
+// True when some frame of the batch does not fill the H x W canvas (a ragged batch: padding mask path).
+static bool is_ragged(const int32_t* valid_hw, int B, int H, int W) {
+    if (!valid_hw) return false;
+    for (int b = 0; b < B; ++b)
+        if (valid_hw[2 * b] != H || valid_hw[2 * b + 1] != W) return true;
+    return false;
+}
+
+// Valid extent of a frame on the feature map: the reference down-samples the pixel mask with nearest-neighbour
+// interpolation (HF:models/detr/modeling_detr.py:283-289: F.interpolate(mask, size=feature_map.shape[-2:])), i.e. feature
+// position i looks at pixel floor(i * in / out) (float32 scale, like ATen's nearest kernel); the mask is a top-left
+// rectangle, so the valid feature positions are a prefix.
+static int valid_prefix(int valid, int in, int out) {
+    const float scale = (float)in / (float)out;
+    int n = 0;
+    for (int i = 0; i < out; ++i) {
+        const int src = std::min((int)floorf((float)i * scale), in - 1);
+        if (src < valid) ++n;
+    }
+    return n;
+}
+
+// `valid_hw` (host, nullable): [B][2] = (h, w) of each frame inside the H x W canvas.
+static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw = nullptr) {
     const Arch& a = m->arch;
     Dims d;
     compute_dims(B, H, W, &d);
+    const int fh = d.sh[3], fw = d.sw[3];
+    const bool ragged = is_ragged(valid_hw, B, H, W);
     Plan* plan = nullptr;
-    RCCHK(get_plan(m, d.sh[3], d.sw[3], &plan));
+    const float* const* enc_bias_ptrs[16] = {};   // per encoder layer: device array of B per-frame fold pointers (ragged only)
+    const float* const* kv_bias_ptrs = nullptr;
+    const int32_t *d_valid = nullptr, *d_keyv = nullptr;
+    if (!ragged) {
+        RCCHK(get_plan(m, fh, fw, fh, fw, &plan));
+    } else {
+        if (a.enc_layers > 16) return fail(OPD_EINVAL, "ragged batches: at most 16 encoder layers");
+        m->h_valid_hw.assign(valid_hw, valid_hw + 2 * B);
+        m->h_key_valid.resize((size_t)2 * B);
+        m->h_bias_ptrs.assign((size_t)(a.enc_layers + 1) * B, nullptr);
+        for (int b = 0; b < B; ++b) {
+            const int vh = valid_hw[2 * b], vw = valid_hw[2 * b + 1];
+            if (vh < 1 || vw < 1 || vh > H || vw > W) return fail(OPD_EINVAL, "valid_hw outside the frame canvas");
+            const int vfh = valid_prefix(vh, H, fh), vfw = valid_prefix(vw, W, fw);
+            if (vfh < 1 || vfw < 1) return fail(OPD_EINVAL, "frame too small: no valid feature-map position");
+            m->h_key_valid[2 * b] = vfh; m->h_key_valid[2 * b + 1] = vfw;
+            Plan* pb = nullptr;
+            RCCHK(get_plan(m, fh, fw, vfh, vfw, &pb));
+            if (b == 0) plan = pb;
+            for (int i = 0; i < a.enc_layers; ++i) m->h_bias_ptrs[(size_t)i * B + b] = pb->rb_enc[i];
+            m->h_bias_ptrs[(size_t)a.enc_layers * B + b] = pb->rb_kv;
+        }
+        // (member vectors: they outlive the asynchronous copies; every entry point synchronises before it returns)
+        HIPCHK(hipMemcpyAsync(m->d_valid_hw, m->h_valid_hw.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->d_key_valid, m->h_key_valid.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, m->stream));
+        HIPCHK(hipMemcpyAsync(m->d_bias_ptrs, m->h_bias_ptrs.data(), m->h_bias_ptrs.size() * sizeof(float*), hipMemcpyHostToDevice, m->stream));
+        for (int i = 0; i < a.enc_layers; ++i) enc_bias_ptrs[i] = m->d_bias_ptrs + (size_t)i * B;
+        kv_bias_ptrs = m->d_bias_ptrs + (size_t)a.enc_layers * B;
+        d_valid = m->d_valid_hw;
+        d_keyv = m->d_key_valid;
+    }
     timed_reset(m);
     MARK(0);
     const int Hp = 2 * d.H1 + 6, Wp = 2 * d.W1 + 6;  // padded image seen by the stem: rows/cols 2*o + k, k = 0..7
     if (pixel_format == OPD_PIXELS_U8_BGR_HWC)
-        HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, m->stream));
+        HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
     else
-        HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, m->stream));
+        HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
     if (m->fuse_stem_pool) {
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
         HIPCHK(opd_launch_stem_pool(m->d_x4, m->stem.w, m->stem.bias, m->d_pool, B, Hp, Wp, d.H1, d.W1, d.H2, d.W2, m->stream));
@@ -691,8 +762,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV));
     for (int i = 0; i < a.enc_layers; ++i) {
         const EncLayer& L = m->enc[i];
-        RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr));
-        RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw));
+        RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i]));
+        RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw, d_keyv, cw));
         if (m->fuse_gemm_ln && D == 256) {
             RCCHK(run_gemm_ln(m, m->d_attn16, L.o.w, L.o.b, M, D, m->d_x32, L.ln1, m->d_x32, m->d_x16));
         } else {
@@ -705,7 +776,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     MARK(6);
     // ---- decoder -----------------------------------------------------------------------------------------------
     const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
-    RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr));
+    RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs));
     HIPCHK(hipMemsetAsync(m->d_h32, 0, (size_t)Md * D * 4, m->stream));
     HIPCHK(hipMemsetAsync(m->d_h16, 0, (size_t)Md * D * 2, m->stream));
     for (int i = 0; i < a.dec_layers; ++i) {
@@ -721,7 +792,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false));
         else RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qd16, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
-                       m->d_attnd16, D, B, Q, hw));
+                       m->d_attnd16, D, B, Q, hw, d_keyv, cw));
         if (m->fuse_gemm_ln && D == 256)
             RCCHK(run_gemm_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, m->d_h32, L.ln2, m->d_h32, m->d_h16));
         else
@@ -746,7 +817,9 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
 
 // Forward through the graph cache.  First call of a (shape, pixel pointer) key runs eagerly (one-time function-attribute
 // setup and plan building are not capturable); the second call captures the stream into a hipGraph; later calls replay it.
-static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W) {
+static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw = nullptr) {
+    // ragged batches run eagerly: their launch sequence depends on per-call host data (fold pointers, valid sizes)
+    if (is_ragged(valid_hw, B, H, W)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W, valid_hw);
     if (m->profiling || (m->cfg.flags & OPD_FLAG_NO_GRAPH)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
     opd_detr::GraphEntry* e = nullptr;
     for (auto& g : m->graphs)
@@ -918,11 +991,15 @@ int opd_detr_info(const opd_detr* m, opd_model_info* info) {
 
 int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float* logits,
                      float* boxes, float* enc_features) {
+    return opd_detr_forward_ragged(m, pixels, pixel_format, mem_kind, B, H, W, nullptr, logits, boxes, enc_features);
+}
+int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+                            const int32_t* valid_hw, float* logits, float* boxes, float* enc_features) {
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
-    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W));
+    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
     const hipMemcpyKind kind = mem_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
     const size_t Md = (size_t)B * m->arch.queries;
     if (logits) HIPCHK(hipMemcpyAsync(logits, m->d_logits, Md * m->arch.ncls * 4, kind, m->stream));
@@ -944,12 +1021,16 @@ int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, o
 
 int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
                     const int32_t* orig_hw, opd_det* out, int32_t* counts) {
+    return opd_detr_detect_ragged(m, pixels, pixel_format, mem_kind, B, H, W, nullptr, threshold, orig_hw, out, counts);
+}
+int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+                           const int32_t* valid_hw, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts) {
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect: null output buffer");
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
-    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W));
+    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
     RCCHK(enqueue_postprocess(m, threshold, orig_hw));
     return fetch_records(m, out, counts, mem_kind);
 }
@@ -1033,6 +1114,15 @@ int opd_test_set_gemm_variant(int v) {
     return opd_get_gemm_variant();
 }
 
+// host-only pieces of the ragged-batch path, exported for the CPU tests
+int opd_test_valid_prefix(int valid, int in, int out) { return valid_prefix(valid, in, out); }
+int opd_test_sine_pos_embed(int h, int w, int vh, int vw, int D, float* out) {
+    if (!out || h < 1 || w < 1 || vh < 1 || vw < 1 || vh > h || vw > w || D < 2 || (D & 1)) return fail(OPD_EINVAL, "bad sine_pos_embed arguments");
+    std::vector<float> pos;
+    sine_pos_embed(h, w, vh, vw, D, &pos);
+    memcpy(out, pos.data(), pos.size() * sizeof(float));
+    return OPD_OK;
+}
 int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_gemm_ln = on ? 1 : 0;

@@ -296,6 +296,26 @@ int opd_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, 
     return OPD_OK;
 }
 
+// attention with a per-frame key mask: key k = (k / key_row, k % key_row) is valid inside key_valid[b] = (rows, cols)
+int opd_test_attention_masked(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int B, int heads, int Lq,
+                              int Lk, float scale, const int32_t* key_valid, int key_row) {
+    DevMem dm;
+    const int D = heads * 32;
+    AttnParams p{};
+    p.q = dm.up(q, (size_t)B * Lq * D);
+    p.k = dm.up(k, (size_t)B * Lk * D);
+    p.v = dm.up(v, (size_t)B * Lk * D);
+    p.o = dm.up<uint16_t>(nullptr, (size_t)B * Lq * D);
+    p.key_valid = dm.up(key_valid, (size_t)B * 2);
+    if (!p.q || !p.k || !p.v || !p.o || !p.key_valid) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = p.ldk = p.ldv = p.ldo = D; p.scale = scale; p.use_tr_read = 1;
+    p.key_row = key_row;
+    TCHK(opd_launch_attention(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(o, p.o, (size_t)B * Lq * D * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 int opd_test_layernorm(const float* x, const float* g, const float* b, float* y, uint16_t* y16, int rows) {
     DevMem dm;
     const float* dx = dm.up(x, (size_t)rows * 256);
@@ -322,12 +342,14 @@ int opd_test_maxpool(const uint16_t* x, uint16_t* out, int B, int H, int W, int 
     return OPD_OK;
 }
 
-int opd_test_preprocess_u8(const uint8_t* frames, uint16_t* out, int B, int H, int W, int Hp, int Wp) {
+// valid_hw (nullable): host [B][2] per-frame (h, w) inside the H x W canvas
+int opd_test_preprocess_u8(const uint8_t* frames, uint16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw) {
     DevMem dm;
     const uint8_t* din = dm.up(frames, (size_t)B * H * W * 3);
     uint16_t* dout = dm.up<uint16_t>(nullptr, (size_t)B * Hp * Wp * 4);
-    if (!din || !dout) return tfail(OPD_ENOMEM, "test alloc failed");
-    TCHK(opd_launch_preprocess_u8(din, dout, B, H, W, Hp, Wp, nullptr));
+    const int32_t* dvalid = valid_hw ? dm.up(valid_hw, (size_t)B * 2) : nullptr;
+    if (!din || !dout || (valid_hw && !dvalid)) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_preprocess_u8(din, dout, B, H, W, Hp, Wp, dvalid, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(out, dout, (size_t)B * Hp * Wp * 8, hipMemcpyDeviceToHost));
     return OPD_OK;

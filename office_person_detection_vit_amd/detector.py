@@ -163,9 +163,14 @@ class HipDetrDetector:
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
 
-    def _preprocess_batch(self, frames: Sequence[np.ndarray]) -> Tuple[np.ndarray, List[Tuple[int, int]]]:
+    def _preprocess_batch(self, frames: Sequence[np.ndarray]):
         """Host part of ``_preprocess_batch`` (deleted vit_detector.py 562-578): validate, resize to the model size,
-        stack to one contiguous uint8 [B,H,W,3] BGR block.  BGR->RGB, 1/255 and mean/std run on the device."""
+        stack to one contiguous uint8 [B,H,W,3] BGR block.  BGR->RGB, 1/255 and mean/std run on the device.
+
+        Frames whose model-input sizes differ form a RAGGED batch: like HF's ``DetrImageProcessor.pad``
+        (``image_processing_detr.py:639-668``) every frame sits in the top-left corner of a canvas of the batch-maximum
+        size, and the per-frame valid sizes are returned so that the device applies the padding-mask paths.
+        Returns (batch, original sizes, valid sizes [B,2] int32 or None)."""
         if len(frames) == 0:
             raise ValueError("empty frame batch")
         orig, out = [], []
@@ -178,39 +183,47 @@ class HipDetrDetector:
                 f = resize_frame(f, th, tw)
             out.append(f)
         shapes = {o.shape for o in out}
-        if len(shapes) != 1:
-            raise ValueError(f"all frames of a batch must share one model-input size, got {sorted(shapes)} "
-                             "(ragged batches with a padding mask are not supported by the HIP path yet)")
-        return np.ascontiguousarray(np.stack(out)), orig
+        if len(shapes) == 1:
+            return np.ascontiguousarray(np.stack(out)), orig, None
+        H, W = max(o.shape[0] for o in out), max(o.shape[1] for o in out)
+        if H > self.max_size[0] or W > self.max_size[1]:
+            raise ValueError(f"ragged batch canvas {H}x{W} exceeds the configured maximum {self.max_size}")
+        canvas = np.zeros((len(out), H, W, 3), np.uint8)
+        for i, o in enumerate(out):
+            canvas[i, :o.shape[0], :o.shape[1]] = o
+        valid = np.asarray([[o.shape[0], o.shape[1]] for o in out], dtype=np.int32)
+        return canvas, orig, valid
 
     def forward_raw(self, frames: Sequence[np.ndarray], want_encoder: bool = True):
         """Model outputs for a batch of BGR frames: (logits [B,Q,C+1], pred_boxes [B,Q,4], encoder [B,hw,256] | None)."""
         self._require_model()
-        batch, orig = self._preprocess_batch(frames)
+        batch, orig, valid = self._preprocess_batch(frames)
         B, H, W, _ = batch.shape
         Q, ncls, D = self._info.num_queries, self._info.num_classes_plus1, self._info.d_model
         fh, fw = _feature_hw(H), _feature_hw(W)
         logits = np.empty((B, Q, ncls), np.float32)
         boxes = np.empty((B, Q, 4), np.float32)
         enc = np.empty((B, fh * fw, D), np.float32) if want_encoder else None
-        rc = self._lib.opd_detr_forward(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC,
-                                        _capi.OPD_MEM_HOST, B, H, W, logits.ctypes.data_as(C.c_void_p),
-                                        boxes.ctypes.data_as(C.c_void_p),
-                                        enc.ctypes.data_as(C.c_void_p) if enc is not None else None)
+        rc = self._lib.opd_detr_forward_ragged(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p),
+                                               _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,
+                                               valid.ctypes.data_as(C.c_void_p) if valid is not None else None,
+                                               logits.ctypes.data_as(C.c_void_p), boxes.ctypes.data_as(C.c_void_p),
+                                               enc.ctypes.data_as(C.c_void_p) if enc is not None else None)
         _capi.check(rc, "opd_detr_forward")
         self._last_orig = orig
         return logits, boxes, enc
 
     def _detect_records(self, frames: Sequence[np.ndarray]):
-        batch, orig = self._preprocess_batch(frames)
+        batch, orig, valid = self._preprocess_batch(frames)
         B, H, W, _ = batch.shape
         Q = self._info.num_queries
         recs = (_capi.OpdDet * (B * Q))()
         counts = (C.c_int32 * B)()
         hw = np.asarray(orig, dtype=np.int32).reshape(B, 2)
-        rc = self._lib.opd_detr_detect(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC,
-                                       _capi.OPD_MEM_HOST, B, H, W, float(self.confidence_threshold),
-                                       hw.ctypes.data_as(C.c_void_p), recs, counts)
+        rc = self._lib.opd_detr_detect_ragged(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p),
+                                              _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,
+                                              valid.ctypes.data_as(C.c_void_p) if valid is not None else None,
+                                              float(self.confidence_threshold), hw.ctypes.data_as(C.c_void_p), recs, counts)
         _capi.check(rc, "opd_detr_detect")
         self._last_orig = orig
         return recs, counts, Q

@@ -152,6 +152,34 @@ def test_graph_replay_matches_eager(weight_cache):
     assert np.abs(outs[True][0][1] - outs[True][3][1]).max() > 0
 
 
+def test_ragged_batch_matches_hf_golden(detectors, golden_dir):
+    """Frames of different sizes in one batch (HF pads to the batch maximum and applies the pixel mask: nearest mask
+    down-sampling, mask-dependent position embedding, key masks in encoder self-attention and decoder cross-attention).
+    Golden: HF on frames 256x320 and 224x288.  The encoder map is compared on every position, padded ones included."""
+    g = np.load(os.path.join(golden_dir, "r50_mild_ragged.npz"))
+    det = detectors(ga=float(g["attention_gain"]))
+    frames = _golden_frames(g)
+    assert frames[0].shape != frames[1].shape
+    logits, boxes, enc = det.forward_raw(frames)
+    tb, tp, te = TOL[1.0]
+    assert float(np.abs(boxes - g["pred_boxes"]).max()) <= tb
+    assert float(np.abs(_softmax(logits) - _softmax(g["logits"])).max()) <= tp
+    assert float(np.abs(enc - g["encoder_last_hidden_state"]).max()) <= te
+    # the padded frame must NOT equal what it gives alone on its own canvas (border leakage through the padded region is
+    # part of the reference's behaviour), while the full-size frame is unaffected by its smaller neighbour
+    lg0, bx0, _ = det.forward_raw([frames[0]])
+    np.testing.assert_allclose(bx0[0], boxes[0], atol=1e-6)
+    lg1, bx1, _ = det.forward_raw([frames[1]])
+    assert float(np.abs(bx1[0] - boxes[1]).max()) > 1e-5
+    # detections of the ragged batch follow the golden post-processing
+    dets = det.detect_batch(frames)
+    for b in range(2):
+        want_q = {int(i) for i in np.nonzero(np.abs(_softmax(g["logits"][b])[:, :-1].max(-1) - 0.5) > 8e-3)[0]
+                  if _softmax(g["logits"][b])[i, :-1].max() > 0.5 and _softmax(g["logits"][b])[i, :-1].argmax() == 1}
+        got_q = {d.query_index for d in dets[b] if abs(d.confidence - 0.5) > 8e-3}
+        assert got_q <= want_q    # NMS may only remove
+
+
 def test_fused_bottleneck_tail_matches_unfused(weight_cache):
     """Stages 1-2 through kernels_btail.hip (default) against the same layers as three launches each: identical fp16
     rounding points, so only fp32 summation order differs (k-permuted 1x1 operands)."""

@@ -165,3 +165,50 @@ def test_person_nms_host_routine():
         kept = lib.opd_person_nms(recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), n, 1, 0.4)
         assert kept == len(want)
         assert list(recs["query_index"][:kept]) == want
+
+
+# ---- ragged batches (padding mask path): host-side pieces ------------------------------------------------------------------
+def test_ragged_batch_canvas_and_valid_sizes():
+    """Frames of different model-input sizes -> one zero canvas of the batch maximum + per-frame valid sizes, like HF's
+    ``DetrImageProcessor.pad`` (image_processing_detr.py:639-668); equal sizes -> plain stack, no mask."""
+    det = HipDetrDetector(model_path="unused.safetensors", resize=False, max_size=(64, 96))
+    a, b = structured_frames(1, 40, 60, seed=1)[0], structured_frames(1, 33, 72, seed=2)[0]
+    canvas, orig, valid = det._preprocess_batch([a, b])
+    assert canvas.shape == (2, 40, 72, 3) and orig == [(40, 60), (33, 72)]
+    np.testing.assert_array_equal(valid, [[40, 60], [33, 72]])
+    np.testing.assert_array_equal(canvas[0, :, :60], a)
+    np.testing.assert_array_equal(canvas[1, :33], b)
+    assert not canvas[0, :, 60:].any() and not canvas[1, 33:].any()
+    same, _, none = det._preprocess_batch([a, a])
+    assert none is None and same.shape == (2, 40, 60, 3)
+    with pytest.raises(ValueError):
+        det._preprocess_batch([a, structured_frames(1, 70, 60, seed=3)[0]])   # canvas taller than max_size
+
+
+def test_mask_downsampling_matches_torch_nearest():
+    """valid_prefix == number of True positions of F.interpolate(mask, size) (nearest), HF:modeling_detr.py:283-289."""
+    import torch
+    import torch.nn.functional as F
+    lib = _capi.load_library()
+    for size, out in [(256, 8), (224, 7), (800, 25), (1333, 42), (750, 24), (203, 7), (333, 11), (1066, 34)]:
+        for valid in {1, 2, size // 3, size // 2, size - 33, size - 1, size}:
+            if valid < 1:
+                continue
+            m = torch.zeros(1, 1, size, 1)
+            m[:, :, :valid] = 1
+            want = int(F.interpolate(m, size=(out, 1)).bool().sum())
+            assert lib.opd_test_valid_prefix(valid, size, out) == want, (size, out, valid)
+
+
+def test_masked_sine_position_embedding_matches_oracle():
+    """Position embedding of a frame whose valid region is a top-left rectangle of the map: equals the oracle's
+    cumulative-sum formulation (HF:modeling_detr.py:294-368) at EVERY position, padded ones included."""
+    import torch
+    lib = _capi.load_library()
+    for h, w, vh, vw in [(8, 10, 8, 10), (8, 10, 7, 9), (25, 42, 24, 42), (25, 42, 25, 30), (7, 11, 1, 1)]:
+        mask = torch.zeros(1, h, w, dtype=torch.bool)
+        mask[:, :vh, :vw] = True
+        want = O.sine_position_embedding(mask, 256)[0].numpy()
+        got = np.empty((h * w, 256), np.float32)
+        _capi.check(lib.opd_test_sine_pos_embed(h, w, vh, vw, 256, got.ctypes.data_as(C.c_void_p)), "sine_pos_embed")
+        np.testing.assert_allclose(got, want, atol=2e-6)

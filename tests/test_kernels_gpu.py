@@ -283,7 +283,7 @@ def test_preprocess_matches_oracle(lib):
     OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
     Hp, Wp = 2 * OH + 6, 2 * OW + 6
     out = np.empty((2, Hp, Wp, 4), np.uint16)
-    _capi.check(lib.opd_test_preprocess_u8(_p(batch), _p(out), 2, H, W, Hp, Wp), "opd_test_preprocess_u8")
+    _capi.check(lib.opd_test_preprocess_u8(_p(batch), _p(out), 2, H, W, Hp, Wp, None), "opd_test_preprocess_u8")
     got = out.view(np.float16)
     want = pv.permute(0, 2, 3, 1).numpy().astype(np.float16)
     np.testing.assert_array_equal(got[:, 3:3 + H, 3:3 + W, :3], want)  # same op order in fp32, one rounding to fp16
@@ -291,6 +291,59 @@ def test_preprocess_matches_oracle(lib):
     border = got.copy()
     border[:, 3:3 + H, 3:3 + W, :] = 0
     assert not border.any()  # the zero border is the stem's padding
+
+
+def test_preprocess_ragged_batch_matches_oracle(lib):
+    """Frames of different sizes on one canvas: the device writes zeros outside each frame's valid rectangle, exactly
+    HF's pad-after-normalise (oracle ``preprocess`` on the ragged list)."""
+    from office_person_detection_vit_amd.frames import structured_frames
+    from oracle import detr_oracle as O
+
+    sizes = [(37, 53), (29, 41)]
+    frames = [structured_frames(1, h, w, seed=5 + i)[0] for i, (h, w) in enumerate(sizes)]
+    pv, pm = O.preprocess(frames)                      # [2, 3, 37, 53] zero padded, mask
+    H, W = 37, 53
+    canvas = np.full((2, H, W, 3), 201, np.uint8)      # garbage outside the frames: must be ignored
+    for i, f in enumerate(frames):
+        canvas[i, :f.shape[0], :f.shape[1]] = f
+    valid = np.asarray(sizes, np.int32)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    Hp, Wp = 2 * OH + 6, 2 * OW + 6
+    out = np.empty((2, Hp, Wp, 4), np.uint16)
+    _capi.check(lib.opd_test_preprocess_u8(_p(canvas), _p(out), 2, H, W, Hp, Wp, _p(valid)), "opd_test_preprocess_u8")
+    got = out.view(np.float16)
+    want = pv.permute(0, 2, 3, 1).numpy().astype(np.float16)
+    np.testing.assert_array_equal(got[:, 3:3 + H, 3:3 + W, :3], want)
+    assert int(pm[1].sum()) == 29 * 41 and not got[1, 3 + 29:, :, :].any() and not got[1, :, 3 + 41:, :].any()
+
+
+def test_attention_key_mask_matches_torch(lib):
+    """Ragged batch: keys outside each frame's valid (rows x cols) rectangle of the key map contribute nothing —
+    the reference adds finfo.min to their scores (HF:models/detr/modeling_detr.py:402-427)."""
+    B, heads, D, fh, fw = 3, 8, 256, 9, 14
+    Lk, Lq = fh * fw, 100
+    rng = np.random.default_rng(21)
+    q, qb = _h(rng.standard_normal((B, Lq, D)) * 1.5)
+    k, kb = _h(rng.standard_normal((B, Lk, D)) * 1.5)
+    v, vb = _h(rng.standard_normal((B, Lk, D)))
+    valid = np.asarray([[9, 14], [7, 9], [1, 1]], np.int32)     # full map, a proper sub-rectangle, a single key
+    out = np.empty((B, Lq, D), np.uint16)
+    scale = 32 ** -0.5
+    _capi.check(lib.opd_test_attention_masked(_p(qb), _p(kb), _p(vb), _p(out), B, heads, Lq, Lk, scale, _p(valid), fw),
+                "opd_test_attention_masked")
+    got = out.view(np.float16).astype(np.float32)
+    dh = D // heads
+    Q = torch.from_numpy(q).view(B, Lq, heads, dh).transpose(1, 2)
+    K = torch.from_numpy(k).view(B, Lk, heads, dh).transpose(1, 2)
+    V = torch.from_numpy(v).view(B, Lk, heads, dh).transpose(1, 2)
+    sc = Q @ K.transpose(2, 3) * scale
+    ys, xs = torch.meshgrid(torch.arange(fh), torch.arange(fw), indexing="ij")
+    for b in range(B):
+        ok = ((ys < int(valid[b, 0])) & (xs < int(valid[b, 1]))).flatten()
+        sc[b, :, :, ~ok] = torch.finfo(torch.float32).min
+    want = (torch.softmax(sc, -1) @ V).transpose(1, 2).reshape(B, Lq, D).numpy()
+    np.testing.assert_allclose(got, want, atol=2e-3, rtol=2e-3)
+    np.testing.assert_allclose(got[2], np.broadcast_to(v[2, :1], (Lq, D)), atol=1e-3)   # one valid key: output = its value
 
 
 @pytest.mark.parametrize("H,W", [(45, 51), (64, 96), (37, 34)])
