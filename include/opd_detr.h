@@ -108,6 +108,17 @@ int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_
 int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                             const int32_t* valid_hw, float* logits, float* boxes, float* enc_features);
 
+/* Device-side resize: frames at CAMERA resolution in, the resize half of `_preprocess_batch` on the GPU.
+ * `frames` = [B][h][w][3] uint8 BGR (host or device per `mem_kind`), all of one size; they are resized to H x W — the caller
+ * computes (H, W) with the HF size rule (HF:image_transforms.py:206-242; `model_input_size` in the Python shim) — by a kernel
+ * that is BIT-EXACT with Pillow's 8-bit bilinear resampler, i.e. with `DetrImageProcessor.resize`
+ * (HF:models/detr/image_processing_detr.py:424-436), then run through the same path as opd_detr_forward.
+ * Outputs follow `mem_kind`. */
+int opd_detr_forward_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W,
+                             float* logits, float* boxes, float* enc_features);
+/* The resize alone (host in, host out): [B][h][w][3] -> [B][out_h][out_w][3]; for parity tests against Pillow. */
+int opd_detr_resize_u8(opd_detr* m, const uint8_t* frames, int B, int h, int w, int out_h, int out_w, uint8_t* out);
+
 /* Replaces `_postprocess_batch` part 1 = HF `post_process_object_detection` (deleted vit_detector.py 591-647;
  * HF:models/detr/image_processing_detr.py:805-856): softmax over C+1, max over the first C classes, cxcywh->xyxy,
  * scale by the ORIGINAL (height,width) of each frame, keep score > threshold.  Runs on the device on the logits and
@@ -121,6 +132,10 @@ int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_k
                     float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
 /* With `mem_kind == OPD_MEM_DEVICE`, `out` ([B][Q] records) and `counts` ([B]) are DEVICE pointers too, so a sharded
  * caller can hand them straight to an RCCL all-gather; `orig_hw` is always a host array. */
+/* Camera-resolution form (see opd_detr_forward_resized): resize on the device, detect, and scale the boxes back to the
+ * camera frame size (h, w). */
+int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W,
+                            float threshold, opd_det* out, int32_t* counts);
 /* Ragged-batch form (see opd_detr_forward_ragged); `valid_hw` and `orig_hw` are host arrays. */
 int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                            const int32_t* valid_hw, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);

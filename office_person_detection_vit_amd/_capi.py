@@ -47,6 +47,9 @@ API = {
                                    C.c_void_p, C.c_void_p]),
     "opd_detr_forward_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "opd_detr_forward_resized": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 3),
+    "opd_detr_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
+    "opd_detr_detect_resized": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_detr_postprocess": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_detr_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
@@ -84,6 +87,7 @@ TEST_API = {
     "opd_test_f16_to_f32": (C.c_float, [C.c_uint16]),
     "opd_test_normalise_key": (C.c_int, [C.c_char_p, C.c_char_p, C.c_int]),
     "opd_test_inspect_checkpoint": (C.c_int, [C.c_char_p, C.POINTER(C.c_int32)]),
+    "opd_test_resize_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "opd_test_valid_prefix": (C.c_int, [C.c_int] * 3),
     "opd_test_sine_pos_embed": (C.c_int, [C.c_int] * 5 + [C.c_void_p]),
     "opd_test_set_tr_read": (C.c_int, [C.c_void_p, C.c_int]),

@@ -8,6 +8,7 @@
 //   roi_features a17: FeatureExtractor.extract_roi_features           (src/tracking/feature_extractor.py:39-88)
 #include <hip/hip_runtime.h>
 #include <math.h>
+#include <vector>
 #include "opd_kernels.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
@@ -69,6 +70,50 @@ __global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __res
         o[2] = (_Float16)s[2 * HW];
     }
     *reinterpret_cast<half4*>(out + i * 4) = o;
+}
+
+// Bilinear resize of uint8 HxWx3 frames, bit-exact with Pillow's two-pass 8-bit resampler, which is what HF's image
+// processor runs on the host (HF:models/detr/image_processing_detr.py:424-436 -> PIL Image.resize(BILINEAR);
+// Pillow src/libImaging/Resample.c: ImagingResampleHorizontal_8bpc / ImagingResampleVertical_8bpc).  Both passes use
+// 22-bit fixed-point coefficients (tables built on the host by opd_resize_coeffs with Pillow's formulas) and each pass
+// rounds to uint8: out = clip8((2^21 + sum_k pixel_k * coeff_k) >> 22).  One thread per output pixel computes the few
+// horizontally resampled source rows it needs (rounded, like the intermediate image) and combines them vertically.
+__global__ void resize_bilinear_u8_kernel(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, int B, int h, int w, int oh,
+                                          int ow, const int32_t* __restrict__ bh, const int32_t* __restrict__ kh, int ksh,
+                                          const int32_t* __restrict__ bv, const int32_t* __restrict__ kv, int ksv) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)B * oh * ow) return;
+    const int xo = (int)(i % ow);
+    const size_t t = i / ow;
+    const int yo = (int)(t % oh);
+    const int b = (int)(t / oh);
+    const int xmin = bh[2 * xo], xcnt = bh[2 * xo + 1];
+    const int ymin = bv[2 * yo], ycnt = bv[2 * yo + 1];
+    const int32_t* ckh = kh + (size_t)xo * ksh;
+    const int32_t* ckv = kv + (size_t)yo * ksv;
+    const int half = 1 << 21;
+    int a0 = half, a1 = half, a2 = half;
+    for (int j = 0; j < ycnt; ++j) {
+        const uint8_t* row = in + (((size_t)b * h + ymin + j) * w + xmin) * 3;
+        int s0 = half, s1 = half, s2 = half;
+        for (int k = 0; k < xcnt; ++k) {
+            const int c = ckh[k];
+            s0 += (int)row[3 * k] * c;
+            s1 += (int)row[3 * k + 1] * c;
+            s2 += (int)row[3 * k + 2] * c;
+        }
+        s0 >>= 22; s1 >>= 22; s2 >>= 22;   // arithmetic shift, then clip8
+        s0 = s0 < 0 ? 0 : (s0 > 255 ? 255 : s0);
+        s1 = s1 < 0 ? 0 : (s1 > 255 ? 255 : s1);
+        s2 = s2 < 0 ? 0 : (s2 > 255 ? 255 : s2);
+        const int c = ckv[j];
+        a0 += s0 * c; a1 += s1 * c; a2 += s2 * c;
+    }
+    a0 >>= 22; a1 >>= 22; a2 >>= 22;
+    uint8_t* o = out + i * 3;
+    o[0] = (uint8_t)(a0 < 0 ? 0 : (a0 > 255 ? 255 : a0));
+    o[1] = (uint8_t)(a1 < 0 ? 0 : (a1 > 255 ? 255 : a1));
+    o[2] = (uint8_t)(a2 < 0 ? 0 : (a2 > 255 ? 255 : a2));
 }
 
 // One thread per (output pixel, 8-channel group); 9 x 16-byte loads, 1 x 16-byte store.
@@ -361,6 +406,53 @@ hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, 
     const size_t npix = (size_t)B * Hp * Wp;
     hipLaunchKernelGGL(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H, W, Hp, Wp, valid_hw);
     return hipGetLastError();
+}
+
+hipError_t opd_launch_resize_u8(const uint8_t* in, uint8_t* out, int B, int h, int w, int oh, int ow, const int32_t* bounds_h,
+                                const int32_t* coeff_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeff_v, int ksize_v,
+                                hipStream_t stream) {
+    if (B <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0) return hipErrorInvalidValue;
+    const size_t npix = (size_t)B * oh * ow;
+    hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, in, out, B, h, w, oh, ow, bounds_h,
+                       coeff_h, ksize_h, bounds_v, coeff_v, ksize_v);
+    return hipGetLastError();
+}
+
+// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear (triangle, support 1) filter over the whole axis
+// (box = [0, in_size)): per output position the first source index, the tap count, and the 22-bit fixed-point taps.
+void opd_resize_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs, int* ksize_out) {
+    const double scale = (double)in_size / out_size;
+    const double filterscale = scale < 1.0 ? 1.0 : scale;
+    const double support = 1.0 * filterscale;
+    const int ksize = (int)ceil(support) * 2 + 1;
+    bounds->assign((size_t)out_size * 2, 0);
+    coeffs->assign((size_t)out_size * ksize, 0);
+    std::vector<double> k(ksize);
+    for (int xx = 0; xx < out_size; ++xx) {
+        const double center = 0.0 + (xx + 0.5) * scale;
+        double ww = 0.0;
+        const double ss = 1.0 / filterscale;
+        int xmin = (int)(center - support + 0.5);
+        if (xmin < 0) xmin = 0;
+        int xmax = (int)(center + support + 0.5);
+        if (xmax > in_size) xmax = in_size;
+        xmax -= xmin;
+        for (int x = 0; x < xmax; ++x) {
+            double a = (x + xmin - center + 0.5) * ss;
+            if (a < 0.0) a = -a;
+            const double wgt = a < 1.0 ? 1.0 - a : 0.0;
+            k[x] = wgt;
+            ww += wgt;
+        }
+        for (int x = 0; x < xmax; ++x) {
+            if (ww != 0.0) k[x] /= ww;
+            const double v = k[x] * (double)(1 << 22);
+            (*coeffs)[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + v) : (int)(0.5 + v);
+        }
+        (*bounds)[2 * xx] = xmin;
+        (*bounds)[2 * xx + 1] = xmax;
+    }
+    *ksize_out = ksize;
 }
 
 hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW,

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <vector>
 
 typedef uint16_t f16_t;  // raw IEEE half bits on the host side
 
@@ -91,6 +92,11 @@ hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, in
 // float32 NCHW pixel_values -> the same padded fp16 NHWC4 image.
 hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
                                      hipStream_t stream);
+// Pillow-exact bilinear resize of uint8 HxWx3 frames (two 8-bit passes, 22-bit fixed-point taps); tables from opd_resize_coeffs.
+void opd_resize_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs, int* ksize_out);  // host
+hipError_t opd_launch_resize_u8(const uint8_t* in, uint8_t* out, int B, int h, int w, int oh, int ow, const int32_t* bounds_h,
+                                const int32_t* coeff_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeff_v, int ksize_v,
+                                hipStream_t stream);
 // 3x3 stride-2 pad-1 max-pool, NHWC fp16, C % 8 == 0.
 hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW, hipStream_t stream);
 // y = LayerNorm(x) * gamma + beta over the last dim (D == 256); writes fp32 y and optional fp16 copy.

@@ -135,6 +135,11 @@ struct opd_detr {
     const float** d_bias_ptrs = nullptr;   // [(enc_layers + 1)][max_batch]
     std::vector<int32_t> h_valid_hw, h_key_valid;
     std::vector<const float*> h_bias_ptrs;
+    // device-side resize (camera resolution -> model resolution): source staging (grown on demand) and coefficient tables
+    uint8_t* d_src = nullptr;
+    size_t src_bytes = 0;
+    struct ResizeTab { int h, w, oh, ow, ksh, ksv; int32_t *bh, *kh, *bv, *kv; };
+    std::vector<ResizeTab> resize_tabs;
     int32_t* d_rois = nullptr;
     float* d_roi_out = nullptr;
     std::vector<int32_t> h_orig_hw;
@@ -883,6 +888,45 @@ static int stage_pixels(opd_detr* m, const void* pixels, int pixel_format, int m
     return OPD_OK;
 }
 
+// Frames at camera resolution -> m->d_u8 at model resolution (Pillow-exact bilinear, kernels_misc.hip).
+static int enqueue_resize(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int oh, int ow) {
+    if (h < 1 || w < 1 || (size_t)h * w > (size_t)1 << 26) return fail(OPD_EINVAL, "source frame size out of range");
+    const size_t need = (size_t)B * h * w * 3;
+    const uint8_t* d_in = frames;
+    if (mem_kind == OPD_MEM_HOST) {
+        if (need > m->src_bytes) {
+            HIPCHK(hipStreamSynchronize(m->stream));
+            if (m->d_src) (void)hipFree(m->d_src);
+            m->d_src = nullptr; m->src_bytes = 0;
+            void* q = nullptr;
+            if (hipMalloc(&q, need) != hipSuccess) return fail(OPD_ENOMEM, "source frame staging allocation failed");
+            m->d_src = reinterpret_cast<uint8_t*>(q);
+            m->src_bytes = need;
+        }
+        HIPCHK(hipMemcpyAsync(m->d_src, frames, need, hipMemcpyHostToDevice, m->stream));
+        d_in = m->d_src;
+    }
+    const opd_detr::ResizeTab* tab = nullptr;
+    for (const auto& t : m->resize_tabs)
+        if (t.h == h && t.w == w && t.oh == oh && t.ow == ow) tab = &t;
+    if (!tab) {
+        std::vector<int32_t> bh, kh, bv, kv;
+        opd_detr::ResizeTab t{h, w, oh, ow, 0, 0, nullptr, nullptr, nullptr, nullptr};
+        opd_resize_coeffs(w, ow, &bh, &kh, &t.ksh);
+        opd_resize_coeffs(h, oh, &bv, &kv, &t.ksv);
+        auto up = [&](const std::vector<int32_t>& v, int32_t** d) -> int {
+            RCCHK(dalloc(m, d, v.size(), false));
+            HIPCHK(hipMemcpy(*d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+            return OPD_OK;
+        };
+        RCCHK(up(bh, &t.bh)); RCCHK(up(kh, &t.kh)); RCCHK(up(bv, &t.bv)); RCCHK(up(kv, &t.kv));
+        m->resize_tabs.push_back(t);
+        tab = &m->resize_tabs.back();
+    }
+    HIPCHK(opd_launch_resize_u8(d_in, m->d_u8, B, h, w, oh, ow, tab->bh, tab->kh, tab->ksh, tab->bv, tab->kv, tab->ksv, m->stream));
+    return OPD_OK;
+}
+
 static int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw) {
     const int B = m->last_B;
     std::vector<int32_t>& hw = m->h_orig_hw;  // member: must outlive the async copy
@@ -947,6 +991,7 @@ int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_
     if (device_ordinal < 0 || device_ordinal >= ndev) return fail(OPD_EINVAL, "device_ordinal out of range");
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
+    if (m->d_src) (void)hipFree(m->d_src);
         if (m->stream) (void)hipStreamDestroy(m->stream);
         return code;
     };
@@ -989,6 +1034,20 @@ int opd_detr_info(const opd_detr* m, opd_model_info* info) {
     return OPD_OK;
 }
 
+// forward on device-resident pixels; outputs go to host or device memory according to `out_kind`
+static int forward_device(opd_detr* m, const void* d_pixels, int pixel_format, int out_kind, int B, int H, int W,
+                          const int32_t* valid_hw, float* logits, float* boxes, float* enc_features) {
+    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
+    const hipMemcpyKind kind = out_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    const size_t Md = (size_t)B * m->arch.queries;
+    if (logits) HIPCHK(hipMemcpyAsync(logits, m->d_logits, Md * m->arch.ncls * 4, kind, m->stream));
+    if (boxes) HIPCHK(hipMemcpyAsync(boxes, m->d_boxes, Md * 4 * 4, kind, m->stream));
+    if (enc_features)
+        HIPCHK(hipMemcpyAsync(enc_features, m->d_x32, (size_t)B * m->last_fh * m->last_fw * m->arch.d_model * 4, kind, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    if (m->profiling) timed_collect(m);
+    return OPD_OK;
+}
 int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float* logits,
                      float* boxes, float* enc_features) {
     return opd_detr_forward_ragged(m, pixels, pixel_format, mem_kind, B, H, W, nullptr, logits, boxes, enc_features);
@@ -999,18 +1058,8 @@ int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, i
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
-    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
-    const hipMemcpyKind kind = mem_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    const size_t Md = (size_t)B * m->arch.queries;
-    if (logits) HIPCHK(hipMemcpyAsync(logits, m->d_logits, Md * m->arch.ncls * 4, kind, m->stream));
-    if (boxes) HIPCHK(hipMemcpyAsync(boxes, m->d_boxes, Md * 4 * 4, kind, m->stream));
-    if (enc_features)
-        HIPCHK(hipMemcpyAsync(enc_features, m->d_x32, (size_t)B * m->last_fh * m->last_fw * m->arch.d_model * 4, kind, m->stream));
-    HIPCHK(hipStreamSynchronize(m->stream));
-    if (m->profiling) timed_collect(m);
-    return OPD_OK;
+    return forward_device(m, d_pixels, pixel_format, mem_kind, B, H, W, valid_hw, logits, boxes, enc_features);
 }
-
 int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts) {
     if (!m || !out || !counts) return fail(OPD_EINVAL, "opd_detr_postprocess: null argument");
     if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_postprocess called before any forward");
@@ -1018,7 +1067,25 @@ int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, o
     RCCHK(enqueue_postprocess(m, threshold, orig_hw));
     return fetch_records(m, out, counts, OPD_MEM_HOST);
 }
-
+int opd_detr_resize_u8(opd_detr* m, const uint8_t* frames, int B, int h, int w, int out_h, int out_w, uint8_t* out) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    if (!frames || !out) return fail(OPD_EINVAL, "opd_detr_resize_u8: null buffer");
+    uint8_t dummy = 0;
+    RCCHK(check_shape(m, &dummy, OPD_PIXELS_U8_BGR_HWC, OPD_MEM_HOST, B, out_h, out_w));
+    HIPCHK(hipSetDevice(m->device));
+    RCCHK(enqueue_resize(m, frames, OPD_MEM_HOST, B, h, w, out_h, out_w));
+    HIPCHK(hipMemcpyAsync(out, m->d_u8, (size_t)B * out_h * out_w * 3, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return OPD_OK;
+}
+int opd_detr_forward_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float* logits,
+                             float* boxes, float* enc_features) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    RCCHK(check_shape(m, frames, OPD_PIXELS_U8_BGR_HWC, mem_kind, B, H, W));
+    HIPCHK(hipSetDevice(m->device));
+    RCCHK(enqueue_resize(m, frames, mem_kind, B, h, w, H, W));
+    return forward_device(m, m->d_u8, OPD_PIXELS_U8_BGR_HWC, mem_kind, B, H, W, nullptr, logits, boxes, enc_features);
+}
 int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
                     const int32_t* orig_hw, opd_det* out, int32_t* counts) {
     return opd_detr_detect_ragged(m, pixels, pixel_format, mem_kind, B, H, W, nullptr, threshold, orig_hw, out, counts);
@@ -1032,6 +1099,19 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
     RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
     RCCHK(enqueue_postprocess(m, threshold, orig_hw));
+    return fetch_records(m, out, counts, mem_kind);
+}
+int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float threshold,
+                            opd_det* out, int32_t* counts) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    RCCHK(check_shape(m, frames, OPD_PIXELS_U8_BGR_HWC, mem_kind, B, H, W));
+    if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect_resized: null output buffer");
+    HIPCHK(hipSetDevice(m->device));
+    RCCHK(enqueue_resize(m, frames, mem_kind, B, h, w, H, W));
+    RCCHK(run_forward(m, m->d_u8, OPD_PIXELS_U8_BGR_HWC, B, H, W, nullptr));
+    std::vector<int32_t> orig((size_t)2 * B);   // boxes are scaled to the ORIGINAL (camera) frame size
+    for (int b = 0; b < B; ++b) { orig[2 * b] = h; orig[2 * b + 1] = w; }
+    RCCHK(enqueue_postprocess(m, threshold, orig.data()));
     return fetch_records(m, out, counts, mem_kind);
 }
 
@@ -1114,6 +1194,16 @@ int opd_test_set_gemm_variant(int v) {
     return opd_get_gemm_variant();
 }
 
+// Pillow coefficient tables of the device resize (host only): bounds [out][2], coeffs [out][ksize]; returns ksize
+int opd_test_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int coeffs_capacity) {
+    std::vector<int32_t> b, k;
+    int ksize = 0;
+    opd_resize_coeffs(in_size, out_size, &b, &k, &ksize);
+    if ((int)k.size() > coeffs_capacity) return fail(OPD_EINVAL, "coefficient buffer too small");
+    memcpy(bounds, b.data(), b.size() * 4);
+    memcpy(coeffs, k.data(), k.size() * 4);
+    return ksize;
+}
 // host-only pieces of the ragged-batch path, exported for the CPU tests
 int opd_test_valid_prefix(int valid, int in, int out) { return valid_prefix(valid, in, out); }
 int opd_test_sine_pos_embed(int h, int w, int vh, int vw, int D, float* out) {

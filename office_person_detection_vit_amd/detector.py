@@ -50,7 +50,8 @@ def model_input_size(height: int, width: int, shortest_edge: int = 800, longest_
 
 def resize_frame(frame: np.ndarray, out_h: int, out_w: int) -> np.ndarray:
     """PIL bilinear resize of a uint8 HxWx3 frame, exactly what HF's image processor does on the host
-    (HF:models/detr/image_processing_pil_detr.py:497-549).  Device-side resize is a later row."""
+    (HF:models/detr/image_processing_pil_detr.py:497-549).  Used for batches of mixed frame sizes and as the reference
+    of the device-side resize (``opd_detr_*_resized``, bit-exact with this function)."""
     if frame.shape[0] == out_h and frame.shape[1] == out_w:
         return frame
     from PIL import Image
@@ -71,6 +72,7 @@ class HipDetrDetector:
         max_batch: int = 8,
         max_size: Tuple[int, int] = (800, 1333),
         resize: bool = True,
+        device_resize: bool = True,
         use_graph: bool = True,
     ):
         """
@@ -89,6 +91,7 @@ class HipDetrDetector:
         self.max_batch = int(max_batch)
         self.max_size = (int(max_size[0]), int(max_size[1]))
         self.resize = resize
+        self.device_resize = device_resize  # resize camera-resolution frames on the GPU (False: PIL on the host)
         self.use_graph = use_graph  # replay the forward as a captured hipGraph (False: launch every kernel eagerly)
         self.model: Optional[int] = None  # opaque opd_detr* once loaded
         self.feature_extractor = FeatureExtractor()
@@ -170,7 +173,11 @@ class HipDetrDetector:
         Frames whose model-input sizes differ form a RAGGED batch: like HF's ``DetrImageProcessor.pad``
         (``image_processing_detr.py:639-668``) every frame sits in the top-left corner of a canvas of the batch-maximum
         size, and the per-frame valid sizes are returned so that the device applies the padding-mask paths.
-        Returns (batch, original sizes, valid sizes [B,2] int32 or None)."""
+
+        Frames of ONE size that need resizing are NOT resized here: the batch stays at camera resolution and the
+        returned ``target`` = (H, W) tells the caller to use the device-side resize (bit-exact with PIL's bilinear,
+        ``opd_detr_*_resized``); ``device_resize=False`` or mixed sizes keep the host PIL path.
+        Returns (batch, original sizes, valid sizes [B,2] int32 or None, target (H, W) or None)."""
         if len(frames) == 0:
             raise ValueError("empty frame batch")
         orig, out = [], []
@@ -178,13 +185,18 @@ class HipDetrDetector:
             if not isinstance(f, np.ndarray) or f.ndim != 3 or f.shape[2] != 3 or f.dtype != np.uint8:
                 raise ValueError("frames must be uint8 numpy arrays of shape (H, W, 3) in BGR order")
             orig.append((int(f.shape[0]), int(f.shape[1])))
+        if self.resize and self.device_resize and len(set(orig)) == 1:
+            th, tw = model_input_size(orig[0][0], orig[0][1], self.max_size[0], self.max_size[1])
+            if (th, tw) != orig[0]:
+                return np.ascontiguousarray(np.stack(frames)), orig, None, (th, tw)
+        for f in frames:
             if self.resize:
                 th, tw = model_input_size(f.shape[0], f.shape[1], self.max_size[0], self.max_size[1])
                 f = resize_frame(f, th, tw)
             out.append(f)
         shapes = {o.shape for o in out}
         if len(shapes) == 1:
-            return np.ascontiguousarray(np.stack(out)), orig, None
+            return np.ascontiguousarray(np.stack(out)), orig, None, None
         H, W = max(o.shape[0] for o in out), max(o.shape[1] for o in out)
         if H > self.max_size[0] or W > self.max_size[1]:
             raise ValueError(f"ragged batch canvas {H}x{W} exceeds the configured maximum {self.max_size}")
@@ -192,18 +204,28 @@ class HipDetrDetector:
         for i, o in enumerate(out):
             canvas[i, :o.shape[0], :o.shape[1]] = o
         valid = np.asarray([[o.shape[0], o.shape[1]] for o in out], dtype=np.int32)
-        return canvas, orig, valid
+        return canvas, orig, valid, None
 
     def forward_raw(self, frames: Sequence[np.ndarray], want_encoder: bool = True):
         """Model outputs for a batch of BGR frames: (logits [B,Q,C+1], pred_boxes [B,Q,4], encoder [B,hw,256] | None)."""
         self._require_model()
-        batch, orig, valid = self._preprocess_batch(frames)
+        batch, orig, valid, target = self._preprocess_batch(frames)
         B, H, W, _ = batch.shape
+        if target is not None:
+            H, W = target
         Q, ncls, D = self._info.num_queries, self._info.num_classes_plus1, self._info.d_model
         fh, fw = _feature_hw(H), _feature_hw(W)
         logits = np.empty((B, Q, ncls), np.float32)
         boxes = np.empty((B, Q, 4), np.float32)
         enc = np.empty((B, fh * fw, D), np.float32) if want_encoder else None
+        if target is not None:
+            rc = self._lib.opd_detr_forward_resized(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p), _capi.OPD_MEM_HOST,
+                                                    B, batch.shape[1], batch.shape[2], H, W, logits.ctypes.data_as(C.c_void_p),
+                                                    boxes.ctypes.data_as(C.c_void_p),
+                                                    enc.ctypes.data_as(C.c_void_p) if enc is not None else None)
+            _capi.check(rc, "opd_detr_forward_resized")
+            self._last_orig = orig
+            return logits, boxes, enc
         rc = self._lib.opd_detr_forward_ragged(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p),
                                                _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,
                                                valid.ctypes.data_as(C.c_void_p) if valid is not None else None,
@@ -214,11 +236,17 @@ class HipDetrDetector:
         return logits, boxes, enc
 
     def _detect_records(self, frames: Sequence[np.ndarray]):
-        batch, orig, valid = self._preprocess_batch(frames)
+        batch, orig, valid, target = self._preprocess_batch(frames)
         B, H, W, _ = batch.shape
         Q = self._info.num_queries
         recs = (_capi.OpdDet * (B * Q))()
         counts = (C.c_int32 * B)()
+        if target is not None:   # camera-resolution batch: resize on the device, boxes come back in camera pixels
+            rc = self._lib.opd_detr_detect_resized(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p), _capi.OPD_MEM_HOST,
+                                                   B, H, W, target[0], target[1], float(self.confidence_threshold), recs, counts)
+            _capi.check(rc, "opd_detr_detect_resized")
+            self._last_orig = orig
+            return recs, counts, Q
         hw = np.asarray(orig, dtype=np.int32).reshape(B, 2)
         rc = self._lib.opd_detr_detect_ragged(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p),
                                               _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,

@@ -152,6 +152,45 @@ def test_graph_replay_matches_eager(weight_cache):
     assert np.abs(outs[True][0][1] - outs[True][3][1]).max() > 0
 
 
+@pytest.mark.parametrize("src,dst", [((72, 128), (75, 133)), ((90, 160), (75, 133)), ((48, 64), (80, 107)), ((211, 97), (60, 32)),
+                                     ((720, 1280), (750, 1333))])
+def test_device_resize_is_bit_exact_with_pillow(detectors, src, dst):
+    """the device-side resize reproduces ``DetrImageProcessor.resize`` (PIL bilinear on uint8) bit for
+    bit — integer work, so the bar is exact equality.  Last case: the reference's camera frame 1280x720 -> 750x1333."""
+    import ctypes as C
+    from PIL import Image
+    from office_person_detection_vit_amd import _capi
+    det = detectors(ga=1.0, max_batch=2)
+    rng = np.random.default_rng(src[0] + dst[1])
+    frames = rng.integers(0, 256, (2, src[0], src[1], 3), dtype=np.uint8)
+    out = np.empty((2, dst[0], dst[1], 3), np.uint8)
+    rc = _capi.load_library().opd_detr_resize_u8(C.c_void_p(det.model), frames.ctypes.data_as(C.c_void_p), 2, src[0], src[1],
+                                                 dst[0], dst[1], out.ctypes.data_as(C.c_void_p))
+    _capi.check(rc, "opd_detr_resize_u8")
+    for b in range(2):
+        want = np.asarray(Image.fromarray(frames[b]).resize((dst[1], dst[0]), resample=Image.BILINEAR))
+        np.testing.assert_array_equal(out[b], want)
+
+
+def test_camera_resolution_frames_device_resize_equals_host_resize(weight_cache):
+    """detect / forward on camera-resolution frames: resizing on the device gives the SAME model outputs as resizing with
+    PIL on the host (identical uint8 pixels after the resize), and boxes come back in camera pixels."""
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    frames = structured_frames(2, 180, 320, seed=31)           # 16:9 camera frames -> 288 x 512 under max_size (288, 512)
+    outs = {}
+    for dev in (True, False):
+        det = HipDetrDetector(model_path=path, max_batch=2, max_size=(288, 512), resize=True, device_resize=dev, use_graph=False)
+        det.load_model()
+        outs[dev] = (det.forward_raw(frames), det.detect_batch(frames))
+        det.close()
+    for a, b in zip(outs[True][0], outs[False][0]):
+        np.testing.assert_array_equal(a, b)
+    for da, db in zip(outs[True][1], outs[False][1]):
+        assert [(d.query_index, d.bbox, d.confidence) for d in da] == [(d.query_index, d.bbox, d.confidence) for d in db]
+        for d in da:   # camera-frame pixel coordinates (a box may overhang the frame, never by more than its own size)
+            assert 0 < d.bbox[2] <= 2 * 320 and 0 < d.bbox[3] <= 2 * 180 and -320 <= d.bbox[0] <= 320 and -180 <= d.bbox[1] <= 180
+
+
 def test_ragged_batch_matches_hf_golden(detectors, golden_dir):
     """Frames of different sizes in one batch (HF pads to the batch maximum and applies the pixel mask: nearest mask
     down-sampling, mask-dependent position embedding, key masks in encoder self-attention and decoder cross-attention).

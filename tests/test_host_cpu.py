@@ -173,14 +173,23 @@ def test_ragged_batch_canvas_and_valid_sizes():
     ``DetrImageProcessor.pad`` (image_processing_detr.py:639-668); equal sizes -> plain stack, no mask."""
     det = HipDetrDetector(model_path="unused.safetensors", resize=False, max_size=(64, 96))
     a, b = structured_frames(1, 40, 60, seed=1)[0], structured_frames(1, 33, 72, seed=2)[0]
-    canvas, orig, valid = det._preprocess_batch([a, b])
+    canvas, orig, valid, target = det._preprocess_batch([a, b])
+    assert target is None
     assert canvas.shape == (2, 40, 72, 3) and orig == [(40, 60), (33, 72)]
     np.testing.assert_array_equal(valid, [[40, 60], [33, 72]])
     np.testing.assert_array_equal(canvas[0, :, :60], a)
     np.testing.assert_array_equal(canvas[1, :33], b)
     assert not canvas[0, :, 60:].any() and not canvas[1, 33:].any()
-    same, _, none = det._preprocess_batch([a, a])
-    assert none is None and same.shape == (2, 40, 60, 3)
+    same, _, none, target = det._preprocess_batch([a, a])
+    assert none is None and target is None and same.shape == (2, 40, 60, 3)
+    # one camera size that needs resizing: the batch stays at camera resolution, the target size follows the HF rule
+    cam = HipDetrDetector(model_path="unused.safetensors", resize=True)
+    f = structured_frames(1, 72, 128, seed=4)[0]
+    batch, orig, valid, target = cam._preprocess_batch([f, f])
+    assert batch.shape == (2, 72, 128, 3) and valid is None and target == model_input_size(72, 128) == (750, 1333)
+    host = HipDetrDetector(model_path="unused.safetensors", resize=True, device_resize=False)
+    batch, _, _, target = host._preprocess_batch([f])
+    assert target is None and batch.shape == (1, 750, 1333, 3)
     with pytest.raises(ValueError):
         det._preprocess_batch([a, structured_frames(1, 70, 60, seed=3)[0]])   # canvas taller than max_size
 
@@ -212,3 +221,42 @@ def test_masked_sine_position_embedding_matches_oracle():
         got = np.empty((h * w, 256), np.float32)
         _capi.check(lib.opd_test_sine_pos_embed(h, w, vh, vw, 256, got.ctypes.data_as(C.c_void_p)), "sine_pos_embed")
         np.testing.assert_allclose(got, want, atol=2e-6)
+
+
+# ---- device-side resize: the integer algorithm and its coefficient tables against Pillow (host emulation) ---------------------
+def _resize_tables(lib, n_in, n_out):
+    bounds = np.zeros((n_out, 2), np.int32)
+    coeffs = np.zeros(n_out * 64, np.int32)
+    ks = lib.opd_test_resize_coeffs(n_in, n_out, bounds.ctypes.data_as(C.c_void_p), coeffs.ctypes.data_as(C.c_void_p), coeffs.size)
+    assert ks > 0
+    return bounds, coeffs[:n_out * ks].reshape(n_out, ks)
+
+
+def _emulate_resize(lib, img, oh, ow):
+    """numpy restatement of resize_bilinear_u8_kernel: horizontal pass rounded to uint8, then vertical pass."""
+    h, w, _ = img.shape
+    bh, kh = _resize_tables(lib, w, ow)
+    bv, kv = _resize_tables(lib, h, oh)
+    half = 1 << 21
+    tmp = np.empty((h, ow, 3), np.int64)
+    for xo in range(ow):
+        x0, n = int(bh[xo, 0]), int(bh[xo, 1])
+        tmp[:, xo] = np.clip((half + (img[:, x0:x0 + n].astype(np.int64) * kh[xo, :n, None]).sum(1)) >> 22, 0, 255)
+    out = np.empty((oh, ow, 3), np.uint8)
+    for yo in range(oh):
+        y0, n = int(bv[yo, 0]), int(bv[yo, 1])
+        out[yo] = np.clip((half + (tmp[y0:y0 + n] * kv[yo, :n, None, None]).sum(0)) >> 22, 0, 255)
+    return out
+
+
+@pytest.mark.parametrize("src,dst", [((72, 128), (75, 133)), ((90, 160), (75, 133)), ((48, 64), (80, 107)), ((75, 133), (75, 133)),
+                                     ((100, 37), (133, 49)), ((211, 97), (60, 28))])
+def test_resize_algorithm_is_bit_exact_with_pillow(src, dst):
+    """Up- and down-scaling, odd sizes, identity: the fixed-point two-pass algorithm of the device kernel, driven by the
+    library's own coefficient tables, reproduces PIL.Image.resize(BILINEAR) bit for bit."""
+    from PIL import Image
+    lib = _capi.load_library()
+    rng = np.random.default_rng(src[0] * 7 + dst[1])
+    img = rng.integers(0, 256, (src[0], src[1], 3), dtype=np.uint8)
+    want = np.asarray(Image.fromarray(img).resize((dst[1], dst[0]), resample=Image.BILINEAR))
+    np.testing.assert_array_equal(_emulate_resize(lib, img, dst[0], dst[1]), want)
