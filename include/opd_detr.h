@@ -146,6 +146,16 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
  * returns the new count (>= 0) or a negative error. */
 int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold);
 
+/* "Next" row: replaces `SimilarityCalculator.compute_similarity_matrix` / `compute_distance_matrix`
+ * (`src/tracking/similarity.py:42-220`), the tracker's cost matrix built right after the detect path:
+ * similarity[i][j] = clip((aw * clip(f1_i . f2_j, -1, 1) + mw * IoU(box1_i, box2_j)) / (weights used), 0, 1); a row without
+ * features (has == 0, or a NULL feature matrix) drops the appearance term and renormalises.  Boxes are (x, y, w, h).
+ * All pointers are host pointers; `out` = [n1][n2] f32; `as_distance` != 0 returns 1 - similarity.  Runs on the device
+ * `device_ordinal`; needs no model handle. */
+int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* boxes1, const uint8_t* has1, int n1,
+                          const float* feats2, const float* boxes2, const uint8_t* has2, int n2, int D,
+                          double appearance_weight, double motion_weight, int as_distance, float* out);
+
 /* Replaces `FeatureExtractor.extract_roi_features` on the DETR encoder map
  * (`src/tracking/feature_extractor.py:39-88`; deleted vit_detector.py 224-273): for each (x,y,w,h) box in original
  * pixels, mean-pool the last forward's encoder map of frame `frame` over the int-truncated, clamped ROI and

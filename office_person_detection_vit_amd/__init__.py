@@ -6,6 +6,9 @@
 
 from .data_models import Detection  # noqa: F401
 from .detector import HipDetrDetector, model_input_size  # noqa: F401
+from .export import detections_to_coco, write_coco  # noqa: F401
 from .feature_extractor import FeatureExtractor  # noqa: F401
+from .similarity import SimilarityCalculator  # noqa: F401
 
-__all__ = ["Detection", "HipDetrDetector", "FeatureExtractor", "model_input_size"]
+__all__ = ["Detection", "HipDetrDetector", "FeatureExtractor", "SimilarityCalculator", "detections_to_coco", "write_coco",
+           "model_input_size"]

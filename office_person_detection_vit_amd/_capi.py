@@ -56,6 +56,8 @@ API = {
     "opd_detr_detect_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_float, C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_person_nms": (C.c_int, [C.POINTER(OpdDet), C.c_int, C.c_int, C.c_float]),
+    "opd_similarity_matrix": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "opd_detr_roi_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_detr_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),

@@ -501,6 +501,66 @@ hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream) {
     return hipGetLastError();
 }
 
+// Tracker cost matrix (src/tracking/similarity.py:42-220): one thread per (track i, detection j).
+//   cos = clip(dot_fp32(f1[i], f2[j]), -1, 1)  if both carry features        (appearance term, weight aw)
+//   iou of the xywh boxes, 0 when the intersection is empty or the union is not positive, clipped to [0, 1]   (weight mw)
+//   similarity = clip((aw*cos + mw*iou) / (weights used), 0, 1) in double like the reference's Python floats, stored as fp32;
+//   as_distance: 1 - similarity (computed on the fp32 value, like `1.0 - similarity_matrix`).
+__global__ void similarity_matrix_kernel(const float* __restrict__ f1, const float* __restrict__ b1, const uint8_t* __restrict__ has1,
+                                         int n1, const float* __restrict__ f2, const float* __restrict__ b2,
+                                         const uint8_t* __restrict__ has2, int n2, int D, double aw, double mw, int as_distance,
+                                         float* __restrict__ out) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n1 * n2) return;
+    const int i = idx / n2, j = idx - i * n2;
+    double score = 0.0, total = 0.0;
+    if (f1 && f2 && (!has1 || has1[i]) && (!has2 || has2[j])) {
+        const float* a = f1 + (size_t)i * D;
+        const float* c = f2 + (size_t)j * D;
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 4 <= D; k += 4) {
+            acc[0] = fmaf(a[k], c[k], acc[0]); acc[1] = fmaf(a[k + 1], c[k + 1], acc[1]);
+            acc[2] = fmaf(a[k + 2], c[k + 2], acc[2]); acc[3] = fmaf(a[k + 3], c[k + 3], acc[3]);
+        }
+        for (; k < D; ++k) acc[0] = fmaf(a[k], c[k], acc[0]);
+        float dot = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+        dot = dot < -1.f ? -1.f : (dot > 1.f ? 1.f : dot);
+        score += aw * (double)dot;
+        total += aw;
+    }
+    {
+        const double x1 = b1[4 * i], y1 = b1[4 * i + 1], w1 = b1[4 * i + 2], h1 = b1[4 * i + 3];
+        const double x2 = b2[4 * j], y2 = b2[4 * j + 1], w2 = b2[4 * j + 2], h2 = b2[4 * j + 3];
+        const double ix0 = x1 > x2 ? x1 : x2, iy0 = y1 > y2 ? y1 : y2;
+        const double ix1 = (x1 + w1) < (x2 + w2) ? (x1 + w1) : (x2 + w2), iy1 = (y1 + h1) < (y2 + h2) ? (y1 + h1) : (y2 + h2);
+        double iou = 0.0;
+        if (ix1 > ix0 && iy1 > iy0) {
+            const double inter = (ix1 - ix0) * (iy1 - iy0);
+            const double uni = w1 * h1 + w2 * h2 - inter;
+            if (uni > 0.0) {
+                iou = inter / uni;
+                iou = iou < 0.0 ? 0.0 : (iou > 1.0 ? 1.0 : iou);
+            }
+        }
+        score += mw * iou;
+        total += mw;
+    }
+    double sim = total > 0.0 ? score / total : 0.0;
+    sim = sim < 0.0 ? 0.0 : (sim > 1.0 ? 1.0 : sim);
+    const float simf = (float)sim;
+    out[idx] = as_distance ? 1.0f - simf : simf;
+}
+
+hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const uint8_t* has1, int n1, const float* f2, const float* b2,
+                                        const uint8_t* has2, int n2, int D, double aw, double mw, int as_distance, float* out,
+                                        hipStream_t stream) {
+    if (n1 <= 0 || n2 <= 0 || D <= 0 || !b1 || !b2 || !out) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(similarity_matrix_kernel, dim3((n1 * n2 + 127) / 128), dim3(128), 0, stream, f1, b1, has1, n1, f2, b2, has2, n2, D, aw,
+                       mw, as_distance, out);
+    return hipGetLastError();
+}
+
 hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois, float* out, int n, int h, int w,
                                    hipStream_t stream) {
     if (n <= 0) return hipErrorInvalidValue;

@@ -136,6 +136,11 @@ hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream);
 hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois /*[n][4] x0,y0,x1,y1 map coords*/, float* out,
                                    int n, int h, int w, hipStream_t stream);
 
+// tracker cost matrix: similarity (or 1 - similarity) of n1 x n2 (features [n][D] nullable, xywh boxes [n][4], per-row feature flags)
+hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const uint8_t* has1, int n1, const float* f2, const float* b2,
+                                        const uint8_t* has2, int n2, int D, double aw, double mw, int as_distance, float* out,
+                                        hipStream_t stream);
+
 // ---- attention (kernels_attn.hip) -----------------------------------------------------------------------------------
 // O[b][q][h*32 + d] = softmax(Q K^T * scale) V, head_dim 32; Q/K/V are fp16 row-major with independent leading dims:
 // Q at q_ptr[(b*Lq + i)*ldq + h*32 + d] etc.  Output fp16 [B*Lq][ldo].

@@ -1145,6 +1145,42 @@ int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold) 
     return (int)kept.size();
 }
 
+int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* boxes1, const uint8_t* has1, int n1,
+                          const float* feats2, const float* boxes2, const uint8_t* has2, int n2, int D, double appearance_weight,
+                          double motion_weight, int as_distance, float* out) {
+    if (n1 < 0 || n2 < 0 || D < 1) return fail(OPD_EINVAL, "opd_similarity_matrix: bad sizes");
+    if (n1 == 0 || n2 == 0) return OPD_OK;
+    if (!boxes1 || !boxes2 || !out) return fail(OPD_EINVAL, "opd_similarity_matrix: null boxes / output");
+    if (fabs(appearance_weight + motion_weight - 1.0) > 1e-6)
+        return fail(OPD_EINVAL, "appearance_weight + motion_weight must equal 1.0");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return fail(OPD_EHIP, "no HIP device visible (this library has no CPU fallback)");
+    HIPCHK(hipSetDevice(device_ordinal));
+    struct Tmp {
+        std::vector<void*> p;
+        ~Tmp() { for (void* q : p) (void)hipFree(q); }
+    } tmp;
+    auto up = [&](const void* h, size_t bytes, void** d) -> int {
+        *d = nullptr;
+        if (!h) return OPD_OK;
+        if (hipMalloc(d, bytes) != hipSuccess) return fail(OPD_ENOMEM, "opd_similarity_matrix: device allocation failed");
+        tmp.p.push_back(*d);
+        HIPCHK(hipMemcpy(*d, h, bytes, hipMemcpyHostToDevice));
+        return OPD_OK;
+    };
+    void *df1, *df2, *db1, *db2, *dh1, *dh2, *dout = nullptr;
+    RCCHK(up(feats1, (size_t)n1 * D * 4, &df1)); RCCHK(up(feats2, (size_t)n2 * D * 4, &df2));
+    RCCHK(up(boxes1, (size_t)n1 * 16, &db1)); RCCHK(up(boxes2, (size_t)n2 * 16, &db2));
+    RCCHK(up(has1, (size_t)n1, &dh1)); RCCHK(up(has2, (size_t)n2, &dh2));
+    if (hipMalloc(&dout, (size_t)n1 * n2 * 4) != hipSuccess) return fail(OPD_ENOMEM, "opd_similarity_matrix: device allocation failed");
+    tmp.p.push_back(dout);
+    HIPCHK(opd_launch_similarity_matrix((const float*)df1, (const float*)db1, (const uint8_t*)dh1, n1, (const float*)df2, (const float*)db2,
+                                        (const uint8_t*)dh2, n2, D, appearance_weight, motion_weight, as_distance,
+                                        (float*)dout, nullptr));
+    HIPCHK(hipMemcpy(out, dout, (size_t)n1 * n2 * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n, int orig_h, int orig_w, float* features) {
     if (!m || (n > 0 && (!boxes_xywh || !features))) return fail(OPD_EINVAL, "opd_detr_roi_features: null argument");
     if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_roi_features called before any forward");

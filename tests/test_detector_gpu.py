@@ -15,6 +15,7 @@ import pytest
 import torch
 
 from office_person_detection_vit_amd import HipDetrDetector
+from office_person_detection_vit_amd.data_models import Detection
 from office_person_detection_vit_amd.frames import structured_frames
 from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file, load_safetensors
 from oracle import detr_oracle as O
@@ -301,3 +302,29 @@ def test_error_conventions(weight_cache):
     det2 = HipDetrDetector(model_path=bad)
     with pytest.raises(RuntimeError, match="Failed to load DETR model"):
         det2.load_model()
+
+
+def test_similarity_matrix_on_device_matches_reference_golden(golden_dir):
+    """the tracker's cost matrix on the device against the reference's own SimilarityCalculator
+    (tests/golden/similarity.npz).  Tolerance 1e-6: the fp32 feature dot product is summed in a different order than
+    BLAS; the IoU / weighting arithmetic is double like the reference's, so feature-less columns are exact."""
+    from office_person_detection_vit_amd.similarity import SimilarityCalculator
+    from oracle import similarity_oracle as SO
+    g = np.load(os.path.join(golden_dir, "similarity.npz"))
+    mk = lambda f, b, ok: Detection(bbox=tuple(float(v) for v in b), confidence=0.9, class_id=1, class_name="person",
+                                    camera_coords=(0.0, 0.0), features=f if ok else None)
+    d1 = [mk(g["f1"][i], g["b1"][i], True) for i in range(len(g["b1"]))]
+    d2 = [mk(g["f2"][j], g["b2"][j], bool(g["has2"][j])) for j in range(len(g["b2"]))]
+    s = SimilarityCalculator(0.7, 0.3)
+    sim = s.compute_similarity_matrix(d1, d2)
+    dist = s.compute_distance_matrix(d1, d2)
+    np.testing.assert_allclose(sim, g["similarity"], atol=1e-6)
+    np.testing.assert_allclose(dist, g["distance"], atol=1e-6)
+    np.testing.assert_array_equal(sim[:, 6], g["similarity"][:, 6])    # motion term only: exact
+    np.testing.assert_allclose(sim, SO.similarity_matrix(g["f1"], g["b1"], None, g["f2"], g["b2"], g["has2"]), atol=1e-6)
+    # no features anywhere: pure IoU
+    for d in d1 + d2:
+        d.features = None
+    iou = s.compute_similarity_matrix(d1, d2)
+    want = np.array([[SO.iou_xywh(a.bbox, b.bbox) for b in d2] for a in d1], np.float32)
+    np.testing.assert_array_equal(iou, want)

@@ -1,0 +1,69 @@
+"""'Next' rows of SURVEY.md §8(f) on the host: the similarity oracle against the reference's own SimilarityCalculator
+(golden made by tools/gen_golden.py from src/tracking/similarity.py), and the COCO exporter against the JSON the reference's
+DetectionBenchmark evaluator accepted (precision / recall recorded at fixture time)."""
+
+import json
+import os
+
+import numpy as np
+import pytest
+
+from office_person_detection_vit_amd.data_models import Detection
+from office_person_detection_vit_amd.export import detections_to_coco, write_coco
+from office_person_detection_vit_amd.similarity import SimilarityCalculator
+from oracle import similarity_oracle as SO
+
+
+def test_similarity_oracle_matches_reference_golden(golden_dir):
+    g = np.load(os.path.join(golden_dir, "similarity.npz"))
+    sim = SO.similarity_matrix(g["f1"], g["b1"], None, g["f2"], g["b2"], g["has2"], 0.7, 0.3)
+    np.testing.assert_allclose(sim, g["similarity"], atol=1e-7)      # fp32 dot: BLAS summation order
+    np.testing.assert_allclose(1.0 - sim, g["distance"], atol=1e-7)
+    # the feature-less detection (column 6) carries the motion term alone, renormalised: similarity == IoU
+    want = [SO.iou_xywh(g["b1"][i], g["b2"][6]) for i in range(len(g["b1"]))]
+    np.testing.assert_allclose(g["similarity"][:, 6], want, atol=1e-7)
+
+
+def test_similarity_scalar_helpers_and_errors():
+    """Known answers in the style of the reference's tests: identical boxes -> IoU 1, disjoint -> 0, half overlap -> 1/3;
+    identical unit features -> cosine 1; weights must sum to one (similarity.py:31-34)."""
+    s = SimilarityCalculator(0.7, 0.3)
+    assert s.iou((0, 0, 10, 10), (0, 0, 10, 10)) == 1.0
+    assert s.iou((0, 0, 10, 10), (20, 20, 5, 5)) == 0.0
+    assert abs(s.iou((0, 0, 10, 10), (5, 0, 10, 10)) - 1.0 / 3.0) < 1e-12
+    assert s.iou((0, 0, 0, 0), (0, 0, 0, 0)) == 0.0
+    f = np.zeros(256, np.float32); f[3] = 1.0
+    assert s.cosine_similarity(f, f) == 1.0 and s.cosine_distance(f, f) == 0.0
+    with pytest.raises(ValueError):
+        s.cosine_similarity(f, f[:128])
+    with pytest.raises(ValueError):
+        SimilarityCalculator(0.7, 0.4)
+    d1 = Detection(bbox=(0, 0, 10, 10), confidence=0.9, class_id=1, class_name="person", camera_coords=(5, 10), features=f)
+    d2 = Detection(bbox=(0, 0, 10, 10), confidence=0.9, class_id=1, class_name="person", camera_coords=(5, 10))
+    assert s.compute_similarity(d1, d1) == 1.0
+    assert s.compute_similarity(d1, d2) == 1.0      # no features on one side: IoU alone, renormalised
+    assert s.compute_distance(d1, d1) == 0.0
+    assert s.compute_similarity_matrix([], [d1]).shape == (0, 1)
+
+
+def test_coco_export_matches_fixture_accepted_by_reference_evaluator(golden_dir, tmp_path):
+    g = json.load(open(os.path.join(golden_dir, "coco_export.json"), encoding="utf-8"))
+    pred = g["prediction"]
+    dets = [[], []]
+    for a in pred["annotations"]:
+        x, y, w, h = a["bbox"]
+        dets[a["image_id"]].append(Detection(bbox=(x, y, w, h), confidence=a["score"], class_id=1, class_name="person",
+                                             camera_coords=(x + w / 2, y + h)))
+    sizes = [(im["height"], im["width"]) for im in pred["images"]]
+    got = detections_to_coco(dets, sizes, [im["file_name"] for im in pred["images"]])
+    assert got == pred
+    # the reference's DetectionBenchmark.evaluate scored this JSON at fixture time: 5 TP, 1 FP, 1 FN
+    assert g["evaluator"] == "DetectionBenchmark"
+    assert (g["metrics"]["true_positives"], g["metrics"]["false_positives"], g["metrics"]["false_negatives"]) == (5, 1, 1)
+    assert set(got) == {"images", "categories", "annotations"} and got["categories"] == [{"id": 0, "name": "person"}]
+    assert set(got["annotations"][0]) == {"id", "image_id", "category_id", "bbox", "area", "score", "iscrowd"}
+    path = tmp_path / "out" / "detections.json"
+    write_coco(str(path), got)
+    assert json.load(open(path, encoding="utf-8")) == pred
+    with pytest.raises(ValueError):
+        detections_to_coco(dets, sizes[:1])

@@ -14,6 +14,7 @@ Usage:  python tools/gen_golden.py            (writes tests/golden/*.npz)
 from __future__ import annotations
 
 import importlib.util
+import json
 import os
 import sys
 
@@ -109,6 +110,66 @@ def feature_extractor_case():
     print("feature_extractor: roi", roi.shape, "norms", np.linalg.norm(roi, axis=1)[:3])
 
 
+def _load_ref(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(REFERENCE, rel))
+    mod = importlib.util.module_from_spec(spec)
+    sys.modules[name] = mod   # dataclasses look their module up while the class body executes
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def similarity_and_export_case():
+    """Next rows: the reference's own SimilarityCalculator (tracker cost matrix) and its detection
+    evaluator run on seeded data; inputs are regenerated in the tests from the stored seed."""
+    import types
+    sim = _load_ref("ref_similarity", "src/tracking/similarity.py").SimilarityCalculator(0.7, 0.3)
+    rng = np.random.default_rng(11)
+    n1, n2 = 7, 9
+    f1 = rng.standard_normal((n1, 256)).astype(np.float32)
+    f2 = rng.standard_normal((n2, 256)).astype(np.float32)
+    f1 /= np.linalg.norm(f1, axis=1, keepdims=True)
+    f2 /= np.linalg.norm(f2, axis=1, keepdims=True)
+    f2[:4] = (0.8 * f1[:4] + 0.2 * f2[:4]) / np.linalg.norm(0.8 * f1[:4] + 0.2 * f2[:4], axis=1, keepdims=True)
+    b1 = (rng.uniform(0, 900, (n1, 4)) * [1, 0.6, 0.2, 0.3] + [0, 0, 20, 40]).astype(np.float32)
+    b2 = (rng.uniform(0, 900, (n2, 4)) * [1, 0.6, 0.2, 0.3] + [0, 0, 20, 40]).astype(np.float32)
+    b2[:4] = b1[:4] + rng.uniform(-8, 8, (4, 4)).astype(np.float32)
+    has2 = np.ones(n2, bool)
+    has2[6] = False   # a detection without features: the motion term alone, renormalised
+    mk = lambda f, b, ok: types.SimpleNamespace(features=f if ok else None, bbox=tuple(float(v) for v in b))
+    d1 = [mk(f1[i], b1[i], True) for i in range(n1)]
+    d2 = [mk(f2[j], b2[j], bool(has2[j])) for j in range(n2)]
+    simm = sim.compute_similarity_matrix(d1, d2)
+    dist = sim.compute_distance_matrix(d1, d2)
+    np.savez_compressed(os.path.join(GOLD, "similarity.npz"), seed=np.array(11), f1=f1, f2=f2, b1=b1, b2=b2, has2=has2,
+                        similarity=simm, distance=dist)
+    print("similarity:", simm.shape, float(simm.max()), float(simm.min()))
+
+    # exporter + the reference evaluator: predictions = ground truth boxes jittered, one false positive, one miss
+    from office_person_detection_vit_amd.data_models import Detection
+    from office_person_detection_vit_amd.export import detections_to_coco
+    bench = _load_ref("ref_detection_benchmark", "src/evaluation/detection_benchmark.py")
+    gt = {"images": [{"id": 0, "file_name": "a.jpg", "width": 1280, "height": 720}, {"id": 1, "file_name": "b.jpg", "width": 1280, "height": 720}],
+          "categories": [{"id": 0, "name": "person"}],
+          "annotations": [{"id": i, "image_id": i // 3, "category_id": 0, "bbox": [100.0 + 200 * (i % 3), 150.0, 80.0, 200.0], "area": 16000.0, "iscrowd": 0}
+                          for i in range(6)]}
+    dets = [[], []]
+    for a in gt["annotations"][:5]:   # the sixth ground-truth box is missed
+        x, y, w, h = a["bbox"]
+        bb = (x + 3.0, y - 2.0, w, h + 4.0)
+        dets[a["image_id"]].append(Detection(bbox=bb, confidence=0.9 - 0.05 * a["id"], class_id=1, class_name="person",
+                                             camera_coords=(bb[0] + bb[2] / 2, bb[1] + bb[3])))
+    dets[1].append(Detection(bbox=(900.0, 400.0, 60.0, 120.0), confidence=0.55, class_id=1, class_name="person", camera_coords=(930.0, 520.0)))
+    pred = detections_to_coco(dets, [(720, 1280), (720, 1280)], ["a.jpg", "b.jpg"])
+    ev_cls = [getattr(bench, n) for n in dir(bench) if n.endswith("Benchmark") or n.endswith("Evaluator")]
+    ev = ev_cls[0]()
+    m = ev.evaluate(gt, pred)
+    with open(os.path.join(GOLD, "coco_export.json"), "w", encoding="utf-8") as f:
+        json.dump({"ground_truth": gt, "prediction": pred, "evaluator": type(ev).__name__,
+                   "metrics": {"precision": m.precision, "recall": m.recall, "f1_score": m.f1_score, "true_positives": m.true_positives,
+                               "false_positives": m.false_positives, "false_negatives": m.false_negatives, "pred_count": m.pred_count}}, f, indent=1)
+    print("coco export:", type(ev).__name__, m.precision, m.recall, m.true_positives, m.false_positives, m.false_negatives)
+
+
 def resize_case():
     """HF image processor with its default resize (shortest 800 / longest 1333, PIL bilinear) on camera-sized frames."""
     from transformers import DetrImageProcessor
@@ -141,6 +202,7 @@ def main():
     # r101 (config 4 architecture) at small size
     model_case("r101_mild_256x320", DetrArch.resnet101(), 0, 1.0, [(256, 320)], 1234)
     feature_extractor_case()
+    similarity_and_export_case()
 
 
 if __name__ == "__main__":
