@@ -27,12 +27,15 @@ def build(verbose: bool = False, force: bool = False) -> str:
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []
     common = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+    # per-file code-generation options: the attention kernel consumes its S = K.Q^T accumulators with VALU right away, so its
+    # MFMAs should write VGPRs (the default AGPR form costs 56 v_accvgpr moves per key tile in a VALU-bound loop)
+    extra = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
     for src in SOURCES:
         sp = os.path.join(HERE, src)
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
-            cmd = [hipcc] + common + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
+            cmd = [hipcc] + common + extra.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

@@ -34,6 +34,9 @@ __device__ __forceinline__ half4 lds_tr16(const unsigned char* p) {
     return r;
 }
 
+// TR: V^T fragments through ds_read_b64_tr_b16 (hardware transpose) or scalar LDS gathers (cross-check path).
+// MASKED: per-frame key mask of a ragged batch.  Both are compile-time so that the inner loop carries no branches.
+template <bool TR, bool MASKED>
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];  // [buf][K|V]
     const int tid = threadIdx.x;
@@ -75,8 +78,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 
     // ragged batch: keys outside the frame's valid (rows x cols) rectangle of the key map get -inf, like the additive
     // attention mask of the reference (HF:models/detr/modeling_detr.py:402-427, 933-991); key 0 is always valid
-    const bool masked = p.key_valid != nullptr;
-    const int kv_rows = masked ? p.key_valid[2 * b] : 0, kv_cols = masked ? p.key_valid[2 * b + 1] : 0;
+    const int kv_rows = MASKED ? p.key_valid[2 * b] : 0, kv_cols = MASKED ? p.key_valid[2 * b + 1] : 0;
     const int ntiles = (p.Lk + KT - 1) / KT;
     const float scale2 = p.scale * 1.44269504088896340736f;  // scores are kept pre-multiplied by log2(e)
     load_tile(0);
@@ -96,9 +98,10 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             const half8 kf = *reinterpret_cast<const half8*>(Kl + (kt * 16 + li) * LDS_ROW + g * 16);
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        // ---- online softmax (fp32, base-2 domain: exp(x) = exp2(x * log2 e), one v_exp_f32 per score) ------------------
+        // ---- online softmax (fp32, base-2 domain: p = exp2(s * scale*log2(e) - m), one v_fma + one v_exp per score; the
+        //      running maximum is taken on the RAW scores and scaled once: scale > 0 keeps the order) ----------------------
         float mx = -INFINITY;
-        if (masked) {
+        if (MASKED) {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
@@ -106,40 +109,34 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                     const int key = t * KT + kt * 16 + g * 4 + r;
                     const int kr = key / p.key_row, kc = key - kr * p.key_row;
                     const bool ok = key < p.Lk && kr < kv_rows && kc < kv_cols;
-                    const float v = ok ? s[kt][r] * scale2 : -INFINITY;
-                    s[kt][r] = v;
-                    mx = fmaxf(mx, v);
+                    s[kt][r] = ok ? s[kt][r] : -INFINITY;
+                    mx = fmaxf(mx, s[kt][r]);
                 }
         } else if (t + 1 < ntiles) {  // full tile: no key masking needed
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    const float v = s[kt][r] * scale2;
-                    s[kt][r] = v;
-                    mx = fmaxf(mx, v);
-                }
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[kt][r]);
         } else {
 #pragma unroll
             for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int key = t * KT + kt * 16 + g * 4 + r;
-                    const float v = key < p.Lk ? s[kt][r] * scale2 : -INFINITY;
-                    s[kt][r] = v;
-                    mx = fmaxf(mx, v);
+                    s[kt][r] = key < p.Lk ? s[kt][r] : -INFINITY;
+                    mx = fmaxf(mx, s[kt][r]);
                 }
         }
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);  // finite: tile 0 always holds key 0
+        const float m_new = fmaxf(m_run, mx * scale2);  // finite: tile 0 always holds key 0 (the product rounds once, like s*scale2)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         float psum = 0.f;
 #pragma unroll
         for (int kt = 0; kt < 4; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(s[kt][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale2, -m_new));   // masked: fma(-inf) = -inf -> 0
                 s[kt][r] = e;
                 psum += e;
             }
@@ -162,7 +159,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
                 half8 vf;
-                if (p.use_tr_read) {
+                if (TR) {
                     const unsigned char* a0 = Vl + (kb * 32 + g * 4 + (li >> 2)) * LDS_ROW + (dt * 16 + (li & 3) * 4) * 2;
                     const half4 lo = lds_tr16(a0);
                     const half4 hi = lds_tr16(a0 + 16 * LDS_ROW);
@@ -202,7 +199,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Lq <= 0 || p.Lk <= 0) return hipErrorInvalidValue;
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;  // 16-byte row chunks
+    if (p.key_valid && p.key_row < 1) return hipErrorInvalidValue;
     dim3 grid((p.Lq + 63) / 64, p.heads, p.B);
-    hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, stream, p);
+    if (p.key_valid) {
+        if (p.use_tr_read) hipLaunchKernelGGL((attention_kernel<true, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_kernel<false, true>), grid, dim3(256), 0, stream, p);
+    } else {
+        if (p.use_tr_read) hipLaunchKernelGGL((attention_kernel<true, false>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_kernel<false, false>), grid, dim3(256), 0, stream, p);
+    }
     return hipGetLastError();
 }
