@@ -87,10 +87,17 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    # OPD_BENCH_BACKEND=gloo is a REHEARSAL mode for a one-GPU box: every rank uses device 0 and the records travel through
+    # host memory; it exercises the multi-rank control flow (barriers, max-over-ranks timing, rank-0 JSON), not RCCL.
+    backend = os.environ.get("OPD_BENCH_BACKEND", "nccl")
+    device_index = local_rank if backend == "nccl" else 0
+    torch.cuda.set_device(device_index)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device_index))
+        else:
+            dist.init_process_group(backend)
 
     B, H, W = args.batch, args.height, args.width
     cache = os.environ.get("OPD_WEIGHT_CACHE", "/tmp/opd_weights")
@@ -103,7 +110,7 @@ def main() -> None:
     lib = _capi.load_library()
     cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
     handle = C.c_void_p()
-    _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), local_rank, C.byref(handle)), "opd_detr_create")
+    _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), device_index, C.byref(handle)), "opd_detr_create")
     info = _capi.OpdModelInfo()
     _capi.check(lib.opd_detr_info(handle, C.byref(info)), "opd_detr_info")
     Q = info.num_queries
@@ -113,8 +120,9 @@ def main() -> None:
     d_frames = torch.from_numpy(frames).cuda()
     d_records = torch.zeros((B, Q, 8), dtype=torch.int32, device="cuda")   # opd_det = 8 x 4 bytes
     d_counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
-    g_records = torch.zeros((world * B, Q, 8), dtype=torch.int32, device="cuda") if world > 1 else None
-    g_counts = torch.zeros((world * B,), dtype=torch.int32, device="cuda") if world > 1 else None
+    gdev = "cuda" if backend == "nccl" else "cpu"
+    g_records = torch.zeros((world * B, Q, 8), dtype=torch.int32, device=gdev) if world > 1 else None
+    g_counts = torch.zeros((world * B,), dtype=torch.int32, device=gdev) if world > 1 else None
     hw = np.asarray([[H, W]] * B, dtype=np.int32)
 
     def local_detect():
@@ -127,8 +135,8 @@ def main() -> None:
     def step():
         local_detect()
         if world > 1:  # the path's one exchange step: fixed-size detection records back to the orchestrator
-            dist.all_gather_into_tensor(g_records, d_records)
-            dist.all_gather_into_tensor(g_counts, d_counts)
+            dist.all_gather_into_tensor(g_records, d_records if backend == "nccl" else d_records.cpu())
+            dist.all_gather_into_tensor(g_counts, d_counts if backend == "nccl" else d_counts.cpu())
             return g_counts.cpu(), (g_records.cpu() if rank == 0 else None)
         return d_counts.cpu(), d_records.cpu()
 
@@ -147,7 +155,7 @@ def main() -> None:
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=gdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -198,7 +206,8 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"facebook/detr-resnet-50 architecture (seeded synthetic weights), batch {B} per GPU, "
                                    f"{H}x{W} uint8 BGR frames resident in HBM, forward + device post-process"
-                                   + (", RCCL all-gather of detection records" if world > 1 else ""),
+                                   + ((", RCCL all-gather of detection records" if backend == "nccl" else f", {backend} REHEARSAL (ranks share device 0)")
+                                      if world > 1 else ""),
                        "global_batch": B * world, "parallelism": f"frame-sharded dp{world}"},
             "roofline": roof,
             "stage_ms": stage_ms,
