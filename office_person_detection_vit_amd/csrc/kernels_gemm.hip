@@ -1179,6 +1179,156 @@ __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Input-stationary stem + max-pool (the default).  stem_pool_kernel above stages the im2col matrix: every input pixel goes
+// through the LDS-DMA path up to 16 times and the 64 x 256 weight tile once per 160 output pixels (112 KiB per tile).  The
+// k-loop is LDS-bandwidth bound, so this form stages what is unique instead:
+//   * the folded weights without the all-zero eighth filter row ([7 kh][64 n][32 k] = 28 KiB) ONCE per workgroup, which
+//     then walks up to STEM_TPW tiles along x;
+//   * per tile the INPUT PATCH (15 rows x 70 NHWC4 pixels = 8.4 KiB, double buffered) instead of the 80 KiB im2col tile:
+//     the B fragment of output pixel (r, c), filter row kh, column pair g is the 16 bytes at patch[(2r + kh)][2c + 2g], so
+//     the 7 k-steps (K = 7 x 32 = 224 instead of 256) run straight from LDS without a barrier between them.
+// Tile, pooling and output are those of stem_pool_kernel (5 x 32 convolution outputs -> 2 x 15 pooled pixels).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int STEM_TPW = 6;              // tiles per workgroup
+constexpr int STEM_PROW = 70 * 8;        // bytes per patch row (70 NHWC4 pixels)
+constexpr int STEM_PATCH = 9 * 1024;     // 15 rows x 560 B = 8400 B, staged as 9 one-KiB pieces
+constexpr int STEM_W_BYTES = 7 * 64 * 64;
+
+__global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned char* const Wl = smem;                              // [7][64][64 B], rows swizzled (swz_t<32>)
+    unsigned char* const Pin = smem + STEM_W_BYTES;              // two input patches
+    unsigned char* const patch = Pin + 2 * STEM_PATCH;           // [160 pixels][64 ch] fp16 convolution outputs for the pooling
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int g = lane >> 4, li = lane & 15;
+
+    const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
+    const int seg = blockIdx.x % nseg;
+    const int ty = (blockIdx.x / nseg) % p.tiles_y;
+    const int b = blockIdx.x / (nseg * p.tiles_y);
+    const int tx_first = seg * STEM_TPW;
+    const int tx_end = tx_first + STEM_TPW < p.tiles_x ? tx_first + STEM_TPW : p.tiles_x;
+    const int py0 = ty * 2;
+    const int cy0 = 2 * py0 - 1;                 // first convolution-output row of the tile (may be -1)
+    const int iy0 = 2 * cy0;                     // first padded-image row of the patch
+
+    const __amdgpu_buffer_rsrc_t rsrc_a =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x4p), 0, (unsigned)((size_t)p.B * p.Hp * p.Wp * 8), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, 64 * 256 * 2, 0x00020000);
+
+    // ---- weights: 28 pieces of 16 rows x 64 B (piece q: filter row q>>2, output channels 16*(q&3)..+15), 7 per wave ------
+    {
+        const int wrow = lane >> 2, wslot = lane & 3;
+#pragma unroll
+        for (int i = 0; i < 7; ++i) {
+            const int q = wave * 7 + i;
+            const int kh = q >> 2, n = (q & 3) * 16 + wrow;
+            const int chunk = wslot ^ ((0 - (n >> 2)) & 3);       // source-side swizzle of a 64-byte row
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Wl + q * 1024), 16,
+                                                     (unsigned)((n * 256 + kh * 32 + chunk * 8) * 2), 0, 0, 0);
+        }
+    }
+    // ---- input patch: 525 chunks of 16 B (2 pixels); chunk c sits at patch row c / 35, pixel pair c % 35 ------------------
+    int prow[3], pcol[3];    // this wave stages pieces wave, wave + 4, (wave + 8 for wave 0)
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = (wave + 4 * i) * 64 + lane;
+        prow[i] = c / 35;
+        pcol[i] = c - prow[i] * 35;
+    }
+    auto issue_patch = [&](int tx, int buf) {
+        const int ix0 = 2 * (2 * (tx * 15) - 1);             // first padded-image column of the patch
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = wave + 4 * i;
+            if (q < 9) {
+                const int iy = iy0 + prow[i], ix = ix0 + 2 * pcol[i];
+                const bool ok = prow[i] < 15 && (unsigned)iy < (unsigned)p.Hp && ix >= 0 && ix < p.Wp;
+                const unsigned off = ok ? (unsigned)(((b * p.Hp + iy) * p.Wp + ix) * 8) : 0x80000000u;   // out of range -> zeros
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(Pin + buf * STEM_PATCH + q * 1024),
+                                                         16, off, 0, 0, 0);
+            }
+        }
+    };
+    issue_patch(tx_first, 0);
+
+    float4v bias2[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) bias2[nt] = *reinterpret_cast<const float4v*>(p.bias + wn * 32 + nt * 16 + g * 4);
+
+    for (int tx = tx_first; tx < tx_end; ++tx) {
+        const int buf = (tx - tx_first) & 1;
+        __syncthreads();   // vmcnt(0): this tile's patch (and, first time, the weights) landed; the previous tile's pooling is done
+        if (tx + 1 < tx_end) issue_patch(tx + 1, buf ^ 1);
+        const int px0 = tx * 15, cx0 = 2 * px0 - 1;
+        float4v acc[2][5];
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = bias2[nt];
+        const unsigned char* P = Pin + buf * STEM_PATCH + (li + g) * 16;
+#pragma unroll
+        for (int kh = 0; kh < 7; ++kh) {
+            half8 wf[2], xf[5];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+                wf[nt] = *reinterpret_cast<const half8*>(Wl + kh * 4096 + swz_t<32>(wn * 32 + nt * 16 + li, g));
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                const int m10 = wm * 5 + mt;      // m-tile: convolution row m10 >> 1, column half m10 & 1
+                xf[mt] = *reinterpret_cast<const half8*>(P + (2 * (m10 >> 1) + kh) * STEM_PROW + (m10 & 1) * 256);
+            }
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+        // ---- ReLU -> fp16 patch [160 pixels][64 ch] (pixels outside the image: -65504 so that the max ignores them) -------
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < 5; ++mt) {
+                const int r = wm * 80 + mt * 16 + li;
+                const int cy = cy0 + (r >> 5), cx = cx0 + (r & 31);
+                const bool ok = (unsigned)cy < (unsigned)p.OH && (unsigned)cx < (unsigned)p.OW;
+                float4v v = acc[nt][mt];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = ok ? (v[j] > 0.f ? v[j] : 0.f) : -65504.f;
+                const int cb = wn * 64 + nt * 32 + g * 8;  // byte offset of the quad in the 128-byte pixel row
+                const int off = r * 128 + ((((cb >> 4) ^ (r & 7)) << 4) | (cb & 8));
+                *reinterpret_cast<uint2*>(patch + off) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+            }
+        __syncthreads();
+        // ---- 3x3 s2 max over the patch: thread -> (pooled pixel 0..29, 8-channel group 0..7) -------------------------------
+        if (tid < 240) {
+            const int c8 = tid & 7, pp = tid >> 3;
+            const int ly = pp / 15, lx = pp - ly * 15;
+            const int py = py0 + ly, px = px0 + lx;
+            if (py < p.PH && px < p.PW) {
+                half8 m;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.f);
+#pragma unroll
+                for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int r = (2 * ly + dy) * 32 + 2 * lx + dx;
+                        const half8 v = *reinterpret_cast<const half8*>(patch + r * 128 + ((c8 ^ (r & 7)) << 4));
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+                    }
+                *reinterpret_cast<half8*>(p.out + (((size_t)b * p.PH + py) * p.PW + px) * 64 + c8 * 8) = m;
+            }
+        }
+    }
+#endif
+}
+
 template <int BN, bool STEM>
 hipError_t launch(const ConvGemmParams& p, hipStream_t stream) {
     using S = Smem<BN>;
@@ -1259,6 +1409,9 @@ void opd_set_gemm_variant(int v) {
 int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32) | (g_tile_mt << 8); }
 
 // x4p: zero-bordered NHWC4 image [B][Hp = 2*OH+6][Wp = 2*OW+6][4]; out: pooled [B][PH][PW][64]
+static int g_stem_variant = 2;  // 2: input-stationary stem_pool2_kernel (default); 1: im2col stem_pool_kernel (cross-check)
+void opd_set_stem_variant(int v) { g_stem_variant = v == 1 ? 1 : 2; }
+
 hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
                                 int OW, int PH, int PW, hipStream_t stream) {
     if (Hp < 2 * OH + 6 || Wp < 2 * OW + 6 || (Wp & 1) || PH != (OH - 1) / 2 + 1 || PW != (OW - 1) / 2 + 1 ||
@@ -1268,6 +1421,18 @@ hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* b
     p.x4p = x4p; p.w = w; p.bias = bias; p.out = out; p.B = B; p.Hp = Hp; p.Wp = Wp; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
     p.tiles_y = (PH + 1) / 2;
     p.tiles_x = (PW + 14) / 15;
+    if (g_stem_variant == 2) {
+        constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
+        static bool attr2 = false;
+        if (!attr2) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            if (e != hipSuccess) return e;
+            attr2 = true;
+        }
+        const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
+        hipLaunchKernelGGL(stem_pool2_kernel, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
+        return hipGetLastError();
+    }
     constexpr int LDS = 2 * (160 + 64) * ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {

@@ -51,6 +51,7 @@ struct BtailParams {
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);
 void opd_permute_k32(const f16_t* w, f16_t* out, int rows, int K);  // host
+void opd_set_stem_variant(int v);  // 2 = input-stationary fused stem (default), 1 = im2col fused stem (cross-check)
 void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LDS-DMA v2 (default), 2/3 = ring variants;
                                    // +16 enables the experimental 3x3 row-strip kernel, +32 disables buffer-descriptor staging
 int opd_get_gemm_variant();

@@ -1249,6 +1249,10 @@ int opd_test_sine_pos_embed(int h, int w, int vh, int vw, int D, float* out) {
     memcpy(out, pos.data(), pos.size() * sizeof(float));
     return OPD_OK;
 }
+int opd_test_set_stem_variant(int v) {
+    opd_set_stem_variant(v);
+    return OPD_OK;
+}
 int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_gemm_ln = on ? 1 : 0;

@@ -369,10 +369,13 @@ def test_stem_conv_padded_dma(lib, H, W):
     np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
 
 
-@pytest.mark.parametrize("H,W", [(45, 51), (64, 96), (37, 34), (120, 131)])
-def test_fused_stem_pool(lib, H, W):
+@pytest.mark.parametrize("variant", [2, 1], ids=["input_stationary", "im2col"])
+@pytest.mark.parametrize("H,W", [(45, 51), (64, 96), (37, 34), (120, 131), (90, 410)])
+def test_fused_stem_pool(lib, H, W, variant):
     """Stem conv + FrozenBN/ReLU + 3x3 s2 max-pool in ONE kernel vs conv2d -> relu -> max_pool2d (odd / even sizes, tiles
-    that overhang the map on every side)."""
+    that overhang the map on every side; the last case makes a workgroup of the input-stationary kernel walk 6 tiles and
+    the next one the remaining one).  Both generations: input patch in LDS (default) and im2col staging."""
+    lib.opd_test_set_stem_variant(variant)
     rng = np.random.default_rng(H * 1000 + W)
     B, N = 2, 64
     x, _ = _h(rng.standard_normal((B, H, W, 3)))
@@ -388,6 +391,7 @@ def test_fused_stem_pool(lib, H, W):
     out = np.empty((B, PH, PW, N), np.uint16)
     rc = lib.opd_test_stem_pool(_p(np.ascontiguousarray(x4p.view(np.uint16))), _p(np.ascontiguousarray(wt.view(np.uint16))), _p(bias),
                                 _p(out), B, Hp, Wp, OH, OW, PH, PW)
+    lib.opd_test_set_stem_variant(2)
     _capi.check(rc, "opd_test_stem_pool")
     got = out.view(np.float16).astype(np.float32)
     conv = torch.from_numpy(ref_conv(x, w, bias, 2, 3, True)).permute(0, 3, 1, 2)
