@@ -991,7 +991,6 @@ int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_
     if (device_ordinal < 0 || device_ordinal >= ndev) return fail(OPD_EINVAL, "device_ordinal out of range");
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
-    if (m->d_src) (void)hipFree(m->d_src);
         if (m->stream) (void)hipStreamDestroy(m->stream);
         return code;
     };
@@ -1013,6 +1012,7 @@ void opd_detr_destroy(opd_detr* m) {
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (void* p : m->allocs) (void)hipFree(p);
+    if (m->d_src) (void)hipFree(m->d_src);
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : m->event_pool) (void)hipEventDestroy(e);
