@@ -30,7 +30,8 @@
 // Measured (tools/bench_btail.py, batch 8): stage-1 tail 188 us against 287 us for the three launches it replaces,
 // stage-2 tail 135 against 170.  What does NOT move it further (each built, measured, removed):
 // the residual staged through LDS by a dedicated fifth wave (SIMD imbalance: 238 us) or by one of the four waves with the
-// operand staging split over the other three (190 us), whole-line y/z stores transposed through LDS (190 us), a
+// operand staging split over the other three (190 us), whole-line y/z stores transposed through LDS (190 us), an
+// input-stationary 3x3 loop on 8 x 16 pixel tiles with the halo patch of x1 in LDS (43 % fewer staged bytes: 188 us), a
 // start-up stagger between workgroups sharing a CU (no phase locking), three instead of two workgroups per CU (185 vs
 // 189 us).  PMC: no HBM credit stalls, the vector-memory address FIFO is full 45 % of the busy cycles.
 #include <hip/hip_runtime.h>
