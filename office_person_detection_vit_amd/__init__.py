@@ -9,6 +9,7 @@ from .detector import HipDetrDetector, model_input_size  # noqa: F401
 from .export import detections_to_coco, write_coco  # noqa: F401
 from .feature_extractor import FeatureExtractor  # noqa: F401
 from .similarity import SimilarityCalculator  # noqa: F401
+from .tiling import TiledDetector  # noqa: F401
 
-__all__ = ["Detection", "HipDetrDetector", "FeatureExtractor", "SimilarityCalculator", "detections_to_coco", "write_coco",
+__all__ = ["Detection", "HipDetrDetector", "FeatureExtractor", "SimilarityCalculator", "TiledDetector", "detections_to_coco", "write_coco",
            "model_input_size"]

@@ -328,3 +328,41 @@ def test_similarity_matrix_on_device_matches_reference_golden(golden_dir):
     iou = s.compute_similarity_matrix(d1, d2)
     want = np.array([[SO.iou_xywh(a.bbox, b.bbox) for b in d2] for a in d1], np.float32)
     np.testing.assert_array_equal(iou, want)
+
+
+def test_config4_r101_1080p_batch8(detectors, weight_cache):
+    """BASELINE.json configs[3]: detr-resnet-101, batch 8, 1080p frames (1066x1920 after the size rule).  Parity on one
+    frame against the live oracle (r101 bounds: deeper trunk, more fp16 roundings) and batch invariance at the full batch."""
+    det = detectors(depths=(3, 4, 23, 3), ga=1.0, max_batch=8, max_size=(1066, 1920))
+    frames = structured_frames(8, 1066, 1920, seed=606)
+    lg8, bx8, _ = det.forward_raw(frames, want_encoder=False)
+    assert np.isfinite(lg8).all() and (bx8 >= 0).all() and (bx8 <= 1).all()
+    assert float(bx8.std(axis=1).mean()) > 5e-3
+    lg1, bx1, enc1 = det.forward_raw([frames[2]])
+    np.testing.assert_allclose(bx8[2], bx1[0], atol=1e-6)
+    w = O.to_torch(load_safetensors(det.model_path))
+    pv, pm = O.preprocess([frames[2]])
+    lg, bx, mem = O.forward(w, pv, pm)
+    assert float(np.abs(bx1[0] - bx[0].numpy()).max()) <= 3e-3
+    assert float(np.abs(_softmax(lg1[0]) - _softmax(lg[0].numpy())).max()) <= 6e-3
+
+
+def test_config5_tiled_4k_frame(detectors):
+    """BASELINE.json configs[4]: a 4K frame as 2 x 2 tiles of 1080p through detect_batch (device resize 1080x1920 -> 750x1333),
+    merged on the host: equals the per-tile results shifted by the tile origins, de-duplicated across the seams."""
+    from office_person_detection_vit_amd.tiling import TiledDetector, merge_tile_detections, split_tiles
+    path = detectors(ga=1.0).model_path
+    det = HipDetrDetector(model_path=path, max_batch=4, max_size=(800, 1333), resize=True)
+    det.load_model()
+    frame = structured_frames(1, 2160, 3840, seed=707)[0]
+    tiled = TiledDetector(det, 2, 2, nms_threshold=0.4)
+    got = tiled.detect(frame)
+    tiles, origins = split_tiles(frame, 2, 2)
+    per_tile = [det.detect(t) for t in tiles]
+    det.close()
+    want = merge_tile_detections(per_tile, origins, 0.4)
+    # batch of 4 tiles vs one tile at a time: same kernels per frame -> same records
+    assert [(d.bbox, d.confidence) for d in got] == [(d.bbox, d.confidence) for d in want]
+    for d in got:
+        assert -3840 <= d.bbox[0] <= 3840 and -2160 <= d.bbox[1] <= 2160 and d.camera_coords == (d.bbox[0] + d.bbox[2] / 2, d.bbox[1] + d.bbox[3])
+    assert sum(len(p) for p in per_tile) >= len(got)

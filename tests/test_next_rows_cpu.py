@@ -67,3 +67,35 @@ def test_coco_export_matches_fixture_accepted_by_reference_evaluator(golden_dir,
     assert json.load(open(path, encoding="utf-8")) == pred
     with pytest.raises(ValueError):
         detections_to_coco(dets, sizes[:1])
+
+
+# ---- BASELINE configs[4]: tiled high-resolution detection (host logic) -------------------------------------------------------
+def test_tile_grid_and_merge():
+    from office_person_detection_vit_amd.tiling import TiledDetector, merge_tile_detections, split_tiles, tile_grid
+    assert tile_grid(2160, 3840) == [(0, 0, 1080, 1920), (0, 1920, 1080, 1920), (1080, 0, 1080, 1920), (1080, 1920, 1080, 1920)]
+    assert tile_grid(7, 5, 2, 2) == [(0, 0, 3, 2), (0, 2, 3, 3), (3, 0, 4, 2), (3, 2, 4, 3)]      # remainders go last
+    frame = np.arange(7 * 5 * 3, dtype=np.uint8).reshape(7, 5, 3)
+    tiles, origins = split_tiles(frame, 2, 2)
+    assert origins == [(0, 0), (0, 2), (3, 0), (3, 2)] and all(t.flags["C_CONTIGUOUS"] for t in tiles)
+    rebuilt = np.zeros_like(frame)
+    for t, (y, x) in zip(tiles, origins):
+        rebuilt[y:y + t.shape[0], x:x + t.shape[1]] = t
+    np.testing.assert_array_equal(rebuilt, frame)
+    mk = lambda b, c, q: Detection(bbox=b, confidence=c, class_id=1, class_name="person", camera_coords=(0.0, 0.0), query_index=q)
+    # a person on the vertical seam seen by both left tiles' neighbours: tile 0 box touches x = 1920, tile 1 sees the same body
+    t0 = [mk((1800.0, 500.0, 120.0, 300.0), 0.9, 3)]
+    t1 = [mk((0.0, 505.0, 30.0, 290.0), 0.6, 7), mk((400.0, 100.0, 80.0, 200.0), 0.8, 9)]
+    out = merge_tile_detections([t0, t1, [], []], [(0, 0), (0, 1920), (1080, 0), (1080, 1920)], nms_threshold=0.4)
+    assert [d.query_index for d in out] == [3, 9, 7]                      # disjoint in frame coordinates: all kept, by score
+    assert out[1].bbox == (2320.0, 100.0, 80.0, 200.0) and out[1].camera_coords == (2360.0, 300.0)
+    dup = merge_tile_detections([[mk((1900.0, 500.0, 100.0, 300.0), 0.9, 1)], [mk((-18.0, 502.0, 98.0, 296.0), 0.7, 2)]],
+                                [(0, 0), (0, 1920)], nms_threshold=0.4)
+    assert [d.query_index for d in dup] == [1]                              # same body across the seam: the weaker one goes
+
+    class Fake:                                                             # detect_batch contract: one list per tile, in order
+        def detect_batch(self, tiles):
+            return [[mk((1.0, 2.0, 3.0, 4.0), 0.5 + 0.1 * i, i)] for i, _ in enumerate(tiles)]
+    res = TiledDetector(Fake()).detect_batch([np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8)])
+    assert [len(r) for r in res] == [4, 4] and res[1][0].bbox == (5.0, 6.0, 3.0, 4.0)
+    with pytest.raises(ValueError):
+        tile_grid(1, 5, 2, 2)
