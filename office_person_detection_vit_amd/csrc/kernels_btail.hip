@@ -84,9 +84,14 @@ __device__ __forceinline__ void wait_vmcnt() {
 }
 __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory"); }
 
-template <int C1, int C3>
+// RDMA = true (C1 == 64): the residual travels global -> LDS through LDS-DMA instead of global -> VGPR.  Loads through
+// VGPRs move ~16 B/clk/CU, LDS-DMA 33-42 (tools/microbench/ldpath.hip); each wave stages only ITS OWN 32 rows (four
+// 8-row x 128-byte pieces per 64-channel chunk) into a wave-private quarter of two 16-KiB buffers, so no barrier and no
+// special wave are involved: chunk j+2 is requested right after the wave has read chunk j out of the same buffer.
+template <int C1, int C3, bool RDMA>
 __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(!RDMA || C1 == 64, "residual staging buffers are budgeted for C1 == 64 (80 KiB of LDS per workgroup)");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int C2 = 4 * C1;
     constexpr int NT1 = C1 / 16;               // c1 accumulator tiles per wave (all C1 channels)
@@ -193,15 +198,30 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const int pr_m = wm0 + (g & 1) * 16 + li;
     const bool pr_ok = pr_m < p.M;
     const size_t pr_row = (size_t)pr_m * C2 + (g >> 1) * 8;
+    // RDMA: wave-private residual staging: rows of this wave, whole 128-byte rows, swizzled like every other tile
+    unsigned char* const res_lds = smem + 2 * STAGE_BYTES + wave * 4096;   // + (j & 1) * 16384 for chunk j
+    const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<f16_t*>(p.res ? p.res : p.x1), 0, p.res ? (unsigned)((size_t)p.M * C2 * 2) : 0u, 0x00020000);   // rows >= M: zeros
+    const unsigned res_voff = (unsigned)((wm0 + lrow) * C2) * 2u + (unsigned)lchunk * 16u;
+    auto issue_res = [&](int j) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (__attribute__((address_space(3))) void*)(res_lds + (j & 1) * 16384 + i * 1024), 16,
+                                                     res_voff + (unsigned)(i * 8 * C2 * 2), j * 128, 0, 0);
+    };
     const bool has_res = p.res != nullptr && !(p.dbg & 4);
     // Counted waits (below) rely on every wave issuing exactly 4 residual loads and 4 stores per chunk: true on full
     // tiles with a residual; otherwise (ragged last tile, no residual) the waits fall back to vmcnt(0).
     const bool counted = has_res && m_base + 128 <= p.M && !(p.dbg & 2);
     auto load_res = [&](int j, uint4 (&r)[4]) {
+        if constexpr (RDMA) {
+            if (has_res) issue_res(j);
+        } else {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            r[nt] = make_uint4(0u, 0u, 0u, 0u);
-            if (has_res && pr_ok) r[nt] = *reinterpret_cast<const uint4*>(p.res + pr_row + j * 64 + nt * 16);
+            for (int nt = 0; nt < 4; ++nt) {
+                r[nt] = make_uint4(0u, 0u, 0u, 0u);
+                if (has_res && pr_ok) r[nt] = *reinterpret_cast<const uint4*>(p.res + pr_row + j * 64 + nt * 16);
+            }
         }
     };
 
@@ -247,7 +267,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     load_res(1, res[1]);
     compiler_fence();
     compute_main((nk - 1) & 1);
-    if (counted) wait_vmcnt<8>(); else wait_vmcnt<0>();  // chunk 0 operands landed (the 8 residual loads may still fly)
+    if (RDMA && counted) wait_vmcnt<4>();        // chunk 0 operands and residual chunk 0 landed (chunk 1's 4 pieces may still fly)
+    else if (counted) wait_vmcnt<8>();           // chunk 0 operands landed (the 8 residual loads may still fly)
+    else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
 
     // ---- a1 = relu(c1) as fp16 B operands: k-block kk <- accumulator tiles 2kk, 2kk+1 -----------------------------------
@@ -283,7 +305,17 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         uint4 (&res_cur)[4] = res[j % 3];
         if (j + 1 < NCH) issue_chunk(j + 1, buf ^ 1);
         compiler_fence();
-        if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]);
+        if constexpr (RDMA) {
+            if (has_res) {   // paired layout out of this wave's rows of the staged chunk; then the buffer is free for chunk j+2
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+                    res_cur[nt] = *reinterpret_cast<const uint4*>(res_lds + (j & 1) * 16384 + swz((g & 1) * 16 + li, nt * 2 + (g >> 1)));
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (j + 2 < NCH) issue_res(j + 2);
+            }
+        } else {
+            if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]);
+        }
         compiler_fence();
         const unsigned char* W2s = smem + buf * STAGE_BYTES;
         float4v acc2[4][2];
@@ -377,16 +409,16 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #endif
 }
 
-template <int C1, int C3>
+template <int C1, int C3, bool RDMA>
 hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * (128 + C1) * ROW_BYTES;
+    constexpr int LDS = 2 * (128 + C1) * ROW_BYTES + (RDMA ? 2 * 16384 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3, RDMA>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((btail_kernel<C1, C3>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -398,13 +430,15 @@ hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream) {
     if (!opd_btail_supported(p.C1, p.C3)) return hipErrorInvalidValue;
     // 31-bit byte offsets in the buffer descriptors
     if ((size_t)p.B * p.H * p.W * p.C1 * 2 + (size_t)(p.W + 1) * p.C1 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
+    if ((size_t)p.M * p.C1 * 8 >= 0x7fffff00ull) return hipErrorInvalidValue;
     if (p.C1 == 64) {
-        if (p.C3 == 0) return launch_btail_t<64, 0>(p, stream);
-        if (p.C3 == 64) return launch_btail_t<64, 64>(p, stream);
-        return launch_btail_t<64, 128>(p, stream);
+        const bool rdma = !(p.dbg & 16);   // dbg 16: residual through VGPR loads (the first form: cross-check / timing)
+        if (p.C3 == 0) return rdma ? launch_btail_t<64, 0, true>(p, stream) : launch_btail_t<64, 0, false>(p, stream);
+        if (p.C3 == 64) return rdma ? launch_btail_t<64, 64, true>(p, stream) : launch_btail_t<64, 64, false>(p, stream);
+        return rdma ? launch_btail_t<64, 128, true>(p, stream) : launch_btail_t<64, 128, false>(p, stream);
     }
-    if (p.C3 == 0) return launch_btail_t<128, 0>(p, stream);
-    return launch_btail_t<128, 128>(p, stream);
+    if (p.C3 == 0) return launch_btail_t<128, 0, false>(p, stream);
+    return launch_btail_t<128, 128, false>(p, stream);
 }
 
 // K-permutation of a [rows][K] fp16 weight matrix (K % 32 == 0) that makes two fp16-rounded 16x16 accumulator tiles a

@@ -27,11 +27,11 @@ for s in SHAPES:
     print(f"{str(s):>28s} {us[0]:9.1f} {us[1]:7.1f} {us[2]:7.1f} {us[3]:7.1f} {us[1] + us[2] + us[3]:8.1f} {byt / us[0] / 1e6:10.2f}", flush=True)
 
 if "--ablate" in sys.argv:
-    print("\nablations (us): full | no 3x3 loop | no stores | no residual | no stores+residual | 3x3 only | no 3x3, no stores, no residual")
+    print("\nablations (us): full | no 3x3 loop | no stores | no residual | no stores+residual | 3x3 only | no 3x3, no stores, no residual | residual through VGPRs")
     for s in SHAPES:
         B, H, W, C1, C3, st = s
         t = []
-        for dbg in (0, 1, 2, 4, 6, 8, 7):
+        for dbg in (0, 1, 2, 4, 6, 8, 7, 16):
             us = (C.c_float * 4)()
             _capi.check(lib.opd_test_bench_btail(B, H, W, C1, C3, st, dbg, 20, us), "bench_btail")
             t.append(us[0])
