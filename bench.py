@@ -118,11 +118,13 @@ def main() -> None:
     # synthetic office-camera frames, resident in HBM before the timed region (torch = device memory plumbing only)
     frames = np.stack([structured_frame(H, W, 1234 + rank * B + i) for i in range(B)])
     d_frames = torch.from_numpy(frames).cuda()
-    d_records = torch.zeros((B, Q, 8), dtype=torch.int32, device="cuda")   # opd_det = 8 x 4 bytes
-    d_counts = torch.zeros((B,), dtype=torch.int32, device="cuda")
+    # one flat int32 buffer per rank: B*Q records (opd_det = 8 x 4 bytes) followed by the B per-frame counts, so that the
+    # path's exchange step is ONE all-gather
+    NREC = B * Q * 8
+    d_flat = torch.zeros((NREC + B,), dtype=torch.int32, device="cuda")
+    d_records, d_counts = d_flat[:NREC].view(B, Q, 8), d_flat[NREC:]
     gdev = "cuda" if backend == "nccl" else "cpu"
-    g_records = torch.zeros((world * B, Q, 8), dtype=torch.int32, device=gdev) if world > 1 else None
-    g_counts = torch.zeros((world * B,), dtype=torch.int32, device=gdev) if world > 1 else None
+    g_flat = torch.zeros((world * (NREC + B),), dtype=torch.int32, device=gdev) if world > 1 else None
     hw = np.asarray([[H, W]] * B, dtype=np.int32)
 
     def local_detect():
@@ -134,11 +136,12 @@ def main() -> None:
 
     def step():
         local_detect()
-        if world > 1:  # the path's one exchange step: fixed-size detection records back to the orchestrator
-            dist.all_gather_into_tensor(g_records, d_records if backend == "nccl" else d_records.cpu())
-            dist.all_gather_into_tensor(g_counts, d_counts if backend == "nccl" else d_counts.cpu())
-            return g_counts.cpu(), (g_records.cpu() if rank == 0 else None)
-        return d_counts.cpu(), d_records.cpu()
+        if world > 1:  # the path's one exchange step: fixed-size detection records (+ counts) back to the orchestrator
+            dist.all_gather_into_tensor(g_flat, d_flat if backend == "nccl" else d_flat.cpu())
+            g = g_flat.cpu().view(world, NREC + B)
+            return g[:, NREC:].reshape(-1), (g[:, :NREC].reshape(world * B, Q, 8) if rank == 0 else None)
+        h = d_flat.cpu()
+        return h[NREC:], h[:NREC].view(B, Q, 8)
 
     def sync():
         torch.cuda.synchronize()

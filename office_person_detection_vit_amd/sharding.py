@@ -52,17 +52,18 @@ def exchange(rec: np.ndarray, cnt: np.ndarray, device=None):
     import torch.distributed as dist
 
     world = dist.get_world_size()
-    t_rec = torch.from_numpy(rec)
-    t_cnt = torch.from_numpy(cnt)
+    # records and counts travel in ONE flat int32 tensor per rank (the collective is latency bound: one launch, not two)
+    nrec = rec.size
+    flat = torch.from_numpy(np.concatenate([np.ascontiguousarray(rec, dtype=np.int32).reshape(-1),
+                                            np.ascontiguousarray(cnt, dtype=np.int32).reshape(-1)]))
     if device is not None:
-        t_rec, t_cnt = t_rec.to(device), t_cnt.to(device)
+        flat = flat.to(device)
     # concatenated-along-dim-0 output form: accepted by both the RCCL and the gloo backend
-    g_rec = torch.empty((world * t_rec.shape[0],) + tuple(t_rec.shape[1:]), dtype=t_rec.dtype, device=t_rec.device)
-    g_cnt = torch.empty((world * t_cnt.shape[0],), dtype=t_cnt.dtype, device=t_cnt.device)
-    dist.all_gather_into_tensor(g_rec, t_rec)
-    dist.all_gather_into_tensor(g_cnt, t_cnt)
-    return (g_rec.cpu().numpy().reshape((world,) + tuple(t_rec.shape)),
-            g_cnt.cpu().numpy().reshape(world, t_cnt.shape[0]))
+    gathered = torch.empty((world * flat.shape[0],), dtype=flat.dtype, device=flat.device)
+    dist.all_gather_into_tensor(gathered, flat)
+    g = gathered.cpu().numpy().reshape(world, flat.shape[0])
+    return (np.ascontiguousarray(g[:, :nrec]).reshape((world,) + tuple(rec.shape)),
+            np.ascontiguousarray(g[:, nrec:]).reshape(world, cnt.shape[0]))
 
 
 def assemble(g_rec: np.ndarray, g_cnt: np.ndarray, n_frames: int, person_label: int = 1, nms_threshold: float = 0.4,
