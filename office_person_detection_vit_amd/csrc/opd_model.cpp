@@ -927,18 +927,26 @@ static int enqueue_resize(opd_detr* m, const uint8_t* frames, int mem_kind, int 
     return OPD_OK;
 }
 
-static int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw) {
+// `dev_out` / `dev_counts` (nullable): device buffers of the caller; the kernel then writes there directly instead of the
+// library's own record buffers (no device-to-device copies afterwards).
+static int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* dev_out = nullptr,
+                               int32_t* dev_counts = nullptr) {
     const int B = m->last_B;
-    std::vector<int32_t>& hw = m->h_orig_hw;  // member: must outlive the async copy
-    hw.resize((size_t)B * 2);
+    std::vector<int32_t> hw((size_t)B * 2);
     for (int b = 0; b < B; ++b) {
         hw[2 * b] = orig_hw ? orig_hw[2 * b] : m->last_H;
         hw[2 * b + 1] = orig_hw ? orig_hw[2 * b + 1] : m->last_W;
     }
-    HIPCHK(hipMemcpyAsync(m->d_orig_hw, hw.data(), hw.size() * 4, hipMemcpyHostToDevice, m->stream));
+    if (hw != m->h_orig_hw) {   // the frame sizes of a video do not change from call to call: upload only when they do
+        HIPCHK(hipStreamSynchronize(m->stream));   // (an earlier asynchronous copy may still be reading the old host vector)
+        m->h_orig_hw = hw;      // member: must outlive the async copy
+        HIPCHK(hipMemcpyAsync(m->d_orig_hw, m->h_orig_hw.data(), m->h_orig_hw.size() * 4, hipMemcpyHostToDevice, m->stream));
+    }
     PostParams pp{};
-    pp.logits = m->d_logits; pp.boxes = m->d_boxes; pp.orig_hw = m->d_orig_hw; pp.records = m->d_records;
-    pp.counts = m->d_counts; pp.B = B; pp.Q = m->arch.queries; pp.ncls = m->arch.ncls; pp.threshold = threshold;
+    pp.logits = m->d_logits; pp.boxes = m->d_boxes; pp.orig_hw = m->d_orig_hw;
+    pp.records = dev_out ? dev_out : m->d_records;
+    pp.counts = dev_counts ? dev_counts : m->d_counts;
+    pp.B = B; pp.Q = m->arch.queries; pp.ncls = m->arch.ncls; pp.threshold = threshold;
     HIPCHK(opd_launch_postprocess(pp, m->stream));
     MARK(8);
     return OPD_OK;
@@ -946,9 +954,10 @@ static int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig
 
 static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kind) {
     const int B = m->last_B, Q = m->arch.queries;
-    const hipMemcpyKind kind = mem_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
-    HIPCHK(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 4, kind, m->stream));
-    HIPCHK(hipMemcpyAsync(out, m->d_records, (size_t)B * Q * sizeof(opd_det), kind, m->stream));
+    if (mem_kind == OPD_MEM_HOST) {   // (device callers had the post-process kernel write into their buffers)
+        HIPCHK(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(out, m->d_records, (size_t)B * Q * sizeof(opd_det), hipMemcpyDeviceToHost, m->stream));
+    }
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->profiling) {
         for (int i = 0; i < 8; ++i) {
@@ -1098,7 +1107,8 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
     RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
-    RCCHK(enqueue_postprocess(m, threshold, orig_hw));
+    const bool dev = mem_kind == OPD_MEM_DEVICE;
+    RCCHK(enqueue_postprocess(m, threshold, orig_hw, dev ? out : nullptr, dev ? counts : nullptr));
     return fetch_records(m, out, counts, mem_kind);
 }
 int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float threshold,
@@ -1111,7 +1121,8 @@ int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, in
     RCCHK(run_forward(m, m->d_u8, OPD_PIXELS_U8_BGR_HWC, B, H, W, nullptr));
     std::vector<int32_t> orig((size_t)2 * B);   // boxes are scaled to the ORIGINAL (camera) frame size
     for (int b = 0; b < B; ++b) { orig[2 * b] = h; orig[2 * b + 1] = w; }
-    RCCHK(enqueue_postprocess(m, threshold, orig.data()));
+    const bool dev = mem_kind == OPD_MEM_DEVICE;
+    RCCHK(enqueue_postprocess(m, threshold, orig.data(), dev ? out : nullptr, dev ? counts : nullptr));
     return fetch_records(m, out, counts, mem_kind);
 }
 
