@@ -71,6 +71,9 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sync-steps", action="store_true",
+                    help="one blocking detect call per step (default: steps are submitted asynchronously, results of step i-1 are "
+                         "fetched while step i computes)")
     args = ap.parse_args()
 
     import torch
@@ -121,7 +124,8 @@ def main() -> None:
     # one flat int32 buffer per rank: B*Q records (opd_det = 8 x 4 bytes) followed by the B per-frame counts, so that the
     # path's exchange step is ONE all-gather
     NREC = B * Q * 8
-    d_flat = torch.zeros((NREC + B,), dtype=torch.int32, device="cuda")
+    d_flats = [torch.zeros((NREC + B,), dtype=torch.int32, device="cuda") for _ in range(2)]   # alternating output buffers
+    d_flat = d_flats[0]
     d_records, d_counts = d_flat[:NREC].view(B, Q, 8), d_flat[NREC:]
     gdev = "cuda" if backend == "nccl" else "cpu"
     g_flat = torch.zeros((world * (NREC + B),), dtype=torch.int32, device=gdev) if world > 1 else None
@@ -134,14 +138,44 @@ def main() -> None:
                                  C.cast(C.c_void_p(d_counts.data_ptr()), C.POINTER(C.c_int32)))
         _capi.check(rc, "opd_detr_detect")
 
-    def step():
-        local_detect()
-        if world > 1:  # the path's one exchange step: fixed-size detection records (+ counts) back to the orchestrator
-            dist.all_gather_into_tensor(g_flat, d_flat if backend == "nccl" else d_flat.cpu())
+    def collect(buf):
+        """records (+ counts) of one finished step to the orchestrator's host memory (the path's one exchange step for N > 1)"""
+        if world > 1:
+            dist.all_gather_into_tensor(g_flat, buf if backend == "nccl" else buf.cpu())
             g = g_flat.cpu().view(world, NREC + B)
             return g[:, NREC:].reshape(-1), (g[:, :NREC].reshape(world * B, Q, 8) if rank == 0 else None)
-        h = d_flat.cpu()
+        h = buf.cpu()
         return h[NREC:], h[:NREC].view(B, Q, 8)
+
+    def step():
+        local_detect()
+        return collect(d_flat)
+
+    def submit(i):
+        """enqueue step i on the library's stream (forward + post-process into buffer i & 1) and return its ticket"""
+        buf = d_flats[i & 1]
+        ticket = C.c_int()
+        rc = lib.opd_detr_detect_async(handle, C.c_void_p(d_frames.data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, B, H, W, 0.5,
+                                       hw.ctypes.data_as(C.c_void_p), C.cast(C.c_void_p(buf.data_ptr()), C.POINTER(_capi.OpdDet)),
+                                       C.cast(C.c_void_p(buf[NREC:].data_ptr()), C.POINTER(C.c_int32)), C.byref(ticket))
+        _capi.check(rc, "opd_detr_detect_async")
+        return ticket.value
+
+    def run_steps(n):
+        """n steps; every step's records reach host memory.  Pipelined form: step i is submitted before step i-1 is collected."""
+        if args.sync_steps:
+            out = None
+            for _ in range(n):
+                out = step()
+            return out
+        out, ticket = None, submit(0)
+        for i in range(1, n):
+            nxt = submit(i)
+            _capi.check(lib.opd_detr_wait(handle, ticket), "opd_detr_wait")
+            out = collect(d_flats[(i - 1) & 1])
+            ticket = nxt
+        _capi.check(lib.opd_detr_wait(handle, ticket), "opd_detr_wait")
+        return collect(d_flats[(n - 1) & 1])
 
     def sync():
         torch.cuda.synchronize()
@@ -149,12 +183,11 @@ def main() -> None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    if args.warmup:
+        run_steps(args.warmup)
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        counts, _ = step()
+    counts, _ = run_steps(args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -208,7 +241,8 @@ def main() -> None:
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"facebook/detr-resnet-50 architecture (seeded synthetic weights), batch {B} per GPU, "
-                                   f"{H}x{W} uint8 BGR frames resident in HBM, forward + device post-process"
+                                   f"{H}x{W} uint8 BGR frames resident in HBM, forward + device post-process, "
+                                   + ("blocking steps" if args.sync_steps else "steps submitted asynchronously (depth 2), every step's records fetched to host")
                                    + ((", RCCL all-gather of detection records" if backend == "nccl" else f", {backend} REHEARSAL (ranks share device 0)")
                                       if world > 1 else ""),
                        "global_batch": B * world, "parallelism": f"frame-sharded dp{world}"},

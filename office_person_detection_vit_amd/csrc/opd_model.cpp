@@ -135,6 +135,9 @@ struct opd_detr {
     const float** d_bias_ptrs = nullptr;   // [(enc_layers + 1)][max_batch]
     std::vector<int32_t> h_valid_hw, h_key_valid;
     std::vector<const float*> h_bias_ptrs;
+    // asynchronous submissions (opd_detr_detect_async): one completion event per in-flight ticket
+    hipEvent_t ev_async[4] = {};
+    unsigned async_next = 0;
     // device-side resize (camera resolution -> model resolution): source staging (grown on demand) and coefficient tables
     uint8_t* d_src = nullptr;
     size_t src_bytes = 0;
@@ -1022,6 +1025,8 @@ void opd_detr_destroy(opd_detr* m) {
     if (m->stream) (void)hipStreamSynchronize(m->stream);
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->d_src) (void)hipFree(m->d_src);
+    for (auto& e : m->ev_async)
+        if (e) (void)hipEventDestroy(e);
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : m->event_pool) (void)hipEventDestroy(e);
@@ -1110,6 +1115,26 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
     const bool dev = mem_kind == OPD_MEM_DEVICE;
     RCCHK(enqueue_postprocess(m, threshold, orig_hw, dev ? out : nullptr, dev ? counts : nullptr));
     return fetch_records(m, out, counts, mem_kind);
+}
+int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int B, int H, int W, float threshold,
+                          const int32_t* orig_hw, opd_det* out, int32_t* counts, int* ticket) {
+    RCCHK(check_shape(m, pixels, pixel_format, OPD_MEM_DEVICE, B, H, W));
+    if (!out || !counts || !ticket) return fail(OPD_EINVAL, "opd_detr_detect_async: null argument");
+    if (m->profiling) return fail(OPD_ESTATE, "opd_detr_detect_async is not available in profiling mode");
+    HIPCHK(hipSetDevice(m->device));
+    RCCHK(run_forward(m, pixels, pixel_format, B, H, W, nullptr));
+    RCCHK(enqueue_postprocess(m, threshold, orig_hw, out, counts));
+    const unsigned t = m->async_next++ & 3u;
+    if (!m->ev_async[t]) HIPCHK(hipEventCreateWithFlags(&m->ev_async[t], hipEventDisableTiming));
+    HIPCHK(hipEventRecord(m->ev_async[t], m->stream));
+    *ticket = (int)t;
+    return OPD_OK;
+}
+int opd_detr_wait(opd_detr* m, int ticket) {
+    if (!m || ticket < 0 || ticket > 3 || !m->ev_async[ticket]) return fail(OPD_EINVAL, "opd_detr_wait: bad handle or ticket");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipEventSynchronize(m->ev_async[ticket]));
+    return OPD_OK;
 }
 int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float threshold,
                             opd_det* out, int32_t* counts) {

@@ -366,3 +366,42 @@ def test_config5_tiled_4k_frame(detectors):
     for d in got:
         assert -3840 <= d.bbox[0] <= 3840 and -2160 <= d.bbox[1] <= 2160 and d.camera_coords == (d.bbox[0] + d.bbox[2] / 2, d.bbox[1] + d.bbox[3])
     assert sum(len(p) for p in per_tile) >= len(got)
+
+
+def test_async_submission_equals_blocking_detect(detectors):
+    """opd_detr_detect_async / opd_detr_wait (the pipelined bench loop): two submissions in flight on alternating device
+    buffers give exactly the records of the blocking call, in submission order."""
+    import ctypes as C
+    from office_person_detection_vit_amd import _capi
+    det = detectors(ga=1.0)
+    lib = _capi.load_library()
+    h = C.c_void_p(det.model)
+    Q = 100
+    sets = [np.ascontiguousarray(np.stack(structured_frames(2, 256, 320, seed=s))) for s in (41, 42)]
+    d_frames = [torch.from_numpy(a).cuda() for a in sets]
+    hw = np.asarray([[256, 320]] * 2, np.int32)
+    want = []
+    for a in sets:      # blocking reference (host buffers)
+        recs, counts = (_capi.OpdDet * (2 * Q))(), (C.c_int32 * 2)()
+        _capi.check(lib.opd_detr_detect(h, a.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320,
+                                        0.5, hw.ctypes.data_as(C.c_void_p), recs, counts), "detect")
+        want.append((list(counts), bytes(recs)))
+    bufs = [torch.zeros((2 * Q * 8 + 2,), dtype=torch.int32, device="cuda") for _ in range(2)]
+    tickets = []
+    for i in range(2):  # both submitted before either is waited for
+        t = C.c_int()
+        _capi.check(lib.opd_detr_detect_async(h, C.c_void_p(d_frames[i].data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, 2, 256, 320, 0.5,
+                                              hw.ctypes.data_as(C.c_void_p), C.cast(C.c_void_p(bufs[i].data_ptr()), C.POINTER(_capi.OpdDet)),
+                                              C.cast(C.c_void_p(bufs[i][2 * Q * 8:].data_ptr()), C.POINTER(C.c_int32)), C.byref(t)),
+                    "detect_async")
+        tickets.append(t.value)
+    for i in range(2):
+        _capi.check(lib.opd_detr_wait(h, tickets[i]), "wait")
+        host = bufs[i].cpu().numpy()
+        counts = host[2 * Q * 8:].tolist()
+        assert counts == want[i][0]
+        got = host[:2 * Q * 8].reshape(2, Q, 8)
+        ref = np.frombuffer(want[i][1], dtype=np.int32).reshape(2, Q, 8)
+        for b in range(2):
+            np.testing.assert_array_equal(got[b, :counts[b]], ref[b, :counts[b]])
+    assert lib.opd_detr_wait(h, 7) != 0     # bad ticket -> error code, not a hang
