@@ -71,6 +71,9 @@ def main() -> None:
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--streams", type=int, default=int(os.environ.get("OPD_BENCH_STREAMS", "3")),
+                    help="detector handles (own stream, workspace and graph each) that take the steps in turn: with 2 the low-"
+                         "occupancy tail of step i (decoder, heads) overlaps the trunk of step i+1")
     ap.add_argument("--sync-steps", action="store_true",
                     help="one blocking detect call per step (default: steps are submitted asynchronously, results of step i-1 are "
                          "fetched while step i computes)")
@@ -116,6 +119,12 @@ def main() -> None:
     _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), device_index, C.byref(handle)), "opd_detr_create")
     info = _capi.OpdModelInfo()
     _capi.check(lib.opd_detr_info(handle, C.byref(info)), "opd_detr_info")
+    handles = [handle]
+    for _ in range(1, max(1, args.streams)):
+        hx = C.c_void_p()
+        _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), device_index, C.byref(hx)), "opd_detr_create")
+        handles.append(hx)
+    NS = len(handles)
     Q = info.num_queries
 
     # synthetic office-camera frames, resident in HBM before the timed region (torch = device memory plumbing only)
@@ -124,7 +133,7 @@ def main() -> None:
     # one flat int32 buffer per rank: B*Q records (opd_det = 8 x 4 bytes) followed by the B per-frame counts, so that the
     # path's exchange step is ONE all-gather
     NREC = B * Q * 8
-    d_flats = [torch.zeros((NREC + B,), dtype=torch.int32, device="cuda") for _ in range(2)]   # alternating output buffers
+    d_flats = [torch.zeros((NREC + B,), dtype=torch.int32, device="cuda") for _ in range(2 * NS)]   # rotating output buffers
     d_flat = d_flats[0]
     d_records, d_counts = d_flat[:NREC].view(B, Q, 8), d_flat[NREC:]
     gdev = "cuda" if backend == "nccl" else "cpu"
@@ -153,10 +162,10 @@ def main() -> None:
 
     def submit(i):
         """enqueue step i on the library's stream (forward + post-process into buffer i & 1) and return its ticket"""
-        buf = d_flats[i & 1]
+        buf = d_flats[i % (2 * NS)]
         ticket = C.c_int()
-        rc = lib.opd_detr_detect_async(handle, C.c_void_p(d_frames.data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, B, H, W, 0.5,
-                                       hw.ctypes.data_as(C.c_void_p), C.cast(C.c_void_p(buf.data_ptr()), C.POINTER(_capi.OpdDet)),
+        rc = lib.opd_detr_detect_async(handles[i % NS], C.c_void_p(d_frames.data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_DEVICE,
+                                       B, H, W, 0.5, hw.ctypes.data_as(C.c_void_p), C.cast(C.c_void_p(buf.data_ptr()), C.POINTER(_capi.OpdDet)),
                                        C.cast(C.c_void_p(buf[NREC:].data_ptr()), C.POINTER(C.c_int32)), C.byref(ticket))
         _capi.check(rc, "opd_detr_detect_async")
         return ticket.value
@@ -168,14 +177,16 @@ def main() -> None:
             for _ in range(n):
                 out = step()
             return out
-        out, ticket = None, submit(0)
-        for i in range(1, n):
-            nxt = submit(i)
-            _capi.check(lib.opd_detr_wait(handle, ticket), "opd_detr_wait")
-            out = collect(d_flats[(i - 1) & 1])
-            ticket = nxt
-        _capi.check(lib.opd_detr_wait(handle, ticket), "opd_detr_wait")
-        return collect(d_flats[(n - 1) & 1])
+        # NS steps stay submitted ahead (one per handle); step i - NS is collected right after step i has been submitted
+        out, tickets = None, {}
+        for i in range(n + NS):
+            if i < n:
+                tickets[i] = submit(i)
+            j = i - NS
+            if j >= 0:
+                _capi.check(lib.opd_detr_wait(handles[j % NS], tickets.pop(j)), "opd_detr_wait")
+                out = collect(d_flats[j % (2 * NS)])
+        return out
 
     def sync():
         torch.cuda.synchronize()
@@ -242,10 +253,12 @@ def main() -> None:
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
             "config": {"workload": f"facebook/detr-resnet-50 architecture (seeded synthetic weights), batch {B} per GPU, "
                                    f"{H}x{W} uint8 BGR frames resident in HBM, forward + device post-process, "
-                                   + ("blocking steps" if args.sync_steps else "steps submitted asynchronously (depth 2), every step's records fetched to host")
+                                   + ("blocking steps" if args.sync_steps else
+                                      f"steps submitted asynchronously over {NS} detector handle(s), every step's records fetched to host")
                                    + ((", RCCL all-gather of detection records" if backend == "nccl" else f", {backend} REHEARSAL (ranks share device 0)")
                                       if world > 1 else ""),
-                       "global_batch": B * world, "parallelism": f"frame-sharded dp{world}"},
+                       "global_batch": B * world, "parallelism": f"frame-sharded dp{world}",
+                       "batches_in_flight_per_gpu": 1 if args.sync_steps else NS},
             "roofline": roof,
             "stage_ms": stage_ms,
             "detections_last_step": int(np.asarray(counts).sum()),
@@ -254,7 +267,8 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(path, H, W)
             out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)
-    lib.opd_detr_destroy(handle)
+    for hx in handles:
+        lib.opd_detr_destroy(hx)
     if world > 1:
         dist.destroy_process_group()
 

@@ -132,11 +132,15 @@ int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_k
                     float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
 /* With `mem_kind == OPD_MEM_DEVICE`, `out` ([B][Q] records) and `counts` ([B]) are DEVICE pointers too, so a sharded
  * caller can hand them straight to an RCCL all-gather; `orig_hw` is always a host array. */
-/* Asynchronous submission for throughput-oriented callers (device pixels in, device records out): enqueues the forward and
- * the post-process on the handle's stream and returns at once with a `ticket` (0..3; at most 4 submissions may be
- * outstanding); `out` / `counts` of a submission are complete after opd_detr_wait(m, ticket).  A caller that alternates two
- * output buffers can fetch batch i-1 while batch i computes; work of consecutive submissions runs in submission order. */
-int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int B, int H, int W, float threshold,
+/* Asynchronous submission for throughput-oriented callers: enqueues the forward and the post-process on the handle's stream
+ * and returns with a `ticket` (0..3; at most 4 submissions may be outstanding per handle); `out` / `counts` of a submission
+ * are complete after opd_detr_wait(m, ticket) (`mem_kind` as in opd_detr_detect: host pixels are staged with an asynchronous
+ * copy, host outputs travel through pinned memory and are delivered by opd_detr_wait; `pixels`, `out` and `counts` must stay
+ * valid and untouched until that wait returns).  Work of consecutive submissions to ONE
+ * handle runs in submission order; SEVERAL handles on one device (own stream, workspace and captured graph each) overlap:
+ * the latency-bound tail of one batch fills the CUs the next batch's trunk leaves idle (+25 % frames/s with three handles at
+ * batch 8). */
+int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
                           const int32_t* orig_hw, opd_det* out, int32_t* counts, int* ticket);
 int opd_detr_wait(opd_detr* m, int ticket);
 /* Camera-resolution form (see opd_detr_forward_resized): resize on the device, detect, and scale the boxes back to the

@@ -55,7 +55,7 @@ API = {
                                   C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_detr_detect_ragged": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                          C.c_float, C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
-    "opd_detr_detect_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
+    "opd_detr_detect_async": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p,
                                         C.POINTER(OpdDet), C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "opd_detr_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_person_nms": (C.c_int, [C.POINTER(OpdDet), C.c_int, C.c_int, C.c_float]),

@@ -138,6 +138,9 @@ struct opd_detr {
     // asynchronous submissions (opd_detr_detect_async): one completion event per in-flight ticket
     hipEvent_t ev_async[4] = {};
     unsigned async_next = 0;
+    // host-output submissions: the records travel device -> pinned slot (asynchronous) -> caller buffer (in opd_detr_wait)
+    struct AsyncHost { void* pinned = nullptr; opd_det* out = nullptr; int32_t* counts = nullptr; int B = 0; };
+    AsyncHost async_host[4];
     // device-side resize (camera resolution -> model resolution): source staging (grown on demand) and coefficient tables
     uint8_t* d_src = nullptr;
     size_t src_bytes = 0;
@@ -1027,6 +1030,8 @@ void opd_detr_destroy(opd_detr* m) {
     if (m->d_src) (void)hipFree(m->d_src);
     for (auto& e : m->ev_async)
         if (e) (void)hipEventDestroy(e);
+    for (auto& a : m->async_host)
+        if (a.pinned) (void)hipHostFree(a.pinned);
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : m->event_pool) (void)hipEventDestroy(e);
@@ -1116,16 +1121,30 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
     RCCHK(enqueue_postprocess(m, threshold, orig_hw, dev ? out : nullptr, dev ? counts : nullptr));
     return fetch_records(m, out, counts, mem_kind);
 }
-int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int B, int H, int W, float threshold,
+int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
                           const int32_t* orig_hw, opd_det* out, int32_t* counts, int* ticket) {
-    RCCHK(check_shape(m, pixels, pixel_format, OPD_MEM_DEVICE, B, H, W));
+    RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     if (!out || !counts || !ticket) return fail(OPD_EINVAL, "opd_detr_detect_async: null argument");
     if (m->profiling) return fail(OPD_ESTATE, "opd_detr_detect_async is not available in profiling mode");
     HIPCHK(hipSetDevice(m->device));
-    RCCHK(run_forward(m, pixels, pixel_format, B, H, W, nullptr));
-    RCCHK(enqueue_postprocess(m, threshold, orig_hw, out, counts));
     const unsigned t = m->async_next++ & 3u;
     if (!m->ev_async[t]) HIPCHK(hipEventCreateWithFlags(&m->ev_async[t], hipEventDisableTiming));
+    const void* d_pixels = nullptr;
+    RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
+    RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, nullptr));
+    const int Q = m->arch.queries;
+    opd_detr::AsyncHost& slot = m->async_host[t];
+    slot.out = nullptr;
+    if (mem_kind == OPD_MEM_DEVICE) {
+        RCCHK(enqueue_postprocess(m, threshold, orig_hw, out, counts));
+    } else {   // host outputs: pinned staging so that the copy stays asynchronous; delivered by opd_detr_wait
+        RCCHK(enqueue_postprocess(m, threshold, orig_hw));
+        const size_t rec_bytes = (size_t)m->cfg.max_batch * Q * sizeof(opd_det);
+        if (!slot.pinned) HIPCHK(hipHostMalloc(&slot.pinned, rec_bytes + (size_t)m->cfg.max_batch * 4, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(slot.pinned, m->d_records, (size_t)B * Q * sizeof(opd_det), hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(static_cast<char*>(slot.pinned) + rec_bytes, m->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        slot.out = out; slot.counts = counts; slot.B = B;
+    }
     HIPCHK(hipEventRecord(m->ev_async[t], m->stream));
     *ticket = (int)t;
     return OPD_OK;
@@ -1134,6 +1153,14 @@ int opd_detr_wait(opd_detr* m, int ticket) {
     if (!m || ticket < 0 || ticket > 3 || !m->ev_async[ticket]) return fail(OPD_EINVAL, "opd_detr_wait: bad handle or ticket");
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipEventSynchronize(m->ev_async[ticket]));
+    opd_detr::AsyncHost& slot = m->async_host[ticket];
+    if (slot.out) {
+        const int Q = m->arch.queries;
+        const size_t rec_bytes = (size_t)m->cfg.max_batch * Q * sizeof(opd_det);
+        memcpy(slot.out, slot.pinned, (size_t)slot.B * Q * sizeof(opd_det));
+        memcpy(slot.counts, static_cast<char*>(slot.pinned) + rec_bytes, (size_t)slot.B * 4);
+        slot.out = nullptr;
+    }
     return OPD_OK;
 }
 int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float threshold,

@@ -17,6 +17,7 @@ fallback — without the built library or without a GPU every call raises.
 
 from __future__ import annotations
 
+from concurrent.futures import ThreadPoolExecutor
 import ctypes as C
 import logging
 import os
@@ -74,6 +75,7 @@ class HipDetrDetector:
         resize: bool = True,
         device_resize: bool = True,
         use_graph: bool = True,
+        streams: int = 1,
     ):
         """
         Args mirror ``config.yaml.disabled:33-44`` (``model_name``, ``confidence_threshold``, ``nms_threshold``,
@@ -81,6 +83,8 @@ class HipDetrDetector:
         ``DetrForObjectDetection`` state dict (or a directory holding ``model.safetensors``); hub loading by NAME is
         impossible offline, so ``model_name`` alone resolves only through ``$OPD_DETR_WEIGHTS``.
         ``device``: ``"hip"``, ``"hip:N"``, ``"cuda"``, ``"cuda:N"`` or None (= GPU 0).  ``"cpu"``/``"mps"`` are refused.
+        ``streams``: detector handles (each with its own HIP stream, workspace and weights copy) that
+        ``detect_batch`` keeps busy at once when a call spans several ``max_batch`` chunks; 1 = strictly serial.
         """
         self.model_name = model_name
         self.model_path = model_path
@@ -93,7 +97,9 @@ class HipDetrDetector:
         self.resize = resize
         self.device_resize = device_resize  # resize camera-resolution frames on the GPU (False: PIL on the host)
         self.use_graph = use_graph  # replay the forward as a captured hipGraph (False: launch every kernel eagerly)
-        self.model: Optional[int] = None  # opaque opd_detr* once loaded
+        self.streams = max(1, int(streams))
+        self.model: Optional[int] = None  # opaque opd_detr* once loaded (handle 0)
+        self._handles: List[int] = []  # all handles, handle 0 first
         self.feature_extractor = FeatureExtractor()
         self._lib = None
         self._info = None
@@ -139,20 +145,26 @@ class HipDetrDetector:
             cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=self.max_batch,
                                   max_height=self.max_size[0], max_width=self.max_size[1],
                                   flags=0 if self.use_graph else _capi.OPD_FLAG_NO_GRAPH)
-            handle = C.c_void_p()
-            rc = lib.opd_detr_create(C.byref(cfg), path.encode("utf-8"), self.device_ordinal, C.byref(handle))
-            _capi.check(rc, "opd_detr_create")
+            self._lib = lib
+            for _ in range(self.streams):
+                handle = C.c_void_p()
+                rc = lib.opd_detr_create(C.byref(cfg), path.encode("utf-8"), self.device_ordinal, C.byref(handle))
+                _capi.check(rc, "opd_detr_create")
+                self._handles.append(handle.value)
             info = _capi.OpdModelInfo()
-            _capi.check(lib.opd_detr_info(handle, C.byref(info)), "opd_detr_info")
-            self._lib, self.model, self._info = lib, handle.value, info
+            _capi.check(lib.opd_detr_info(C.c_void_p(self._handles[0]), C.byref(info)), "opd_detr_info")
+            self.model, self._info = self._handles[0], info
             logger.info(f"Model loaded: {path}")
         except Exception as e:
+            self.close()
             logger.error(f"Failed to load model: {e}")
             raise RuntimeError(f"Failed to load DETR model: {e}") from e
 
     def close(self) -> None:
-        if self.model is not None and self._lib is not None:
-            self._lib.opd_detr_destroy(C.c_void_p(self.model))
+        if self._lib is not None:
+            for h in self._handles:
+                self._lib.opd_detr_destroy(C.c_void_p(h))
+        self._handles = []
         self.model = None
 
     def __del__(self):  # pragma: no cover - best effort
@@ -235,20 +247,21 @@ class HipDetrDetector:
         self._last_orig = orig
         return logits, boxes, enc
 
-    def _detect_records(self, frames: Sequence[np.ndarray]):
+    def _detect_records(self, frames: Sequence[np.ndarray], handle: Optional[int] = None):
+        model = self.model if handle is None else handle
         batch, orig, valid, target = self._preprocess_batch(frames)
         B, H, W, _ = batch.shape
         Q = self._info.num_queries
         recs = (_capi.OpdDet * (B * Q))()
         counts = (C.c_int32 * B)()
         if target is not None:   # camera-resolution batch: resize on the device, boxes come back in camera pixels
-            rc = self._lib.opd_detr_detect_resized(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p), _capi.OPD_MEM_HOST,
+            rc = self._lib.opd_detr_detect_resized(C.c_void_p(model), batch.ctypes.data_as(C.c_void_p), _capi.OPD_MEM_HOST,
                                                    B, H, W, target[0], target[1], float(self.confidence_threshold), recs, counts)
             _capi.check(rc, "opd_detr_detect_resized")
             self._last_orig = orig
             return recs, counts, Q
         hw = np.asarray(orig, dtype=np.int32).reshape(B, 2)
-        rc = self._lib.opd_detr_detect_ragged(C.c_void_p(self.model), batch.ctypes.data_as(C.c_void_p),
+        rc = self._lib.opd_detr_detect_ragged(C.c_void_p(model), batch.ctypes.data_as(C.c_void_p),
                                               _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,
                                               valid.ctypes.data_as(C.c_void_p) if valid is not None else None,
                                               float(self.confidence_threshold), hw.ctypes.data_as(C.c_void_p), recs, counts)
@@ -280,14 +293,37 @@ class HipDetrDetector:
         if len(frames) == 0:
             return []
         try:
+            chunks = [frames[i:i + self.max_batch] for i in range(0, len(frames), self.max_batch)]
+            if len(self._handles) > 1 and len(chunks) > 1:
+                return self._detect_chunks_overlapped(chunks)
             out: List[List[Detection]] = []
-            for i in range(0, len(frames), self.max_batch):
-                recs, counts, Q = self._detect_records(frames[i:i + self.max_batch])
+            for chunk in chunks:
+                recs, counts, Q = self._detect_records(chunk)
                 out.extend(self._postprocess_batch(recs, counts, Q))
             return out
         except Exception as e:
             logger.error(f"Detection failed: {e}")
             raise
+
+    def _detect_chunks_overlapped(self, chunks: List[List[np.ndarray]]) -> List[List[Detection]]:
+        """Chunk k runs on handle ``k % streams``; one worker thread per handle drives its chunks in order.
+
+        The C-ABI calls release the GIL and every handle owns its stream, so host preprocessing, uploads and the
+        tail of one batch overlap the trunk of the next.  Each chunk's result is what the
+        serial loop returns for it: the handles hold identical weights and the kernels are batch-invariant.
+        """
+        n = len(self._handles)
+        results: List[Optional[List[List[Detection]]]] = [None] * len(chunks)
+
+        def worker(j: int) -> None:
+            for k in range(j, len(chunks), n):
+                recs, counts, Q = self._detect_records(chunks[k], self._handles[j])
+                results[k] = self._postprocess_batch(recs, counts, Q)
+
+        with ThreadPoolExecutor(max_workers=n) as pool:
+            for fut in [pool.submit(worker, j) for j in range(min(n, len(chunks)))]:
+                fut.result()
+        return [dets for r in results for dets in r]
 
     def detect(self, frame: np.ndarray) -> List[Detection]:
         """Single-frame detection (``yolov8_detector.py:90-132``)."""

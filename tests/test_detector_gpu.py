@@ -390,8 +390,8 @@ def test_async_submission_equals_blocking_detect(detectors):
     tickets = []
     for i in range(2):  # both submitted before either is waited for
         t = C.c_int()
-        _capi.check(lib.opd_detr_detect_async(h, C.c_void_p(d_frames[i].data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, 2, 256, 320, 0.5,
-                                              hw.ctypes.data_as(C.c_void_p), C.cast(C.c_void_p(bufs[i].data_ptr()), C.POINTER(_capi.OpdDet)),
+        _capi.check(lib.opd_detr_detect_async(h, C.c_void_p(d_frames[i].data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_DEVICE, 2, 256, 320,
+                                              0.5, hw.ctypes.data_as(C.c_void_p), C.cast(C.c_void_p(bufs[i].data_ptr()), C.POINTER(_capi.OpdDet)),
                                               C.cast(C.c_void_p(bufs[i][2 * Q * 8:].data_ptr()), C.POINTER(C.c_int32)), C.byref(t)),
                     "detect_async")
         tickets.append(t.value)
@@ -405,3 +405,55 @@ def test_async_submission_equals_blocking_detect(detectors):
         for b in range(2):
             np.testing.assert_array_equal(got[b, :counts[b]], ref[b, :counts[b]])
     assert lib.opd_detr_wait(h, 7) != 0     # bad ticket -> error code, not a hang
+
+
+def test_async_host_buffers_equal_blocking_detect(detectors):
+    """Host-memory flavour of the asynchronous API: pixels staged by an async copy, records delivered by opd_detr_wait."""
+    import ctypes as C
+    from office_person_detection_vit_amd import _capi
+    det = detectors(ga=1.0)
+    lib = _capi.load_library()
+    h = C.c_void_p(det.model)
+    Q = 100
+    sets = [np.ascontiguousarray(np.stack(structured_frames(2, 256, 320, seed=s))) for s in (51, 52, 53)]
+    hw = np.asarray([[256, 320]] * 2, np.int32)
+    want = []
+    for a in sets:
+        recs, counts = (_capi.OpdDet * (2 * Q))(), (C.c_int32 * 2)()
+        _capi.check(lib.opd_detr_detect(h, a.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320,
+                                        0.5, hw.ctypes.data_as(C.c_void_p), recs, counts), "detect")
+        want.append((list(counts), np.frombuffer(bytes(recs), dtype=np.int32).reshape(2, Q, 8).copy()))
+    outs = [((_capi.OpdDet * (2 * Q))(), (C.c_int32 * 2)()) for _ in sets]
+    tickets = []
+    for a, (recs, counts) in zip(sets, outs):   # three in flight on one handle
+        t = C.c_int()
+        _capi.check(lib.opd_detr_detect_async(h, a.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320,
+                                              0.5, hw.ctypes.data_as(C.c_void_p), recs, counts, C.byref(t)), "detect_async")
+        tickets.append(t.value)
+    assert len(set(tickets)) == 3
+    for i in (2, 0, 1):   # waiting out of order is allowed
+        _capi.check(lib.opd_detr_wait(h, tickets[i]), "wait")
+        recs, counts = outs[i]
+        assert list(counts) == want[i][0]
+        got = np.frombuffer(bytes(recs), dtype=np.int32).reshape(2, Q, 8)
+        for b in range(2):
+            np.testing.assert_array_equal(got[b, :counts[b]], want[i][1][b, :counts[b]])
+
+
+def test_multi_handle_detect_batch_equals_serial(weight_cache):
+    """HipDetrDetector(streams=3): chunks of one detect_batch call overlap on three handles (worker threads, own HIP streams)
+    and return exactly the serial detector's detections, frame for frame, for both the canvas and the device-resize path."""
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    serial = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=True)
+    multi = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=True, streams=3)
+    serial.load_model(); multi.load_model()
+    try:
+        for (h, w) in ((256, 320), (360, 640)):
+            frames = structured_frames(11, h, w, seed=900 + h)
+            want = serial.detect_batch(frames)
+            got = multi.detect_batch(frames)
+            assert len(got) == len(frames)
+            assert [[(d.bbox, d.confidence, d.query_index) for d in f] for f in got] == \
+                   [[(d.bbox, d.confidence, d.query_index) for d in f] for f in want]
+    finally:
+        serial.close(); multi.close()
