@@ -263,6 +263,11 @@ def main() -> None:
             "stage_ms": stage_ms,
             "detections_last_step": int(np.asarray(counts).sum()),
         }
+        if (H, W) == (800, 1333) and roof is not None:
+            # SURVEY.md section 8(d) headline: the whole path's algorithmic FLOPs (203.2 GFLOP per r50 frame at 800x1333) x frames/s
+            # per GPU against the dense MFMA peak; this one includes every gap, the attention, pre- and post-processing
+            path_tf = 203.2e9 * fps / world / 1e12
+            roof["whole_path"] = {"flops_per_frame": 203.2e9, "achieved": round(path_tf, 2), "frac": round(path_tf / PEAK_MFMA_TFLOPS, 4)}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(path, H, W)
             out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)

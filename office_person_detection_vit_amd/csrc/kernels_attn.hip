@@ -46,8 +46,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     const int wave = tid >> 6;
     const int g = lane >> 4;
     const int li = lane & 15;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int q = blockIdx.x * 64 + wave * 16 + li;
+    // XCD-aware tile map: workgroup L runs on XCD L % 8, so XCD x takes the x-th contiguous eighth of the (frame, head, query
+    // tile) order.  The query tiles of one frame then share one L2: its K/V rows (all heads of a key share 128-byte lines) come
+    // from HBM once instead of once per XCD.
+    const int nq = (p.Lq + 63) >> 6;
+    const int total = nq * p.heads * p.B;
+    const int chunk = (total + 7) >> 3;
+    const int n = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    if (n >= total) return;   // whole workgroup leaves before the first barrier
+    const int b = n / (nq * p.heads), h = (n / nq) % p.heads;
+    const int q = (n % nq) * 64 + wave * 16 + li;
     const bool q_ok = q < p.Lq;
 
     half8 qf;
@@ -209,7 +217,8 @@ hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Lq <= 0 || p.Lk <= 0) return hipErrorInvalidValue;
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;  // 16-byte row chunks
     if (p.key_valid && p.key_row < 1) return hipErrorInvalidValue;
-    dim3 grid((p.Lq + 63) / 64, p.heads, p.B);
+    const int total = ((p.Lq + 63) / 64) * p.heads * p.B;
+    dim3 grid(8 * ((total + 7) / 8));   // 8 XCDs x their share of the tiles (attention_kernel's tile map)
     const bool wide = p.Lq <= 128 && p.Lk > 128;   // few query tiles, long key loop: decoder cross-attention
 #define OPD_ATTN_LAUNCH(TRV, MV)                                                                             \
     do {                                                                                                     \

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Round-end evidence run on the GPU box (from the repo root): full GPU test suite, the default bench line with the CPU
+# baseline, rocprofv3 kernel traces of the default command and of the one-batch-in-flight form, the two HBM-traffic PMC
+# passes and the 2-rank gloo rehearsal of the sharded bench path.  Everything lands under gpurun_out/final/.
+set -o pipefail
+R=$PWD
+O=$R/gpurun_out/final
+mkdir -p $O
+export TMPDIR=/tmp
+timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/tests_gpu.log 2>&1 && tail -2 $O/tests_gpu.log &&
+timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err && cat $O/bench.json &&
+cd /tmp &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_default -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_default.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_streams1 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 > $O/prof_streams1.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 > $O/pmc_fetch.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 > $O/pmc_write.log 2>&1 &&
+cd $R &&
+OPD_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_gloo2.json 2> $O/bench_gloo2.err && tail -1 $O/bench_gloo2.json | cut -c1-300 &&
+find $O -name "*.csv" | head -30 && du -sh $O
