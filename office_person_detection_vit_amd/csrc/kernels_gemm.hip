@@ -349,7 +349,7 @@ __device__ __forceinline__ void prefetch_res16(const ConvGemmParams& p, uint4 (&
 // Register epilogue: (+fp32 residual) (+fp16 residual) -> ReLU -> store.  v_permlane16_swap pairs the 4-channel
 // accumulator quads of two m-tiles so each lane owns 8 consecutive channels of one row: 16-byte loads and stores.
 // An unpaired last m-tile (odd MT) is stored as 8-byte quads.
-// `wave_stage` (optional, MT == 4, fp16 output): a wave-private NT*16 x 64-row fp16 staging area in LDS.  The wave
+// `wave_stage` (optional, fp16 output): a wave-private NT*16 x 64-row fp16 staging area in LDS.  The wave
 // transposes its output tile through it so that every global store instruction writes whole contiguous row segments
 // (8 lanes x 16 B = 128 B per row for BN = 128) instead of 32-byte pieces of 32 different rows: the 32-byte pattern is
 // request-rate bound at ~2.7 TB/s on the store-heavy 64->256 / 128->512 layers.
@@ -359,39 +359,104 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
                                               unsigned char* wave_stage = nullptr) {
     const int g = lane >> 4, li = lane & 15;
     constexpr int WROW = NT * 32;  // bytes per staged row (NT*16 channels fp16)
-    const bool staged = (MT == 4) && wave_stage != nullptr && !p.out_f32;
+    const bool staged = wave_stage != nullptr && !p.out_f32;
+    // values of the m-tile pair (2*mp, 2*mp + 1) of column tile nt in accumulator layout: + residuals, ReLU
+    auto pair_values = [&](const int nt, const int mp, float4v (&v)[2]) {
+        const int nq = n0 + nt * 16 + g * 4;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int m = m0 + (mp * 2 + h) * 16 + li;
+            v[h] = acc[nt][mp * 2 + h];
+            if (p.res32 && m < p.M) v[h] += *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * p.N + nq);
+        }
+        if (p.res16) {
+            const uint4 r = res[nt][mp];
+            const uint2v s0 = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
+            const uint2v s1 = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
+            float a, b;
+            unpack2h(s0[0], a, b); v[0][0] += a; v[0][1] += b;
+            unpack2h(s1[0], a, b); v[0][2] += a; v[0][3] += b;
+            unpack2h(s0[1], a, b); v[1][0] += a; v[1][1] += b;
+            unpack2h(s1[1], a, b); v[1][2] += a; v[1][3] += b;
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[h][r] = v[h][r] > 0.f ? v[h][r] : 0.f;
+        }
+    };
+    // the unpaired last m-tile of an odd MT (its fp16 residual was fetched as 8-byte quads in accumulator layout)
+    auto last_values = [&](const int nt, float4v& v) {
+        const int m = m0 + (MT - 1) * 16 + li;
+        const int nq = n0 + nt * 16 + g * 4;
+        v = acc[nt][MT - 1];
+        if (p.res32 && m < p.M) v += *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * p.N + nq);
+        if (p.res16) {
+            float a, b;
+            unpack2h(res[nt][MT / 2].x, a, b); v[0] += a; v[1] += b;
+            unpack2h(res[nt][MT / 2].y, a, b); v[2] += a; v[3] += b;
+        }
+        if (p.relu) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
+        }
+    };
+
+    if (staged) {
+        // Groups of up to four 16-row m-tiles pass through the wave's 64-row staging area one after the other (LDS operations
+        // of one wave execute in order, so the area is re-used without a barrier).  Accumulator layout -> LDS [row][channel],
+        // 16-byte chunks XOR-swizzled by row to spread the banks; read back row-contiguous: CPRW lanes cover one staged row.
+        constexpr int CPRW = WROW / 16;         // 16-byte chunks per staged row (8 for BN = 128, 4 for BN = 64)
+        constexpr int RPI = 64 / CPRW;          // rows per store instruction
+        const int c = lane % CPRW, r0 = lane / CPRW;
+        f16_t* o16 = reinterpret_cast<f16_t*>(out);
+        auto stage_quad = [&](const int nt, const int slot, const float4v& v) {
+            const int r = slot * 16 + li;
+            const int cb = nt * 32 + g * 8;  // byte offset of this quad inside the row
+            const int off = r * WROW + ((((cb >> 4) ^ (r & (WROW / 16 - 1))) << 4) | (cb & 8));
+            *reinterpret_cast<uint2*>(wave_stage + off) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+        };
+#pragma unroll
+        for (int g0 = 0; g0 < MT; g0 += 4) {
+            const int gt = (MT - g0) < 4 ? (MT - g0) : 4;   // m-tiles in this group (compile-time after unrolling)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+#pragma unroll
+                for (int t = 0; t + 1 < gt; t += 2) {
+                    float4v v[2];
+                    pair_values(nt, (g0 + t) / 2, v);
+                    stage_quad(nt, t, v[0]);
+                    stage_quad(nt, t + 1, v[1]);
+                }
+                if (gt & 1) {
+                    float4v v;
+                    last_values(nt, v);
+                    stage_quad(nt, gt - 1, v);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < gt * 16 / RPI; ++i) {
+                const int r = r0 + i * RPI;
+                const uint4 v = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ (r & (CPRW - 1))) << 4));
+                const int m = m0 + g0 * 16 + r;
+                if (m < p.M) *reinterpret_cast<uint4*>(o16 + (size_t)m * p.N + n0 + c * 8) = v;
+            }
+        }
+        return;
+    }
+
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int nq = n0 + nt * 16 + g * 4;  // this lane's 4 channels in accumulator layout
 #pragma unroll
         for (int mp = 0; mp < MT / 2; ++mp) {
             float4v v[2];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                const int m = m0 + (mp * 2 + h) * 16 + li;
-                v[h] = acc[nt][mp * 2 + h];
-                if (p.res32 && m < p.M) v[h] += *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * p.N + nq);
-            }
+            pair_values(nt, mp, v);
             // lane's row / channels in the paired (16-byte) layout: even g -> first m-tile of the pair, odd g -> second
             const int my_m = m0 + (mp * 2 + (g & 1)) * 16 + li;
             const int my_n = n0 + nt * 16 + (g >> 1) * 8;
             const size_t my_o = (size_t)my_m * p.N + my_n;
-            if (p.res16) {
-                const uint4 r = res[nt][mp];
-                const uint2v s0 = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
-                const uint2v s1 = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
-                float a, b;
-                unpack2h(s0[0], a, b); v[0][0] += a; v[0][1] += b;
-                unpack2h(s1[0], a, b); v[0][2] += a; v[0][3] += b;
-                unpack2h(s0[1], a, b); v[1][0] += a; v[1][1] += b;
-                unpack2h(s1[1], a, b); v[1][2] += a; v[1][3] += b;
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int h = 0; h < 2; ++h)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) v[h][r] = v[h][r] > 0.f ? v[h][r] : 0.f;
-            }
             if (p.out_f32) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -400,16 +465,7 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
                 }
             }
             f16_t* o16 = p.out_f32 ? p.out16_aux : reinterpret_cast<f16_t*>(out);
-            if (staged) {
-                // accumulator layout -> LDS [row][channel]; 16-byte chunks XOR-swizzled by row to spread the banks
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int r = (mp * 2 + h) * 16 + li;
-                    const int cb = nt * 32 + g * 8;  // byte offset of this quad inside the row
-                    const int off = r * WROW + ((((cb >> 4) ^ (r & (WROW / 16 - 1))) << 4) | (cb & 8));
-                    *reinterpret_cast<uint2*>(wave_stage + off) = make_uint2(pack2h(v[h][0], v[h][1]), pack2h(v[h][2], v[h][3]));
-                }
-            } else if (o16) {
+            if (o16) {
                 const uint2v s0 = __builtin_amdgcn_permlane16_swap(pack2h(v[0][0], v[0][1]), pack2h(v[1][0], v[1][1]), false, false);
                 const uint2v s1 = __builtin_amdgcn_permlane16_swap(pack2h(v[0][2], v[0][3]), pack2h(v[1][2], v[1][3]), false, false);
                 if (my_m < p.M) *reinterpret_cast<uint4*>(o16 + my_o) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
@@ -418,36 +474,13 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
         if constexpr (MT & 1) {  // unpaired last m-tile: accumulator layout, 8-byte accesses
             const int m = m0 + (MT - 1) * 16 + li;
             const size_t o = (size_t)m * p.N + nq;
-            float4v v = acc[nt][MT - 1];
-            if (p.res32 && m < p.M) v += *reinterpret_cast<const float4v*>(p.res32 + o);
-            if (p.res16) {
-                float a, b;
-                unpack2h(res[nt][MT / 2].x, a, b); v[0] += a; v[1] += b;
-                unpack2h(res[nt][MT / 2].y, a, b); v[2] += a; v[3] += b;
-            }
-            if (p.relu) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.f;
-            }
+            float4v v;
+            last_values(nt, v);
             if (m < p.M) {
                 if (p.out_f32) *reinterpret_cast<float4v*>(reinterpret_cast<float*>(out) + o) = v;
                 f16_t* o16 = p.out_f32 ? p.out16_aux : reinterpret_cast<f16_t*>(out);
                 if (o16) *reinterpret_cast<uint2*>(o16 + o) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
             }
-        }
-    }
-    if (staged) {
-        // read back row-contiguous: CPRW lanes cover one staged row, 64 / CPRW rows per store instruction
-        constexpr int CPRW = WROW / 16;         // 16-byte chunks per staged row (8 for BN = 128, 4 for BN = 64)
-        constexpr int RPI = 64 / CPRW;          // rows per instruction
-        const int c = lane % CPRW, r0 = lane / CPRW;
-        f16_t* o16 = reinterpret_cast<f16_t*>(out);
-#pragma unroll
-        for (int i = 0; i < 64 / RPI; ++i) {
-            const int r = r0 + i * RPI;
-            const uint4 v = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ (r & (CPRW - 1))) << 4));
-            const int m = m0 + r;
-            if (m < p.M) *reinterpret_cast<uint4*>(o16 + (size_t)m * p.N + n0 + c * 8) = v;
         }
     }
 }
@@ -643,8 +676,14 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     compute((nk - 1) & 1);
     // the stage buffer NOT used by the last k-step is free: each wave takes a private quarter of it for the output transpose
     unsigned char* wave_stage = nullptr;
-    if constexpr (MT == 4) {  // (single-k-step launches allocate ONE stage buffer: nothing free to stage through)
-        if (!(p.dbg & 32) && nk >= 2) wave_stage = smem + (((nk - 1) & 1) ^ 1) * STAGE_BYTES + wave * (64 * NT * 32);
+    // (single-k-step launches allocate ONE stage buffer: it is free once every wave has finished its fragment reads)
+    if (!(p.dbg & 32)) {
+        if (nk >= 2) {
+            wave_stage = smem + (((nk - 1) & 1) ^ 1) * STAGE_BYTES + wave * (64 * NT * 32);
+        } else {
+            __syncthreads();
+            wave_stage = smem + wave * (64 * NT * 32);
+        }
     }
     epilogue_regs<NT, MT>(p, out_ptr, acc, res, wm0, wn0, lane, wave_stage);
 #endif
