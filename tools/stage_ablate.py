@@ -3,7 +3,8 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from office_person_detection_vit_amd import _capi
-SHAPES = [("s2.c2 256->1024 +res", 8, 50, 84, 256, 1024, 1, 1, 1), ("s2b0.sc 512->1024 s2", 8, 100, 167, 512, 1024, 1, 2, 0),
+SHAPES = [("s0b0.sc 64->256", 8, 200, 334, 64, 256, 1, 1, 0), ("s0b0.c0 64->64", 8, 200, 334, 64, 64, 1, 1, 0),
+          ("s2.c2 256->1024 +res", 8, 50, 84, 256, 1024, 1, 1, 1), ("s2b0.sc 512->1024 s2", 8, 100, 167, 512, 1024, 1, 2, 0),
           ("s3.c2 512->2048 +res", 8, 25, 42, 512, 2048, 1, 1, 1), ("s3b0.sc 1024->2048 s2", 8, 50, 84, 1024, 2048, 1, 2, 0),
           ("s2.c0 1024->256", 8, 50, 84, 1024, 256, 1, 1, 0), ("s2.c1 3x3 256", 8, 50, 84, 256, 256, 3, 1, 0),
           ("s3.c0 2048->512", 8, 25, 42, 2048, 512, 1, 1, 0), ("s3.c1 3x3 512", 8, 25, 42, 512, 512, 3, 1, 0),
