@@ -22,6 +22,7 @@
 #ifndef OPD_DETR_H
 #define OPD_DETR_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -156,6 +157,12 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
  * descending score order at `nms_threshold` (pass >= 1 to disable).  Host-side, in place: compacts `dets[0..n)` and
  * returns the new count (>= 0) or a negative error. */
 int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold);
+
+/* Page-locked host memory for frame batches handed over with OPD_MEM_HOST: the upload of such a buffer is one asynchronous DMA
+ * instead of the runtime's staged copy of pageable memory.  Optional (any host pointer is accepted everywhere); the Python shim
+ * stacks the caller's frames (`detect_batch(frames: list[np.ndarray])`, the reference's calling convention) directly into it. */
+int opd_host_alloc(size_t bytes, void** out);
+void opd_host_free(void* p);
 
 /* "Next" row: replaces `SimilarityCalculator.compute_similarity_matrix` / `compute_distance_matrix`
  * (`src/tracking/similarity.py:42-220`), the tracker's cost matrix built right after the detect path:

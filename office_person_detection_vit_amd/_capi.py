@@ -59,6 +59,8 @@ API = {
                                         C.POINTER(OpdDet), C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "opd_detr_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_person_nms": (C.c_int, [C.POINTER(OpdDet), C.c_int, C.c_int, C.c_float]),
+    "opd_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "opd_host_free": (None, [C.c_void_p]),
     "opd_similarity_matrix": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "opd_detr_roi_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),

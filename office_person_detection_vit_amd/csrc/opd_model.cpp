@@ -1178,6 +1178,16 @@ int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, in
     return fetch_records(m, out, counts, mem_kind);
 }
 
+int opd_host_alloc(size_t bytes, void** out) {
+    if (!out || bytes == 0) return fail(OPD_EINVAL, "opd_host_alloc: null output or zero size");
+    *out = nullptr;
+    HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
+    return OPD_OK;
+}
+void opd_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
 int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold) {
     if (n < 0 || (n > 0 && !dets)) return fail(OPD_EINVAL, "opd_person_nms: bad arguments");
     std::vector<int> idx;

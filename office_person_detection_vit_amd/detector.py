@@ -76,6 +76,7 @@ class HipDetrDetector:
         device_resize: bool = True,
         use_graph: bool = True,
         streams: int = 1,
+        pinned_staging: bool = True,
     ):
         """
         Args mirror ``config.yaml.disabled:33-44`` (``model_name``, ``confidence_threshold``, ``nms_threshold``,
@@ -85,6 +86,8 @@ class HipDetrDetector:
         ``device``: ``"hip"``, ``"hip:N"``, ``"cuda"``, ``"cuda:N"`` or None (= GPU 0).  ``"cpu"``/``"mps"`` are refused.
         ``streams``: detector handles (each with its own HIP stream, workspace and weights copy) that
         ``detect_batch`` keeps busy at once when a call spans several ``max_batch`` chunks; 1 = strictly serial.
+        ``pinned_staging``: stack the caller's frames into page-locked memory (``opd_host_alloc``) so that the upload is
+        one DMA; False stacks into ordinary numpy memory.
         """
         self.model_name = model_name
         self.model_path = model_path
@@ -100,6 +103,8 @@ class HipDetrDetector:
         self.streams = max(1, int(streams))
         self.model: Optional[int] = None  # opaque opd_detr* once loaded (handle 0)
         self._handles: List[int] = []  # all handles, handle 0 first
+        self.pinned_staging = bool(pinned_staging)
+        self._staging: dict = {}  # handle slot -> (pinned pointer, capacity in bytes)
         self.feature_extractor = FeatureExtractor()
         self._lib = None
         self._info = None
@@ -164,6 +169,9 @@ class HipDetrDetector:
         if self._lib is not None:
             for h in self._handles:
                 self._lib.opd_detr_destroy(C.c_void_p(h))
+            for ptr, _ in self._staging.values():
+                self._lib.opd_host_free(C.c_void_p(ptr))
+        self._staging = {}
         self._handles = []
         self.model = None
 
@@ -178,7 +186,30 @@ class HipDetrDetector:
         if self.model is None:
             raise RuntimeError("Model not loaded. Call load_model() first.")
 
-    def _preprocess_batch(self, frames: Sequence[np.ndarray]):
+    def _stage_array(self, slot: int, shape: Tuple[int, ...]) -> np.ndarray:
+        """uint8 array of ``shape`` to stack a batch into: page-locked memory owned by handle ``slot`` (grown on demand,
+        freed in ``close``; valid until the slot's next batch), or plain numpy memory without ``pinned_staging``."""
+        n = int(np.prod(shape))
+        if not self.pinned_staging or self._lib is None:
+            return np.empty(shape, np.uint8)
+        ptr, cap = self._staging.get(slot, (None, 0))
+        if cap < n:
+            if ptr:
+                self._lib.opd_host_free(C.c_void_p(ptr))
+                self._staging.pop(slot)
+            p = C.c_void_p()
+            _capi.check(self._lib.opd_host_alloc(n, C.byref(p)), "opd_host_alloc")
+            ptr, cap = p.value, n
+            self._staging[slot] = (ptr, cap)
+        return np.ctypeslib.as_array((C.c_uint8 * n).from_address(ptr)).reshape(shape)
+
+    def _stack(self, slot: int, frames: Sequence[np.ndarray]) -> np.ndarray:
+        batch = self._stage_array(slot, (len(frames),) + tuple(frames[0].shape))
+        for i, f in enumerate(frames):
+            batch[i] = f
+        return batch
+
+    def _preprocess_batch(self, frames: Sequence[np.ndarray], slot: int = 0):
         """Host part of ``_preprocess_batch`` (deleted vit_detector.py 562-578): validate, resize to the model size,
         stack to one contiguous uint8 [B,H,W,3] BGR block.  BGR->RGB, 1/255 and mean/std run on the device.
 
@@ -200,7 +231,7 @@ class HipDetrDetector:
         if self.resize and self.device_resize and len(set(orig)) == 1:
             th, tw = model_input_size(orig[0][0], orig[0][1], self.max_size[0], self.max_size[1])
             if (th, tw) != orig[0]:
-                return np.ascontiguousarray(np.stack(frames)), orig, None, (th, tw)
+                return self._stack(slot, frames), orig, None, (th, tw)
         for f in frames:
             if self.resize:
                 th, tw = model_input_size(f.shape[0], f.shape[1], self.max_size[0], self.max_size[1])
@@ -208,11 +239,12 @@ class HipDetrDetector:
             out.append(f)
         shapes = {o.shape for o in out}
         if len(shapes) == 1:
-            return np.ascontiguousarray(np.stack(out)), orig, None, None
+            return self._stack(slot, out), orig, None, None
         H, W = max(o.shape[0] for o in out), max(o.shape[1] for o in out)
         if H > self.max_size[0] or W > self.max_size[1]:
             raise ValueError(f"ragged batch canvas {H}x{W} exceeds the configured maximum {self.max_size}")
-        canvas = np.zeros((len(out), H, W, 3), np.uint8)
+        canvas = self._stage_array(slot, (len(out), H, W, 3))
+        canvas[...] = 0
         for i, o in enumerate(out):
             canvas[i, :o.shape[0], :o.shape[1]] = o
         valid = np.asarray([[o.shape[0], o.shape[1]] for o in out], dtype=np.int32)
@@ -249,7 +281,7 @@ class HipDetrDetector:
 
     def _detect_records(self, frames: Sequence[np.ndarray], handle: Optional[int] = None):
         model = self.model if handle is None else handle
-        batch, orig, valid, target = self._preprocess_batch(frames)
+        batch, orig, valid, target = self._preprocess_batch(frames, self._handles.index(model))
         B, H, W, _ = batch.shape
         Q = self._info.num_queries
         recs = (_capi.OpdDet * (B * Q))()

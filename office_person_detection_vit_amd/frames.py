@@ -41,7 +41,8 @@ def structured_frame(height: int, width: int, seed: int, cell: int = 32, rects: 
         y = int(rng.integers(0, max(1, height - rh)))
         x = int(rng.integers(0, max(1, width - rw)))
         img[y:y + rh, x:x + rw, :] = rng.random(3, dtype=np.float32)
-    return np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8)
+    # C-contiguous like a decoded camera frame (the up-sampling above leaves a transposed view behind)
+    return np.ascontiguousarray(np.clip(np.rint(img * 255.0), 0, 255).astype(np.uint8))
 
 
 def structured_frames(n: int, height: int, width: int, seed: int = 1234) -> list:

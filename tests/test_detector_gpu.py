@@ -442,9 +442,10 @@ def test_async_host_buffers_equal_blocking_detect(detectors):
 
 def test_multi_handle_detect_batch_equals_serial(weight_cache):
     """HipDetrDetector(streams=3): chunks of one detect_batch call overlap on three handles (worker threads, own HIP streams)
-    and return exactly the serial detector's detections, frame for frame, for both the canvas and the device-resize path."""
+    and return exactly the serial detector's detections, frame for frame, for both the canvas and the device-resize path
+    (the serial one stacks into pageable numpy memory, the other into the page-locked staging of ``opd_host_alloc``)."""
     path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
-    serial = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=True)
+    serial = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=True, pinned_staging=False)
     multi = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=True, streams=3)
     serial.load_model(); multi.load_model()
     try:

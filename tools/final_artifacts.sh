@@ -16,4 +16,5 @@ timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv 
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 > $O/pmc_write.log 2>&1 &&
 cd $R &&
 OPD_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_gloo2.json 2> $O/bench_gloo2.err && tail -1 $O/bench_gloo2.json | cut -c1-300 &&
+timeout -k 10 300 python tools/host_rate.py 96 > $O/host_rate.txt 2>&1 && timeout -k 10 300 python tools/host_rate.py 96 720 1280 >> $O/host_rate.txt 2>&1 && cat $O/host_rate.txt &&
 find $O -name "*.csv" | head -30 && du -sh $O
