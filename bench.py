@@ -70,6 +70,7 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
+    ap.add_argument("--arch", choices=["r50", "r101"], default="r50", help="backbone depth (r101 = BASELINE configs[3]; not the headline workload)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("OPD_BENCH_STREAMS", "3")),
                     help="detector handles (own stream, workspace and graph each) that take the steps in turn: with 2 the low-"
@@ -107,11 +108,12 @@ def main() -> None:
 
     B, H, W = args.batch, args.height, args.width
     cache = os.environ.get("OPD_WEIGHT_CACHE", "/tmp/opd_weights")
+    arch = DetrArch.resnet101() if args.arch == "r101" else DetrArch.resnet50()
     if rank == 0:
-        path = ensure_weight_file(cache, DetrArch.resnet50(), 0, 1.0, "r50")
+        path = ensure_weight_file(cache, arch, 0, 1.0, args.arch)
     if world > 1:
         dist.barrier()
-    path = ensure_weight_file(cache, DetrArch.resnet50(), 0, 1.0, "r50")
+    path = ensure_weight_file(cache, arch, 0, 1.0, args.arch)
 
     lib = _capi.load_library()
     cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
@@ -234,7 +236,7 @@ def main() -> None:
         # in separate runs, gfx950 x2 fetch correction: tools/pmc_traffic.py) — valid for the default 8 x 800x1333 workload
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-        if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333):
+        if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333) and args.arch == "r50":
             traffic = round(json.load(open(tpath))["conv_gemm_family"]["bytes_per_launch"])
         roof = {"bound": "mfma", "kernel": "implicit-GEMM family (conv_gemm_dma_kernel, btail_kernel, gemm_ln256_kernel, gemm_k256_kernel, stem_pool2_kernel)", "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
@@ -247,11 +249,11 @@ def main() -> None:
     fps = total_frames / elapsed
     if rank == 0:
         out = {
-            "metric": "frames/sec (Phase-2 DETR detect) at 800x1333 batch 8",
+            "metric": f"frames/sec (Phase-2 DETR detect) at {H}x{W} batch {B}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": f"facebook/detr-resnet-50 architecture (seeded synthetic weights), batch {B} per GPU, "
+            "config": {"workload": f"facebook/detr-resnet-{50 if args.arch == 'r50' else 101} architecture (seeded synthetic weights), batch {B} per GPU, "
                                    f"{H}x{W} uint8 BGR frames resident in HBM, forward + device post-process, "
                                    + ("blocking steps" if args.sync_steps else
                                       f"steps submitted asynchronously over {NS} detector handle(s), every step's records fetched to host")
@@ -263,12 +265,12 @@ def main() -> None:
             "stage_ms": stage_ms,
             "detections_last_step": int(np.asarray(counts).sum()),
         }
-        if (H, W) == (800, 1333) and roof is not None:
+        if (H, W) == (800, 1333) and args.arch == "r50" and roof is not None:
             # SURVEY.md section 8(d) headline: the whole path's algorithmic FLOPs (203.2 GFLOP per r50 frame at 800x1333) x frames/s
             # per GPU against the dense MFMA peak; this one includes every gap, the attention, pre- and post-processing
             path_tf = 203.2e9 * fps / world / 1e12
             roof["whole_path"] = {"flops_per_frame": 203.2e9, "achieved": round(path_tf, 2), "frac": round(path_tf / PEAK_MFMA_TFLOPS, 4)}
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.arch == "r50":
             out["cpu_baseline"] = cpu_baseline(path, H, W)
             out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), flush=True)

@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <memory>
+#include <mutex>
+#include <shared_mutex>
 #include <string>
 #include <vector>
 
@@ -826,6 +828,26 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     return OPD_OK;
 }
 
+// Stream capture and other threads: the Python shim drives several handles from worker threads (HipDetrDetector(streams=N)).
+// ROCm invalidates a capture in progress when ANOTHER thread allocates or frees memory, pins host memory or runs its
+// one-time eager setup meanwhile, even in thread-local capture mode ("operation failed due to a previous error during
+// capture").  Every entry point therefore holds this lock shared; a capture takes it exclusively for its few milliseconds.
+static std::shared_mutex g_api_mu;
+static thread_local std::shared_lock<std::shared_mutex>* tl_api_lock = nullptr;
+struct ApiScope {   // first statement of every HIP-calling entry point; entry points calling each other nest harmlessly
+    std::shared_lock<std::shared_mutex> lk;
+    bool outer;
+    ApiScope() : lk(g_api_mu, std::defer_lock), outer(tl_api_lock == nullptr) {
+        if (outer) { lk.lock(); tl_api_lock = &lk; }
+    }
+    ~ApiScope() { if (outer) tl_api_lock = nullptr; }
+};
+struct CaptureExclusive {   // the calling thread's shared hold is handed back for the duration
+    std::shared_lock<std::shared_mutex>* s;
+    CaptureExclusive() : s(tl_api_lock) { if (s) s->unlock(); g_api_mu.lock(); }
+    ~CaptureExclusive() { g_api_mu.unlock(); if (s) s->lock(); }
+};
+
 // Forward through the graph cache.  First call of a (shape, pixel pointer) key runs eagerly (one-time function-attribute
 // setup and plan building are not capturable); the second call captures the stream into a hipGraph; later calls replay it.
 static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw = nullptr) {
@@ -850,9 +872,14 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
     }
     if (e->uses++ == 0) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
     hipGraph_t graph = nullptr;
-    HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
-    const int rc = enqueue_forward(m, d_pixels, pixel_format, B, H, W);
-    const hipError_t ec = hipStreamEndCapture(m->stream, &graph);
+    int rc;
+    hipError_t ec;
+    {
+        CaptureExclusive alone;
+        HIPCHK(hipStreamBeginCapture(m->stream, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_forward(m, d_pixels, pixel_format, B, H, W);
+        ec = hipStreamEndCapture(m->stream, &graph);
+    }
     if (rc != OPD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
     if (ec != hipSuccess || !graph) {  // capture refused: stay eager for this key
         e->uses = -1000000;
@@ -986,6 +1013,7 @@ const char* opd_last_error(void) { return opd::g_err.c_str(); }
 const char* opd_version(void) { return "opd_hip 0.1 gfx950 (fp16 MFMA, fp32 accumulate)"; }
 
 int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out) {
+    ApiScope api_scope;
     if (!cfg || !weights_path || !out) return fail(OPD_EINVAL, "opd_detr_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(opd_config)) return fail(OPD_EINVAL, "opd_config.struct_size mismatch");
     if (cfg->max_batch < 1 || cfg->max_height < 32 || cfg->max_width < 32) return fail(OPD_EINVAL, "opd_config maxima must be >= 1 x 32 x 32");
@@ -1023,6 +1051,7 @@ int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_
 }
 
 void opd_detr_destroy(opd_detr* m) {
+    ApiScope api_scope;
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
@@ -1069,10 +1098,12 @@ static int forward_device(opd_detr* m, const void* d_pixels, int pixel_format, i
 }
 int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float* logits,
                      float* boxes, float* enc_features) {
+    ApiScope api_scope;
     return opd_detr_forward_ragged(m, pixels, pixel_format, mem_kind, B, H, W, nullptr, logits, boxes, enc_features);
 }
 int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                             const int32_t* valid_hw, float* logits, float* boxes, float* enc_features) {
+    ApiScope api_scope;
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
@@ -1080,6 +1111,7 @@ int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, i
     return forward_device(m, d_pixels, pixel_format, mem_kind, B, H, W, valid_hw, logits, boxes, enc_features);
 }
 int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts) {
+    ApiScope api_scope;
     if (!m || !out || !counts) return fail(OPD_EINVAL, "opd_detr_postprocess: null argument");
     if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_postprocess called before any forward");
     HIPCHK(hipSetDevice(m->device));
@@ -1087,6 +1119,7 @@ int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, o
     return fetch_records(m, out, counts, OPD_MEM_HOST);
 }
 int opd_detr_resize_u8(opd_detr* m, const uint8_t* frames, int B, int h, int w, int out_h, int out_w, uint8_t* out) {
+    ApiScope api_scope;
     if (!m) return fail(OPD_EINVAL, "null model handle");
     if (!frames || !out) return fail(OPD_EINVAL, "opd_detr_resize_u8: null buffer");
     uint8_t dummy = 0;
@@ -1099,6 +1132,7 @@ int opd_detr_resize_u8(opd_detr* m, const uint8_t* frames, int B, int h, int w, 
 }
 int opd_detr_forward_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float* logits,
                              float* boxes, float* enc_features) {
+    ApiScope api_scope;
     if (!m) return fail(OPD_EINVAL, "null model handle");
     RCCHK(check_shape(m, frames, OPD_PIXELS_U8_BGR_HWC, mem_kind, B, H, W));
     HIPCHK(hipSetDevice(m->device));
@@ -1107,10 +1141,12 @@ int opd_detr_forward_resized(opd_detr* m, const uint8_t* frames, int mem_kind, i
 }
 int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
                     const int32_t* orig_hw, opd_det* out, int32_t* counts) {
+    ApiScope api_scope;
     return opd_detr_detect_ragged(m, pixels, pixel_format, mem_kind, B, H, W, nullptr, threshold, orig_hw, out, counts);
 }
 int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                            const int32_t* valid_hw, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts) {
+    ApiScope api_scope;
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect: null output buffer");
     HIPCHK(hipSetDevice(m->device));
@@ -1123,6 +1159,7 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
 }
 int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
                           const int32_t* orig_hw, opd_det* out, int32_t* counts, int* ticket) {
+    ApiScope api_scope;
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     if (!out || !counts || !ticket) return fail(OPD_EINVAL, "opd_detr_detect_async: null argument");
     if (m->profiling) return fail(OPD_ESTATE, "opd_detr_detect_async is not available in profiling mode");
@@ -1150,6 +1187,7 @@ int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int
     return OPD_OK;
 }
 int opd_detr_wait(opd_detr* m, int ticket) {
+    ApiScope api_scope;
     if (!m || ticket < 0 || ticket > 3 || !m->ev_async[ticket]) return fail(OPD_EINVAL, "opd_detr_wait: bad handle or ticket");
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipEventSynchronize(m->ev_async[ticket]));
@@ -1165,6 +1203,7 @@ int opd_detr_wait(opd_detr* m, int ticket) {
 }
 int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float threshold,
                             opd_det* out, int32_t* counts) {
+    ApiScope api_scope;
     if (!m) return fail(OPD_EINVAL, "null model handle");
     RCCHK(check_shape(m, frames, OPD_PIXELS_U8_BGR_HWC, mem_kind, B, H, W));
     if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect_resized: null output buffer");
@@ -1179,12 +1218,14 @@ int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, in
 }
 
 int opd_host_alloc(size_t bytes, void** out) {
+    ApiScope api_scope;
     if (!out || bytes == 0) return fail(OPD_EINVAL, "opd_host_alloc: null output or zero size");
     *out = nullptr;
     HIPCHK(hipHostMalloc(out, bytes, hipHostMallocDefault));
     return OPD_OK;
 }
 void opd_host_free(void* p) {
+    ApiScope api_scope;
     if (p) (void)hipHostFree(p);
 }
 
@@ -1221,6 +1262,7 @@ int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold) 
 int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* boxes1, const uint8_t* has1, int n1,
                           const float* feats2, const float* boxes2, const uint8_t* has2, int n2, int D, double appearance_weight,
                           double motion_weight, int as_distance, float* out) {
+    ApiScope api_scope;
     if (n1 < 0 || n2 < 0 || D < 1) return fail(OPD_EINVAL, "opd_similarity_matrix: bad sizes");
     if (n1 == 0 || n2 == 0) return OPD_OK;
     if (!boxes1 || !boxes2 || !out) return fail(OPD_EINVAL, "opd_similarity_matrix: null boxes / output");
@@ -1255,6 +1297,7 @@ int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* 
 }
 
 int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n, int orig_h, int orig_w, float* features) {
+    ApiScope api_scope;
     if (!m || (n > 0 && (!boxes_xywh || !features))) return fail(OPD_EINVAL, "opd_detr_roi_features: null argument");
     if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_roi_features called before any forward");
     if (frame < 0 || frame >= m->last_B || n < 0 || n > 128 || orig_h <= 0 || orig_w <= 0)
@@ -1286,12 +1329,14 @@ int opd_detr_set_profiling(opd_detr* m, int enabled) {
 }
 
 int opd_detr_stage_times(const opd_detr* m, float* ms8) {
+    ApiScope api_scope;
     if (!m || !ms8) return fail(OPD_EINVAL, "opd_detr_stage_times: null argument");
     for (int i = 0; i < 8; ++i) ms8[i] = m->stage_ms[i];
     return OPD_OK;
 }
 
 int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, double* flops4) {
+    ApiScope api_scope;
     if (!m || !ms4 || !launches4 || !flops4) return fail(OPD_EINVAL, "opd_detr_kernel_times: null argument");
     for (int i = 0; i < 4; ++i) { ms4[i] = m->class_ms[i]; launches4[i] = m->class_launches[i]; flops4[i] = m->class_flops[i]; }
     return OPD_OK;

@@ -17,4 +17,6 @@ timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv 
 cd $R &&
 OPD_BENCH_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_gloo2.json 2> $O/bench_gloo2.err && tail -1 $O/bench_gloo2.json | cut -c1-300 &&
 timeout -k 10 300 python tools/host_rate.py 96 > $O/host_rate.txt 2>&1 && timeout -k 10 300 python tools/host_rate.py 96 720 1280 >> $O/host_rate.txt 2>&1 && cat $O/host_rate.txt &&
+timeout -k 10 300 python bench.py --arch r101 --height 1066 --width 1920 --no-cpu-baseline > $O/bench_r101_1066x1920.json 2> $O/bench_r101.err && cut -c1-200 $O/bench_r101_1066x1920.json &&
+timeout -k 10 300 python bench.py --height 1080 --width 1920 --batch 4 --no-cpu-baseline > $O/bench_r50_tile1080p_b4.json 2> $O/bench_tile.err && cut -c1-200 $O/bench_r50_tile1080p_b4.json &&
 find $O -name "*.csv" | head -30 && du -sh $O
