@@ -411,10 +411,14 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
         constexpr int RPI = 64 / CPRW;          // rows per store instruction
         const int c = lane % CPRW, r0 = lane / CPRW;
         f16_t* o16 = reinterpret_cast<f16_t*>(out);
+        // chunk swizzle: 128-byte rows take r & 7; two 64-byte rows share one 128-byte bank line, so there the row's low bit
+        // already separates the halves and bits 1..2 pick the chunk (r & 3 left the 8-byte writes of a half-wave on 8 of the
+        // 16 bank granules: SQ_LDS_BANK_CONFLICT 12 cycles per LDS instruction on the 64-channel tiles, tools/pmc_one_layer.sh)
+        auto row_swz = [](const int r) { return CPRW == 8 ? (r & 7) : ((r >> 1) & (CPRW - 1)); };
         auto stage_quad = [&](const int nt, const int slot, const float4v& v) {
             const int r = slot * 16 + li;
             const int cb = nt * 32 + g * 8;  // byte offset of this quad inside the row
-            const int off = r * WROW + ((((cb >> 4) ^ (r & (WROW / 16 - 1))) << 4) | (cb & 8));
+            const int off = r * WROW + ((((cb >> 4) ^ row_swz(r)) << 4) | (cb & 8));
             *reinterpret_cast<uint2*>(wave_stage + off) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
         };
 #pragma unroll
@@ -438,7 +442,7 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
 #pragma unroll
             for (int i = 0; i < gt * 16 / RPI; ++i) {
                 const int r = r0 + i * RPI;
-                const uint4 v = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ (r & (CPRW - 1))) << 4));
+                const uint4 v = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ row_swz(r)) << 4));
                 const int m = m0 + g0 * 16 + r;
                 if (m < p.M) *reinterpret_cast<uint4*>(o16 + (size_t)m * p.N + n0 + c * 8) = v;
             }

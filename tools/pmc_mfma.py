@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Per-kernel SQ picture of ONE forward from a rocprofv3 --pmc pass of bench.py (SQ block only, 8 counters):
+MFMA pipe utilisation, what the waves do with their cycles, LDS bank conflicts.
+
+  rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY \
+            SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d DIR -- python3 bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline
+
+Units (MI355X_MICROARCH.md): SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
+(cycles), the wave counters are quad-cycles summed over waves.  MFMA utilisation = MFMA_BUSY / (1024 x kernel cycles) with
+kernel cycles = SQ_BUSY_CYCLES / 32.
+usage: pmc_mfma.py <counter_collection.csv>"""
+import collections, csv, sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+ids = sorted({int(r["Dispatch_Id"]) for r in rows})
+by = collections.defaultdict(dict)
+name, dur = {}, {}
+for r in rows:
+    d = int(r["Dispatch_Id"])
+    by[d][r["Counter_Name"]] = float(r["Counter_Value"])
+    n = r["Kernel_Name"]
+    name[d] = (n[n.find("::") + 2:] if "::" in n else n).split("(")[0]
+    dur[d] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
+start = max(d for d in ids if "preprocess_u8" in name[d])   # last forward of the trace
+agg = collections.OrderedDict()
+for d in ids:
+    if d < start:
+        continue
+    a = agg.setdefault(name[d], collections.defaultdict(float))
+    a["n"] += 1; a["us"] += dur[d]
+    for k, v in by[d].items():
+        a[k] += v
+print(f"{'kernel':40s} {'n':>3s} {'us':>8s} {'MFMA util':>9s} {'active':>7s} {'wait':>6s} {'issue-stall':>11s} {'LDS conflict / LDS active':>26s}")
+tot_mfma = tot_cyc = 0.0
+for k, a in agg.items():
+    cyc = a["SQ_BUSY_CYCLES"] / 32.0
+    util = a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc) if cyc else 0.0
+    wc = a["SQ_WAVE_CYCLES"] or 1.0
+    lds = a["SQ_LDS_BANK_CONFLICT"] / a["SQ_ACTIVE_INST_LDS"] if a["SQ_ACTIVE_INST_LDS"] else 0.0
+    tot_mfma += a["SQ_VALU_MFMA_BUSY_CYCLES"]; tot_cyc += cyc
+    print(f"{k:40s} {int(a['n']):3d} {a['us']:8.1f} {100 * util:8.1f}% {100 * a['SQ_ACTIVE_INST_ANY'] / wc:6.1f}% {100 * a['SQ_WAIT_ANY'] / wc:5.1f}% "
+          f"{100 * a['SQ_WAIT_INST_ANY'] / wc:10.1f}% {100 * lds:25.1f}%")
+print(f"whole forward: MFMA pipes busy {100 * tot_mfma / (1024.0 * tot_cyc):.1f} % of the kernel cycles")

@@ -5,13 +5,16 @@ R=$PWD; O=$R/gpurun_out/pmc1; mkdir -p $O; export TMPDIR=/tmp; cd /tmp
 run() {  # tag counter args...
   tag=$1; ctr=$2; shift 2
   timeout -k 10 120 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d $O/$tag -- python3 $R/tools/one_layer.py "$@" > $O/$tag.log 2>&1 || return 1
-  python3 - "$O/$tag" "$ctr" "$tag" <<'PY'
-import csv,glob,sys
+  python3 - "$O/$tag" "$tag" <<'PY'
+import csv,glob,sys,collections
 f=glob.glob(sys.argv[1]+'/*/*_counter_collection.csv')[0]
-v=[float(r['Counter_Value']) for r in csv.DictReader(open(f)) if r['Counter_Name']==sys.argv[2] and 'conv_gemm' in r['Kernel_Name']]
-print(sys.argv[3], sys.argv[2], 'launches', len(v), 'MiB/launch (raw)', round(sum(v[2:])/max(len(v)-2,1)/1024,2), flush=True)
+acc=collections.defaultdict(list)
+for r in csv.DictReader(open(f)):
+    if 'conv_gemm' in r['Kernel_Name']: acc[r['Counter_Name']].append(float(r['Counter_Value']))
+print(sys.argv[2], ' '.join(f"{k}={sum(v[2:])/max(len(v)-2,1):.0f}" for k,v in sorted(acc.items())), flush=True)
 PY
 }
+
 if [ $# -gt 0 ]; then
   # usage: pmc_one_layer.sh tag COUNTER one_layer-args...   (several triples separated by --)
   while [ $# -gt 0 ]; do
