@@ -22,7 +22,13 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 namespace {
 
-constexpr int LDS_ROW = 80;  // bytes per key row in LDS (64 payload + 16 pad; 16-byte aligned)
+constexpr int LDS_ROW = 80;  // bytes per K row in LDS (64 payload + 16 pad): 16-byte fragment reads of 16 rows hit 16 distinct slots
+// V rows are read 4 rows x 32 bytes per 16 lanes by ds_read_b64_tr_b16: a 96-byte stride tiles those four pieces over the
+// 128-byte bank line exactly (80 bytes leaves rows 0 and 3 overlapping); measured: attention -1 %, the loop is not LDS bound
+#ifndef OPD_ATTN_V_ROW
+#define OPD_ATTN_V_ROW 96
+#endif
+constexpr int V_ROW = OPD_ATTN_V_ROW;
 
 __device__ __forceinline__ half4 lds_tr16(const unsigned char* p) {
     short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -39,8 +45,8 @@ __device__ __forceinline__ half4 lds_tr16(const unsigned char* p) {
 template <bool TR, bool MASKED, int KT>
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     constexpr int NKT = KT / 16;              // 16-key score tiles per LDS tile
-    constexpr int TILE_BYTES = KT * LDS_ROW;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 2 * TILE_BYTES];  // [buf][K|V]
+    constexpr int K_BYTES = KT * LDS_ROW, TILE_BYTES = KT * (LDS_ROW + V_ROW);   // one buffer = K tile then V tile
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];  // [buf][K|V]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
@@ -81,11 +87,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         }
     };
     auto store_tile = [&](int buf) {
-        unsigned char* base = lds + buf * 2 * TILE_BYTES;
+        unsigned char* base = lds + buf * TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             *reinterpret_cast<uint4*>(base + (i * 64 + skey) * LDS_ROW + schunk * 16) = rk[i];
-            *reinterpret_cast<uint4*>(base + TILE_BYTES + (i * 64 + skey) * LDS_ROW + schunk * 16) = rv[i];
+            *reinterpret_cast<uint4*>(base + K_BYTES + (i * 64 + skey) * V_ROW + schunk * 16) = rv[i];
         }
     };
 
@@ -105,8 +111,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) load_tile(t + 1);
-        const unsigned char* Kl = lds + buf * 2 * TILE_BYTES;
-        const unsigned char* Vl = Kl + TILE_BYTES;
+        const unsigned char* Kl = lds + buf * TILE_BYTES;
+        const unsigned char* Vl = Kl + K_BYTES;
 
         // ---- S^T = K Q^T ----------------------------------------------------------------------------------------
         float4v s[NKT];
@@ -177,16 +183,16 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             for (int dt = 0; dt < 2; ++dt) {
                 half8 vf;
                 if (TR) {
-                    const unsigned char* a0 = Vl + (kb * 32 + g * 4 + (li >> 2)) * LDS_ROW + (dt * 16 + (li & 3) * 4) * 2;
+                    const unsigned char* a0 = Vl + (kb * 32 + g * 4 + (li >> 2)) * V_ROW + (dt * 16 + (li & 3) * 4) * 2;
                     const half4 lo = lds_tr16(a0);
-                    const half4 hi = lds_tr16(a0 + 16 * LDS_ROW);
+                    const half4 hi = lds_tr16(a0 + 16 * V_ROW);
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
                 } else {
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const int key = kb * 32 + (j < 4 ? g * 4 + j : 16 + g * 4 + (j - 4));
-                        vf[j] = *reinterpret_cast<const _Float16*>(Vl + key * LDS_ROW + (dt * 16 + li) * 2);
+                        vf[j] = *reinterpret_cast<const _Float16*>(Vl + key * V_ROW + (dt * 16 + li) * 2);
                     }
                 }
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
