@@ -6,10 +6,11 @@
 
 from .data_models import Detection  # noqa: F401
 from .detector import HipDetrDetector, model_input_size  # noqa: F401
+from .evaluation import DetectionEvaluator, evaluate_detections  # noqa: F401
 from .export import detections_to_coco, write_coco  # noqa: F401
 from .feature_extractor import FeatureExtractor  # noqa: F401
 from .similarity import SimilarityCalculator  # noqa: F401
 from .tiling import TiledDetector  # noqa: F401
 
 __all__ = ["Detection", "HipDetrDetector", "FeatureExtractor", "SimilarityCalculator", "TiledDetector", "detections_to_coco", "write_coco",
-           "model_input_size"]
+           "model_input_size", "DetectionEvaluator", "evaluate_detections"]

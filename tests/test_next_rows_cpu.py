@@ -99,3 +99,48 @@ def test_tile_grid_and_merge():
     assert [len(r) for r in res] == [4, 4] and res[1][0].bbox == (5.0, 6.0, 3.0, 4.0)
     with pytest.raises(ValueError):
         tile_grid(1, 5, 2, 2)
+
+
+def test_evaluator_matches_reference_class(golden_dir):
+    """evaluation.py::DetectionEvaluator against the reference's DetectionBenchmark.evaluate (tests/golden/evaluation.json,
+    tools/gen_golden.py evaluation): counts exactly, every float to 1e-12, for both prediction layouts and four threshold pairs."""
+    import json
+    from office_person_detection_vit_amd.evaluation import DetectionEvaluator, evaluate_detections
+    g = json.load(open(os.path.join(golden_dir, "evaluation.json"), encoding="utf-8"))
+    assert len(g["runs"]) == 8
+    for run in g["runs"]:
+        pred = g["pred_coco"] if run["layout"] == "coco" else g["pred_frames"]
+        got = DetectionEvaluator(run["iou_threshold"], run["confidence_threshold"]).evaluate(g["ground_truth"], pred).to_dict()
+        want = run["metrics"]
+        assert set(got) == set(want)
+        for k, v in want.items():
+            if isinstance(v, int):
+                assert got[k] == v, (run, k)
+            else:
+                assert abs(got[k] - v) <= 1e-12, (run, k, got[k], v)
+    m = evaluate_detections(g["ground_truth"], g["pred_coco"])
+    assert m.true_positives + m.false_negatives == m.gt_count and "AP@50" in m.summary()
+    # the exporter's own fixture was scored by the reference class when it was generated: same numbers from this evaluator
+    e = json.load(open(os.path.join(golden_dir, "coco_export.json"), encoding="utf-8"))
+    got = evaluate_detections(e["ground_truth"], e["prediction"]).to_dict()
+    for k, v in e["metrics"].items():
+        assert got[k] == pytest.approx(v, abs=1e-12), k
+
+
+def test_evaluator_edge_cases():
+    from office_person_detection_vit_amd.evaluation import DetectionEvaluator, average_precision_11pt, box_iou_xywh, match_image
+    ev = DetectionEvaluator()
+    empty = ev.evaluate({"annotations": []}, {"annotations": []})
+    assert (empty.precision, empty.recall, empty.ap, empty.num_images) == (0.0, 0.0, 0.0, 0)
+    gt = {"annotations": [{"image_id": 0, "category_id": 0, "bbox": [0, 0, 10, 10]}]}
+    miss = ev.evaluate(gt, {"annotations": []})
+    assert (miss.false_negatives, miss.recall, miss.ap_50) == (1, 0.0, 0.0)
+    hit = ev.evaluate(gt, {"annotations": [{"image_id": 0, "category_id": 0, "bbox": [0, 0, 10, 10], "score": 0.9},
+                                           {"image_id": 0, "category_id": 0, "bbox": [0, 0, 10, 10], "score": 0.8}]})
+    assert (hit.true_positives, hit.false_positives, hit.precision, hit.recall) == (1, 1, 0.5, 1.0)   # the duplicate is a false positive
+    assert abs(hit.ap_50 - 1.0) < 1e-12 and abs(hit.ap - 1.0) < 1e-12
+    assert box_iou_xywh([0, 0, 10, 10], [5, 0, 10, 10]) == pytest.approx(1 / 3) and box_iou_xywh([0, 0, 0, 0], [0, 0, 0, 0]) == 0.0
+    assert box_iou_xywh([0, 0, 1], [0, 0, 1, 1]) == 0.0
+    tps, fps, missed = match_image([{"bbox": [0, 0, 10, 10]}, {"bbox": [20, 0, 10, 10]}], [{"bbox": [1, 0, 10, 10], "score": 0.5}], 0.5)
+    assert len(tps) == 1 and fps == [] and missed == 1
+    assert average_precision_11pt([]) == 0.0 and average_precision_11pt([(0.9, False)]) == 0.0

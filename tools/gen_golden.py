@@ -170,6 +170,54 @@ def similarity_and_export_case():
     print("coco export:", type(ev).__name__, m.precision, m.recall, m.true_positives, m.false_positives, m.false_negatives)
 
 
+def evaluation_case():
+    """Next row (accuracy harness): the reference's DetectionBenchmark.evaluate on seeded ground truth and
+    predictions (jittered boxes, duplicates, score ties, low-confidence clutter, images without one side, a non-person category)
+    at several (IoU, confidence) settings, in both prediction layouts it accepts."""
+    bench = _load_ref("ref_detection_benchmark", "src/evaluation/detection_benchmark.py")
+    rng = np.random.default_rng(23)
+    gt_ann, pred_ann, frames = [], [], []
+    aid = 0
+    for img in range(7):
+        n = int(rng.integers(0, 6)) if img != 5 else 0          # image 5 has predictions only
+        boxes = []
+        for _ in range(n):
+            x, y = float(rng.uniform(0, 1000)), float(rng.uniform(0, 500))
+            w, h = float(rng.uniform(40, 160)), float(rng.uniform(80, 220))
+            boxes.append([x, y, w, h])
+            gt_ann.append({"id": aid, "image_id": img, "category_id": 0, "bbox": [x, y, w, h], "area": w * h, "iscrowd": 0}); aid += 1
+        if img == 2:   # a ground-truth box of another category: ignored by the evaluator
+            gt_ann.append({"id": aid, "image_id": img, "category_id": 3, "bbox": [10.0, 10.0, 50.0, 50.0], "area": 2500.0, "iscrowd": 0}); aid += 1
+        dets = []
+        if img != 6:   # image 6 has ground truth only
+            for b in boxes:
+                if rng.random() < 0.85:
+                    j = rng.normal(0, [6, 6, 10, 14])
+                    dets.append(([b[0] + j[0], b[1] + j[1], max(8.0, b[2] + j[2]), max(8.0, b[3] + j[3])], round(float(rng.uniform(0.3, 0.99)), 2)))
+                if rng.random() < 0.3:   # a duplicate of the same person, shifted
+                    dets.append(([b[0] + 15.0, b[1] - 10.0, b[2], b[3]], round(float(rng.uniform(0.2, 0.8)), 2)))
+            for _ in range(int(rng.integers(0, 3))):   # clutter
+                dets.append(([float(rng.uniform(0, 1100)), float(rng.uniform(0, 600)), float(rng.uniform(30, 120)), float(rng.uniform(60, 200))],
+                             round(float(rng.uniform(0.05, 0.6)), 2)))
+        for k, (bb, sc) in enumerate(dets):
+            bb = [float(v) for v in bb]
+            pred_ann.append({"id": len(pred_ann), "image_id": img, "category_id": 0, "bbox": bb, "score": sc})
+        frames.append({"frame_idx": img, "det": [{"bb": [float(v) for v in bb], "conf": sc} for bb, sc in dets]})
+    pred_ann.append({"id": len(pred_ann), "image_id": 1, "category_id": 2, "bbox": [5.0, 5.0, 40.0, 90.0], "score": 0.99})   # other category
+    gt = {"images": [{"id": i, "file_name": f"{i}.jpg", "width": 1280, "height": 720} for i in range(7)],
+          "categories": [{"id": 0, "name": "person"}], "annotations": gt_ann}
+    pred_coco = {"images": gt["images"], "categories": gt["categories"], "annotations": pred_ann}
+    pred_frames = {"frames": frames}
+    runs = []
+    for layout, pred in (("coco", pred_coco), ("frames", pred_frames)):
+        for iou, conf in ((0.5, 0.0), (0.5, 0.5), (0.75, 0.3), (0.3, 0.0)):
+            m = bench.DetectionBenchmark(iou_threshold=iou, confidence_threshold=conf, output_diagnostics=False).evaluate(gt, pred)
+            runs.append({"layout": layout, "iou_threshold": iou, "confidence_threshold": conf, "metrics": m.to_dict()})
+            print("evaluation", layout, iou, conf, m.summary())
+    with open(os.path.join(GOLD, "evaluation.json"), "w", encoding="utf-8") as f:
+        json.dump({"ground_truth": gt, "pred_coco": pred_coco, "pred_frames": pred_frames, "runs": runs}, f)
+
+
 def resize_case():
     """HF image processor with its default resize (shortest 800 / longest 1333, PIL bilinear) on camera-sized frames."""
     from transformers import DetrImageProcessor
@@ -188,6 +236,9 @@ def resize_case():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "evaluation":   # only the (fast) evaluator fixture
+        evaluation_case()
+        return
     resize_case()
     r50 = DetrArch.resnet50()
     # equal-size batches (pixel_mask all ones): the configuration the HIP path serves
@@ -203,6 +254,7 @@ def main():
     model_case("r101_mild_256x320", DetrArch.resnet101(), 0, 1.0, [(256, 320)], 1234)
     feature_extractor_case()
     similarity_and_export_case()
+    evaluation_case()
 
 
 if __name__ == "__main__":
