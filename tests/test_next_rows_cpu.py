@@ -144,3 +144,22 @@ def test_evaluator_edge_cases():
     tps, fps, missed = match_image([{"bbox": [0, 0, 10, 10]}, {"bbox": [20, 0, 10, 10]}], [{"bbox": [1, 0, 10, 10], "score": 0.5}], 0.5)
     assert len(tps) == 1 and fps == [] and missed == 1
     assert average_precision_11pt([]) == 0.0 and average_precision_11pt([(0.9, False)]) == 0.0
+
+
+def test_assignment_matches_reference_class(golden_dir):
+    """assignment.py::HungarianAlgorithm.solve against the reference's class on seeded cost matrices (tests/golden/assignment.json):
+    the same assignment vector (-1 = unassigned, forbidden pairs never taken) and total cost."""
+    from office_person_detection_vit_amd.assignment import HungarianAlgorithm, assign_tracks
+    g = json.load(open(os.path.join(golden_dir, "assignment.json"), encoding="utf-8"))
+    assert len(g["cases"]) == 7
+    for case in g["cases"]:
+        n, m = case["shape"]
+        cost = np.array([[np.inf if v is None else v for v in row] for row in case["cost"]], dtype=np.float64).reshape(n, m)
+        a, total = HungarianAlgorithm().solve(cost)
+        assert a.dtype == np.int32 and a.tolist() == case["assignment"]
+        assert total == pytest.approx(case["total"], abs=1e-12)
+        for r, c in enumerate(a):
+            assert c == -1 or np.isfinite(cost[r, c])
+    d = np.array([[0.1, 0.9], [0.8, 0.2], [0.95, 0.97]])
+    a, total = assign_tracks(d, 0.5)
+    assert a.tolist() == [0, 1, -1] and total == pytest.approx(0.3)
