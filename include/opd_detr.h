@@ -14,7 +14,9 @@
  *     RuntimeError("Failed to load ... model: ...") (`yolov8_detector.py:86-88`), inference errors re-raised
  *     (`:130-132`) and converted to an empty detection list by the phase (`src/pipeline/phases/detection.py:124-127`).
  *   - output buffers are caller-allocated; the library owns only the model, its workspace and its HIP stream.
- *   - single caller at a time per handle (the reference is strictly single-threaded).
+ *   - single caller at a time per handle (the reference is strictly single-threaded).  DIFFERENT handles may
+ *     be driven from different threads at once (throughput mode: several handles per GPU); the library serialises the one
+ *     operation that needs it, hipGraph capture, internally.
  *   - tensors: logits [B][Q][C+1] f32, boxes [B][Q][4] f32 (cx,cy,w,h in [0,1]), encoder features [B][h*w][D] f32
  *     with h = ceil(H/32), w = ceil(W/32) (HF `DetrObjectDetectionOutput`: logits, pred_boxes,
  *     encoder_last_hidden_state; HF:models/detr/modeling_detr.py:1329-1443).
