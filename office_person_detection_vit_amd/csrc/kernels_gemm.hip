@@ -1250,10 +1250,13 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int g = lane >> 4, li = lane & 15;
 
+    // XCD-aware order: an XCD walks a contiguous run of tile rows top to bottom (one frame each at batch 8), so the 7 patch
+    // rows that vertically adjacent tiles share come from its L2 instead of from HBM a second time
     const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
-    const int seg = blockIdx.x % nseg;
-    const int ty = (blockIdx.x / nseg) % p.tiles_y;
-    const int b = blockIdx.x / (nseg * p.tiles_y);
+    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
+    const int seg = lbid % nseg;
+    const int ty = (lbid / nseg) % p.tiles_y;
+    const int b = lbid / (nseg * p.tiles_y);
     const int tx_first = seg * STEM_TPW;
     const int tx_end = tx_first + STEM_TPW < p.tiles_x ? tx_first + STEM_TPW : p.tiles_x;
     const int py0 = ty * 2;
