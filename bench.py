@@ -123,8 +123,8 @@ def main() -> None:
     _capi.check(lib.opd_detr_info(handle, C.byref(info)), "opd_detr_info")
     handles = [handle]
     for _ in range(1, max(1, args.streams)):
-        hx = C.c_void_p()
-        _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), device_index, C.byref(hx)), "opd_detr_create")
+        hx = C.c_void_p()   # same weights in HBM, own stream / workspace / graph
+        _capi.check(lib.opd_detr_clone(handle, C.byref(hx)), "opd_detr_clone")
         handles.append(hx)
     NS = len(handles)
     Q = info.num_queries

@@ -89,6 +89,12 @@ int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_
 /* Replaces `cleanup_resources` / detector release (`src/utils/memory_utils.py:33-41`). */
 void opd_detr_destroy(opd_detr* m);
 
+/* A second handle on the SAME model: own stream, workspace and graph cache, the weights in HBM shared with `src` (read-only after
+ * creation; freed when the last handle that uses them is destroyed, in any order).  For several batches in flight on one GPU
+ * (`HipDetrDetector(streams=N)`, bench.py): no second parse of the checkpoint, one copy of the 83 MB of weights for L2 and the
+ * Infinity Cache to hold instead of N.  No reference counterpart (one detector object per process there). */
+int opd_detr_clone(const opd_detr* src, opd_detr** out);
+
 int opd_detr_info(const opd_detr* m, opd_model_info* info);
 
 /* Replaces `with torch.no_grad(): outputs = model(pixel_values, pixel_mask)` in `ViTDetector.detect_batch`

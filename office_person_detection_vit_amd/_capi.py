@@ -42,6 +42,7 @@ class OpdModelInfo(C.Structure):
 API = {
     "opd_detr_create": (C.c_int, [C.POINTER(OpdConfig), C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]),
     "opd_detr_destroy": (None, [C.c_void_p]),
+    "opd_detr_clone": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "opd_detr_info": (C.c_int, [C.c_void_p, C.POINTER(OpdModelInfo)]),
     "opd_detr_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p,
                                    C.c_void_p, C.c_void_p]),

@@ -96,12 +96,24 @@ static int down2(int n) { return (n - 1) / 2 + 1; }
 
 using namespace opd;
 
+// Device buffers of the folded weights: shared (read-only after opd_detr_create) by a handle and its clones, freed with the last one.
+struct WeightSet {
+    std::vector<void*> allocs;
+    int device = 0;
+    ~WeightSet() {
+        (void)hipSetDevice(device);
+        for (void* p : allocs) (void)hipFree(p);
+    }
+};
+
 struct opd_detr {
     Arch arch;
     opd_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
-    std::vector<void*> allocs;
+    std::vector<void*> allocs;              // this handle's own buffers: workspace, per-resolution plans
+    std::shared_ptr<WeightSet> weights;     // the model's weights (shared with clones)
+    bool weights_sealed = false;            // set once the weights are built: later "weight" allocations (plans) are the handle's own
     int64_t weight_bytes = 0, workspace_bytes = 0;
 
     Conv stem;
@@ -185,7 +197,7 @@ static int dalloc(opd_detr* m, T** p, size_t count, bool weight) {
     const size_t bytes = count * sizeof(T);
     hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
     if (e != hipSuccess) return fail(OPD_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
-    m->allocs.push_back(q);
+    ((weight && !m->weights_sealed && m->weights) ? m->weights->allocs : m->allocs).push_back(q);
     (weight ? m->weight_bytes : m->workspace_bytes) += (int64_t)bytes;
     *p = reinterpret_cast<T*>(q);
     return OPD_OK;
@@ -1042,7 +1054,43 @@ int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
         if (e != hipSuccess) return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e));
     }
+    m->weights = std::make_shared<WeightSet>();
+    m->weights->device = device_ordinal;
     if ((rc = build_weights(m.get(), sd))) return cleanup(rc);
+    m->weights_sealed = true;
+    if ((rc = build_workspace(m.get()))) return cleanup(rc);
+    for (auto& e : m->ev)
+        if (hipEventCreate(&e) != hipSuccess) return cleanup(fail(OPD_EHIP, "hipEventCreate failed"));
+    *out = m.release();
+    return OPD_OK;
+}
+
+int opd_detr_clone(const opd_detr* src, opd_detr** out) {
+    ApiScope api_scope;
+    if (!src || !out) return fail(OPD_EINVAL, "opd_detr_clone: null argument");
+    *out = nullptr;
+    std::unique_ptr<opd_detr> m(new opd_detr());
+    m->arch = src->arch; m->cfg = src->cfg; m->device = src->device;
+    // everything build_weights produced: device pointers into the shared WeightSet and the host copies the plans are folded from
+    m->weights = src->weights; m->weights_sealed = true; m->weight_bytes = src->weight_bytes;
+    m->stem = src->stem; m->blocks = src->blocks; m->stage_first = src->stage_first; m->proj = src->proj;
+    m->enc = src->enc; m->dec = src->dec; m->wkv_all = src->wkv_all; m->dec_ln = src->dec_ln;
+    m->wc = src->wc; m->bc = src->bc; m->w1 = src->w1; m->b1 = src->b1; m->w2 = src->w2; m->b2 = src->b2; m->w3 = src->w3; m->b3 = src->b3;
+    m->zero_bias = src->zero_bias;
+    m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
+    m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
+    m->fuse_btail = src->fuse_btail; m->fuse_stem_pool = src->fuse_stem_pool;
+    auto cleanup = [&](int code) {
+        for (void* p : m->allocs) (void)hipFree(p);
+        if (m->stream) (void)hipStreamDestroy(m->stream);
+        return code;
+    };
+    {
+        hipError_t e = hipSetDevice(m->device);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e));
+    }
+    int rc;
     if ((rc = build_workspace(m.get()))) return cleanup(rc);
     for (auto& e : m->ev)
         if (hipEventCreate(&e) != hipSuccess) return cleanup(fail(OPD_EHIP, "hipEventCreate failed"));

@@ -84,7 +84,7 @@ class HipDetrDetector:
         ``DetrForObjectDetection`` state dict (or a directory holding ``model.safetensors``); hub loading by NAME is
         impossible offline, so ``model_name`` alone resolves only through ``$OPD_DETR_WEIGHTS``.
         ``device``: ``"hip"``, ``"hip:N"``, ``"cuda"``, ``"cuda:N"`` or None (= GPU 0).  ``"cpu"``/``"mps"`` are refused.
-        ``streams``: detector handles (each with its own HIP stream, workspace and weights copy) that
+        ``streams``: detector handles (each with its own HIP stream and workspace; the weights are shared) that
         ``detect_batch`` keeps busy at once when a call spans several ``max_batch`` chunks; 1 = strictly serial.
         ``pinned_staging``: stack the caller's frames into page-locked memory (``opd_host_alloc``) so that the upload is
         one DMA; False stacks into ordinary numpy memory.
@@ -151,11 +151,14 @@ class HipDetrDetector:
                                   max_height=self.max_size[0], max_width=self.max_size[1],
                                   flags=0 if self.use_graph else _capi.OPD_FLAG_NO_GRAPH)
             self._lib = lib
-            for _ in range(self.streams):
-                handle = C.c_void_p()
-                rc = lib.opd_detr_create(C.byref(cfg), path.encode("utf-8"), self.device_ordinal, C.byref(handle))
-                _capi.check(rc, "opd_detr_create")
-                self._handles.append(handle.value)
+            handle = C.c_void_p()
+            rc = lib.opd_detr_create(C.byref(cfg), path.encode("utf-8"), self.device_ordinal, C.byref(handle))
+            _capi.check(rc, "opd_detr_create")
+            self._handles.append(handle.value)
+            for _ in range(1, self.streams):   # further handles share the first one's weights in HBM
+                clone = C.c_void_p()
+                _capi.check(lib.opd_detr_clone(handle, C.byref(clone)), "opd_detr_clone")
+                self._handles.append(clone.value)
             info = _capi.OpdModelInfo()
             _capi.check(lib.opd_detr_info(C.c_void_p(self._handles[0]), C.byref(info)), "opd_detr_info")
             self.model, self._info = self._handles[0], info

@@ -458,3 +458,39 @@ def test_multi_handle_detect_batch_equals_serial(weight_cache):
                    [[(d.bbox, d.confidence, d.query_index) for d in f] for f in want]
     finally:
         serial.close(); multi.close()
+
+
+def test_clone_shares_weights_and_outlives_its_source(weight_cache):
+    """opd_detr_clone: a second handle on the same weights gives bit-identical records, reports the same weight bytes, and keeps
+    working after the handle it was cloned from has been destroyed (shared ownership of the device buffers)."""
+    import ctypes as C
+    from office_person_detection_vit_amd import _capi
+    lib = _capi.load_library()
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=2, max_height=256, max_width=320, flags=0)
+    src, dup = C.c_void_p(), C.c_void_p()
+    _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), 0, C.byref(src)), "create")
+    _capi.check(lib.opd_detr_clone(src, C.byref(dup)), "clone")
+    i1, i2 = _capi.OpdModelInfo(), _capi.OpdModelInfo()
+    _capi.check(lib.opd_detr_info(src, C.byref(i1)), "info"); _capi.check(lib.opd_detr_info(dup, C.byref(i2)), "info")
+    assert i1.weight_bytes_device == i2.weight_bytes_device and i1.num_queries == i2.num_queries
+    frames = np.ascontiguousarray(np.stack(structured_frames(2, 256, 320, seed=77)))
+    hw = np.asarray([[256, 320]] * 2, np.int32)
+    Q = i1.num_queries
+
+    def run(h):
+        recs, counts = (_capi.OpdDet * (2 * Q))(), (C.c_int32 * 2)()
+        for _ in range(3):   # eager, capture, replay
+            _capi.check(lib.opd_detr_detect(h, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320,
+                                            0.5, hw.ctypes.data_as(C.c_void_p), recs, counts), "detect")
+        c = list(counts)
+        r = np.frombuffer(bytes(recs), dtype=np.int32).reshape(2, Q, 8)
+        return c, [r[b, :c[b]].copy() for b in range(2)]
+
+    c1, r1 = run(src)
+    lib.opd_detr_destroy(src)
+    c2, r2 = run(dup)
+    lib.opd_detr_destroy(dup)
+    assert c1 == c2 and sum(c1) > 0
+    for a, b in zip(r1, r2):
+        np.testing.assert_array_equal(a, b)
