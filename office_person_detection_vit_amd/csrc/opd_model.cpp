@@ -100,6 +100,9 @@ using namespace opd;
 struct WeightSet {
     std::vector<void*> allocs;
     int device = 0;
+    // per-resolution bias folds (Plan): functions of the weights and the feature-map size only, so clones share them too
+    std::mutex plan_mu;
+    std::vector<std::unique_ptr<Plan>> plans;
     ~WeightSet() {
         (void)hipSetDevice(device);
         for (void* p : allocs) (void)hipFree(p);
@@ -130,7 +133,6 @@ struct opd_detr {
     // host copies needed to build plans for new resolutions
     std::vector<std::vector<float>> h_enc_cat_w, h_enc_cat_b;  // per enc layer: [768*256] ([Wq;Wk;0]), [768]
     std::vector<float> h_kv_cat_w, h_kv_cat_b;                 // [L*512*256] ([Wk;0] per layer), [L*512]
-    std::vector<std::unique_ptr<Plan>> plans;
 
     // workspace
     uint8_t* d_u8 = nullptr;
@@ -485,8 +487,17 @@ static void sine_pos_embed(int h, int w, int vh, int vw, int D, std::vector<floa
 }
 
 static int get_plan(opd_detr* m, int fh, int fw, int vh, int vw, Plan** out) {
-    for (auto& p : m->plans)
+    // the cache lives with the weights; a fold is built once, on the calling handle's stream, and is complete (stream
+    // synchronised) before the lock is released.  Its buffers belong to the WeightSet: they may outlive this handle.
+    std::lock_guard<std::mutex> plan_lock(m->weights->plan_mu);
+    auto& plans = m->weights->plans;
+    for (auto& p : plans)
         if (p->fh == fh && p->fw == fw && p->vh == vh && p->vw == vw) { *out = p.get(); return OPD_OK; }
+    struct Unseal {
+        opd_detr* m;
+        explicit Unseal(opd_detr* mm) : m(mm) { m->weights_sealed = false; }
+        ~Unseal() { m->weights_sealed = true; }
+    } unseal(m);
     const Arch& a = m->arch;
     const int D = a.d_model, hw = fh * fw;
     std::unique_ptr<Plan> p(new Plan());
@@ -513,7 +524,7 @@ static int get_plan(opd_detr* m, int fh, int fw, int vh, int vw, Plan** out) {
     }
     HIPCHK(hipStreamSynchronize(m->stream));
     *out = p.get();
-    m->plans.push_back(std::move(p));
+    plans.push_back(std::move(p));
     return OPD_OK;
 }
 
