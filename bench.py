@@ -7,6 +7,11 @@ A step = one pass of the hot path over one batch of synthetic frames per rank: u
 HBM -> preprocess -> ResNet-50 -> encoder/decoder -> heads -> device post-process -> detection records; with N > 1
 every rank detects its own shard of the global batch (8 frames per rank, weak scaling) and the records are
 all-gathered over RCCL/xGMI to every rank (rank 0 = the orchestrator) inside the step.  Rank 0 prints ONE JSON line.
+
+Steps are submitted asynchronously to `--streams` detector handles per GPU (default 3: own stream / workspace / graph, one
+shared copy of the weights), so up to three batches of 8 are in flight per GPU; every step's records reach host memory inside
+the timed region, which is bracketed by barrier + device synchronisation.  `--streams 1 --sync-steps` is the strictly serial
+form (one blocking call per step).  DESIGN.md section 5 has the numbers for both.
 """
 
 from __future__ import annotations
