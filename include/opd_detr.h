@@ -51,9 +51,9 @@ typedef struct opd_detr opd_detr; /* opaque model handle */
 
 typedef struct opd_config {
     int32_t struct_size; /* = sizeof(opd_config), for forward compatibility */
-    int32_t max_batch;   /* workspace is sized for [max_batch][max_height][max_width] frames */
-    int32_t max_height;
-    int32_t max_width;
+    int32_t max_batch;   /* workspace is sized for max_batch frames of max_height x max_width pixels, in either orientation:   */
+    int32_t max_height;  /* a call may pass any H x W with H, W <= max(max_height, max_width) and H * W <= max_height * max_width */
+    int32_t max_width;   /* (the HF size rule maps a portrait camera frame to about 1333 x 750)                                    */
     int32_t flags;       /* OPD_FLAG_* */
     int32_t reserved[3];
 } opd_config;
@@ -142,7 +142,8 @@ int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_k
 /* With `mem_kind == OPD_MEM_DEVICE`, `out` ([B][Q] records) and `counts` ([B]) are DEVICE pointers too, so a sharded
  * caller can hand them straight to an RCCL all-gather; `orig_hw` is always a host array. */
 /* Asynchronous submission for throughput-oriented callers: enqueues the forward and the post-process on the handle's stream
- * and returns with a `ticket` (0..3; at most 4 submissions may be outstanding per handle); `out` / `counts` of a submission
+ * and returns with a `ticket` (0..3; at most 4 submissions may be outstanding per handle: a fifth returns OPD_ESTATE until the
+ * oldest ticket has been waited for, and waiting twice for one ticket is OPD_ESTATE too); `out` / `counts` of a submission
  * are complete after opd_detr_wait(m, ticket) (`mem_kind` as in opd_detr_detect: host pixels are staged with an asynchronous
  * copy, host outputs travel through pinned memory and are delivered by opd_detr_wait; `pixels`, `out` and `counts` must stay
  * valid and untouched until that wait returns).  Work of consecutive submissions to ONE

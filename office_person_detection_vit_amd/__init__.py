@@ -4,14 +4,12 @@
 ``include/opd_detr.h`` into hand-written HIP kernels (``csrc/``).  No CPU / PyTorch fallback exists.
 """
 
-from .assignment import HungarianAlgorithm, assign_tracks  # noqa: F401
 from .data_models import Detection  # noqa: F401
 from .detector import HipDetrDetector, model_input_size  # noqa: F401
-from .evaluation import DetectionEvaluator, evaluate_detections  # noqa: F401
 from .export import detections_to_coco, write_coco  # noqa: F401
 from .feature_extractor import FeatureExtractor  # noqa: F401
 from .similarity import SimilarityCalculator  # noqa: F401
 from .tiling import TiledDetector  # noqa: F401
 
 __all__ = ["Detection", "HipDetrDetector", "FeatureExtractor", "SimilarityCalculator", "TiledDetector", "detections_to_coco", "write_coco",
-           "model_input_size", "DetectionEvaluator", "evaluate_detections", "HungarianAlgorithm", "assign_tracks"]
+           "model_input_size"]

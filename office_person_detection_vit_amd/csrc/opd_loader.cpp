@@ -233,7 +233,12 @@ int load_safetensors(const std::string& path, StateDict* out, std::string* err) 
             Entry e;
             if (!parse_entry(c, &e)) { fclose(f); *err = "malformed safetensors entry '" + name + "'"; return OPD_EIO; }
             int64_t n = 1;
-            for (auto s : e.shape) n *= s;
+            bool bad_shape = e.shape.size() > 8;
+            for (auto s : e.shape) {   // negative sizes and products beyond the file size are refused before anything is allocated
+                if (s < 0 || (s > 0 && n > fsize / s)) { bad_shape = true; break; }
+                n *= s;
+            }
+            if (bad_shape) { fclose(f); *err = "tensor '" + name + "' has an invalid shape"; return OPD_EIO; }
             const int esz = (e.dtype == "F32") ? 4 : (e.dtype == "F16" || e.dtype == "BF16") ? 2 : 0;
             if (esz == 0) {  // integer tensors (e.g. num_batches_tracked) are not part of the path: skip
                 if (c.eat(',')) continue;
@@ -315,6 +320,8 @@ int infer_arch(const StateDict& sd, Arch* a, std::string* err) {
     const int64_t d = a->d_model, f = a->ffn;
     // backbone
     if ((rc = want(sd, bb + "embedder.embedder.convolution.weight", {64, 3, 7, 7}, err))) return rc;
+    for (const char* nm : {"weight", "bias", "running_mean", "running_var"})
+        if ((rc = want(sd, bb + "embedder.embedder.normalization." + nm, {64}, err))) return rc;
     int64_t cin = 64;
     for (int s = 0; s < 4; ++s) {
         const int64_t cout = a->hidden[s], mid = cout / 4;
@@ -322,7 +329,8 @@ int infer_arch(const StateDict& sd, Arch* a, std::string* err) {
             const std::string p = bb + "encoder.stages." + std::to_string(s) + ".layers." + std::to_string(l) + ".";
             if (l == 0) {
                 if ((rc = want(sd, p + "shortcut.convolution.weight", {cout, cin, 1, 1}, err))) return rc;
-                if ((rc = want(sd, p + "shortcut.normalization.running_var", {cout}, err))) return rc;
+                for (const char* nm : {"weight", "bias", "running_mean", "running_var"})
+                    if ((rc = want(sd, p + "shortcut.normalization." + nm, {cout}, err))) return rc;
             }
             if ((rc = want(sd, p + "layer.0.convolution.weight", {mid, cin, 1, 1}, err))) return rc;
             if ((rc = want(sd, p + "layer.1.convolution.weight", {mid, mid, 3, 3}, err))) return rc;
@@ -363,6 +371,8 @@ int infer_arch(const StateDict& sd, Arch* a, std::string* err) {
             return rc;
     }
     if ((rc = ln("model.decoder.layernorm"))) return rc;
+    if ((rc = want(sd, "model.query_position_embeddings.weight", {(int64_t)a->queries, d}, err))) return rc;
+    if ((rc = want(sd, "class_labels_classifier.weight", {(int64_t)a->ncls, d}, err))) return rc;
     if ((rc = want(sd, "class_labels_classifier.bias", {(int64_t)a->ncls}, err))) return rc;
     if ((rc = want(sd, "bbox_predictor.layers.0.weight", {d, d}, err))) return rc;
     if ((rc = want(sd, "bbox_predictor.layers.1.weight", {d, d}, err))) return rc;

@@ -12,6 +12,8 @@
 #include <string.h>
 
 #include <memory>
+#include <new>
+#include <stdexcept>
 #include <mutex>
 #include <shared_mutex>
 #include <string>
@@ -154,6 +156,7 @@ struct opd_detr {
     // asynchronous submissions (opd_detr_detect_async): one completion event per in-flight ticket
     hipEvent_t ev_async[4] = {};
     unsigned async_next = 0;
+    bool async_pending[4] = {};   // ticket handed out and not yet waited for: its slot (event, output pointers, staging) is in use
     // host-output submissions: the records travel device -> pinned slot (asynchronous) -> caller buffer (in opd_detr_wait)
     struct AsyncHost { void* pinned = nullptr; opd_det* out = nullptr; int32_t* counts = nullptr; int B = 0; };
     AsyncHost async_host[4];
@@ -408,21 +411,27 @@ static void compute_dims(int B, int H, int W, Dims* d) {
 
 static int build_workspace(opd_detr* m) {
     const Arch& a = m->arch;
-    Dims d;
-    compute_dims(m->cfg.max_batch, m->cfg.max_height, m->cfg.max_width, &d);
-    const size_t B = d.B;
-    const size_t npix = B * d.H * d.W;
+    // Frames may come in either orientation (the HF size rule maps a portrait camera frame to about 1333 x 750): the handle
+    // accepts every H x W with H, W <= max(max_height, max_width) and H * W <= max_height * max_width, so the buffers are sized by
+    // bounds on the pixel COUNT of each pyramid level, not by one shape: down2(n) <= (n + 1) / 2, hence
+    // H1 * W1 <= (H * W + H + W + 1) / 4 <= (n + 2 * L + 1) / 4 for a level with n pixels and sides <= L.
+    const size_t B = m->cfg.max_batch;
+    size_t edge = (size_t)std::max(m->cfg.max_height, m->cfg.max_width);
+    const size_t npix = B * (size_t)m->cfg.max_height * m->cfg.max_width;
+    size_t lvl[6], side[6];   // per-frame pixel bound / side bound of: image, stem, pool (= stage 1), stage 2, 3, 4
+    lvl[0] = (size_t)m->cfg.max_height * m->cfg.max_width; side[0] = edge;
+    for (int k = 1; k < 6; ++k) { lvl[k] = (lvl[k - 1] + 2 * side[k - 1] + 1) / 4 + 1; side[k] = (size_t)down2((int)side[k - 1]); }
     RCCHK(dalloc(m, &m->d_u8, npix * 3, false));
     RCCHK(dalloc(m, &m->d_pv, npix * 3, false));
-    RCCHK(dalloc(m, &m->d_x4, B * (size_t)(2 * d.H1 + 6) * (2 * d.W1 + 6) * 4, false));  // zero-bordered NHWC4
-    RCCHK(dalloc(m, &m->d_stem, B * d.H1 * d.W1 * 64, false));
-    RCCHK(dalloc(m, &m->d_pool, B * d.H2 * d.W2 * 64, false));
+    RCCHK(dalloc(m, &m->d_x4, B * (4 * lvl[1] + 24 * side[1] + 36) * 4, false));  // zero-bordered NHWC4: (2 H1 + 6) x (2 W1 + 6)
+    RCCHK(dalloc(m, &m->d_stem, B * lvl[1] * 64, false));
+    RCCHK(dalloc(m, &m->d_pool, B * lvl[2] * 64, false));
     size_t trunk = 0, mid = 0;
     for (int s = 0; s < 4; ++s) {
-        const size_t hw = (size_t)d.sh[s] * d.sw[s];
+        const size_t hw = lvl[2 + s];
         trunk = std::max(trunk, B * hw * a.hidden[s]);
         // first block of a stage runs its 1x1 reduce at the INPUT resolution of the stage
-        const size_t hw_in = s == 0 ? hw : (size_t)d.sh[s - 1] * d.sw[s - 1];
+        const size_t hw_in = s == 0 ? hw : lvl[1 + s];
         mid = std::max(mid, B * hw_in * (a.hidden[s] / 4));
     }
     RCCHK(dalloc(m, &m->d_t0, trunk, false));
@@ -430,7 +439,7 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_sc, trunk, false));
     RCCHK(dalloc(m, &m->d_m0, mid, false));
     RCCHK(dalloc(m, &m->d_m1, mid, false));
-    const size_t M = B * d.sh[3] * d.sw[3];
+    const size_t M = B * lvl[5];
     const size_t D = a.d_model, Md = B * a.queries;
     RCCHK(dalloc(m, &m->d_x32, M * D, false));
     RCCHK(dalloc(m, &m->d_y32, M * D, false));
@@ -923,11 +932,12 @@ static int check_shape(opd_detr* m, const void* pixels, int pixel_format, int me
     if (!pixels) return fail(OPD_EINVAL, "null pixel buffer");
     if (pixel_format != OPD_PIXELS_U8_BGR_HWC && pixel_format != OPD_PIXELS_F32_NCHW) return fail(OPD_EINVAL, "unknown pixel_format");
     if (mem_kind != OPD_MEM_HOST && mem_kind != OPD_MEM_DEVICE) return fail(OPD_EINVAL, "unknown mem_kind");
-    if (B < 1 || B > m->cfg.max_batch || H < 32 || W < 32 || H > m->cfg.max_height || W > m->cfg.max_width ||
+    const int edge = std::max(m->cfg.max_height, m->cfg.max_width);   // either orientation: see build_workspace
+    if (B < 1 || B > m->cfg.max_batch || H < 32 || W < 32 || H > edge || W > edge ||
         (size_t)H * W > (size_t)m->cfg.max_height * m->cfg.max_width)
         return fail(OPD_EINVAL, "frame batch [" + std::to_string(B) + "," + std::to_string(H) + "," + std::to_string(W) +
                                     "] outside the configured maximum [" + std::to_string(m->cfg.max_batch) + "," +
-                                    std::to_string(m->cfg.max_height) + "," + std::to_string(m->cfg.max_width) + "]");
+                                    std::to_string(m->cfg.max_height) + "," + std::to_string(m->cfg.max_width) + "] (either orientation)");
     return OPD_OK;
 }
 
@@ -1030,6 +1040,23 @@ static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kin
 // =====================================================================================================================
 // C-ABI
 // =====================================================================================================================
+// No C++ exception may cross the C-ABI: creation parses an untrusted file and allocates, so its body runs under a catch-all.
+static int create_impl(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out);
+static int clone_impl(const opd_detr* src, opd_detr** out);
+template <typename F>
+static int guarded(const char* what, F&& body) {
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return fail(OPD_ENOMEM, std::string(what) + ": out of host memory");
+    } catch (const std::out_of_range& e) {
+        return fail(OPD_ESCHEMA, std::string(what) + ": weight file lacks a tensor the model needs (" + e.what() + ")");
+    } catch (const std::exception& e) {
+        return fail(OPD_EINVAL, std::string(what) + ": " + e.what());
+    } catch (...) {
+        return fail(OPD_EINVAL, std::string(what) + ": unknown C++ exception");
+    }
+}
 extern "C" {
 
 const char* opd_last_error(void) { return opd::g_err.c_str(); }
@@ -1037,6 +1064,15 @@ const char* opd_version(void) { return "opd_hip 0.1 gfx950 (fp16 MFMA, fp32 accu
 
 int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out) {
     ApiScope api_scope;
+    if (out) *out = nullptr;
+    return guarded("opd_detr_create", [&] { return create_impl(cfg, weights_path, device_ordinal, out); });
+}
+int opd_detr_clone(const opd_detr* src, opd_detr** out) {
+    ApiScope api_scope;
+    if (out) *out = nullptr;
+    return guarded("opd_detr_clone", [&] { return clone_impl(src, out); });
+}
+static int create_impl(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out) {
     if (!cfg || !weights_path || !out) return fail(OPD_EINVAL, "opd_detr_create: null argument");
     if (cfg->struct_size != (int32_t)sizeof(opd_config)) return fail(OPD_EINVAL, "opd_config.struct_size mismatch");
     if (cfg->max_batch < 1 || cfg->max_height < 32 || cfg->max_width < 32) return fail(OPD_EINVAL, "opd_config maxima must be >= 1 x 32 x 32");
@@ -1076,8 +1112,7 @@ int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_
     return OPD_OK;
 }
 
-int opd_detr_clone(const opd_detr* src, opd_detr** out) {
-    ApiScope api_scope;
+static int clone_impl(const opd_detr* src, opd_detr** out) {
     if (!src || !out) return fail(OPD_EINVAL, "opd_detr_clone: null argument");
     *out = nullptr;
     std::unique_ptr<opd_detr> m(new opd_detr());
@@ -1223,7 +1258,9 @@ int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int
     if (!out || !counts || !ticket) return fail(OPD_EINVAL, "opd_detr_detect_async: null argument");
     if (m->profiling) return fail(OPD_ESTATE, "opd_detr_detect_async is not available in profiling mode");
     HIPCHK(hipSetDevice(m->device));
-    const unsigned t = m->async_next++ & 3u;
+    const unsigned t = m->async_next & 3u;
+    if (m->async_pending[t])
+        return fail(OPD_ESTATE, "opd_detr_detect_async: 4 submissions are outstanding on this handle; opd_detr_wait the oldest ticket first");
     if (!m->ev_async[t]) HIPCHK(hipEventCreateWithFlags(&m->ev_async[t], hipEventDisableTiming));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
@@ -1242,12 +1279,15 @@ int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int
         slot.out = out; slot.counts = counts; slot.B = B;
     }
     HIPCHK(hipEventRecord(m->ev_async[t], m->stream));
+    m->async_pending[t] = true;
+    ++m->async_next;
     *ticket = (int)t;
     return OPD_OK;
 }
 int opd_detr_wait(opd_detr* m, int ticket) {
     ApiScope api_scope;
     if (!m || ticket < 0 || ticket > 3 || !m->ev_async[ticket]) return fail(OPD_EINVAL, "opd_detr_wait: bad handle or ticket");
+    if (!m->async_pending[ticket]) return fail(OPD_ESTATE, "opd_detr_wait: this ticket is not outstanding (already waited for?)");
     HIPCHK(hipSetDevice(m->device));
     HIPCHK(hipEventSynchronize(m->ev_async[ticket]));
     opd_detr::AsyncHost& slot = m->async_host[ticket];
@@ -1258,6 +1298,7 @@ int opd_detr_wait(opd_detr* m, int ticket) {
         memcpy(slot.counts, static_cast<char*>(slot.pinned) + rec_bytes, (size_t)slot.B * 4);
         slot.out = nullptr;
     }
+    m->async_pending[ticket] = false;
     return OPD_OK;
 }
 int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W, float threshold,

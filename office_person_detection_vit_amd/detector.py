@@ -70,6 +70,7 @@ class HipDetrDetector:
         device: Optional[str] = None,
         nms_threshold: float = 0.4,
         model_path: Optional[str] = None,
+        iou_threshold: Optional[float] = None,
         max_batch: int = 8,
         max_size: Tuple[int, int] = (800, 1333),
         resize: bool = True,
@@ -83,6 +84,9 @@ class HipDetrDetector:
         ``device``, ``batch_size`` -> ``max_batch``).  ``model_path`` is a local ``.safetensors`` file with the HF
         ``DetrForObjectDetection`` state dict (or a directory holding ``model.safetensors``); hub loading by NAME is
         impossible offline, so ``model_name`` alone resolves only through ``$OPD_DETR_WEIGHTS``.
+        ``iou_threshold`` is the keyword ``DetectionPhase.initialize`` passes (``src/pipeline/phases/detection.py:47-52``:
+        ``model_path``, ``confidence_threshold``, ``device``, ``iou_threshold``): the same knob as ``nms_threshold``, which it
+        overrides when given.
         ``device``: ``"hip"``, ``"hip:N"``, ``"cuda"``, ``"cuda:N"`` or None (= GPU 0).  ``"cpu"``/``"mps"`` are refused.
         ``streams``: detector handles (each with its own HIP stream and workspace; the weights are shared) that
         ``detect_batch`` keeps busy at once when a call spans several ``max_batch`` chunks; 1 = strictly serial.
@@ -92,6 +96,8 @@ class HipDetrDetector:
         self.model_name = model_name
         self.model_path = model_path
         self.confidence_threshold = confidence_threshold
+        if iou_threshold is not None:
+            nms_threshold = float(iou_threshold)
         self.nms_threshold = nms_threshold
         self.iou_threshold = nms_threshold  # the YOLO-era spelling of the same knob
         self.device = self._setup_device(device)
@@ -244,8 +250,8 @@ class HipDetrDetector:
         if len(shapes) == 1:
             return self._stack(slot, out), orig, None, None
         H, W = max(o.shape[0] for o in out), max(o.shape[1] for o in out)
-        if H > self.max_size[0] or W > self.max_size[1]:
-            raise ValueError(f"ragged batch canvas {H}x{W} exceeds the configured maximum {self.max_size}")
+        if max(H, W) > max(self.max_size) or H * W > self.max_size[0] * self.max_size[1]:
+            raise ValueError(f"ragged batch canvas {H}x{W} exceeds the configured maximum {self.max_size} (either orientation)")
         canvas = self._stage_array(slot, (len(out), H, W, 3))
         canvas[...] = 0
         for i, o in enumerate(out):

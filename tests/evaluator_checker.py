@@ -1,5 +1,6 @@
 """Accuracy harness for the detector's COCO-style output.
 
+TEST INFRASTRUCTURE (checker of tests/test_detector_gpu.py::test_export_scored_like_oracle), not shipped in the package.
 Host-side restatement of the reference's detection evaluator, ``DetectionBenchmark.evaluate``
 (``src/evaluation/detection_benchmark.py:201-503``): it scores what ``export.detections_to_coco`` writes against a COCO ground
 truth and reports precision / recall / F1, AP@0.5, AP@0.75 and AP@[0.5:0.95].  The reference's conventions are kept exactly,

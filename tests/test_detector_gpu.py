@@ -357,10 +357,11 @@ def test_config5_tiled_4k_frame(detectors):
     frame = structured_frames(1, 2160, 3840, seed=707)[0]
     tiled = TiledDetector(det, 2, 2, nms_threshold=0.4)
     got = tiled.detect(frame)
-    tiles, origins = split_tiles(frame, 2, 2)
+    tiles, origins = split_tiles(frame, 2, 2, tiled.overlap)
+    assert [t.shape for t in tiles] == [(1215, 2160, 3)] * 4      # 1080p tiles + the 1/8 overlap band, same 16:9 -> 750x1333
     per_tile = [det.detect(t) for t in tiles]
     det.close()
-    want = merge_tile_detections(per_tile, origins, 0.4)
+    want = merge_tile_detections(per_tile, origins, 0.4, [t.shape[:2] for t in tiles], (2160, 3840))
     # batch of 4 tiles vs one tile at a time: same kernels per frame -> same records
     assert [(d.bbox, d.confidence) for d in got] == [(d.bbox, d.confidence) for d in want]
     for d in got:

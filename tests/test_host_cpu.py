@@ -191,7 +191,9 @@ def test_ragged_batch_canvas_and_valid_sizes():
     batch, _, _, target = host._preprocess_batch([f])
     assert target is None and batch.shape == (1, 750, 1333, 3)
     with pytest.raises(ValueError):
-        det._preprocess_batch([a, structured_frames(1, 70, 60, seed=3)[0]])   # canvas taller than max_size
+        det._preprocess_batch([a, structured_frames(1, 100, 40, seed=3)[0]])   # canvas edge longer than max(max_size)
+    with pytest.raises(ValueError):
+        det._preprocess_batch([b, structured_frames(1, 90, 60, seed=3)[0]])    # canvas 90 x 72: more pixels than 64 x 96
 
 
 def test_mask_downsampling_matches_torch_nearest():
@@ -260,3 +262,71 @@ def test_resize_algorithm_is_bit_exact_with_pillow(src, dst):
     img = rng.integers(0, 256, (src[0], src[1], 3), dtype=np.uint8)
     want = np.asarray(Image.fromarray(img).resize((dst[1], dst[0]), resample=Image.BILINEAR))
     np.testing.assert_array_equal(_emulate_resize(lib, img, dst[0], dst[1]), want)
+
+
+def test_constructor_takes_the_detection_phase_keywords():
+    """``DetectionPhase.initialize`` builds its detector with exactly these keywords (reference
+    ``src/pipeline/phases/detection.py:47-52``): model_path, confidence_threshold, device, iou_threshold."""
+    det = HipDetrDetector(model_path="weights/model.safetensors", confidence_threshold=0.6, device="cuda", iou_threshold=0.45)
+    assert det.nms_threshold == 0.45 and det.iou_threshold == 0.45 and det.confidence_threshold == 0.6 and det.device == "hip:0"
+    assert HipDetrDetector(nms_threshold=0.3).iou_threshold == 0.3                     # the DETR-era keyword still works
+    assert HipDetrDetector(nms_threshold=0.3, iou_threshold=0.5).nms_threshold == 0.5  # iou_threshold wins when both are given
+
+
+def test_schema_check_covers_every_tensor_the_loader_reads(tmp_path):
+    """a checkpoint that lacks a stem / shortcut normalisation tensor must be OPD_ESCHEMA (-3) from the schema check,
+    not a C++ exception inside opd_detr_create; malformed shapes in the header are refused before anything is allocated."""
+    import json
+    import struct
+
+    lib = _capi.load_library()
+    arch = DetrArch(depths=(1, 1, 1, 1), encoder_layers=1, decoder_layers=1, num_queries=20)
+    w = synth_weights(arch, 3, 1.0, calibrate=False)
+    info = (C.c_int32 * 8)()
+    for missing in ("model.backbone.model.embedder.embedder.normalization.running_mean",
+                    "model.backbone.model.encoder.stages.2.layers.0.shortcut.normalization.weight",
+                    "model.backbone.model.encoder.stages.0.layers.0.shortcut.normalization.bias"):
+        w2 = dict(w)
+        del w2[missing]
+        bad = str(tmp_path / "missing.safetensors")
+        save_safetensors(w2, bad)
+        assert lib.opd_test_inspect_checkpoint(bad.encode(), info) == -3
+        assert missing in _capi.last_error()
+    for shape in ([-4, 4], [1 << 40, 1 << 30]):
+        hdr = json.dumps({"t": {"dtype": "F32", "shape": shape, "data_offsets": [0, 64]}}).encode()
+        bad = str(tmp_path / "shape.safetensors")
+        with open(bad, "wb") as f:
+            f.write(struct.pack("<Q", len(hdr)) + hdr + b"\0" * 64)
+        assert lib.opd_test_inspect_checkpoint(bad.encode(), info) == -2
+        assert "invalid shape" in _capi.last_error()
+
+
+def test_portrait_frames_fit_the_configured_maximum():
+    """the HF size rule maps a portrait camera frame to about 1333 x 750; the handle accepts either orientation
+    (include/opd_detr.h, opd_config), and the shim's ragged-canvas check uses the same rule."""
+    assert model_input_size(1280, 720) == (1333, 750)
+    det = HipDetrDetector(max_size=(800, 1333), pinned_staging=False)
+    frames = [np.zeros((1280, 720, 3), np.uint8), np.zeros((1000, 720, 3), np.uint8)]   # -> 1333x750 and 1111x800
+    canvas, orig, valid, target = det._preprocess_batch(frames)
+    assert canvas.shape == (2, 1333, 800, 3) and valid.tolist() == [[1333, 750], [1111, 800]] and target is None
+    with pytest.raises(ValueError, match="exceeds the configured maximum"):
+        HipDetrDetector(max_size=(640, 640), pinned_staging=False, resize=False)._preprocess_batch(
+            [np.zeros((700, 300, 3), np.uint8), np.zeros((300, 500, 3), np.uint8)])
+
+
+def test_feature_extractor_matches_reference_fixture(golden_dir):
+    """The product-side ``FeatureExtractor`` (summed-area-table pooling) against the reference class's captured outputs."""
+    from office_person_detection_vit_amd import FeatureExtractor
+    g = np.load(os.path.join(golden_dir, "feature_extractor.npz"))
+    rng = np.random.default_rng(int(g["rng_seed"]))
+    enc = rng.standard_normal((25, 42, 256)).astype(np.float32)
+    raw = rng.standard_normal((5, 256)).astype(np.float32)
+    raw[3] = 0.0
+    fe = FeatureExtractor()
+    roi = fe.extract_roi_features(enc, [tuple(b) for b in g["bboxes"]], tuple(int(v) for v in g["image_shape"]))
+    assert roi.dtype == np.float32
+    np.testing.assert_allclose(roi, g["roi"], atol=2e-6)
+    np.testing.assert_allclose(fe.normalize_features(raw), g["norm"], atol=1e-7)
+    assert fe.extract_roi_features(enc, [], (800, 1333)).shape == tuple(g["empty_shape"])
+    with pytest.raises(ValueError, match="Expected 3D encoder features"):
+        fe.extract_roi_features(enc[0], [], (800, 1333))

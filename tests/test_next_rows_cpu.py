@@ -92,20 +92,51 @@ def test_tile_grid_and_merge():
                                 [(0, 0), (0, 1920)], nms_threshold=0.4)
     assert [d.query_index for d in dup] == [1]                              # same body across the seam: the weaker one goes
 
+    # --- overlapping tiles + cut-aware merge (a body cut by a seam gives two partial boxes with IoU ~ 0) ---
+    grid = tile_grid(2160, 3840, 2, 2, overlap=0.125)
+    assert grid == [(0, 0, 1215, 2160), (0, 1680, 1215, 2160), (945, 0, 1215, 2160), (945, 1680, 1215, 2160)]
+    origins = [(y, x) for y, x, _, _ in grid]
+    sizes = [(h, w) for _, _, h, w in grid]
+    # (1) a person 150 px wide standing on the base seam x = 1920 (frame x 1850..2000): narrower than the 240-px band, so BOTH
+    # tiles see it whole (tile 0 up to x = 2160, tile 1 from x = 1680) -> ordinary duplicates, IoU-NMS keeps the stronger one
+    whole0 = mk((1850.0, 400.0, 150.0, 400.0), 0.8, 1)
+    whole1 = mk((1850.0 - 1680.0, 402.0, 150.0, 398.0), 0.9, 2)
+    out = merge_tile_detections([[whole0], [whole1], [], []], origins, 0.4, sizes, (2160, 3840))
+    assert [d.query_index for d in out] == [2] and out[0].bbox == (1850.0, 402.0, 150.0, 398.0)
+    # (2) a person at frame x 2100..2250: tile 1 sees it whole, tile 0 only its first 60 px (cut by tile 0's right edge x = 2160);
+    # IoU = 0.4 exactly at best, here 60/150 -> below the NMS threshold, so round 1's merge counted it twice
+    part0 = mk((2100.0, 400.0, 60.0, 400.0), 0.95, 3)             # the partial box even scores higher
+    full1 = mk((2100.0 - 1680.0, 400.0, 150.0, 400.0), 0.7, 4)
+    plain = merge_tile_detections([[part0], [full1], [], []], origins, 0.4)
+    assert len(plain) == 2                                           # no tile geometry -> plain IoU-NMS -> double count
+    out = merge_tile_detections([[part0], [full1], [], []], origins, 0.4, sizes, (2160, 3840))
+    assert len(out) == 1 and out[0].bbox == (2100.0, 400.0, 150.0, 400.0) and out[0].confidence == 0.95
+    assert out[0].camera_coords == (2175.0, 800.0)
+    # (3) a body wider than the band (a desk row, x 1500..2400): both tiles cut it; the parts overlap in the band only
+    left = mk((1500.0, 900.0, 660.0, 200.0), 0.8, 5)              # tile 0: up to its right edge 2160
+    right = mk((0.0, 900.0, 720.0, 200.0), 0.6, 6)                # tile 1: from its left edge 1680 to 2400
+    out = merge_tile_detections([[left], [right], [], []], origins, 0.4, sizes, (2160, 3840))
+    assert len(out) == 1 and out[0].bbox == (1500.0, 900.0, 900.0, 200.0)
+    # (4) two different people in the band, both whole in both tiles: nothing is cut -> no merging, only IoU duplicates go
+    a0, b0 = mk((1700.0, 300.0, 100.0, 300.0), 0.9, 7), mk((1760.0, 320.0, 100.0, 300.0), 0.8, 8)
+    a1, b1 = mk((20.0, 300.0, 100.0, 300.0), 0.85, 9), mk((80.0, 320.0, 100.0, 300.0), 0.75, 10)
+    out = merge_tile_detections([[a0, b0], [a1, b1], [], []], origins, 0.5, sizes, (2160, 3840))
+    assert sorted(d.query_index for d in out) == [7, 8]
+
     class Fake:                                                             # detect_batch contract: one list per tile, in order
         def detect_batch(self, tiles):
             return [[mk((1.0, 2.0, 3.0, 4.0), 0.5 + 0.1 * i, i)] for i, _ in enumerate(tiles)]
-    res = TiledDetector(Fake()).detect_batch([np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8)])
+    res = TiledDetector(Fake(), overlap=0.0).detect_batch([np.zeros((8, 8, 3), np.uint8), np.zeros((8, 8, 3), np.uint8)])
     assert [len(r) for r in res] == [4, 4] and res[1][0].bbox == (5.0, 6.0, 3.0, 4.0)
     with pytest.raises(ValueError):
         tile_grid(1, 5, 2, 2)
 
 
 def test_evaluator_matches_reference_class(golden_dir):
-    """evaluation.py::DetectionEvaluator against the reference's DetectionBenchmark.evaluate (tests/golden/evaluation.json,
+    """tests/evaluator_checker.py::DetectionEvaluator (the checker of the GPU export test) against the reference's DetectionBenchmark.evaluate (tests/golden/evaluation.json,
     tools/gen_golden.py evaluation): counts exactly, every float to 1e-12, for both prediction layouts and four threshold pairs."""
     import json
-    from office_person_detection_vit_amd.evaluation import DetectionEvaluator, evaluate_detections
+    from evaluator_checker import DetectionEvaluator, evaluate_detections
     g = json.load(open(os.path.join(golden_dir, "evaluation.json"), encoding="utf-8"))
     assert len(g["runs"]) == 8
     for run in g["runs"]:
@@ -128,7 +159,7 @@ def test_evaluator_matches_reference_class(golden_dir):
 
 
 def test_evaluator_edge_cases():
-    from office_person_detection_vit_amd.evaluation import DetectionEvaluator, average_precision_11pt, box_iou_xywh, match_image
+    from evaluator_checker import DetectionEvaluator, average_precision_11pt, box_iou_xywh, match_image
     ev = DetectionEvaluator()
     empty = ev.evaluate({"annotations": []}, {"annotations": []})
     assert (empty.precision, empty.recall, empty.ap, empty.num_images) == (0.0, 0.0, 0.0, 0)
@@ -144,22 +175,3 @@ def test_evaluator_edge_cases():
     tps, fps, missed = match_image([{"bbox": [0, 0, 10, 10]}, {"bbox": [20, 0, 10, 10]}], [{"bbox": [1, 0, 10, 10], "score": 0.5}], 0.5)
     assert len(tps) == 1 and fps == [] and missed == 1
     assert average_precision_11pt([]) == 0.0 and average_precision_11pt([(0.9, False)]) == 0.0
-
-
-def test_assignment_matches_reference_class(golden_dir):
-    """assignment.py::HungarianAlgorithm.solve against the reference's class on seeded cost matrices (tests/golden/assignment.json):
-    the same assignment vector (-1 = unassigned, forbidden pairs never taken) and total cost."""
-    from office_person_detection_vit_amd.assignment import HungarianAlgorithm, assign_tracks
-    g = json.load(open(os.path.join(golden_dir, "assignment.json"), encoding="utf-8"))
-    assert len(g["cases"]) == 7
-    for case in g["cases"]:
-        n, m = case["shape"]
-        cost = np.array([[np.inf if v is None else v for v in row] for row in case["cost"]], dtype=np.float64).reshape(n, m)
-        a, total = HungarianAlgorithm().solve(cost)
-        assert a.dtype == np.int32 and a.tolist() == case["assignment"]
-        assert total == pytest.approx(case["total"], abs=1e-12)
-        for r, c in enumerate(a):
-            assert c == -1 or np.isfinite(cost[r, c])
-    d = np.array([[0.1, 0.9], [0.8, 0.2], [0.95, 0.97]])
-    a, total = assign_tracks(d, 0.5)
-    assert a.tolist() == [0, 1, -1] and total == pytest.approx(0.3)

@@ -218,25 +218,6 @@ def evaluation_case():
         json.dump({"ground_truth": gt, "pred_coco": pred_coco, "pred_frames": pred_frames, "runs": runs}, f)
 
 
-def assignment_case():
-    """Next row: the reference's HungarianAlgorithm.solve on seeded cost matrices (square, wide, tall,
-    with forbidden = infinite pairs, a row with nothing allowed, empty)."""
-    hung = _load_ref("ref_hungarian", "src/tracking/hungarian.py").HungarianAlgorithm()
-    rng = np.random.default_rng(31)
-    cases = []
-    for (n, m, p_inf) in ((5, 5, 0.0), (4, 7, 0.2), (8, 3, 0.2), (6, 6, 0.5), (1, 1, 0.0), (3, 4, 0.0), (0, 0, 0.0)):
-        c = rng.random((n, m))
-        c[rng.random((n, m)) < p_inf] = np.inf
-        if n == 6:
-            c[2, :] = np.inf   # a track that may not take any detection
-        a, total = hung.solve(c)
-        cases.append({"cost": [[None if np.isinf(v) else float(v) for v in row] for row in c], "shape": [n, m],
-                      "assignment": [int(v) for v in a], "total": float(total)})
-        print("assignment", (n, m), [int(v) for v in a], float(total))
-    with open(os.path.join(GOLD, "assignment.json"), "w", encoding="utf-8") as f:
-        json.dump({"cases": cases}, f)
-
-
 def resize_case():
     """HF image processor with its default resize (shortest 800 / longest 1333, PIL bilinear) on camera-sized frames."""
     from transformers import DetrImageProcessor
@@ -255,8 +236,8 @@ def resize_case():
 
 def main():
     os.makedirs(GOLD, exist_ok=True)
-    if len(sys.argv) > 1 and sys.argv[1] in ("evaluation", "assignment"):   # only one of the (fast) host-side fixtures
-        {"evaluation": evaluation_case, "assignment": assignment_case}[sys.argv[1]]()
+    if len(sys.argv) > 1 and sys.argv[1] == "evaluation":   # only the (fast) host-side fixture
+        evaluation_case()
         return
     resize_case()
     r50 = DetrArch.resnet50()
@@ -274,7 +255,6 @@ def main():
     feature_extractor_case()
     similarity_and_export_case()
     evaluation_case()
-    assignment_case()
 
 
 if __name__ == "__main__":
