@@ -48,6 +48,8 @@ typedef struct opd_detr opd_detr; /* opaque model handle */
 /* Where the caller's buffers live. */
 #define OPD_MEM_HOST 0
 #define OPD_MEM_DEVICE 1 /* pointers are HIP device pointers on the handle's device */
+#define OPD_MEM_HOST_PIXELS_DEVICE_OUT 2 /* pixels in host memory, every output pointer a device pointer: a sharded caller uploads
+                                          * camera frames and hands the records straight to an RCCL all-gather (sharding.py) */
 
 typedef struct opd_config {
     int32_t struct_size; /* = sizeof(opd_config), for forward compatibility */
@@ -166,6 +168,10 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
  * descending score order at `nms_threshold` (pass >= 1 to disable).  Host-side, in place: compacts `dets[0..n)` and
  * returns the new count (>= 0) or a negative error. */
 int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold);
+/* The same for a whole batch in one call: frame f owns `dets[f * stride .. f * stride + counts[f])` (the fixed-slot layout
+ * opd_detr_detect writes, stride = num_queries); every frame is compacted in place and `counts[f]` becomes its new count.
+ * A negative `counts[f]` (padding slot of an uneven shard) is left alone.  Returns 0 or a negative error. */
+int opd_person_nms_batch(opd_det* dets, int32_t* counts, int n_frames, int stride, int person_label, float nms_threshold);
 
 /* Page-locked host memory for frame batches handed over with OPD_MEM_HOST: the upload of such a buffer is one asynchronous DMA
  * instead of the runtime's staged copy of pageable memory.  Optional (any host pointer is accepted everywhere); the Python shim

@@ -17,6 +17,7 @@ OPD_PIXELS_U8_BGR_HWC = 0
 OPD_PIXELS_F32_NCHW = 1
 OPD_MEM_HOST = 0
 OPD_MEM_DEVICE = 1
+OPD_MEM_HOST_PIXELS_DEVICE_OUT = 2
 OPD_FLAG_NO_GRAPH = 1
 
 
@@ -60,6 +61,7 @@ API = {
                                         C.POINTER(OpdDet), C.POINTER(C.c_int32), C.POINTER(C.c_int)]),
     "opd_detr_wait": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_person_nms": (C.c_int, [C.POINTER(OpdDet), C.c_int, C.c_int, C.c_float]),
+    "opd_person_nms_batch": (C.c_int, [C.POINTER(OpdDet), C.POINTER(C.c_int32), C.c_int, C.c_int, C.c_int, C.c_float]),
     "opd_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "opd_host_free": (None, [C.c_void_p]),
     "opd_similarity_matrix": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,

@@ -615,8 +615,10 @@ static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const
     RCCHK(timed_begin(m, cls, 2.0 * M * (double)N * K));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     HIPCHK(opd_launch_reduce_ln(m->d_slab, splits, (size_t)M * N, res32, ln ? ln->g : nullptr, ln ? ln->b : nullptr, y32, y16, M,
                                 m->stream));
+    RCCHK(timed_end(m));
     return OPD_OK;
 }
 
@@ -650,7 +652,9 @@ static int run_small_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const 
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * 256.0 * K));
     HIPCHK(opd_launch_gemm_k256(p, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     HIPCHK(opd_launch_reduce_ln(m->d_slab, p.slices, (size_t)M * 256, res32, ln.g, ln.b, y32, y16, M, m->stream));
+    RCCHK(timed_end(m));
     return OPD_OK;
 }
 
@@ -738,10 +742,12 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     timed_reset(m);
     MARK(0);
     const int Hp = 2 * d.H1 + 6, Wp = 2 * d.W1 + 6;  // padded image seen by the stem: rows/cols 2*o + k, k = 0..7
+    RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     if (pixel_format == OPD_PIXELS_U8_BGR_HWC)
         HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
     else
         HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
+    RCCHK(timed_end(m));
     if (m->fuse_stem_pool) {
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
         HIPCHK(opd_launch_stem_pool(m->d_x4, m->stem.w, m->stem.bias, m->d_pool, B, Hp, Wp, d.H1, d.W1, d.H2, d.W2, m->stream));
@@ -754,7 +760,9 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * 64.0 * 147.0));
         HIPCHK(opd_launch_conv_gemm(p, m->stream));
         RCCHK(timed_end(m));
+        RCCHK(timed_begin(m, CLS_OTHER, 0.0));
         HIPCHK(opd_launch_maxpool(m->d_stem, m->d_pool, B, d.H1, d.W1, 64, d.H2, d.W2, m->stream));
+        RCCHK(timed_end(m));
     }
     MARK(1);
     const f16_t* cur = m->d_pool;
@@ -813,7 +821,9 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(run_gemm_ln(m, m->d_attn16, L.o.w, L.o.b, M, D, m->d_x32, L.ln1, m->d_x32, m->d_x16));
         } else {
             RCCHK(run_gemm(m, m->d_attn16, L.o.w, L.o.b, 0, M, D, D, m->d_y32, true, false, m->d_x32));
+            RCCHK(timed_begin(m, CLS_OTHER, 0.0));
             HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
+            RCCHK(timed_end(m));
         }
         RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
         RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM));
@@ -850,11 +860,15 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(run_gemm_splitk_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, D, F, 8, m->d_h32, &L.ln3, m->d_h32, m->d_h16, CLS_GEMM));
         }
     }
+    RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream));
+    RCCHK(timed_end(m));
     HeadParams hp{};
     hp.hs = m->d_hs32; hp.wc = m->wc; hp.bc = m->bc; hp.w1 = m->w1; hp.b1 = m->b1; hp.w2 = m->w2; hp.b2 = m->b2;
     hp.w3 = m->w3; hp.b3 = m->b3; hp.logits = m->d_logits; hp.boxes = m->d_boxes; hp.rows = Md; hp.ncls = a.ncls;
+    RCCHK(timed_begin(m, CLS_OTHER, 2.0 * Md * 256.0 * (a.ncls + 256 + 256 + 4)));
     HIPCHK(opd_launch_heads(hp, m->stream));
+    RCCHK(timed_end(m));
     MARK(7);
     m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = ch; m->last_fw = cw;
     return OPD_OK;
@@ -927,11 +941,16 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
     return OPD_OK;
 }
 
+// mem_kind: where the pixels come from / where the outputs go
+static inline bool pixels_on_device(int mem_kind) { return mem_kind == OPD_MEM_DEVICE; }
+static inline bool outputs_on_device(int mem_kind) { return mem_kind != OPD_MEM_HOST; }
+
 static int check_shape(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     if (!pixels) return fail(OPD_EINVAL, "null pixel buffer");
     if (pixel_format != OPD_PIXELS_U8_BGR_HWC && pixel_format != OPD_PIXELS_F32_NCHW) return fail(OPD_EINVAL, "unknown pixel_format");
-    if (mem_kind != OPD_MEM_HOST && mem_kind != OPD_MEM_DEVICE) return fail(OPD_EINVAL, "unknown mem_kind");
+    if (mem_kind != OPD_MEM_HOST && mem_kind != OPD_MEM_DEVICE && mem_kind != OPD_MEM_HOST_PIXELS_DEVICE_OUT)
+        return fail(OPD_EINVAL, "unknown mem_kind");
     const int edge = std::max(m->cfg.max_height, m->cfg.max_width);   // either orientation: see build_workspace
     if (B < 1 || B > m->cfg.max_batch || H < 32 || W < 32 || H > edge || W > edge ||
         (size_t)H * W > (size_t)m->cfg.max_height * m->cfg.max_width)
@@ -942,7 +961,7 @@ static int check_shape(opd_detr* m, const void* pixels, int pixel_format, int me
 }
 
 static int stage_pixels(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, const void** d_pixels) {
-    if (mem_kind == OPD_MEM_DEVICE) { *d_pixels = pixels; return OPD_OK; }
+    if (pixels_on_device(mem_kind)) { *d_pixels = pixels; return OPD_OK; }
     const size_t n = (size_t)B * H * W * 3;
     if (pixel_format == OPD_PIXELS_U8_BGR_HWC) {
         HIPCHK(hipMemcpyAsync(m->d_u8, pixels, n, hipMemcpyHostToDevice, m->stream));
@@ -959,7 +978,7 @@ static int enqueue_resize(opd_detr* m, const uint8_t* frames, int mem_kind, int 
     if (h < 1 || w < 1 || (size_t)h * w > (size_t)1 << 26) return fail(OPD_EINVAL, "source frame size out of range");
     const size_t need = (size_t)B * h * w * 3;
     const uint8_t* d_in = frames;
-    if (mem_kind == OPD_MEM_HOST) {
+    if (!pixels_on_device(mem_kind)) {
         if (need > m->src_bytes) {
             HIPCHK(hipStreamSynchronize(m->stream));
             if (m->d_src) (void)hipFree(m->d_src);
@@ -1013,14 +1032,16 @@ static int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig
     pp.records = dev_out ? dev_out : m->d_records;
     pp.counts = dev_counts ? dev_counts : m->d_counts;
     pp.B = B; pp.Q = m->arch.queries; pp.ncls = m->arch.ncls; pp.threshold = threshold;
+    RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     HIPCHK(opd_launch_postprocess(pp, m->stream));
+    RCCHK(timed_end(m));
     MARK(8);
     return OPD_OK;
 }
 
 static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kind) {
     const int B = m->last_B, Q = m->arch.queries;
-    if (mem_kind == OPD_MEM_HOST) {   // (device callers had the post-process kernel write into their buffers)
+    if (!outputs_on_device(mem_kind)) {   // (device callers had the post-process kernel write into their buffers)
         HIPCHK(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipMemcpyAsync(out, m->d_records, (size_t)B * Q * sizeof(opd_det), hipMemcpyDeviceToHost, m->stream));
     }
@@ -1180,7 +1201,7 @@ int opd_detr_info(const opd_detr* m, opd_model_info* info) {
 static int forward_device(opd_detr* m, const void* d_pixels, int pixel_format, int out_kind, int B, int H, int W,
                           const int32_t* valid_hw, float* logits, float* boxes, float* enc_features) {
     RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
-    const hipMemcpyKind kind = out_kind == OPD_MEM_HOST ? hipMemcpyDeviceToHost : hipMemcpyDeviceToDevice;
+    const hipMemcpyKind kind = outputs_on_device(out_kind) ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     const size_t Md = (size_t)B * m->arch.queries;
     if (logits) HIPCHK(hipMemcpyAsync(logits, m->d_logits, Md * m->arch.ncls * 4, kind, m->stream));
     if (boxes) HIPCHK(hipMemcpyAsync(boxes, m->d_boxes, Md * 4 * 4, kind, m->stream));
@@ -1247,7 +1268,7 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
     RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, valid_hw));
-    const bool dev = mem_kind == OPD_MEM_DEVICE;
+    const bool dev = outputs_on_device(mem_kind);
     RCCHK(enqueue_postprocess(m, threshold, orig_hw, dev ? out : nullptr, dev ? counts : nullptr));
     return fetch_records(m, out, counts, mem_kind);
 }
@@ -1268,7 +1289,7 @@ int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int
     const int Q = m->arch.queries;
     opd_detr::AsyncHost& slot = m->async_host[t];
     slot.out = nullptr;
-    if (mem_kind == OPD_MEM_DEVICE) {
+    if (outputs_on_device(mem_kind)) {
         RCCHK(enqueue_postprocess(m, threshold, orig_hw, out, counts));
     } else {   // host outputs: pinned staging so that the copy stays asynchronous; delivered by opd_detr_wait
         RCCHK(enqueue_postprocess(m, threshold, orig_hw));
@@ -1312,7 +1333,7 @@ int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, in
     RCCHK(run_forward(m, m->d_u8, OPD_PIXELS_U8_BGR_HWC, B, H, W, nullptr));
     std::vector<int32_t> orig((size_t)2 * B);   // boxes are scaled to the ORIGINAL (camera) frame size
     for (int b = 0; b < B; ++b) { orig[2 * b] = h; orig[2 * b + 1] = w; }
-    const bool dev = mem_kind == OPD_MEM_DEVICE;
+    const bool dev = outputs_on_device(mem_kind);
     RCCHK(enqueue_postprocess(m, threshold, orig.data(), dev ? out : nullptr, dev ? counts : nullptr));
     return fetch_records(m, out, counts, mem_kind);
 }
@@ -1357,6 +1378,18 @@ int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold) 
     }
     for (size_t i = 0; i < kept.size(); ++i) dets[i] = kept[i];
     return (int)kept.size();
+}
+
+int opd_person_nms_batch(opd_det* dets, int32_t* counts, int n_frames, int stride, int person_label, float nms_threshold) {
+    if (n_frames < 0 || stride < 0 || (n_frames > 0 && (!dets || !counts))) return fail(OPD_EINVAL, "opd_person_nms_batch: bad arguments");
+    for (int f = 0; f < n_frames; ++f) {
+        if (counts[f] < 0) continue;
+        if (counts[f] > stride) return fail(OPD_EINVAL, "opd_person_nms_batch: a frame holds more records than its slots");
+        const int kept = opd_person_nms(dets + (size_t)f * stride, counts[f], person_label, nms_threshold);
+        if (kept < 0) return kept;
+        counts[f] = kept;
+    }
+    return OPD_OK;
 }
 
 int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* boxes1, const uint8_t* has1, int n1,

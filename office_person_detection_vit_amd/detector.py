@@ -290,38 +290,61 @@ class HipDetrDetector:
 
     def _detect_records(self, frames: Sequence[np.ndarray], handle: Optional[int] = None):
         model = self.model if handle is None else handle
-        batch, orig, valid, target = self._preprocess_batch(frames, self._handles.index(model))
-        B, H, W, _ = batch.shape
-        Q = self._info.num_queries
+        B, Q = len(frames), self._info.num_queries
         recs = (_capi.OpdDet * (B * Q))()
         counts = (C.c_int32 * B)()
+        self._detect_into(frames, model, C.addressof(recs), C.addressof(counts), on_device=False)
+        return recs, counts, Q
+
+    def _detect_into(self, frames: Sequence[np.ndarray], model: int, rec_ptr: int, cnt_ptr: int, on_device: bool) -> None:
+        """One ``max_batch`` chunk of host frames -> ``[B][Q]`` ``opd_det`` records at ``rec_ptr`` and ``[B]`` counts at
+        ``cnt_ptr``; ``on_device``: both are HIP device pointers on this detector's GPU (``OPD_MEM_HOST_PIXELS_DEVICE_OUT``)."""
+        batch, orig, valid, target = self._preprocess_batch(frames, self._handles.index(model))
+        B, H, W, _ = batch.shape
+        kind = _capi.OPD_MEM_HOST_PIXELS_DEVICE_OUT if on_device else _capi.OPD_MEM_HOST
+        recs, counts = C.cast(C.c_void_p(rec_ptr), C.POINTER(_capi.OpdDet)), C.cast(C.c_void_p(cnt_ptr), C.POINTER(C.c_int32))
         if target is not None:   # camera-resolution batch: resize on the device, boxes come back in camera pixels
-            rc = self._lib.opd_detr_detect_resized(C.c_void_p(model), batch.ctypes.data_as(C.c_void_p), _capi.OPD_MEM_HOST,
+            rc = self._lib.opd_detr_detect_resized(C.c_void_p(model), batch.ctypes.data_as(C.c_void_p), kind,
                                                    B, H, W, target[0], target[1], float(self.confidence_threshold), recs, counts)
             _capi.check(rc, "opd_detr_detect_resized")
-            self._last_orig = orig
-            return recs, counts, Q
-        hw = np.asarray(orig, dtype=np.int32).reshape(B, 2)
-        rc = self._lib.opd_detr_detect_ragged(C.c_void_p(model), batch.ctypes.data_as(C.c_void_p),
-                                              _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,
-                                              valid.ctypes.data_as(C.c_void_p) if valid is not None else None,
-                                              float(self.confidence_threshold), hw.ctypes.data_as(C.c_void_p), recs, counts)
-        _capi.check(rc, "opd_detr_detect")
+        else:
+            hw = np.asarray(orig, dtype=np.int32).reshape(B, 2)
+            rc = self._lib.opd_detr_detect_ragged(C.c_void_p(model), batch.ctypes.data_as(C.c_void_p),
+                                                  _capi.OPD_PIXELS_U8_BGR_HWC, kind, B, H, W,
+                                                  valid.ctypes.data_as(C.c_void_p) if valid is not None else None,
+                                                  float(self.confidence_threshold), hw.ctypes.data_as(C.c_void_p), recs, counts)
+            _capi.check(rc, "opd_detr_detect")
         self._last_orig = orig
-        return recs, counts, Q
+
+    @property
+    def num_queries(self) -> int:
+        self._require_model()
+        return int(self._info.num_queries)
+
+    def detect_records_into(self, frames: Sequence[np.ndarray], records, counts) -> None:
+        """Frame-sharded callers (``sharding.ShardedDetector``): detect ``frames`` (at most ``max_batch``) and write their fixed-size
+        records / counts into caller-owned int32 buffers ``records`` ``[len(frames), Q, 8]`` and ``counts`` ``[len(frames)]``.
+        The buffers are anything with ``data_ptr()`` / ``is_cuda`` / ``is_contiguous()`` (torch tensors: the library itself never
+        imports torch); device buffers are written by the post-process kernel directly, so the records can go into a collective
+        without touching the host."""
+        self._require_model()
+        if len(frames) == 0:
+            return
+        if len(frames) > self.max_batch:
+            raise ValueError(f"{len(frames)} frames exceed max_batch = {self.max_batch}")
+        if not (records.is_contiguous() and counts.is_contiguous()):
+            raise ValueError("records / counts must be contiguous")
+        self._detect_into(frames, self.model, int(records.data_ptr()), int(counts.data_ptr()), on_device=bool(records.is_cuda))
 
     def _postprocess_batch(self, recs, counts, Q: int) -> List[List[Detection]]:
         """``_postprocess_batch`` (deleted vit_detector.py 591-647): person filter + NMS (C-ABI), xyxy -> xywh, foot point."""
+        rc = self._lib.opd_person_nms_batch(recs, counts, len(counts), Q, PERSON_LABEL, float(self.nms_threshold))   # in place
+        _capi.check(rc, "opd_person_nms_batch")
         results: List[List[Detection]] = []
         for b in range(len(counts)):
-            n = int(counts[b])
-            frame_recs = (_capi.OpdDet * max(n, 1)).from_buffer(recs, b * Q * C.sizeof(_capi.OpdDet))
-            kept = self._lib.opd_person_nms(frame_recs, n, PERSON_LABEL, float(self.nms_threshold))
-            if kept < 0:
-                _capi.check(kept, "opd_person_nms")
             dets = []
-            for i in range(kept):
-                r = frame_recs[i]
+            for i in range(int(counts[b])):
+                r = recs[b * Q + i]
                 bbox = (float(r.x1), float(r.y1), float(r.x2 - r.x1), float(r.y2 - r.y1))
                 dets.append(Detection(bbox=bbox, confidence=float(r.score), class_id=PERSON_LABEL, class_name="person",
                                       camera_coords=self._get_foot_position(bbox), query_index=int(r.query_index)))

@@ -34,91 +34,65 @@ def shard_bounds(n_frames: int, rank: int, world: int) -> Tuple[int, int, int]:
     return start, min(n_frames, start + per), per
 
 
-def pack_local(records: np.ndarray, counts: np.ndarray, per_rank: int, num_queries: int) -> Tuple[np.ndarray, np.ndarray]:
-    """Pad this rank's ``[n_local, Q]`` records / ``[n_local]`` counts to the fixed per-rank shape (int32 words);
-    padding frames carry count -1 so the orchestrator can drop them."""
-    rec = np.zeros((per_rank, num_queries, 8), np.int32)
-    cnt = np.full((per_rank,), -1, np.int32)
-    n = len(counts)
-    if n:
-        rec[:n] = np.ascontiguousarray(records).view(np.int32).reshape(n, num_queries, 8)
-        cnt[:n] = counts
-    return rec, cnt
-
-
-def exchange(rec: np.ndarray, cnt: np.ndarray, device=None):
-    """The path's one collective: all-gather of the packed records and counts.  Returns ([R, per, Q, 8], [R, per])."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size()
-    # records and counts travel in ONE flat int32 tensor per rank (the collective is latency bound: one launch, not two)
-    nrec = rec.size
-    flat = torch.from_numpy(np.concatenate([np.ascontiguousarray(rec, dtype=np.int32).reshape(-1),
-                                            np.ascontiguousarray(cnt, dtype=np.int32).reshape(-1)]))
-    if device is not None:
-        flat = flat.to(device)
-    # concatenated-along-dim-0 output form: accepted by both the RCCL and the gloo backend
-    gathered = torch.empty((world * flat.shape[0],), dtype=flat.dtype, device=flat.device)
-    dist.all_gather_into_tensor(gathered, flat)
-    g = gathered.cpu().numpy().reshape(world, flat.shape[0])
-    return (np.ascontiguousarray(g[:, :nrec]).reshape((world,) + tuple(rec.shape)),
-            np.ascontiguousarray(g[:, nrec:]).reshape(world, cnt.shape[0]))
-
-
 def assemble(g_rec: np.ndarray, g_cnt: np.ndarray, n_frames: int, person_label: int = 1, nms_threshold: float = 0.4,
              foot=lambda b: (b[0] + b[2] / 2, b[1] + b[3])) -> List[List[Detection]]:
     """Orchestrator side: gathered records -> ``list[list[Detection]]`` in global frame order (person filter + NMS via
     the C-ABI's host routine ``opd_person_nms``; xyxy -> xywh; foot point)."""
     lib = _capi.load_library()
     world, per, Q, _ = g_rec.shape
+    recs = np.ascontiguousarray(g_rec, dtype=np.int32).reshape(world * per * Q, 8).view(DET_DTYPE).reshape(world * per, Q).copy()
+    counts = np.ascontiguousarray(g_cnt, dtype=np.int32).reshape(world * per).copy()
+    rc = lib.opd_person_nms_batch(recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), counts.ctypes.data_as(C.POINTER(C.c_int32)),
+                                  world * per, Q, person_label, float(nms_threshold))   # padding slots (count -1) are skipped
+    _capi.check(rc, "opd_person_nms_batch")
     out: List[List[Detection]] = []
-    for r in range(world):
-        for i in range(per):
-            n = int(g_cnt[r, i])
-            if n < 0:
-                continue  # padding slot of an uneven shard
-            recs = np.ascontiguousarray(g_rec[r, i]).view(DET_DTYPE).reshape(Q).copy()
-            kept = lib.opd_person_nms(recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), n, person_label, float(nms_threshold))
-            if kept < 0:
-                _capi.check(kept, "opd_person_nms")
-            dets = []
-            for k in range(kept):
-                d = recs[k]
-                bbox = (float(d["x1"]), float(d["y1"]), float(d["x2"] - d["x1"]), float(d["y2"] - d["y1"]))
-                dets.append(Detection(bbox=bbox, confidence=float(d["score"]), class_id=person_label, class_name="person",
-                                      camera_coords=foot(bbox), query_index=int(d["query_index"])))
-            out.append(dets)
+    for f in range(world * per):
+        if counts[f] < 0:
+            continue  # padding slot of an uneven shard
+        dets = []
+        for d in recs[f, :counts[f]]:
+            bbox = (float(d["x1"]), float(d["y1"]), float(d["x2"] - d["x1"]), float(d["y2"] - d["y1"]))
+            dets.append(Detection(bbox=bbox, confidence=float(d["score"]), class_id=person_label, class_name="person",
+                                  camera_coords=foot(bbox), query_index=int(d["query_index"])))
+        out.append(dets)
     if len(out) != n_frames:
         raise RuntimeError(f"gathered {len(out)} frames, expected {n_frames}")
     return out
 
 
 class ShardedDetector:
-    """``detect_batch`` over all ranks of an initialised ``torch.distributed`` process group (one rank per GPU)."""
+    """``detect_batch`` over all ranks of an initialised ``torch.distributed`` process group (one rank per GPU).
+
+    ``detector``: anything with ``max_batch``, ``num_queries``, ``nms_threshold``, ``_get_foot_position`` and
+    ``detect_records_into(frames, records, counts)`` — a loaded ``HipDetrDetector`` bound to this rank's GPU (the CPU tests
+    inject a stand-in for the compute).  ``device``: torch device of the exchange buffer: this rank's GPU under RCCL — the
+    post-process kernel then writes the records straight into the tensor the all-gather reads — or None (host memory, gloo)."""
 
     def __init__(self, detector, device: Optional[str] = None):
-        self.detector = detector          # a loaded HipDetrDetector bound to this rank's GPU
-        self.device = device              # torch device of the collective's tensors (None = CPU/gloo)
+        self.detector = detector
+        self.device = device
 
     def detect_batch(self, frames: Sequence[np.ndarray]) -> List[List[Detection]]:
         """Every rank passes the SAME global frame list; every rank returns the full result."""
+        import torch
         import torch.distributed as dist
 
         rank, world = dist.get_rank(), dist.get_world_size()
         start, stop, per = shard_bounds(len(frames), rank, world)
         det = self.detector
-        Q = det._info.num_queries
-        if stop > start:
-            parts, cparts = [], []
-            for s0 in range(start, stop, det.max_batch):  # the handle's workspace holds max_batch frames
-                chunk = list(frames[s0:min(stop, s0 + det.max_batch)])
-                recs, counts, _ = det._detect_records(chunk)
-                parts.append(np.frombuffer(recs, dtype=DET_DTYPE).reshape(len(chunk), Q).copy())
-                cparts.append(np.frombuffer(counts, dtype=np.int32).copy())
-            local, local_counts = np.concatenate(parts), np.concatenate(cparts)
-        else:
-            local, local_counts = np.zeros((0, Q), DET_DTYPE), np.zeros((0,), np.int32)
-        rec, cnt = pack_local(local, local_counts, per, Q)
-        g_rec, g_cnt = exchange(rec, cnt, self.device)
+        Q = det.num_queries
+        nrec = per * Q * 8
+        # ONE flat int32 buffer per rank: per x Q records (8 words each), then per counts; -1 marks the padding slots of an
+        # uneven shard.  The collective is latency bound: one launch, not two.
+        flat = torch.zeros((nrec + per,), dtype=torch.int32, device=self.device or "cpu")
+        flat[nrec:] = -1
+        rec_view, cnt_view = flat[:nrec].view(per, Q, 8), flat[nrec:]
+        for s0 in range(start, stop, det.max_batch):   # the handle's workspace holds max_batch frames
+            s1 = min(stop, s0 + det.max_batch)
+            det.detect_records_into(list(frames[s0:s1]), rec_view[s0 - start:s1 - start], cnt_view[s0 - start:s1 - start])
+        gathered = torch.empty((world * flat.shape[0],), dtype=torch.int32, device=flat.device)
+        dist.all_gather_into_tensor(gathered, flat)   # concatenated form: accepted by both the RCCL and the gloo backend
+        g = gathered.cpu().numpy().reshape(world, flat.shape[0])
+        g_rec = np.ascontiguousarray(g[:, :nrec]).reshape(world, per, Q, 8)
+        g_cnt = np.ascontiguousarray(g[:, nrec:])
         return assemble(g_rec, g_cnt, len(frames), nms_threshold=det.nms_threshold, foot=det._get_foot_position)

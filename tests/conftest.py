@@ -29,3 +29,35 @@ def weight_cache(tmp_path_factory):
         os.makedirs(d, exist_ok=True)
         return d
     return str(tmp_path_factory.mktemp("weights"))
+
+
+# ---- parity table: measured |delta| of every end-to-end comparison, printed at the end of the run (also with -q) and written to
+# gpurun_out/parity_table.json, so that the driver's log carries numbers and not just dots (VERDICT r1, next #1b) -------------
+PARITY_ROWS = []
+
+
+@pytest.fixture(scope="session")
+def parity_log():
+    def add(config, dbox=None, dprob=None, denc=None, bound_box=None, note=""):
+        PARITY_ROWS.append({"config": config, "dbox": dbox, "dprob": dprob, "denc": denc, "bound_box": bound_box, "note": note})
+    return add
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY_ROWS:
+        return
+    tr = terminalreporter
+    tr.write_line("")
+    tr.write_line("parity vs the fp32 oracle / HF golden vectors (max abs; boxes normalised cxcywh, 1e-3 = 1.3 px at width 1333)")
+    tr.write_line(f"{'config':58s} {'|dbox|':>9s} {'bound':>8s} {'|dprob|':>9s} {'|denc|':>9s}  note")
+    f = lambda v: "        -" if v is None else f"{v:9.2e}"
+    for r in PARITY_ROWS:
+        tr.write_line(f"{r['config'][:58]:58s} {f(r['dbox'])} {f(r['bound_box'])[1:]} {f(r['dprob'])} {f(r['denc'])}  {r['note']}")
+    try:
+        import json
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "parity_table.json"), "w") as fh:
+            json.dump(PARITY_ROWS, fh, indent=1)
+    except OSError:
+        pass

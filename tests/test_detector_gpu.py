@@ -54,7 +54,7 @@ def _golden_frames(g):
 
 
 @pytest.mark.parametrize("tag", ["r50_mild_256x320", "r50_sharp_256x320", "r50_mild_odd_203x333"])
-def test_forward_matches_hf_golden(detectors, golden_dir, tag):
+def test_forward_matches_hf_golden(detectors, golden_dir, tag, parity_log):
     g = np.load(os.path.join(golden_dir, tag + ".npz"))
     ga = float(g["attention_gain"])
     det = detectors(ga=ga)
@@ -63,29 +63,32 @@ def test_forward_matches_hf_golden(detectors, golden_dir, tag):
     dbox = float(np.abs(boxes - g["pred_boxes"]).max())
     dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
     denc = float(np.abs(enc - g["encoder_last_hidden_state"]).max())
-    print(f"{tag}: dbox {dbox:.2e} dprob {dprob:.2e} denc {denc:.2e}")
+    parity_log(f"{tag} vs HF golden", dbox, dprob, denc, tb)
     assert dbox <= tb and dprob <= tp and denc <= te
 
 
-def test_full_resolution_matches_golden(detectors, golden_dir):
-    """One 800x1333 frame (BASELINE config resolution) against the HF golden logits / boxes."""
+def test_full_resolution_matches_golden(detectors, golden_dir, parity_log):
+    """One 800x1333 frame (BASELINE config resolution) against the HF golden logits / boxes, at the north-star tolerance:
+    boxes within 1e-3 (normalised cxcywh = 1.3 px at width 1333)."""
     g = np.load(os.path.join(golden_dir, "r50_mild_800x1333.npz"))
     det = detectors(ga=1.0)
     logits, boxes, enc = det.forward_raw(_golden_frames(g))
     dbox = float(np.abs(boxes - g["pred_boxes"]).max())
     dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
     denc = float(np.abs(enc[:, ::97, ::13] - g["encoder_sample"]).max())
-    print(f"800x1333: dbox {dbox:.2e} dprob {dprob:.2e} denc {denc:.2e}")
-    assert dbox <= 2e-3 and dprob <= 4e-3 and denc <= 3e-2
+    parity_log("r50 mild 800x1333 (BASELINE configs[1] resolution) vs HF golden", dbox, dprob, denc, 1e-3)
+    assert dbox <= 1e-3 and dprob <= 2e-3 and denc <= 3e-2
 
 
-def test_r101_matches_golden(detectors, golden_dir):
+def test_r101_matches_golden(detectors, golden_dir, parity_log):
+    """r101 (33 bottlenecks): the stated exception to the 1e-3 target — fp16 storage of 33 block outputs alone gives 2.1e-3 in the
+    oracle's emulation (tools/drift_split.py, profiles/r02_drift_split.txt)."""
     g = np.load(os.path.join(golden_dir, "r101_mild_256x320.npz"))
     det = detectors(depths=(3, 4, 23, 3), ga=1.0)
     logits, boxes, enc = det.forward_raw(_golden_frames(g))
     dbox = float(np.abs(boxes - g["pred_boxes"]).max())
     dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
-    print(f"r101: dbox {dbox:.2e} dprob {dprob:.2e}")
+    parity_log("r101 mild 256x320 vs HF golden", dbox, dprob, None, 3e-3, "stated exception: 33 fp16-stored block outputs")
     assert dbox <= 3e-3 and dprob <= 6e-3
 
 
@@ -330,7 +333,7 @@ def test_similarity_matrix_on_device_matches_reference_golden(golden_dir):
     np.testing.assert_array_equal(iou, want)
 
 
-def test_config4_r101_1080p_batch8(detectors, weight_cache):
+def test_config4_r101_1080p_batch8(detectors, weight_cache, parity_log):
     """BASELINE.json configs[3]: detr-resnet-101, batch 8, 1080p frames (1066x1920 after the size rule).  Parity on one
     frame against the live oracle (r101 bounds: deeper trunk, more fp16 roundings) and batch invariance at the full batch."""
     det = detectors(depths=(3, 4, 23, 3), ga=1.0, max_batch=8, max_size=(1066, 1920))
@@ -343,8 +346,10 @@ def test_config4_r101_1080p_batch8(detectors, weight_cache):
     w = O.to_torch(load_safetensors(det.model_path))
     pv, pm = O.preprocess([frames[2]])
     lg, bx, mem = O.forward(w, pv, pm)
-    assert float(np.abs(bx1[0] - bx[0].numpy()).max()) <= 3e-3
-    assert float(np.abs(_softmax(lg1[0]) - _softmax(lg[0].numpy())).max()) <= 6e-3
+    dbox, dprob = float(np.abs(bx1[0] - bx[0].numpy()).max()), float(np.abs(_softmax(lg1[0]) - _softmax(lg[0].numpy())).max())
+    parity_log("r101 mild 1066x1920 batch 8 (BASELINE configs[3]), frame 2 vs live oracle", dbox, dprob, None, 3e-3,
+               "stated exception: 33 fp16-stored block outputs")
+    assert dbox <= 3e-3 and dprob <= 6e-3
 
 
 def test_config5_tiled_4k_frame(detectors):
@@ -495,3 +500,198 @@ def test_clone_shares_weights_and_outlives_its_source(weight_cache):
     assert c1 == c2 and sum(c1) > 0
     for a, b in zip(r1, r2):
         np.testing.assert_array_equal(a, b)
+
+
+def test_batch8_full_size_frames_match_live_oracle(detectors, parity_log):
+    """BASELINE configs[1] (batch 8, 800x1333): three frames of ONE batch-8 forward against the oracle run live on the same
+    frames, at the north-star tolerance (|dbox| <= 1e-3), plus the post-processed person boxes in pixels."""
+    det = detectors(ga=1.0, max_batch=8)
+    frames = structured_frames(8, 800, 1333, seed=8800)
+    lg8, bx8, enc8 = det.forward_raw(frames)
+    dets8 = det.detect_batch(frames)
+    w = O.to_torch(load_safetensors(det.model_path))
+    for i in (0, 3, 7):
+        pv, pm = O.preprocess([frames[i]])
+        lg, bx, mem = O.forward(w, pv, pm)
+        dbox = float(np.abs(bx8[i] - bx[0].numpy()).max())
+        dprob = float(np.abs(_softmax(lg8[i]) - _softmax(lg[0].numpy())).max())
+        denc = float(np.abs(enc8[i] - mem[0].numpy()).max())
+        parity_log(f"r50 mild 800x1333 batch 8 (BASELINE configs[1]), frame {i} vs live oracle", dbox, dprob, denc, 1e-3)
+        assert dbox <= 1e-3 and dprob <= 2e-3 and denc <= 3e-2
+        want = O.person_detections(O.post_process_object_detection(lg.numpy(), bx.numpy(), 0.5, [(800, 1333)])[0], 0.4)
+        ref_q = {d["query_index"]: d for d in want if abs(d["confidence"] - 0.5) > 4e-3}
+        got_q = {d.query_index: d for d in dets8[i] if abs(d.confidence - 0.5) > 4e-3}
+        assert set(ref_q) == set(got_q) and len(ref_q) > 0
+        for qi, r in ref_q.items():
+            np.testing.assert_allclose(got_q[qi].bbox, r["bbox"], atol=1e-3 * 1333 * 2)   # x and w each within 1e-3 of the width
+
+
+def test_export_scored_like_oracle(detectors, tmp_path):
+    """SURVEY.md section 8(f) rank 3 on the GPU: detector -> `detections_to_coco` -> `write_coco` -> evaluator, scored against
+    detections derived from the ORACLE on the same frames as ground truth.  Away from the score threshold every oracle box is
+    matched at IoU >= 0.9 (TP) and nothing else is reported (no FP / FN); the ambiguous ones can only add one FP or FN each."""
+    import json
+    from evaluator_checker import DetectionEvaluator
+    from office_person_detection_vit_amd import detections_to_coco, write_coco
+    det = detectors(ga=1.0)
+    frames = structured_frames(2, 288, 352, seed=3100)
+    dets = det.detect_batch(frames)
+    w = O.to_torch(load_safetensors(det.model_path))
+    pv, pm = O.preprocess(frames)
+    lg, bx, _ = O.forward(w, pv, pm)
+    ref = [O.person_detections(r, 0.4) for r in O.post_process_object_detection(lg.numpy(), bx.numpy(), 0.5, [(288, 352)] * 2)]
+    sizes = [(288, 352)] * 2
+    path = tmp_path / "pred" / "detections.json"
+    write_coco(str(path), detections_to_coco(dets, sizes))
+    pred = json.load(open(path, encoding="utf-8"))
+    gt = {"images": pred["images"], "categories": pred["categories"],
+          "annotations": [{"id": k, "image_id": i, "category_id": 0, "bbox": list(d["bbox"]), "area": d["bbox"][2] * d["bbox"][3], "iscrowd": 0}
+                          for i, f in enumerate(ref) for k, d in enumerate(f)]}
+    for k, a in enumerate(gt["annotations"]):
+        a["id"] = k
+    ambiguous = sum(abs(d["confidence"] - 0.5) <= 8e-3 for f in ref for d in f) + sum(abs(d.confidence - 0.5) <= 8e-3 for f in dets for d in f)
+    m = DetectionEvaluator(iou_threshold=0.9, confidence_threshold=0.0).evaluate(gt, pred)
+    n_ref = sum(len(f) for f in ref)
+    assert n_ref > 0 and m.true_positives >= n_ref - ambiguous
+    assert m.false_positives <= ambiguous and m.false_negatives <= ambiguous
+    assert len(pred["annotations"]) == sum(len(f) for f in dets)
+
+
+def _to_4x_name(k):
+    """HF 5.x state-dict name -> the 4.x / timm name of the same tensor (inverse of csrc/opd_loader.cpp::normalise_key;
+    HF:conversion_mapping.py:1036-1041 + the timm ResNet layout of `use_timm_backbone=True` checkpoints)."""
+    import re
+    bb = "model.backbone.model."
+    if k.startswith(bb):
+        r = k[len(bb):]
+        r = r.replace("embedder.embedder.convolution.", "conv1.").replace("embedder.embedder.normalization.", "bn1.")
+        m = re.match(r"encoder\.stages\.(\d)\.layers\.(\d+)\.(.*)", r)
+        if m:
+            st, ly, rest = int(m.group(1)), m.group(2), m.group(3)
+            mm = re.match(r"layer\.(\d)\.(convolution|normalization)\.(.*)", rest)
+            if mm:
+                rest = f"{'conv' if mm.group(2) == 'convolution' else 'bn'}{int(mm.group(1)) + 1}.{mm.group(3)}"
+            else:
+                rest = rest.replace("shortcut.convolution.", "downsample.0.").replace("shortcut.normalization.", "downsample.1.")
+            r = f"layer{st + 1}.{ly}.{rest}"
+        return "model.backbone.conv_encoder.model." + r
+    k = k.replace(".o_proj.", ".out_proj.")
+    if k.startswith(("model.encoder.layers.", "model.decoder.layers.")):
+        k = k.replace(".mlp.fc1.", ".fc1.").replace(".mlp.fc2.", ".fc2.")
+    return k
+
+
+def test_checkpoint_with_4x_timm_names_gives_identical_outputs(detectors, tmp_path):
+    """a checkpoint in the reference pin's naming (transformers 4.57 + timm backbone: `conv_encoder`,
+    `out_proj`, `fc1/fc2`, `layer1.0.conv1`, `downsample.0`) loads as is and gives bit-identical outputs."""
+    from office_person_detection_vit_amd.weights import save_safetensors
+    det = detectors(ga=1.0)
+    w = load_safetensors(det.model_path)
+    old = {_to_4x_name(k): v for k, v in w.items()}
+    assert len(old) == len(w) and "model.backbone.conv_encoder.model.layer3.5.bn2.running_var" in old
+    assert "model.decoder.layers.2.encoder_attn.out_proj.weight" in old and "model.encoder.layers.0.fc1.weight" in old
+    assert not any(".o_proj." in k or ".mlp." in k or "embedder" in k for k in old)
+    path = str(tmp_path / "detr_4x_names.safetensors")
+    save_safetensors(old, path)
+    det4 = HipDetrDetector(model_path=path, max_batch=2, max_size=(800, 1333), resize=False)
+    det4.load_model()
+    try:
+        frames = structured_frames(2, 256, 320, seed=1212)
+        a, b = det.forward_raw(frames), det4.forward_raw(frames)
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y)
+    finally:
+        det4.close()
+
+
+def test_sharded_detector_device_direct_exchange(detectors):
+    """`ShardedDetector.detect_batch` with the exchange buffer in HBM (world size 1 RCCL group on this GPU): the post-process kernel
+    writes the records into the tensor the all-gather reads (OPD_MEM_HOST_PIXELS_DEVICE_OUT); same detections as detect_batch,
+    for both the plain and the device-resize path."""
+    import socket
+    import torch.distributed as dist
+    from office_person_detection_vit_amd.sharding import ShardedDetector
+    det = detectors(ga=1.0)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        sharded = ShardedDetector(det, device="cuda:0")
+        for frames in (structured_frames(5, 256, 320, seed=77), ):
+            want = det.detect_batch(frames)
+            got = sharded.detect_batch(frames)
+            assert [[(d.bbox, d.confidence, d.query_index) for d in f] for f in got] == \
+                   [[(d.bbox, d.confidence, d.query_index) for d in f] for f in want]
+            assert sum(len(f) for f in got) > 0
+    finally:
+        dist.destroy_process_group()
+    cam = HipDetrDetector(model_path=det.model_path, max_batch=2, max_size=(256, 320), resize=True)
+    cam.load_model()
+    try:   # camera-resolution frames: resize on the device, records into a device buffer
+        frames = structured_frames(2, 360, 450, seed=78)
+        rec = torch.zeros((2, cam.num_queries, 8), dtype=torch.int32, device="cuda")
+        cnt = torch.full((2,), -1, dtype=torch.int32, device="cuda")
+        cam.detect_records_into(frames, rec, cnt)
+        recs, counts, Q = cam._detect_records(frames)
+        assert cnt.cpu().tolist() == list(counts)
+        rec_h, cnt_h = torch.zeros((2, Q, 8), dtype=torch.int32), torch.zeros((2,), dtype=torch.int32)   # host exchange buffer (gloo)
+        cam.detect_records_into(frames, rec_h, cnt_h)
+        assert cnt_h.tolist() == list(counts) and torch.equal(rec_h[0, :counts[0]], rec[0, :counts[0]].cpu())
+        host = np.frombuffer(bytes(recs), dtype=np.int32).reshape(2, Q, 8)
+        for b in range(2):
+            np.testing.assert_array_equal(rec[b, :counts[b]].cpu().numpy(), host[b, :counts[b]])
+    finally:
+        cam.close()
+
+
+def test_fifth_async_submission_is_refused(detectors):
+    """a submission slot is not reused before its ticket has been waited for."""
+    import ctypes as C
+    from office_person_detection_vit_amd import _capi
+    det = detectors(ga=1.0)
+    lib = _capi.load_library()
+    h = C.c_void_p(det.model)
+    Q = det.num_queries
+    frames = np.ascontiguousarray(np.stack(structured_frames(1, 256, 320, seed=5)))
+    hw = np.asarray([[256, 320]], np.int32)
+    outs = [((_capi.OpdDet * Q)(), (C.c_int32 * 1)()) for _ in range(5)]
+    tickets = []
+    for i, (recs, counts) in enumerate(outs):
+        t = C.c_int(-1)
+        rc = lib.opd_detr_detect_async(h, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 1, 256, 320,
+                                       0.5, hw.ctypes.data_as(C.c_void_p), recs, counts, C.byref(t))
+        if i < 4:
+            assert rc == 0
+            tickets.append(t.value)
+        else:
+            assert rc == -6 and "outstanding" in _capi.last_error()     # OPD_ESTATE
+    assert sorted(tickets) == [0, 1, 2, 3]
+    _capi.check(lib.opd_detr_wait(h, tickets[0]), "wait")
+    assert lib.opd_detr_wait(h, tickets[0]) == -6                       # waiting twice for one ticket
+    t = C.c_int(-1)
+    _capi.check(lib.opd_detr_detect_async(h, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 1, 256, 320,
+                                          0.5, hw.ctypes.data_as(C.c_void_p), outs[4][0], outs[4][1], C.byref(t)), "detect_async")
+    for tk in tickets[1:] + [t.value]:
+        _capi.check(lib.opd_detr_wait(h, tk), "wait")
+    assert [list(c) for _, c in outs] == [list(outs[0][1])] * 5         # five runs of the same frame
+
+
+def test_portrait_frames_are_accepted(weight_cache, parity_log):
+    """the HF size rule maps a portrait camera frame to a portrait model input; a handle configured for 256 x 320 takes
+    320 x 256 too, and the result matches the oracle like the landscape case."""
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    det = HipDetrDetector(model_path=path, max_batch=1, max_size=(256, 320), resize=False)
+    det.load_model()
+    try:
+        frame = structured_frames(1, 320, 256, seed=640)[0]
+        logits, boxes, enc = det.forward_raw([frame])
+        w = O.to_torch(load_safetensors(path))
+        pv, pm = O.preprocess([frame])
+        lg, bx, mem = O.forward(w, pv, pm)
+        dbox = float(np.abs(boxes - bx.numpy()).max())
+        parity_log("r50 mild 320x256 (portrait) vs live oracle", dbox, None, float(np.abs(enc - mem.numpy()).max()), 2e-3)
+        assert dbox <= 2e-3
+        with pytest.raises(RuntimeError):
+            det.forward_raw([structured_frames(1, 330, 256, seed=1)[0]])     # more pixels than the handle was sized for
+    finally:
+        det.close()
