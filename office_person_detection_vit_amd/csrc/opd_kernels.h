@@ -84,6 +84,30 @@ struct GemmK256Params {
 };
 hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream);
 
+// ---- two chained 1x1 GEMMs through a wide hidden layer in one kernel (kernels_ffn.hip) ------------------------------------
+// etail == 0 (transformer feed-forward block):  y = LayerNorm(res32 + W_b . relu(W_a . x16 + b1) + b2) over rows of 256; the
+//     hidden activations never reach HBM.  y32 may alias res32 and y16 may alias x16 (a workgroup reads its own rows first).
+// etail == 1 (stage-3 bottleneck tail):  hid16 = relu(W_a . x16 + b1 + res16)  (the block output, [M][F] fp16, stored);
+//     y16 = relu(W_b . hid16 + b2)  (the next block's 1x1 reduce, [M][256] fp16).  hid16 may alias res16.
+struct FfnParams {
+    const f16_t* x16;    // [M][256] fp16 (GEMM operand)
+    const float* res32;  // FFN: [M][256] fp32 residual stream
+    const f16_t* w1;     // W_a [F][256] fp16 (fc1 / 1x1 expand)
+    const float* b1;     // [F]
+    const f16_t* w2p;    // W_b [256][F] fp16 (fc2 / next 1x1 reduce), K-permuted with opd_permute_k32
+    const float* b2;     // [256]
+    const float* gamma;  // FFN: [256]
+    const float* beta;   // FFN: [256]
+    float* y32;          // FFN: [M][256] or null
+    f16_t* y16;          // [M][256] (FFN: or null)
+    const f16_t* res16;  // ETAIL: [M][F] fp16 residual
+    f16_t* hid16;        // ETAIL: [M][F] fp16 hidden output
+    f16_t* dump;         // ETAIL: >= 16 writable bytes on the device (rows >= M of the last workgroup store here)
+    int M, F;            // F % 64 == 0
+    int etail;
+};
+hipError_t opd_launch_ffn(const FfnParams& p, hipStream_t stream);
+
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
 // uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order, written into a
 // zero-bordered image [B][Hp][Wp][4] with the frame at offset (3, 3) (Hp >= H + 6, Wp >= W + 6): the stem's padding.

@@ -69,6 +69,7 @@ struct Block {
 struct EncLayer {
     f16_t* wqkv = nullptr;  // [768][256] = [Wq; Wk; Wv]
     Lin o, fc1, fc2;
+    f16_t* fc2p = nullptr;  // fc2 weights K-permuted for the fused feed-forward kernel (opd_permute_k32)
     LNp ln1, ln2;
 };
 struct DecLayer {
@@ -179,6 +180,9 @@ struct opd_detr {
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
+    int fuse_ffn = 1;        // encoder feed-forward block in one kernel (0: fc1, split-K fc2, reduce + LayerNorm)
+    int fuse_etail = 1;      // stage 3: 1x1 expand + residual -> next block's 1x1 reduce in one kernel (0: two launches)
+    f16_t* d_dump = nullptr; // 256 bytes nobody reads (out-of-range rows of kernels_ffn.hip's last workgroup store here)
 
     // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
     struct GraphEntry { int B, H, W, fmt, fh, fw; const void* pixels; int uses; hipGraphExec_t exec; };
@@ -259,7 +263,7 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
                             w.data[(((size_t)o * Cin + ci) * KH + kh) * KW + kw] * scale[o];
     }
     RCCHK(upload_f16(m, &c->w, wt));
-    if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 512) {  // operands of kernels_btail.hip (stages 1-2)
+    if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 1024) {  // operands of kernels_btail.hip (stages 1-2) / kernels_ffn.hip (stage 3)
         std::vector<float> wp(wt.size());
         for (int o = 0; o < Cout; ++o)
             for (int b = 0; b < Cin; b += 32)
@@ -338,6 +342,14 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_ln(m, sd, p + ".self_attn_layer_norm", &L.ln1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
+        if (L.fc2.K % 64 == 0 && L.fc2.N == 256) {   // operand of kernels_ffn.hip
+            const HostTensor& w2 = T(sd, p + ".mlp.fc2.weight");
+            std::vector<f16_t> h(w2.data.size()), hp(w2.data.size());
+            for (size_t j = 0; j < h.size(); ++j) h[j] = f32_to_f16(w2.data[j]);
+            opd_permute_k32(h.data(), hp.data(), L.fc2.N, L.fc2.K);
+            RCCHK(dalloc(m, &L.fc2p, hp.size(), true));
+            HIPCHK(hipMemcpy(L.fc2p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
+        }
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln2));
     }
     // decoder: query-position folds are resolution independent -> build them now with the fp32 plan GEMM
@@ -465,6 +477,7 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_valid_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_key_valid, B * 2, false));
     RCCHK(dalloc(m, &m->d_bias_ptrs, (size_t)(a.enc_layers + 1) * B, false));
+    RCCHK(dalloc(m, &m->d_dump, (size_t)128, false));
     RCCHK(dalloc(m, &m->d_rois, (size_t)128 * 4, false));
     RCCHK(dalloc(m, &m->d_roi_out, (size_t)128 * D, false));
     return OPD_OK;
@@ -801,6 +814,20 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 HIPCHK(opd_launch_btail(p, m->stream));
                 RCCHK(timed_end(m));
                 if (C3) z_ready = z;
+            } else if (m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nb && nb->c0.wp &&
+                       nb->c0.Cin == 1024 && nb->c0.Cout == 256 && nb->c0.KH == 1 && nb->c0.stride == 1) {
+                // stage 3: the 3x3 as an implicit GEMM, then ONE kernel for 1x1 expand + residual + ReLU (block output, stored) and the
+                // next block's 1x1 reduce (kernels_ffn.hip, ETAIL); z takes the buffer the 3x3 has just finished reading
+                f16_t* a1 = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
+                f16_t* z = (x1 == m->d_m0) ? m->d_m0 : m->d_m1;
+                RCCHK(run_conv(m, b.c1, x1, B, ch, cw, oh, ow, a1, true, nullptr));
+                FfnParams fp{};
+                fp.x16 = a1; fp.w1 = b.c2.w; fp.b1 = b.c2.bias; fp.res16 = res; fp.hid16 = out; fp.w2p = nb->c0.wp; fp.b2 = nb->c0.bias;
+                fp.y16 = z; fp.dump = m->d_dump; fp.M = B * oh * ow; fp.F = 1024; fp.etail = 1;
+                RCCHK(timed_begin(m, CLS_CONV, 2.0 * fp.M * (256.0 * 1024 + 1024.0 * 256)));
+                HIPCHK(opd_launch_ffn(fp, m->stream));
+                RCCHK(timed_end(m));
+                z_ready = z;
             } else {
                 f16_t* a1 = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
                 RCCHK(run_conv(m, b.c1, x1, B, ch, cw, oh, ow, a1, true, nullptr));
@@ -825,8 +852,17 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
             RCCHK(timed_end(m));
         }
-        RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
-        RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM));
+        if (m->fuse_ffn && L.fc2p && D == 256) {
+            FfnParams fp{};
+            fp.x16 = m->d_x16; fp.res32 = m->d_x32; fp.w1 = L.fc1.w; fp.b1 = L.fc1.b; fp.w2p = L.fc2p; fp.b2 = L.fc2.b;
+            fp.gamma = L.ln2.g; fp.beta = L.ln2.b; fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F;
+            RCCHK(timed_begin(m, CLS_GEMM, 4.0 * M * (double)D * F));
+            HIPCHK(opd_launch_ffn(fp, m->stream));
+            RCCHK(timed_end(m));
+        } else {
+            RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
+            RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM));
+        }
     }
     MARK(6);
     // ---- decoder -----------------------------------------------------------------------------------------------
@@ -1146,7 +1182,8 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
-    m->fuse_btail = src->fuse_btail; m->fuse_stem_pool = src->fuse_stem_pool;
+    m->fuse_btail = src->fuse_btail; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail;
+    m->d_dump = nullptr;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -1508,6 +1545,15 @@ int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_gemm_ln = on ? 1 : 0;
     m->small_m_gemm = on ? 1 : 0;   // the switch covers both transformer-side specialisations
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+int opd_test_set_fuse_ffn(opd_detr* m, int on) {   // bit 0: encoder feed-forward kernel, bit 1: stage-3 expand tail kernel
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->fuse_ffn = (on & 1) ? 1 : 0;
+    m->fuse_etail = (on & 2) ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();

@@ -123,6 +123,60 @@ int opd_test_gemm_ln(const uint16_t* x, const uint16_t* w, const float* bias, co
     return OPD_OK;
 }
 
+// fused feed-forward block (kernels_ffn.hip): w2 in plain K order [256][F] (the hook applies opd_permute_k32)
+int opd_test_ffn(const uint16_t* x16, const float* res32, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2,
+                 const float* gamma, const float* beta, float* y, uint16_t* y16, int M, int F, int in_place) {
+    DevMem dm;
+    std::vector<uint16_t> w2p((size_t)256 * F);
+    opd_permute_k32(w2, w2p.data(), 256, F);
+    FfnParams p{};
+    uint16_t* dx = dm.up(x16, (size_t)M * 256);
+    float* dres = dm.up(res32, (size_t)M * 256);
+    p.x16 = dx; p.res32 = dres;
+    p.w1 = dm.up(w1, (size_t)F * 256);
+    p.b1 = dm.up(b1, (size_t)F);
+    p.w2p = dm.up(w2p.data(), w2p.size());
+    p.b2 = dm.up(b2, 256);
+    p.gamma = dm.up(gamma, 256);
+    p.beta = dm.up(beta, 256);
+    p.y32 = in_place ? dres : dm.up<float>(nullptr, (size_t)M * 256);
+    p.y16 = in_place ? dx : dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    if (!p.x16 || !p.res32 || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.gamma || !p.beta || !p.y32 || !p.y16) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.M = M; p.F = F;
+    TCHK(opd_launch_ffn(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, p.y32, (size_t)M * 256 * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(y16, p.y16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// stage-3 expand tail (kernels_ffn.hip, ETAIL): hid = relu(a1 W_a^T + b1 + res) [M][F], z = relu(hid W_b^T + b2) [M][256];
+// wb in plain K order [256][F] (the hook applies opd_permute_k32)
+int opd_test_etail(const uint16_t* a1, const uint16_t* res16, const uint16_t* wa, const float* b1, const uint16_t* wb, const float* b2,
+                   uint16_t* hid, uint16_t* z, int M, int F, int in_place) {
+    DevMem dm;
+    std::vector<uint16_t> wbp((size_t)256 * F);
+    opd_permute_k32(wb, wbp.data(), 256, F);
+    FfnParams p{};
+    p.x16 = dm.up(a1, (size_t)M * 256);
+    uint16_t* dres = dm.up(res16, (size_t)M * F);
+    p.res16 = dres;
+    p.w1 = dm.up(wa, (size_t)F * 256);
+    p.b1 = dm.up(b1, (size_t)F);
+    p.w2p = dm.up(wbp.data(), wbp.size());
+    p.b2 = dm.up(b2, 256);
+    p.hid16 = in_place ? dres : dm.up<uint16_t>(nullptr, (size_t)M * F);
+    p.y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    p.dump = dm.up<uint16_t>(nullptr, 64);
+    if (!p.x16 || !p.res16 || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.hid16 || !p.y16 || !p.dump) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.M = M; p.F = F; p.etail = 1;
+    TCHK(opd_launch_ffn(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(hid, p.hid16, (size_t)M * F * 2, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(z, p.y16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 // one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel): slices == 1 -> fp16 out; slices > 1 -> the fp32
 // slabs are summed by reduce_ln256 without LayerNorm (gamma == null) into out32
 int opd_test_gemm_k256(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* out16, float* out32, int M, int N,

@@ -51,7 +51,8 @@ def assemble(g_rec: np.ndarray, g_cnt: np.ndarray, n_frames: int, person_label: 
             continue  # padding slot of an uneven shard
         dets = []
         for d in recs[f, :counts[f]]:
-            bbox = (float(d["x1"]), float(d["y1"]), float(d["x2"] - d["x1"]), float(d["y2"] - d["y1"]))
+            x1, y1, x2, y2 = float(d["x1"]), float(d["y1"]), float(d["x2"]), float(d["y2"])
+            bbox = (x1, y1, x2 - x1, y2 - y1)   # (double arithmetic on the fp32 corners, like detector._postprocess_batch)
             dets.append(Detection(bbox=bbox, confidence=float(d["score"]), class_id=person_label, class_name="person",
                                   camera_coords=foot(bbox), query_index=int(d["query_index"])))
         out.append(dets)

@@ -14,6 +14,13 @@ the same box), so the recipe below is engineered to be non-deg
 * ``query_position_embeddings ~ N(0,1)``, classifier std ×2 with a bias towards the COCO
   "person" class (id 1) so that the reference's person filter has survivors.
 
+* every tensor a GEMM consumes in fp16 is made exactly fp16-representable as the device sees it ("fold FBN
+  in fp32 first, then round, so the CPU fp32 reference and the GPU use bit-identical weights and only activation rounding
+  differs"): linear weights are rounded to fp16 values, convolution kernels are adjusted so that kernel x FrozenBN scale — the
+  folded kernel the device stores — is an fp16 value (``make_device_exact``).  Without this the comparison measured mostly the
+  fp16 rounding of the weights themselves, a systematic error a real checkpoint has too but one that says nothing about the
+  kernels: at 800x1333 it was 5-7e-4 of the 6-8e-4 box error of the whole backbone (tools/drift_split.py).
+
 Everything is drawn from ``numpy.random.default_rng`` (PCG64: bit-stable across machines), so
 the exact same tensors are regenerated on the GPU box.  Tensor names/shapes follow the HF 5.x
 ``DetrForObjectDetection`` state dict; the file format is ``safetensors``, which
@@ -268,7 +275,34 @@ def synth_weights(arch: DetrArch = DetrArch(), seed: int = 0, attention_gain: fl
         out[name] = np.ascontiguousarray(t, dtype=np.float32)
     if calibrate:
         calibrate_frozen_bn(out, arch)
+    make_device_exact(out)
     return out
+
+
+RECIPE_VERSION = 2   # bump when the tensors of a (arch, seed, gain) triple change: cached files of older recipes are not reused
+
+
+def make_device_exact(weights: "OrderedDict[str, np.ndarray]") -> None:
+    """Make every fp16 GEMM operand of the device path exactly representable (module docstring).
+
+    * 2-D weights of the transformer linears and ``input_projection`` (consumed as fp16): rounded to the nearest fp16 value.
+    * convolution kernels: the device folds FrozenBN in fp32, ``w * (gamma * 1/sqrt(var + 1e-5))`` (``csrc/opd_model.cpp::make_conv``),
+      and stores THAT in fp16.  The kernel is replaced by ``fp16(w * scale) / scale`` (fp64 division, stored fp32): the fold then
+      lands within 2e-7 relative of an fp16 value and rounds to it, while the fp32 reference, which keeps kernel and scale apart,
+      computes with the same number to fp32 accuracy.
+    The fp32-consumed tensors (biases, norms, the heads' weights, the query embeddings) stay as drawn."""
+    for name in list(weights):
+        t = weights[name]
+        if name.endswith(".convolution.weight"):
+            pre = name[: -len(".convolution.weight")] + ".normalization"
+            var = weights[pre + ".running_var"].astype(np.float32)
+            scale = (weights[pre + ".weight"].astype(np.float32) * (np.float32(1.0) / np.sqrt(var + np.float32(1e-5)))).astype(np.float32)
+            sc = scale.reshape(-1, 1, 1, 1)
+            with np.errstate(over="ignore"):
+                folded = (t * sc).astype(np.float32).astype(np.float16)
+            weights[name] = np.ascontiguousarray((folded.astype(np.float64) / sc.astype(np.float64)).astype(np.float32))
+        elif t.ndim >= 2 and name.endswith(".weight") and name.startswith(("model.encoder.", "model.decoder.", "model.input_projection.")):
+            weights[name] = np.ascontiguousarray(t.astype(np.float16).astype(np.float32))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -333,7 +367,7 @@ def ensure_weight_file(cache_dir: str, arch: DetrArch = DetrArch(), seed: int = 
                        tag: str = "r50") -> str:
     """Write (once) and return the path of the safetensors file for a seeded weight set."""
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, f"detr_{tag}_seed{seed}_ga{attention_gain:g}.safetensors")
+    path = os.path.join(cache_dir, f"detr_{tag}_seed{seed}_ga{attention_gain:g}_v{RECIPE_VERSION}.safetensors")
     if not os.path.exists(path):
         save_safetensors(synth_weights(arch, seed, attention_gain), path)
     return path

@@ -11,6 +11,7 @@ import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
+F_ = F  # (some tests use F as a size name)
 
 from office_person_detection_vit_amd import _capi
 
@@ -562,3 +563,110 @@ def test_gemm_k256_integer_exact(lib):
     rc = lib.opd_test_gemm_k256(_p(_h(x)[1]), _p(_h(w)[1]), _p(bias), _p(out16), None, M, N, K, 0, 0)
     _capi.check(rc, "opd_test_gemm_k256")
     np.testing.assert_array_equal(out16.view(np.float16).astype(np.float32), x @ w.T + bias)
+
+
+# ---- feed-forward block in one kernel (kernels_ffn.hip) -------------------------------------------------------------------------
+@pytest.mark.parametrize("M,F,in_place", [(8400, 2048, True), (800, 2048, False), (64, 64, False), (37, 128, True), (129, 192, False)])
+def test_ffn_matches_torch(lib, M, F, in_place):
+    """y = LN(res + fc2(relu(fc1 x + b1)) + b2): fp16 operands, the hidden activations rounded to fp16 once (as the unfused path
+    stored them), fp32 accumulate / statistics.  The reference applies exactly that rounding in fp64 arithmetic, so the bound
+    is fp32 summation order (3e-5 abs on O(1) outputs) + the cases where fp32-vs-fp64 accumulation flips the fp16 rounding of
+    a hidden value (each worth <= 2^-11 x |h| x |w2|, a few of them per row at F = 2048: 5e-4 abs covers it; the mean stays 5e-6).  Partial last workgroups (M % 64 != 0), one chunk
+    (F = 64), in-place outputs (y aliasing x / the residual, as the encoder uses it)."""
+    rng = np.random.default_rng(M * 3 + F)
+    x, xb = _h(rng.standard_normal((M, 256)))
+    res = (x + 0.01 * rng.standard_normal((M, 256))).astype(np.float32)
+    w1, w1b = _h(rng.standard_normal((F, 256)) * np.sqrt(2.0 / 256))
+    w2, w2b = _h(rng.standard_normal((256, F)) / np.sqrt(F))
+    b1 = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    b2 = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    gamma = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    rc = lib.opd_test_ffn(_p(xb), _p(res), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(gamma), _p(beta), _p(y), _p(y16), M, F, int(in_place))
+    _capi.check(rc, "opd_test_ffn")
+    t = lambda a: torch.from_numpy(a).double()
+    hid = torch.relu(t(x) @ t(w1).T + t(b1)).to(torch.float16).double()
+    pre = t(res) + hid @ t(w2).T + t(b2)
+    want = F_.layer_norm(pre, (256,), t(gamma), t(beta), 1e-5).float().numpy()
+    np.testing.assert_allclose(y, want, atol=5e-4, rtol=1e-5)
+    assert float(np.abs(y - want).mean()) < 5e-6
+    np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), want, atol=2e-3, rtol=1e-3)
+
+
+def test_ffn_integer_exact(lib):
+    """Small-integer operands: every product and partial sum is exactly representable, so fc1 / ReLU / fc2 / residual must be
+    bit exact whatever the summation order — this pins the lane maps (x B-fragments, the accumulator-as-operand k permutation
+    of W2, the split of each chunk over two waves and the exchange of their partial sums).  LayerNorm is taken out by
+    comparing pre-norm sums: gamma = 1, beta = 0 and rows engineered to mean 0 / unit variance are not needed — instead the
+    check inverts nothing: it compares LN(kernel) with LN(exact pre-norm) at 1e-6, and the pre-norm sums differ per channel
+    by construction (asymmetric weights), so a swapped row / channel / feature cannot cancel."""
+    rng = np.random.default_rng(5)
+    M, F = 150, 256
+    x = rng.integers(-3, 4, (M, 256)).astype(np.float32)
+    w1 = rng.integers(-2, 3, (F, 256)).astype(np.float32)
+    w2 = rng.integers(-2, 3, (256, F)).astype(np.float32)
+    w1[np.arange(F), np.arange(F) % 256] += 7          # asymmetric: feature f looks at input channel f
+    w2[np.arange(256), (3 * np.arange(256) + 1) % F] += 5
+    b1 = rng.integers(-4, 5, F).astype(np.float32)
+    b2 = rng.integers(-4, 5, 256).astype(np.float32)
+    res = rng.integers(-8, 9, (M, 256)).astype(np.float32)
+    gamma, beta = np.ones(256, np.float32), np.zeros(256, np.float32)
+    _, xb = _h(x); _, w1b = _h(w1); _, w2b = _h(w2)
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    _capi.check(lib.opd_test_ffn(_p(xb), _p(res), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(gamma), _p(beta), _p(y), _p(y16), M, F, 0), "opd_test_ffn")
+    hid = np.maximum(x.astype(np.float64) @ w1.T.astype(np.float64) + b1, 0.0)
+    assert hid.max() < 2048                                 # integers below 2^11: exact in fp16
+    pre = res + hid @ w2.T.astype(np.float64) + b2
+    want = (pre - pre.mean(1, keepdims=True)) / np.sqrt(pre.var(1, keepdims=True) + 1e-5)
+    np.testing.assert_allclose(y, want, atol=2e-6, rtol=2e-6)
+
+
+# ---- stage-3 expand tail: 1x1 expand + residual + ReLU -> next 1x1 reduce in one kernel (kernels_ffn.hip, ETAIL) -----------------
+@pytest.mark.parametrize("M,F,in_place", [(33600, 1024, True), (4200, 1024, False), (64, 128, False), (101, 256, True)])
+def test_etail_matches_torch(lib, M, F, in_place):
+    """hid = relu(a1 W_a^T + b_a + res) (fp16, one rounding), z = relu(hid W_b^T + b_b): both against fp64 arithmetic on the same
+    fp16 operands; z from the kernel's OWN rounded hid (the B operand it really used) within fp32 summation order + one fp16
+    rounding.  Partial last workgroup (M % 64 != 0: rows >= M store to the dump slot), hid written over the residual."""
+    rng = np.random.default_rng(M + F)
+    a1, a1b = _h(np.abs(rng.standard_normal((M, 256))))
+    res, resb = _h(np.abs(rng.standard_normal((M, F))))
+    wa, wab = _h(rng.standard_normal((F, 256)) / 16)
+    wb, wbb = _h(rng.standard_normal((256, F)) / np.sqrt(F))
+    ba = (0.1 * rng.standard_normal(F)).astype(np.float32)
+    bb = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    hid = np.empty((M, F), np.uint16)
+    z = np.empty((M, 256), np.uint16)
+    _capi.check(lib.opd_test_etail(_p(a1b), _p(resb), _p(wab), _p(ba), _p(wbb), _p(bb), _p(hid), _p(z), M, F, int(in_place)), "opd_test_etail")
+    t = lambda a: torch.from_numpy(a).double()
+    want_hid = torch.relu(t(a1) @ t(wa).T + t(ba) + t(res)).numpy()
+    got_hid = hid.view(np.float16).astype(np.float64)
+    np.testing.assert_allclose(got_hid, want_hid, atol=2e-3, rtol=1.1e-3)           # one fp16 rounding of O(1..8) values
+    want_z = torch.relu(torch.from_numpy(got_hid) @ t(wb).T + t(bb)).numpy()
+    np.testing.assert_allclose(z.view(np.float16).astype(np.float64), want_z, atol=2e-3, rtol=1.1e-3)
+
+
+def test_etail_integer_exact(lib):
+    """Small integers: every sum is exact in fp32 and every stored value exact in fp16 -> bit-exact hid and z, pinning the lane
+    maps (paired-layout residual loads and y stores, the k permutation of W_b, the channel-half exchange of the z epilogue)."""
+    rng = np.random.default_rng(9)
+    M, F = 200, 256
+    a1 = rng.integers(0, 4, (M, 256)).astype(np.float32)
+    wa = rng.integers(-1, 2, (F, 256)).astype(np.float32)
+    wa[np.arange(F), (5 * np.arange(F) + 2) % 256] += 3
+    res = rng.integers(0, 9, (M, F)).astype(np.float32)
+    ba = rng.integers(-3, 4, F).astype(np.float32)
+    wb = (rng.integers(-1, 2, (256, F)) * (rng.random((256, F)) < 0.1)).astype(np.float32)
+    wb[np.arange(256), (7 * np.arange(256) + 3) % F] += 1
+    bb = rng.integers(-3, 4, 256).astype(np.float32)
+    _, a1b = _h(a1); _, resb = _h(res); _, wab = _h(wa); _, wbb = _h(wb)
+    hid = np.empty((M, F), np.uint16)
+    z = np.empty((M, 256), np.uint16)
+    _capi.check(lib.opd_test_etail(_p(a1b), _p(resb), _p(wab), _p(ba), _p(wbb), _p(bb), _p(hid), _p(z), M, F, 0), "opd_test_etail")
+    want_hid = np.maximum(a1 @ wa.T + ba + res, 0)
+    want_z = np.maximum(want_hid @ wb.T + bb, 0)
+    assert want_hid.max() < 2048 and want_z.max() < 2048
+    np.testing.assert_array_equal(hid.view(np.float16).astype(np.float32), want_hid)
+    np.testing.assert_array_equal(z.view(np.float16).astype(np.float32), want_z)

@@ -239,7 +239,9 @@ def main():
     if len(sys.argv) > 1 and sys.argv[1] == "evaluation":   # only the (fast) host-side fixture
         evaluation_case()
         return
-    resize_case()
+    models_only = len(sys.argv) > 1 and sys.argv[1] == "models"   # after a change of the weight recipe (weights.RECIPE_VERSION)
+    if not models_only:
+        resize_case()
     r50 = DetrArch.resnet50()
     # equal-size batches (pixel_mask all ones): the configuration the HIP path serves
     model_case("r50_mild_256x320", r50, 0, 1.0, [(256, 320), (256, 320)], 1234)
@@ -252,6 +254,8 @@ def main():
     model_case("r50_mild_800x1333", r50, 0, 1.0, [(800, 1333)], 1234, full_outputs=False)
     # r101 (config 4 architecture) at small size
     model_case("r101_mild_256x320", DetrArch.resnet101(), 0, 1.0, [(256, 320)], 1234)
+    if models_only:
+        return
     feature_extractor_case()
     similarity_and_export_case()
     evaluation_case()
