@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
     const int g = lane >> 4, li = lane & 15;
     const int m_base = blockIdx.x * TM + rg * 32;
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
-    const int nchunks = p.F / FC;
+    const int nchunks = (p.dbg & 16) ? 2 : p.F / FC;   // dbg 16: two chunks only (prologue / epilogue cost)
 
     const __amdgpu_buffer_rsrc_t rsrc_wa = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w1), 0, (unsigned)((size_t)p.F * 256 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_wb = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w2p), 0, (unsigned)((size_t)256 * p.F * 2), 0x00020000);
@@ -125,6 +125,13 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
     // when its value is needed, and waiting for it drains the LDS-DMA of the next chunk that was issued just before it
     float* const b1s = reinterpret_cast<float*>(smem + 2 * STAGE_BYTES);
     for (int i = tid; i < p.F; i += 256) b1s[i] = p.b1[i];
+    // the epilogue's per-channel vectors too: global loads interleaved with its stores made it a chain of 16 exposed L2 round trips
+    float* const b2s = b1s + p.F;
+    b2s[tid] = p.b2[tid];
+    if constexpr (!ETAIL) {
+        b2s[256 + tid] = p.gamma[tid];
+        b2s[512 + tid] = p.beta[tid];
+    }
 
     // ETAIL: hidden tile in the paired 16-byte layout: lane (g, li) <-> row (g & 1) * 16 + li, 8 channels at (g >> 1) * 8 of a
     // 16-channel tile (two row tiles of one accumulator register pair, `v_permlane16_swap`)
@@ -172,6 +179,11 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
         if constexpr (ETAIL) {
             if (c + 1 < nchunks) load_res(c + 1, res_next);   // (the first vector-memory operations of the step: see the wait at its end)
         }
+        const bool dma = !(p.dbg & 2) || c == 0;
+        if ((p.dbg & 4) && dma) issue(c + 1, (c + 1) & 1);
+        // default: two pieces per k-step of GEMM a, so that the last of them has GEMM b's time to land (measured: 64 us against 72 us
+        // for one piece per k-step / tile pair over both GEMMs, 70 us for all sixteen in front: tools/bench_ffn.py)
+        const bool spread = (p.dbg & 8) && dma, early = !(p.dbg & 12) && dma;
         const unsigned char* Was = smem + (c & 1) * STAGE_BYTES;
         const unsigned char* Wbs = Was + WA_BYTES;
         // ---- GEMM a: this wave's 32 hidden channels of the chunk x its 32 rows, K = 256 -----------------------------------
@@ -196,17 +208,21 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
             wa[1][ft] = read_wa(1, ft);
         }
         half8 wb[4];      // GEMM b fragments, read three tiles ahead (the first three during GEMM a's tail)
+        const bool compute = !(p.dbg & 1);
 #pragma unroll
         for (int ks = 0; ks < 8; ++ks) {
+            if (compute) {
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft)
-                if (ks + 2 < 8) wa[(ks + 2) % 3][ft] = read_wa(ks + 2, ft);
-            if (ks >= 5) wb[ks - 5] = read_wb(ks - 5);
+                for (int ft = 0; ft < 2; ++ft)
+                    if (ks + 2 < 8) wa[(ks + 2) % 3][ft] = read_wa(ks + 2, ft);
+                if (ks >= 5) wb[ks - 5] = read_wb(ks - 5);
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft)
+                for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) h[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks % 3][ft], xf[mt][ks], h[ft][mt], 0, 0, 0);
-            issue_piece(c + 1, (c + 1) & 1, ks);
+                    for (int mt = 0; mt < 2; ++mt) h[ft][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wa[ks % 3][ft], xf[mt][ks], h[ft][mt], 0, 0, 0);
+            }
+            if (spread) issue_piece(c + 1, (c + 1) & 1, ks);
+            if (early) { issue_piece(c + 1, (c + 1) & 1, 2 * ks); issue_piece(c + 1, (c + 1) & 1, 2 * ks + 1); }
             __builtin_amdgcn_sched_barrier(0);   // keep the reads two k-steps ahead: the scheduler would sink them next to their use
         }
         // ---- f(.): (+ residual,) ReLU, one fp16 rounding; two channel tiles = one B fragment (k order of opd_permute_k32) ----
@@ -245,17 +261,20 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
         // ---- GEMM b: all 256 output channels += W_b[:, these 32 hidden channels] . H ----------------------------------------
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
-            if (nt + 3 < 16) wb[(nt + 3) & 3] = read_wb(nt + 3);
-            acc2[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[nt & 3], hb[0], acc2[nt][0], 0, 0, 0);
-            acc2[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[nt & 3], hb[1], acc2[nt][1], 0, 0, 0);
-            if (nt & 1) issue_piece(c + 1, (c + 1) & 1, 8 + (nt >> 1));
+            if (compute) {
+                if (nt + 3 < 16) wb[(nt + 3) & 3] = read_wb(nt + 3);
+                acc2[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[nt & 3], hb[0], acc2[nt][0], 0, 0, 0);
+                acc2[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wb[nt & 3], hb[1], acc2[nt][1], 0, 0, 0);
+            }
+            if ((nt & 1) && spread) issue_piece(c + 1, (c + 1) & 1, 8 + (nt >> 1));
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (ETAIL) {
 #pragma unroll
             for (int ft = 0; ft < 2; ++ft) {
                 f16_t* ptr = pr_ok ? p.hid16 + pr_hid + c * FC + ft * 16 : p.dump;
-                asm volatile("global_store_dwordx4 %0, %1, off" ::"v"(ptr), "v"(yv[ft]) : "memory");
+                asm volatile("global_store_dwordx4 %0, %1, off\n\ts_nop 1" ::"v"(ptr), "v"(yv[ft]) : "memory");   // (s_nop: the store reads its data
+                // registers a little after issue; the compiler's next instruction may overwrite them — it pads nothing around asm)
             }
         }
         // chunk c + 1 has landed and every wave is done with chunk c's buffer.  ETAIL: this step's two y stores are its youngest
@@ -275,11 +294,20 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
     }
 
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the last y stores)
+    if (p.dbg & 32) return;                                // dbg 32: no epilogue
     float4v* ex = reinterpret_cast<float4v*>(smem);   // [wave][16][lane] float4: 16 KiB per wave (the stage buffers are free now)
     if constexpr (!ETAIL) {
         // ---- FFN: wave fh finishes row tile mt = fh with all 256 channels -----------------------------------------------------
         // (written once per value of fh with compile-time accumulator indices: a run-time index would move acc2 to scratch)
         float4v v[16];
+        const int m = m_base + fh * 16 + li;
+        const bool live = m < p.M;
+        float4v rs[16];   // residual rows: all sixteen loads in flight across the exchange
+#pragma unroll
+        for (int nt = 0; nt < 16; ++nt) {
+            rs[nt] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (live) rs[nt] = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + nt * 16 + g * 4);
+        }
         if (fh == 0) {
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) ex[(wave * 16 + nt) * 64 + lane] = acc2[nt][1];
@@ -295,14 +323,11 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) v[nt] = ex[((wave ^ 1) * 16 + nt) * 64 + lane] + acc2[nt][1];   // half 0 + half 1
         }
-        const int m = m_base + fh * 16 + li;
-        const bool live = m < p.M;
         float sum = 0.f;
 #pragma unroll
         for (int nt = 0; nt < 16; ++nt) {
             const int ch = nt * 16 + g * 4;
-            float4v t = v[nt] + *reinterpret_cast<const float4v*>(p.b2 + ch);
-            if (live) t += *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + ch);
+            const float4v t = v[nt] + *reinterpret_cast<const float4v*>(b2s + ch) + rs[nt];
             v[nt] = t;
             sum += t[0] + t[1] + t[2] + t[3];
         }
@@ -322,8 +347,8 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
 #pragma unroll
             for (int nt = 0; nt < 16; ++nt) {
                 const int ch = nt * 16 + g * 4;
-                const float4v gm = *reinterpret_cast<const float4v*>(p.gamma + ch);
-                const float4v bt = *reinterpret_cast<const float4v*>(p.beta + ch);
+                const float4v gm = *reinterpret_cast<const float4v*>(b2s + 256 + ch);
+                const float4v bt = *reinterpret_cast<const float4v*>(b2s + 512 + ch);
                 float4v o;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) o[q] = v[nt][q] * rstd * gm[q] + bt[q];
@@ -368,7 +393,7 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
         const size_t zrow = (size_t)pr_m * 256 + fh * 128 + (g >> 1) * 8;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
-            const float4v b = *reinterpret_cast<const float4v*>(p.b2 + fh * 128 + nt * 16 + g * 4);
+            const float4v b = *reinterpret_cast<const float4v*>(b2s + fh * 128 + nt * 16 + g * 4);
             const float4v v0 = relu4(v[nt][0] + b), v1 = relu4(v[nt][1] + b);
             const uint2v s0 = __builtin_amdgcn_permlane16_swap(pack2h(v0[0], v0[1]), pack2h(v1[0], v1[1]), false, false);
             const uint2v s1 = __builtin_amdgcn_permlane16_swap(pack2h(v0[2], v0[3]), pack2h(v1[2], v1[3]), false, false);
@@ -380,10 +405,10 @@ __global__ __launch_bounds__(256, 1) void ffn_kernel(FfnParams p) {
 
 template <bool ETAIL>
 hipError_t launch_ffn_t(const FfnParams& p, hipStream_t stream) {
-    const int LDS = 2 * STAGE_BYTES + p.F * 4;   // stage buffers + b1
+    const int LDS = 2 * STAGE_BYTES + p.F * 4 + 768 * 4;   // stage buffers + b1 + (b2, gamma, beta)
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<ETAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES + 4096 * 4);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(ffn_kernel<ETAIL>), hipFuncAttributeMaxDynamicSharedMemorySize, 2 * STAGE_BYTES + 4096 * 4 + 768 * 4);
         if (e != hipSuccess) return e;
         attr_set = true;
     }

@@ -105,6 +105,8 @@ struct FfnParams {
     f16_t* dump;         // ETAIL: >= 16 writable bytes on the device (rows >= M of the last workgroup store here)
     int M, F;            // F % 64 == 0
     int etail;
+    int dbg;             // timing ablations for tools (0 = normal): 1 skip ds_reads + MFMAs, 2 stage only chunks 0 and 1, 4 all 16 staging
+                         // pieces of a step in front of its MFMAs, 8 all of them during GEMM a (two per k-step)
 };
 hipError_t opd_launch_ffn(const FfnParams& p, hipStream_t stream);
 

@@ -177,6 +177,46 @@ int opd_test_etail(const uint16_t* a1, const uint16_t* res16, const uint16_t* wa
     return OPD_OK;
 }
 
+// timing of kernels_ffn.hip on zero-filled weights / random-free buffers (tools/bench_ffn.py): average us over `iters` launches
+int opd_test_bench_ffn(int M, int F, int etail, int dbg, int iters, float* us_out) {
+    DevMem dm;
+    FfnParams p{};
+    std::vector<uint16_t> hx((size_t)M * 256), hw((size_t)F * 256);
+    for (size_t i = 0; i < hx.size(); ++i) hx[i] = opd::f32_to_f16((float)((i * 2654435761u >> 20) & 255) / 256.0f - 0.5f);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = opd::f32_to_f16(((float)((i * 40503u >> 7) & 255) / 256.0f - 0.5f) / 16.0f);
+    std::vector<float> hb((size_t)F, 0.01f), ones(256, 1.0f);
+    p.x16 = dm.up(hx.data(), hx.size());
+    p.w1 = dm.up(hw.data(), hw.size());
+    p.w2p = dm.up(hw.data(), hw.size());
+    p.b1 = dm.up(hb.data(), (size_t)F);
+    p.b2 = dm.up(hb.data(), 256);
+    p.gamma = dm.up(ones.data(), 256);
+    p.beta = dm.up(hb.data(), 256);
+    float* r32 = dm.up<float>(nullptr, (size_t)M * 256);
+    uint16_t* r16 = dm.up<uint16_t>(nullptr, (size_t)M * F);
+    uint16_t* hid = dm.up<uint16_t>(nullptr, (size_t)M * F);
+    p.res32 = r32; p.res16 = r16; p.hid16 = hid;
+    p.y32 = dm.up<float>(nullptr, (size_t)M * 256);
+    p.y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    p.dump = dm.up<uint16_t>(nullptr, 64);
+    if (!p.x16 || !p.w1 || !p.w2p || !p.b1 || !p.b2 || !r32 || !r16 || !hid || !p.y32 || !p.y16 || !p.dump) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(hipMemset(r32, 0, (size_t)M * 256 * 4));
+    TCHK(hipMemset(r16, 0, (size_t)M * F * 2));
+    p.M = M; p.F = F; p.etail = etail; p.dbg = dbg;
+    hipEvent_t a, b;
+    TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) TCHK(opd_launch_ffn(p, nullptr));
+    TCHK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) TCHK(opd_launch_ffn(p, nullptr));
+    TCHK(hipEventRecord(b, nullptr));
+    TCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    TCHK(hipEventElapsedTime(&ms, a, b));
+    *us_out = 1e3f * ms / (float)iters;
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return OPD_OK;
+}
+
 // one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel): slices == 1 -> fp16 out; slices > 1 -> the fp32
 // slabs are summed by reduce_ln256 without LayerNorm (gamma == null) into out32
 int opd_test_gemm_k256(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* out16, float* out32, int M, int N,
