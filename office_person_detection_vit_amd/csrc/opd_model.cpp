@@ -180,13 +180,14 @@ struct opd_detr {
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
-    // kernels_ffn.hip (64-row workgroups, one per CU, each streaming ALL the weights): 1 = on, 0 = off, -1 = by size (default).
-    // Measured at batch 8, 800x1333 (tools/bench_ffn.py, profiles/r02_*): the fused feed-forward block takes 62 us against
-    // 54 us for the three launches it replaces (M = 8400: 132 workgroups, issue-bound with one wave per SIMD), the stage-3
-    // tail 100-110 us against 74 us (M = 33600: 525 workgroups = 2.05 rounds on 256 CUs); with twice the rows (r101 at
-    // 1066x1920: M = 16320 / 64320) the same kernels take 67 us against ~100 us and ~4 full rounds.  `ffn_pays` / `etail_pays`.
-    int fuse_ffn = -1;       // encoder feed-forward block in one kernel (0: fc1, split-K fc2, reduce + LayerNorm)
-    int fuse_etail = -1;     // stage 3: 1x1 expand + residual -> next block's 1x1 reduce in one kernel (0: two launches)
+    // kernels_ffn.hip (64-row workgroups, one per CU, each streaming ALL the weights of the pair of GEMMs): built, parity-tested,
+    // measured SLOWER than the launches it replaces at every shape of BASELINE.json, so it is OFF by default (DESIGN.md section 2,
+    // profiles/r02_bench_ffn.txt): feed-forward block 62 us against 54 us (M = 8400: 132 workgroups, instruction-issue bound with
+    // one wave per SIMD), stage-3 tail 100-110 us against 74 us (M = 33600: 525 workgroups = 2.05 rounds on 256 CUs); with r101 at
+    // 1066x1920 (M = 16320 / 64320) the forward is 11.2 ms either way.  Not switched by size: a frame's low-order bits would then
+    // depend on the batch it travels in (fp32 summation order), which the batch-invariance tests forbid.
+    int fuse_ffn = 0;        // encoder feed-forward block in one kernel (0: fc1, split-K fc2, reduce + LayerNorm)
+    int fuse_etail = 0;      // stage 3: 1x1 expand + residual -> next block's 1x1 reduce in one kernel (0: two launches)
     f16_t* d_dump = nullptr; // 256 bytes nobody reads (out-of-range rows of kernels_ffn.hip's last workgroup store here)
 
     // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
@@ -594,14 +595,6 @@ static void timed_collect(opd_detr* m) {
     }
 }
 
-// kernels_ffn.hip pays when its 64-row workgroups fill the 256 CUs in (nearly) whole rounds and there are enough rows to beat the
-// 2-D tiled GEMMs: see the note at opd_detr::fuse_ffn.
-static bool ffn_pays(int M) { return M >= 12288; }
-static bool etail_pays(int M) {
-    const int wgs = (M + 63) / 64, rounds = (wgs + 255) / 256;
-    return rounds >= 3 && wgs >= rounds * 256 - 64;   // >= 3 rounds, the last one at least three quarters full
-}
-
 static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, int W, int OH, int OW, void* out, bool relu,
                     const f16_t* res16) {
     ConvGemmParams p{};
@@ -827,7 +820,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 HIPCHK(opd_launch_btail(p, m->stream));
                 RCCHK(timed_end(m));
                 if (C3) z_ready = z;
-            } else if ((m->fuse_etail > 0 || (m->fuse_etail < 0 && etail_pays(B * oh * ow))) && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nb && nb->c0.wp &&
+            } else if (m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nb && nb->c0.wp &&
                        nb->c0.Cin == 1024 && nb->c0.Cout == 256 && nb->c0.KH == 1 && nb->c0.stride == 1) {
                 // stage 3: the 3x3 as an implicit GEMM, then ONE kernel for 1x1 expand + residual + ReLU (block output, stored) and the
                 // next block's 1x1 reduce (kernels_ffn.hip, ETAIL); z takes the buffer the 3x3 has just finished reading
@@ -865,7 +858,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
             RCCHK(timed_end(m));
         }
-        if ((m->fuse_ffn > 0 || (m->fuse_ffn < 0 && ffn_pays(M))) && L.fc2p && D == 256) {
+        if (m->fuse_ffn && L.fc2p && D == 256) {
             FfnParams fp{};
             fp.x16 = m->d_x16; fp.res32 = m->d_x32; fp.w1 = L.fc1.w; fp.b1 = L.fc1.b; fp.w2p = L.fc2p; fp.b2 = L.fc2.b;
             fp.gamma = L.ln2.g; fp.beta = L.ln2.b; fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F;
@@ -1563,10 +1556,10 @@ int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     m->graphs.clear();
     return OPD_OK;
 }
-int opd_test_set_fuse_ffn(opd_detr* m, int on) {   // bit 0: encoder feed-forward kernel, bit 1: stage-3 expand tail kernel; -1: by size
+int opd_test_set_fuse_ffn(opd_detr* m, int on) {   // bit 0: encoder feed-forward kernel, bit 1: stage-3 expand tail kernel
     if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->fuse_ffn = on < 0 ? -1 : (on & 1) ? 1 : 0;
-    m->fuse_etail = on < 0 ? -1 : (on & 2) ? 1 : 0;
+    m->fuse_ffn = (on & 1) ? 1 : 0;
+    m->fuse_etail = (on & 2) ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();
