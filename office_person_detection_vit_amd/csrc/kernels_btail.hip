@@ -88,10 +88,16 @@ __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory")
 // VGPRs move ~16 B/clk/CU, LDS-DMA 33-42 (tools/microbench/ldpath.hip); each wave stages only ITS OWN 32 rows (four
 // 8-row x 128-byte pieces per 64-channel chunk) into a wave-private quarter of two 16-KiB buffers, so no barrier and no
 // special wave are involved: chunk j+2 is requested right after the wave has read chunk j out of the same buffer.
-template <int C1, int C3, bool RDMA>
+// SC = true (first block of stage 1: C1 == 64, shortcut input of 64 channels at the output resolution): the block's 1x1 SHORTCUT
+// convolution is a second GEMM into the same accumulators, y = relu(a1 . W2^T + xs . Wsc^T + (b2 + bsc)), instead of a residual
+// that a separate launch wrote (274 MB at batch 8) and this kernel read back: the 64 shortcut channels of the wave's 32 pixels sit
+// in 16 VGPRs as B fragments, the 64 x 64 slice of Wsc travels with the W2 / W3 chunk operands.  The shortcut is no longer
+// rounded to fp16 on the way (one rounding fewer than the unfused path; the reference rounds nothing).
+template <int C1, int C3, bool RDMA, bool SC = false>
 __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     static_assert(!RDMA || C1 == 64, "residual staging buffers are budgeted for C1 == 64 (80 KiB of LDS per workgroup)");
+    static_assert(!SC || (C1 == 64 && !RDMA), "fused shortcut: 64-channel tails only; it replaces the residual");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int C2 = 4 * C1;
     constexpr int NT1 = C1 / 16;               // c1 accumulator tiles per wave (all C1 channels)
@@ -104,7 +110,8 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     constexpr int W2_PIECES = W2C_BYTES / 4096;
     constexpr int W3_PIECES = C3 / 32;         // slice of W3: [C3 rows][64 halfs]
     constexpr int NT3 = C3 / 16;
-    static_assert(W2C_BYTES + C3 * ROW_BYTES <= STAGE_BYTES, "chunk operands must fit a stage buffer");
+    constexpr int WSC_BYTES = SC ? 64 * ROW_BYTES : 0;   // chunk of Wsc: [64 rows][64 halfs]
+    static_assert(W2C_BYTES + C3 * ROW_BYTES + WSC_BYTES <= STAGE_BYTES, "chunk operands must fit a stage buffer");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -122,7 +129,10 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w1), 0, (unsigned)(C1 * 9 * C1 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w2p), 0, (unsigned)(C2 * C1 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(C3 ? p.w3p : p.w2p), 0, (unsigned)((C3 ? C3 : 1) * C2 * 2), 0x00020000);
-    unsigned rowoff[4], rowmask[4], woff1[W1_PIECES], woff2[W2_PIECES], woff3[W3_PIECES ? W3_PIECES : 1];
+    const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(SC ? p.wsc : p.w2p), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
+    unsigned rowoff[4], rowmask[4], woff1[W1_PIECES], woff2[W2_PIECES], woff3[W3_PIECES ? W3_PIECES : 1], woffsc[2];
+    woffsc[0] = (unsigned)((wave * 16 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;        // rows 8 (2 wave) + lrow of the 64-row chunk
+    woffsc[1] = (unsigned)((wave * 16 + 8 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;
     {
         const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -193,6 +203,13 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (__attribute__((address_space(3))) void*)(W3s + (wave * W3_PIECES + i) * 1024),
                                                          16, woff3[i], j * 128, 0, 0);
         }
+        if constexpr (SC) {
+            unsigned char* Wscs = W2s + W2C_BYTES + C3 * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, (__attribute__((address_space(3))) void*)(Wscs + (wave * 2 + i) * 1024), 16,
+                                                         woffsc[i], j * (64 * 64 * 2), 0, 0);
+        }
     };
     // fp16 residual of y-chunk j in the paired 16-byte layout: lane (g, li) -> row (g&1)*16 + li, 8 channels at (g>>1)*8
     const int pr_m = wm0 + (g & 1) * 16 + li;
@@ -209,10 +226,11 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (__attribute__((address_space(3))) void*)(res_lds + (j & 1) * 16384 + i * 1024), 16,
                                                      res_voff + (unsigned)(i * 8 * C2 * 2), j * 128, 0, 0);
     };
-    const bool has_res = p.res != nullptr && !(p.dbg & 4);
+    const bool has_res = !SC && p.res != nullptr && !(p.dbg & 4);
     // Counted waits (below) rely on every wave issuing exactly 4 residual loads and 4 stores per chunk: true on full
-    // tiles with a residual; otherwise (ragged last tile, no residual) the waits fall back to vmcnt(0).
-    const bool counted = has_res && m_base + 128 <= p.M && !(p.dbg & 2);
+    // tiles with a residual (SC: no residual loads, 4 stores); otherwise (ragged last tile, no residual) the waits fall back
+    // to vmcnt(0).
+    const bool counted = (SC || has_res) && m_base + 128 <= p.M && !(p.dbg & 2);
     auto load_res = [&](int j, uint4 (&r)[4]) {
         if constexpr (RDMA) {
             if (has_res) issue_res(j);
@@ -228,6 +246,21 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     // ---- 3x3 main loop ------------------------------------------------------------------------------------------------
     const int ks_first = (p.dbg & 1) ? nk - 1 : 0;  // dbg: timing ablations (tools/bench_btail.py --ablate), never set by the model
     if (ks_first) { tap_kh = 2; tap_kw = 2; tap_c = kpc - 1; }
+    // SC: the shortcut's input channels of this wave's 32 pixels as B fragments (k in natural order: Wsc is not permuted);
+    // loaded in front of everything else, complete at the first barrier's vmcnt(0)
+    half8 xs[2][2];
+    if constexpr (SC) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = wm0 + mt * 16 + li;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                half8 v = {};
+                if (m < p.M) v = *reinterpret_cast<const half8*>(p.xs + (size_t)m * 64 + kk * 32 + g * 8);
+                xs[mt][kk] = v;
+            }
+        }
+    }
     issue_main(ks_first, ks_first & 1);
     float4v acc1[NT1][2];
 #pragma unroll
@@ -267,7 +300,8 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     load_res(1, res[1]);
     compiler_fence();
     compute_main((nk - 1) & 1);
-    if (RDMA && counted) wait_vmcnt<4>();        // chunk 0 operands and residual chunk 0 landed (chunk 1's 4 pieces may still fly)
+    if (SC) wait_vmcnt<0>();                     // chunk 0 operands landed (nothing else is in flight)
+    else if (RDMA && counted) wait_vmcnt<4>();   // chunk 0 operands and residual chunk 0 landed (chunk 1's 4 pieces may still fly)
     else if (counted) wait_vmcnt<8>();           // chunk 0 operands landed (the 8 residual loads may still fly)
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
@@ -336,6 +370,19 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], a1[mt][kk], acc2[nt][mt], 0, 0, 0);
         }
+        if constexpr (SC) {   // + Wsc[chunk] . xs: the block's shortcut convolution
+            const unsigned char* Wscs = W2s + W2C_BYTES + C3 * ROW_BYTES;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                half8 wf[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Wscs + swz(nt * 16 + li, kk * 4 + g));
+#pragma unroll
+                for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xs[mt][kk], acc2[nt][mt], 0, 0, 0);
+            }
+        }
         // residual (paired layout -> accumulator layout), ReLU, fp16; store y; keep the fp16 values as the next B operand
         unsigned pk[4][2][2];
 #pragma unroll
@@ -384,6 +431,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             // chunk j+1's operands (issued at the top of this step) have landed; this step's y stores and the residual
             // loads of chunk j+2 stay in flight across the barrier (vmcnt retires in issue order)
             if (!counted) wait_vmcnt<0>();
+            else if (SC) wait_vmcnt<4>();            // (this step's 4 stores)
             else if (j + 2 < NCH) wait_vmcnt<8>();
             else wait_vmcnt<4>();
             __builtin_amdgcn_s_barrier();
@@ -409,16 +457,16 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #endif
 }
 
-template <int C1, int C3, bool RDMA>
+template <int C1, int C3, bool RDMA, bool SC = false>
 hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * (128 + C1) * ROW_BYTES + (RDMA ? 2 * 16384 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3, RDMA>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3, RDMA, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA, SC>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -431,6 +479,10 @@ hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream) {
     // 31-bit byte offsets in the buffer descriptors
     if ((size_t)p.B * p.H * p.W * p.C1 * 2 + (size_t)(p.W + 1) * p.C1 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
     if ((size_t)p.M * p.C1 * 8 >= 0x7fffff00ull) return hipErrorInvalidValue;
+    if (p.xs) {   // fused shortcut convolution: stride 1, 64 -> 256 channels next to a 64-channel 3x3 (first block of stage 1)
+        if (p.C1 != 64 || p.C3 != 64 || p.stride != 1 || !p.wsc || p.res || (size_t)p.M * 64 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
+        return launch_btail_t<64, 64, false, true>(p, stream);
+    }
     if (p.C1 == 64) {
         const bool rdma = !(p.dbg & 16);   // dbg 16: residual through VGPR loads (the first form: cross-check / timing)
         if (p.C3 == 0) return rdma ? launch_btail_t<64, 0, true>(p, stream) : launch_btail_t<64, 0, false>(p, stream);

@@ -144,11 +144,161 @@ __global__ __launch_bounds__(256, 2) void gemm_ln256_kernel(GemmLnParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// One-shot form for K = 256 (every attention output projection of the model).  The k-loop above is four dependent staging
+// round trips per workgroup (14.6 us at M = 8400, 10 us at M = 800 for 0.1-1 GFLOP); here a workgroup of 48 rows stages the
+// WHOLE weight matrix (256 x 256 fp16 = 128 KiB) and its 48 activation rows (24 KiB) in one batch of LDS-DMA, waits once and
+// runs its 96 MFMAs per wave back to back, then the same two-pass LayerNorm.  152 KiB of LDS, one workgroup per CU;
+// M = 8400 gives 175 workgroups (one round), M = 800 gives 17.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int OS_TM = 48;
+constexpr int OS_XSUB = OS_TM * ROW_BYTES;   // one [48 rows][64 k] activation sub-tile: 6 KiB
+constexpr int OS_WSUB = 256 * ROW_BYTES;     // one [256 rows][64 k] weight sub-tile: 32 KiB
+constexpr int OS_LDS = 4 * (OS_XSUB + OS_WSUB);
+
+__global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[2][4][OS_TM];       // [pass][wave][row]
+    unsigned char* const Xs = smem;                   // 4 sub-tiles
+    unsigned char* const Ws = smem + 4 * OS_XSUB;     // 4 sub-tiles
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int m_base = blockIdx.x * OS_TM;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x), 0, (unsigned)((size_t)p.M * 256 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)(256 * 256 * 2), 0x00020000);
+    // weights: wave w stages its own 64 rows (8 pieces) of each of the 4 sub-tiles; activations: 6 pieces per sub-tile, 24 in all,
+    // 6 per wave (piece q = 6 wave + i -> sub-tile q / 6, rows 8 (q % 6) ..); rows >= M are outside the descriptor: zero fill
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Ws + t * OS_WSUB + (wave * 8 + i) * 1024), 16,
+                                                     (unsigned)((wave * 64 + i * 8 + lrow) * 256) * 2u + (unsigned)lchunk * 16u, t * 128, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const int q = wave * 6 + i, t = q / 6, r = (q % 6) * 8 + lrow;   // (t == wave)
+        const int m = m_base + r;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(Xs + t * OS_XSUB + (q % 6) * 1024), 16,
+                                                 m < p.M ? (unsigned)(m * 256) * 2u + (unsigned)lchunk * 16u : 0x80000000u, t * 128, 0, 0);
+    }
+    float4v acc[4][3];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.bias + wave * 64 + nt * 16 + g * 4);
+#pragma unroll
+        for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = b;
+    }
+    // residual rows in flight during the MFMAs: lane (g, li) holds, for row mt*16 + li, columns 64 wave + nt*16 + 4g + r
+    float4v res[4][3];
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+        const int m = m_base + mt * 16 + li;
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            res[nt][mt] = float4v{0.f, 0.f, 0.f, 0.f};
+            if (p.res32 && m < p.M) res[nt][mt] = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + wave * 64 + nt * 16 + g * 4);
+        }
+    }
+    __syncthreads();   // vmcnt(0) + barrier: everything is in LDS
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[3], wf[4];
+#pragma unroll
+            for (int mt = 0; mt < 3; ++mt) xf[mt] = *reinterpret_cast<const half8*>(Xs + t * OS_XSUB + swz(mt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + t * OS_WSUB + swz(wave * 64 + nt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    // ---- + residual, LayerNorm over the 256 columns of each row (as in gemm_ln256_kernel) -----------------------------------
+    float sum[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[nt][mt] += res[nt][mt];
+            sum[mt] += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
+        }
+        sum[mt] += __shfl_xor(sum[mt], 16);
+        sum[mt] += __shfl_xor(sum[mt], 32);
+        if (g == 0) red[0][wave][mt * 16 + li] = sum[mt];
+    }
+    __syncthreads();
+    float sq[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+        const int r = mt * 16 + li;
+        const float mean = (red[0][0][r] + red[0][1][r] + red[0][2][r] + red[0][3][r]) * (1.0f / 256.0f);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            acc[nt][mt] -= mean;
+            sq[mt] += acc[nt][mt][0] * acc[nt][mt][0] + acc[nt][mt][1] * acc[nt][mt][1] + acc[nt][mt][2] * acc[nt][mt][2] +
+                      acc[nt][mt][3] * acc[nt][mt][3];
+        }
+        sq[mt] += __shfl_xor(sq[mt], 16);
+        sq[mt] += __shfl_xor(sq[mt], 32);
+        if (g == 0) red[1][wave][r] = sq[mt];
+    }
+    __syncthreads();
+    float4v gm[4], bt[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+        gm[nt] = *reinterpret_cast<const float4v*>(p.gamma + wave * 64 + nt * 16 + g * 4);
+        bt[nt] = *reinterpret_cast<const float4v*>(p.beta + wave * 64 + nt * 16 + g * 4);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 3; ++mt) {
+        const int r = mt * 16 + li;
+        const int m = m_base + r;
+        const float var = (red[1][0][r] + red[1][1][r] + red[1][2][r] + red[1][3][r]) * (1.0f / 256.0f);
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt) {
+            const int c = wave * 64 + nt * 16 + g * 4;
+            float4v o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = acc[nt][mt][q] * rstd * gm[nt][q] + bt[nt][q];
+            if (m < p.M) {
+                if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
+                if (p.y16) {
+                    half4 h;
+                    h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+                    *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
+                }
+            }
+        }
+    }
+#endif
+}
+
 }  // namespace
+
+static int g_gemm_ln_variant = 1;   // 1: one-shot kernel for K == 256 (default), 0: the k-loop kernel (cross-check)
+void opd_set_gemm_ln_variant(int v) { g_gemm_ln_variant = v; }
 
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || !p.gamma || !p.beta || !p.bias) return hipErrorInvalidValue;
     if ((size_t)p.M * p.K * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;  // 31-bit buffer offsets
+    if (p.K == 256 && g_gemm_ln_variant == 1) {
+        static bool attr_os = false;
+        if (!attr_os) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_os_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS);
+            if (e != hipSuccess) return e;
+            attr_os = true;
+        }
+        hipLaunchKernelGGL(gemm_ln256_os_kernel, dim3((p.M + OS_TM - 1) / OS_TM), dim3(256), OS_LDS, stream, p);
+        return hipGetLastError();
+    }
     constexpr int LDS = 2 * STAGE_BYTES;
     static bool attr_set = false;
     if (!attr_set) {

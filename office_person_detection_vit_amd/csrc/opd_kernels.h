@@ -41,6 +41,8 @@ struct BtailParams {
     const f16_t* w2p;  // [4*C1][C1], K-permuted
     const float* b2;
     const f16_t* res;  // [M][4*C1] or null
+    const f16_t* xs;   // optional fused shortcut (C1 == 64, C3 == 64, stride 1, res == null): its input [M][64] fp16 ...
+    const f16_t* wsc;  // ... and its folded 1x1 weights [4*C1][64] (plain K order); b2 then holds b2 + the shortcut's bias
     f16_t* y;          // [M][4*C1]
     const f16_t* w3p;  // [C3][4*C1], K-permuted (C3 > 0)
     const float* b3;
@@ -71,6 +73,7 @@ struct GemmLnParams {
     int M, K;
 };
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream);
+void opd_set_gemm_ln_variant(int v);  // 1 = one-shot kernel for K == 256 (default), 0 = the k-loop kernel everywhere (cross-check)
 // Small-M linear layer, reduction cut into 256-wide slices: slice z computes x[:, 256z : 256z+256] . w[:, 256z : 256z+256]^T.
 // slices == 1: out = act(. + bias) as fp16 (out16) or fp32 (out32).  slices > 1: fp32 slabs out32[z][M][N], bias in slab 0
 // (summed by opd_launch_reduce_ln).  bias_period > 0: row-periodic bias [period][N].

@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <memory>
 #include <new>
 #include <stdexcept>
@@ -65,6 +66,7 @@ struct LNp {
 struct Block {
     Conv c0, c1, c2, sc;
     bool has_sc = false;
+    float* bias2sc = nullptr;   // c2.bias + sc.bias (fp32): the fused bottleneck tail adds the shortcut GEMM into the expand's accumulators
 };
 struct EncLayer {
     f16_t* wqkv = nullptr;  // [768][256] = [Wq; Wk; Wv]
@@ -179,6 +181,7 @@ struct opd_detr {
     int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
+    int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
     // kernels_ffn.hip (64-row workgroups, one per CU, each streaming ALL the weights of the pair of GEMMs): built, parity-tested,
     // measured SLOWER than the launches it replaces at every shape of BASELINE.json, so it is OFF by default (DESIGN.md section 2,
@@ -191,7 +194,7 @@ struct opd_detr {
     f16_t* d_dump = nullptr; // 256 bytes nobody reads (out-of-range rows of kernels_ffn.hip's last workgroup store here)
 
     // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
-    struct GraphEntry { int B, H, W, fmt, fh, fw; const void* pixels; int uses; hipGraphExec_t exec; };
+    struct GraphEntry { int B, H, W, fmt, fh, fw; const void* pixels; int uses; hipGraphExec_t exec; unsigned epoch; };
     std::vector<GraphEntry> graphs;
 
     // per-kernel-class timing (profiling mode only): event pairs around every launch of the last forward
@@ -314,6 +317,13 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
             RCCHK(make_conv(m, sd, p + ".layer.0", 1, &b.c0));
             RCCHK(make_conv(m, sd, p + ".layer.1", stride, &b.c1));
             RCCHK(make_conv(m, sd, p + ".layer.2", 1, &b.c2));
+            if (b.has_sc && b.sc.Cout == b.c2.Cout) {
+                std::vector<float> b2(b.c2.Cout), bs(b.c2.Cout);
+                HIPCHK(hipMemcpy(b2.data(), b.c2.bias, b2.size() * 4, hipMemcpyDeviceToHost));
+                HIPCHK(hipMemcpy(bs.data(), b.sc.bias, bs.size() * 4, hipMemcpyDeviceToHost));
+                for (size_t j = 0; j < b2.size(); ++j) b2[j] += bs[j];
+                RCCHK(upload_f32(m, &b.bias2sc, b2));
+            }
             m->blocks.push_back(b);
         }
     }
@@ -794,7 +804,11 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             const Block* nb = bi + 1 < (int)m->blocks.size() ? &m->blocks[bi + 1] : nullptr;
             const int oh = (b.c1.stride == 2) ? down2(ch) : ch, ow = (b.c1.stride == 2) ? down2(cw) : cw;
             const f16_t* res = cur;
-            if (b.has_sc) {
+            // first block of stage 1 (64 -> 256 channels, stride 1): the shortcut runs inside the fused tail (kernels_btail.hip, SC)
+            const bool sc_in_tail = b.has_sc && m->fuse_shortcut && m->fuse_btail && b.bias2sc && b.sc.KH == 1 && b.sc.stride == 1 &&
+                                    b.sc.Cin == 64 && b.c1.Cin == 64 && b.c1.stride == 1 && b.c2.Cout == 256 && nb && nb->c0.wp &&
+                                    nb->c0.Cin == 256 && nb->c0.Cout == 64;
+            if (b.has_sc && !sc_in_tail) {
                 RCCHK(run_conv(m, b.sc, cur, B, ch, cw, oh, ow, m->d_sc, false, nullptr));
                 res = m->d_sc;
             }
@@ -813,10 +827,11 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 if (nb && nb->c0.wp && nb->c0.Cin == 4 * C1 && opd_btail_supported(C1, nb->c0.Cout)) C3 = nb->c0.Cout;
                 BtailParams p{};
                 p.x1 = x1; p.w1 = b.c1.w; p.b1 = b.c1.bias; p.w2p = b.c2.wp; p.b2 = b.c2.bias; p.res = res; p.y = out;
+                if (sc_in_tail) { p.res = nullptr; p.xs = cur; p.wsc = b.sc.w; p.b2 = b.bias2sc; }
                 f16_t* z = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
                 if (C3) { p.w3p = nb->c0.wp; p.b3 = nb->c0.bias; p.z = z; }
                 p.B = B; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = B * oh * ow; p.C1 = C1; p.C3 = C3;
-                RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3)));
+                RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));
                 HIPCHK(opd_launch_btail(p, m->stream));
                 RCCHK(timed_end(m));
                 if (C3) z_ready = z;
@@ -921,6 +936,11 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
 // one-time eager setup meanwhile, even in thread-local capture mode ("operation failed due to a previous error during
 // capture").  Every entry point therefore holds this lock shared; a capture takes it exclusively for its few milliseconds.
 static std::shared_mutex g_api_mu;
+// Handle churn and captured graphs (ROCm 7.2, observed on MI355X, tools/debug_poison.py): after ANOTHER handle has been destroyed
+// and a third one created in the memory it returned, replaying a graph captured before that gives garbage (NaN), although every
+// pointer the graph holds belongs to its own, live handle and the same launches issued eagerly stay bit-exact.  Every creation
+// and destruction of a handle therefore bumps this epoch; a graph captured in an older epoch is dropped and captured again.
+static std::atomic<unsigned> g_handle_epoch{0};
 static thread_local std::shared_lock<std::shared_mutex>* tl_api_lock = nullptr;
 struct ApiScope {   // first statement of every HIP-calling entry point; entry points calling each other nest harmlessly
     std::shared_lock<std::shared_mutex> lk;
@@ -950,8 +970,13 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
             if (m->graphs.front().exec) (void)hipGraphExecDestroy(m->graphs.front().exec);
             m->graphs.erase(m->graphs.begin());
         }
-        m->graphs.push_back({B, H, W, pixel_format, 0, 0, d_pixels, 0, nullptr});
+        m->graphs.push_back({B, H, W, pixel_format, 0, 0, d_pixels, 0, nullptr, 0u});
         e = &m->graphs.back();
+    }
+    if (e->exec && e->epoch != g_handle_epoch.load()) {   // handles came or went since the capture: capture again (see g_handle_epoch)
+        (void)hipGraphExecDestroy(e->exec);
+        e->exec = nullptr;
+        e->uses = 1;
     }
     if (e->exec) {
         HIPCHK(hipGraphLaunch(e->exec, m->stream));
@@ -978,7 +1003,7 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
     if (ei != hipSuccess) { e->uses = -1000000; (void)hipGetLastError(); return enqueue_forward(m, d_pixels, pixel_format, B, H, W); }
-    e->exec = exec; e->fh = m->last_fh; e->fw = m->last_fw;
+    e->exec = exec; e->fh = m->last_fh; e->fw = m->last_fw; e->epoch = g_handle_epoch.load();
     HIPCHK(hipGraphLaunch(exec, m->stream));
     return OPD_OK;
 }
@@ -1172,6 +1197,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     for (auto& e : m->ev)
         if (hipEventCreate(&e) != hipSuccess) return cleanup(fail(OPD_EHIP, "hipEventCreate failed"));
     *out = m.release();
+    ++g_handle_epoch;
     return OPD_OK;
 }
 
@@ -1188,7 +1214,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
-    m->fuse_btail = src->fuse_btail; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail;
     m->d_dump = nullptr;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
@@ -1205,6 +1231,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     for (auto& e : m->ev)
         if (hipEventCreate(&e) != hipSuccess) return cleanup(fail(OPD_EHIP, "hipEventCreate failed"));
     *out = m.release();
+    ++g_handle_epoch;
     return OPD_OK;
 }
 
@@ -1226,6 +1253,7 @@ void opd_detr_destroy(opd_detr* m) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     if (m->stream) (void)hipStreamDestroy(m->stream);
     delete m;
+    ++g_handle_epoch;
 }
 
 int opd_detr_info(const opd_detr* m, opd_model_info* info) {
@@ -1543,6 +1571,10 @@ int opd_test_sine_pos_embed(int h, int w, int vh, int vw, int D, float* out) {
     memcpy(out, pos.data(), pos.size() * sizeof(float));
     return OPD_OK;
 }
+int opd_test_set_gemm_ln_variant(int v) {
+    opd_set_gemm_ln_variant(v);
+    return OPD_OK;
+}
 int opd_test_set_stem_variant(int v) {
     opd_set_stem_variant(v);
     return OPD_OK;
@@ -1565,9 +1597,10 @@ int opd_test_set_fuse_ffn(opd_detr* m, int on) {   // bit 0: encoder feed-forwar
     m->graphs.clear();
     return OPD_OK;
 }
-int opd_test_set_fuse_btail(opd_detr* m, int on) {
+int opd_test_set_fuse_btail(opd_detr* m, int on) {   // bit 0: fused bottleneck tails, bit 1: the shortcut of stage 1 inside its first tail
     if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->fuse_btail = on ? 1 : 0;
+    m->fuse_btail = (on & 1) ? 1 : 0;
+    m->fuse_shortcut = (on & 2) ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();

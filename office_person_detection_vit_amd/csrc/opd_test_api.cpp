@@ -317,6 +317,37 @@ int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, cons
     return OPD_OK;
 }
 
+// fused tail WITH the block's shortcut convolution inside (first block of stage 1): xs [M][64] = the shortcut's input at the output
+// resolution, wsc [256][64]; b2sc = b2 + the shortcut's bias.  C1 = 64, C3 = 64, stride 1.
+int opd_test_btail_sc(const uint16_t* x1, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2sc, const uint16_t* xs,
+                      const uint16_t* wsc, const uint16_t* w3, const float* b3, uint16_t* y, uint16_t* z, int B, int H, int W) {
+    DevMem dm;
+    const int C1 = 64, C2 = 256, C3 = 64;
+    const size_t M = (size_t)B * H * W;
+    std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)C3 * C2);
+    opd_permute_k32(w2, w2p.data(), C2, C1);
+    opd_permute_k32(w3, w3p.data(), C3, C2);
+    BtailParams p{};
+    p.x1 = dm.up(x1, M * C1);
+    p.w1 = dm.up(w1, (size_t)C1 * 9 * C1);
+    p.b1 = dm.up(b1, C1);
+    p.w2p = dm.up(w2p.data(), w2p.size());
+    p.b2 = dm.up(b2sc, C2);
+    p.xs = dm.up(xs, M * 64);
+    p.wsc = dm.up(wsc, (size_t)C2 * 64);
+    p.y = dm.up<uint16_t>(nullptr, M * C2);
+    p.w3p = dm.up(w3p.data(), w3p.size());
+    p.b3 = dm.up(b3, C3);
+    p.z = dm.up<uint16_t>(nullptr, M * C3);
+    if (!p.x1 || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.xs || !p.wsc || !p.y || !p.w3p || !p.b3 || !p.z) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.H = H; p.W = W; p.OH = H; p.OW = W; p.stride = 1; p.M = (int)M; p.C1 = C1; p.C3 = C3;
+    TCHK(opd_launch_btail(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, p.y, M * C2 * 2, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(z, p.z, M * C3 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 // Times the fused tail (us_out[0]) and the three unfused launches it replaces (us_out[1..3]: c1, c2, c0') on
 // device-resident data of the given shape.
 int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int dbg, int iters, float* us_out) {

@@ -233,9 +233,12 @@ def test_fused_bottleneck_tail_matches_unfused(weight_cache):
     det.load_model()
     frames = structured_frames(2, 256, 320, seed=77)
     lg_f, bx_f, enc_f = det.forward_raw(frames)
+    _capi.check(_capi.load_library().opd_test_set_fuse_btail(C.c_void_p(det.model), 1), "set_fuse_btail")   # tails fused, shortcut on its own
+    lg_s, bx_s, enc_s = det.forward_raw(frames)
     _capi.check(_capi.load_library().opd_test_set_fuse_btail(C.c_void_p(det.model), 0), "set_fuse_btail")
     lg_u, bx_u, enc_u = det.forward_raw(frames)
     det.close()
+    assert 0 < np.abs(enc_f - enc_s).max() < TOL[1.0][2] and np.abs(bx_f - bx_s).max() < TOL[1.0][0]   # shortcut inside the tail or not
     # (fp16 rounding flips caused by the different fp32 summation order propagate like any other fp16-storage noise:
     #  same bound as against the golden vectors)
     assert np.abs(bx_f - bx_u).max() < TOL[1.0][0] and np.abs(_softmax(lg_f) - _softmax(lg_u)).max() < TOL[1.0][1]
@@ -618,15 +621,34 @@ def test_checkpoint_with_4x_timm_names_gives_identical_outputs(detectors, tmp_pa
     assert not any(".o_proj." in k or ".mlp." in k or "embedder" in k for k in old)
     path = str(tmp_path / "detr_4x_names.safetensors")
     save_safetensors(old, path)
-    det4 = HipDetrDetector(model_path=path, max_batch=2, max_size=(800, 1333), resize=False)
-    det4.load_model()
+    frames = structured_frames(2, 256, 320, seed=1212)
+    outs = []
+    for pth in (det.model_path, path):
+        d = HipDetrDetector(model_path=pth, max_batch=2, max_size=(800, 1333), resize=False)
+        d.load_model()
+        try:
+            outs.append(d.forward_raw(frames))
+        finally:
+            d.close()
+    for x, y in zip(*outs):
+        np.testing.assert_array_equal(x, y)
+
+
+def test_long_lived_handle_equals_fresh_handle(detectors):
+    """The module's shared detector has by now served dozens of calls (graphs captured and replayed, ragged batches, ROI pooling,
+    asynchronous submissions): its outputs must still be bit-identical to a fresh handle's."""
+    det = detectors(ga=1.0)
+    frames = structured_frames(2, 256, 320, seed=1213)
+    fresh = HipDetrDetector(model_path=det.model_path, max_batch=2, max_size=(800, 1333), resize=False)
+    fresh.load_model()
     try:
-        frames = structured_frames(2, 256, 320, seed=1212)
-        a, b = det.forward_raw(frames), det4.forward_raw(frames)
-        for x, y in zip(a, b):
-            np.testing.assert_array_equal(x, y)
+        want = fresh.forward_raw(frames)
     finally:
-        det4.close()
+        fresh.close()
+    for rep in range(3):   # eager / captured / replayed on the shared handle (or replayed thrice if this shape was seen before)
+        got = det.forward_raw(frames)
+        for x, y in zip(got, want):
+            np.testing.assert_array_equal(x, y)
 
 
 def test_sharded_detector_device_direct_exchange(detectors):
@@ -720,3 +742,29 @@ def test_portrait_frames_are_accepted(weight_cache, parity_log):
             det.forward_raw([structured_frames(1, 330, 256, seed=1)[0]])     # more pixels than the handle was sized for
     finally:
         det.close()
+
+
+def test_graph_replay_survives_handle_churn(weight_cache):
+    """Regression (round 2): a handle's captured graph must still be right after OTHER handles have been destroyed and created with
+    different weights in the memory they returned.  On ROCm 7.2 the replay then gave NaN although the same launches issued eagerly
+    stayed bit-exact; the library now re-captures its graphs whenever a handle has come or gone (csrc/opd_model.cpp::g_handle_epoch)."""
+    mild = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    sharp = ensure_weight_file(weight_cache, DetrArch(), 0, 2.0, "r50")
+    mk = lambda p: HipDetrDetector(model_path=p, max_batch=2, max_size=(256, 320), resize=False)
+    frames = structured_frames(2, 256, 320, seed=4321)
+    a = mk(mild); a.load_model()
+    try:
+        a.forward_raw(structured_frames(2, 256, 320, seed=1))   # eager
+        ref = a.forward_raw(frames)                             # captured
+        f = mk(mild); f.load_model(); f.forward_raw(frames); f.close()
+        b = mk(sharp); b.load_model()
+        try:
+            b.forward_raw(frames)
+            for _ in range(2):
+                got = a.forward_raw(frames)
+                for x, y in zip(got, ref):
+                    np.testing.assert_array_equal(x, y)
+        finally:
+            b.close()
+    finally:
+        a.close()

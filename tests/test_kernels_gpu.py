@@ -502,10 +502,86 @@ def test_btail_integer_exact_and_equals_unfused(lib, C1, C3):
     np.testing.assert_array_equal(z, zu)
 
 
+def run_btail_sc(lib, x1, w1, b1, w2, b2sc, xs, wsc, w3, b3):
+    """fused tail with the block's shortcut convolution inside: xs [B,H,W,64], wsc [256,64]; stride 1, C1 = C3 = 64."""
+    B, H, W, C1 = x1.shape
+    M = B * H * W
+    f16 = lambda a: np.ascontiguousarray(a.astype(np.float16).view(np.uint16))
+    f32 = lambda a: np.ascontiguousarray(a.astype(np.float32))
+    y = np.empty((M, 256), np.uint16)
+    z = np.empty((M, 64), np.uint16)
+    args = [f16(x1), f16(w1.transpose(0, 2, 3, 1).reshape(C1, 9 * C1)), f32(b1), f16(w2), f32(b2sc), f16(xs.reshape(M, 64)), f16(wsc), f16(w3), f32(b3), y, z]
+    _capi.check(lib.opd_test_btail_sc(*[_p(a) for a in args], B, H, W), "opd_test_btail_sc")
+    return y.view(np.float16).astype(np.float32).reshape(B, H, W, 256), z.view(np.float16).astype(np.float32).reshape(B, H, W, 64)
+
+
+@pytest.mark.parametrize("B,H,W", [(2, 13, 17), (1, 16, 16), (2, 200, 334)])
+def test_btail_with_fused_shortcut(lib, B, H, W):
+    """First block of stage 1: y = relu(conv1x1(a1, w2) + conv1x1(xs, wsc) + b2 + bsc), z = relu(conv1x1(y, w3) + b3) with the
+    shortcut as a second GEMM into the expand's accumulators.  Reference: fp32 with a1 and y rounded to fp16 once (the shortcut
+    itself is not rounded: one rounding fewer than the two-launch path, like the fp32 reference).  Ragged M, full tiles only, and
+    the batch-8 stage-1 shape's row count per frame."""
+    rng = np.random.default_rng(B * H + W)
+    x1, _ = _h(np.abs(rng.standard_normal((B, H, W, 64))))
+    xs, _ = _h(np.abs(rng.standard_normal((B, H, W, 64))))
+    w1, _ = _h(rng.standard_normal((64, 64, 3, 3)) / 24)
+    w2, _ = _h(rng.standard_normal((256, 64)) / 8)
+    wsc, _ = _h(rng.standard_normal((256, 64)) / 8)
+    w3, _ = _h(rng.standard_normal((64, 256)) / 16)
+    b1, b2, bsc, b3 = (0.1 * rng.standard_normal(n).astype(np.float32) for n in (64, 256, 256, 64))
+    y, z = run_btail_sc(lib, x1, w1, b1, w2, b2 + bsc, xs, wsc, w3, b3)
+    r16 = lambda a: a.astype(np.float16).astype(np.float32)
+    a1 = r16(ref_conv(x1, w1, b1, 1, 1, True))
+    pre = ref_conv(a1, w2[:, :, None, None], b2 + bsc, 1, 0, False) + ref_conv(xs, wsc[:, :, None, None], np.zeros(256, np.float32), 1, 0, False)
+    yr = r16(np.maximum(pre, 0))
+    np.testing.assert_allclose(y, yr, atol=4e-3, rtol=2e-3)
+    zr = r16(ref_conv(y, w3[:, :, None, None], b3, 1, 0, True))     # from the kernel's own y
+    np.testing.assert_allclose(z, zr, atol=4e-3, rtol=2e-3)
+
+
+def test_btail_fused_shortcut_integer_exact(lib):
+    """Integer operands: bit-exact against the exact sums, and against the unfused route (shortcut launch -> residual tail)."""
+    rng = np.random.default_rng(77)
+    B, H, W = 2, 10, 9
+    x1 = rng.integers(0, 3, (B, H, W, 64)).astype(np.float32)
+    xs = rng.integers(0, 4, (B, H, W, 64)).astype(np.float32)
+    w1 = np.zeros((64, 64, 3, 3), np.float32)
+    for n in range(64):
+        w1[n, (n * 7 + 3) % 64, n % 3, (n // 3) % 3] = 1 + (n % 3)
+    w2 = np.zeros((256, 64), np.float32)
+    wsc = np.zeros((256, 64), np.float32)
+    for n in range(256):
+        w2[n, (n * 11 + 5) % 64] = 1 + (n % 2)
+        wsc[n, (n * 5 + 9) % 64] = 1
+        wsc[n, (n * 3 + 1) % 64] -= 2
+    w3 = np.zeros((64, 256), np.float32)
+    for n in range(64):
+        w3[n, (n * 13 + 7) % 256] = 1
+        w3[n, (n * 29 + 1) % 256] += 1
+    b1 = rng.integers(-1, 2, 64).astype(np.float32)
+    b2 = rng.integers(-1, 2, 256).astype(np.float32)
+    bsc = rng.integers(-2, 3, 256).astype(np.float32)
+    b3 = rng.integers(-2, 3, 64).astype(np.float32)
+    y, z = run_btail_sc(lib, x1, w1, b1, w2, b2 + bsc, xs, wsc, w3, b3)
+    a1 = ref_conv(x1, w1, b1, 1, 1, True)
+    yr = np.maximum(ref_conv(a1, w2[:, :, None, None], b2, 1, 0, False) + ref_conv(xs, wsc[:, :, None, None], bsc, 1, 0, False), 0)
+    zr = ref_conv(yr, w3[:, :, None, None], b3, 1, 0, True)
+    assert np.abs(yr).max() < 2048 and np.abs(zr).max() < 2048
+    np.testing.assert_array_equal(y, yr)
+    np.testing.assert_array_equal(z, zr)
+    sc = run_conv(lib, xs, wsc[:, :, None, None], bsc, 1, 0, False)          # the two-launch route: shortcut, then residual tail
+    yu, zu = run_btail(lib, x1, w1, b1, w2, b2, sc, w3, b3, 1)
+    np.testing.assert_array_equal(y, yu)
+    np.testing.assert_array_equal(z, zu)
+
+
 # ---- Linear(K -> 256) + bias + residual + LayerNorm in one kernel (kernels_rowln.hip) ---------------------------------------
-@pytest.mark.parametrize("M,K,use_res", [(800, 256, True), (8400, 256, True), (37, 256, True), (100, 2048, False), (33, 64, True)])
-def test_gemm_ln_matches_torch(lib, M, K, use_res):
-    """y = LN(x W^T + b + res): fp16 operands, fp32 accumulate and statistics.  Tolerance: fp32 summation order only
+@pytest.mark.parametrize("variant", [1, 0], ids=["oneshot_k256", "kloop"])
+@pytest.mark.parametrize("M,K,use_res", [(800, 256, True), (8400, 256, True), (37, 256, True), (100, 2048, False), (33, 64, True), (48, 256, False),
+                                         (97, 256, True)])
+def test_gemm_ln_matches_torch(lib, M, K, use_res, variant):
+    """y = LN(x W^T + b + res): fp16 operands, fp32 accumulate and statistics; both kernels (K = 256 goes to the one-shot kernel
+    by default: 48-row workgroups, whole weight matrix staged at once; other K and variant 0 to the k-loop kernel).  Tolerance: fp32 summation order only
     (the reference is computed in fp32 from the same fp16-rounded operands): 2e-5 abs on O(1) outputs; the fp16 copy
     one rounding (2^-11 rel)."""
     rng = np.random.default_rng(M * 7 + K)
@@ -517,7 +593,11 @@ def test_gemm_ln_matches_torch(lib, M, K, use_res):
     beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
     y = np.empty((M, 256), np.float32)
     y16 = np.empty((M, 256), np.uint16)
-    rc = lib.opd_test_gemm_ln(_p(xb), _p(wb), _p(bias), _p(res), _p(gamma), _p(beta), _p(y), _p(y16), M, K)
+    lib.opd_test_set_gemm_ln_variant(variant)
+    try:
+        rc = lib.opd_test_gemm_ln(_p(xb), _p(wb), _p(bias), _p(res), _p(gamma), _p(beta), _p(y), _p(y16), M, K)
+    finally:
+        lib.opd_test_set_gemm_ln_variant(1)
     _capi.check(rc, "opd_test_gemm_ln")
     pre = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
     if use_res:
