@@ -2,10 +2,13 @@
 oracle run live on the same seeded inputs, and through size-independent properties at the benchmark size.
 
 Stated tolerances (normalised cxcywh boxes / softmax probabilities), fp16 storage with fp32 accumulation:
-  * "mild" weight set (attention gain 1):  |dbox| <= 2e-3, |dprob| <= 4e-3      (north-star target 1e-3 is reported)
+  * BASELINE configs[1] (r50, 800x1333, batch 8) and configs[3] (r101, 1066x1920, batch 8): |dbox| <= 1e-3 = the north-star
+    tolerance (measured 4.3e-4 .. 5.5e-4 and 6.8e-4)
+  * small frames (256x320 and the like; fewer tokens, same rounding noise): "mild" weight set |dbox| <= 2e-3, |dprob| <= 4e-3
+    (measured 0.8e-3 .. 1.3e-3, r101 included)
   * "sharp" weight set (attention gain 2): |dbox| <= 3e-2, |dprob| <= 4e-2      (logic-error catcher: box spread is 0.075)
-The oracle's own fp16-storage emulation (``forward(..., emulate="f16")``) shows the same drift, i.e. these bounds are
-set by fp16 activation storage, not by kernel defects.
+The weight recipe makes every fp16 GEMM operand exactly representable (weights.make_device_exact), so these numbers are fp16
+ACTIVATION storage only; the oracle's own storage emulation (``forward(..., emulate="f16")``, tools/drift_split.py) predicts them.
 """
 
 import os
@@ -81,15 +84,15 @@ def test_full_resolution_matches_golden(detectors, golden_dir, parity_log):
 
 
 def test_r101_matches_golden(detectors, golden_dir, parity_log):
-    """r101 (33 bottlenecks): the stated exception to the 1e-3 target — fp16 storage of 33 block outputs alone gives 2.1e-3 in the
-    oracle's emulation (tools/drift_split.py, profiles/r02_drift_split.txt)."""
+    """r101 (33 bottlenecks) at 256x320: the small-frame bound (2e-3); at its BASELINE resolution the 1e-3 bound holds
+    (test_config4_r101_1080p_batch8).  tools/drift_split.py, profiles/r02_drift_split.txt, DESIGN.md section 3."""
     g = np.load(os.path.join(golden_dir, "r101_mild_256x320.npz"))
     det = detectors(depths=(3, 4, 23, 3), ga=1.0)
     logits, boxes, enc = det.forward_raw(_golden_frames(g))
     dbox = float(np.abs(boxes - g["pred_boxes"]).max())
     dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
-    parity_log("r101 mild 256x320 vs HF golden", dbox, dprob, None, 3e-3, "stated exception: 33 fp16-stored block outputs")
-    assert dbox <= 3e-3 and dprob <= 6e-3
+    parity_log("r101 mild 256x320 vs HF golden", dbox, dprob, None, 2e-3, "small frame")
+    assert dbox <= 2e-3 and dprob <= 4e-3
 
 
 def test_matches_live_oracle_and_postprocess(detectors, weight_cache):
@@ -372,9 +375,8 @@ def test_config4_r101_1080p_batch8(detectors, weight_cache, parity_log):
     pv, pm = O.preprocess([frames[2]])
     lg, bx, mem = O.forward(w, pv, pm)
     dbox, dprob = float(np.abs(bx1[0] - bx[0].numpy()).max()), float(np.abs(_softmax(lg1[0]) - _softmax(lg[0].numpy())).max())
-    parity_log("r101 mild 1066x1920 batch 8 (BASELINE configs[3]), frame 2 vs live oracle", dbox, dprob, None, 3e-3,
-               "stated exception: 33 fp16-stored block outputs")
-    assert dbox <= 3e-3 and dprob <= 6e-3
+    parity_log("r101 mild 1066x1920 batch 8 (BASELINE configs[3]), frame 2 vs live oracle", dbox, dprob, None, 1e-3)
+    assert dbox <= 1e-3 and dprob <= 2e-3
 
 
 def test_config5_tiled_4k_frame(detectors):
