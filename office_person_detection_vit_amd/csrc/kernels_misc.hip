@@ -29,25 +29,46 @@ __constant__ float c_std[3] = {0.229f, 0.224f, 0.225f};
 __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp,
                                      const int32_t* __restrict__ valid_hw) {
 #pragma clang fp contract(off)  // keep mul / sub / div separately rounded, like the reference's tensor ops
+    // one thread = 4 consecutive pixels of a padded row: 12 source bytes, two 16-byte stores (one pixel per thread moved
+    // 1.7 TB/s: 35 us at batch 8; the arithmetic per pixel is unchanged)
+    const int groups = (Wp + 3) >> 2;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (size_t)B * Hp * Wp) return;
-    const int xp = (int)(i % Wp);
-    const size_t t = i / Wp;
+    if (i >= (size_t)B * Hp * groups) return;
+    const int xg = (int)(i % groups);
+    const size_t t = i / groups;
     const int yp = (int)(t % Hp);
     const int b = (int)(t / Hp);
-    const int y = yp - 3, x = xp - 3;
-    half4 o;
-    o[0] = o[1] = o[2] = o[3] = (_Float16)0.f;
+    const int y = yp - 3;
     const int vh = valid_hw ? valid_hw[2 * b] : H, vw = valid_hw ? valid_hw[2 * b + 1] : W;
-    if ((unsigned)y < (unsigned)vh && (unsigned)x < (unsigned)vw) {
-        const uint8_t* s = in + (((size_t)b * H + y) * W + x) * 3;
-        const float bl = (float)s[0], g = (float)s[1], r = (float)s[2];
-        const float k = 1.0f / 255.0f;
-        o[0] = (_Float16)((r * k - c_mean[0]) / c_std[0]);
-        o[1] = (_Float16)((g * k - c_mean[1]) / c_std[1]);
-        o[2] = (_Float16)((bl * k - c_mean[2]) / c_std[2]);
+    const bool row_ok = (unsigned)y < (unsigned)vh;
+    const uint8_t* srow = in + ((size_t)b * H + (row_ok ? y : 0)) * W * 3;
+    f16_t* orow = out + (((size_t)b * Hp + yp) * Wp) * 4;
+    const float k = 1.0f / 255.0f;
+    half4 o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int xp = xg * 4 + j, x = xp - 3;
+        o[j][0] = o[j][1] = o[j][2] = o[j][3] = (_Float16)0.f;
+        if (row_ok && (unsigned)x < (unsigned)vw) {
+            const uint8_t* s = srow + (size_t)x * 3;
+            const float bl = (float)s[0], g = (float)s[1], r = (float)s[2];
+            o[j][0] = (_Float16)((r * k - c_mean[0]) / c_std[0]);
+            o[j][1] = (_Float16)((g * k - c_mean[1]) / c_std[1]);
+            o[j][2] = (_Float16)((bl * k - c_mean[2]) / c_std[2]);
+        }
     }
-    *reinterpret_cast<half4*>(out + i * 4) = o;
+    if (xg * 4 + 3 < Wp && (Wp & 1) == 0) {   // rows are 8 Wp bytes long: the 32-byte groups are 16-byte aligned when Wp is even ...
+        typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+        half8v a, c;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { a[q] = o[0][q]; a[4 + q] = o[1][q]; c[q] = o[2][q]; c[4 + q] = o[3][q]; }
+        *reinterpret_cast<half8v*>(orow + (size_t)xg * 16) = a;
+        *reinterpret_cast<half8v*>(orow + (size_t)xg * 16 + 8) = c;
+    } else {                                    // ... otherwise (and for the last partial group) pixel by pixel
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (xg * 4 + j < Wp) *reinterpret_cast<half4*>(orow + (size_t)(xg * 4 + j) * 4) = o[j];
+    }
 }
 
 __global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __restrict__ out, int B, int H, int W, int Hp, int Wp,
@@ -395,8 +416,8 @@ inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + 
 hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
                                     hipStream_t stream) {
     if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
-    const size_t npix = (size_t)B * Hp * Wp;
-    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, frames, out, B, H, W, Hp, Wp, valid_hw);
+    const size_t ngroups = (size_t)B * Hp * ((Wp + 3) / 4);
+    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(ngroups, 256)), dim3(256), 0, stream, frames, out, B, H, W, Hp, Wp, valid_hw);
     return hipGetLastError();
 }
 

@@ -181,6 +181,7 @@ struct opd_detr {
     int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
+    int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
     // kernels_ffn.hip (64-row workgroups, one per CU, each streaming ALL the weights of the pair of GEMMs): built, parity-tested,
@@ -794,70 +795,105 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         RCCHK(timed_end(m));
     }
     MARK(1);
-    const f16_t* cur = m->d_pool;
-    int ch = d.H2, cw = d.W2;
-    const f16_t* z_ready = nullptr;  // the current block's reduce (c0) output when the previous fused tail produced it
-    for (int s = 0; s < 4; ++s) {
-        for (int l = 0; l < a.depths[s]; ++l) {
-            const int bi = m->stage_first[s] + l;
-            const Block& b = m->blocks[bi];
-            const Block* nb = bi + 1 < (int)m->blocks.size() ? &m->blocks[bi + 1] : nullptr;
-            const int oh = (b.c1.stride == 2) ? down2(ch) : ch, ow = (b.c1.stride == 2) ? down2(cw) : cw;
-            const f16_t* res = cur;
-            // first block of stage 1 (64 -> 256 channels, stride 1): the shortcut runs inside the fused tail (kernels_btail.hip, SC)
-            const bool sc_in_tail = b.has_sc && m->fuse_shortcut && m->fuse_btail && b.bias2sc && b.sc.KH == 1 && b.sc.stride == 1 &&
-                                    b.sc.Cin == 64 && b.c1.Cin == 64 && b.c1.stride == 1 && b.c2.Cout == 256 && nb && nb->c0.wp &&
-                                    nb->c0.Cin == 256 && nb->c0.Cout == 64;
-            if (b.has_sc && !sc_in_tail) {
-                RCCHK(run_conv(m, b.sc, cur, B, ch, cw, oh, ow, m->d_sc, false, nullptr));
-                res = m->d_sc;
+    // ---- trunk.  Stages 1-2 may run in SUB-BATCHES (cfg: trunk_subbatch frames at a time through both stages, then the next
+    // frames): their block outputs are 274 / 137 MB at batch 8 — each one written by a fused tail and read back by the next as its
+    // residual — and the Infinity Cache holds 256 MiB, so at full batch that read comes from HBM; with 4 frames a tensor is
+    // 137 / 68 MB and the consumer finds it on the die.  Same kernels, same per-row arithmetic (tiles are cut from the flattened
+    // row index either way), so results do not change; buffers: every tensor of sub-batch [b0, b0 + nb) lives at frame offset b0
+    // of the buffer the full batch would use, the finished stage-2 outputs of earlier sub-batches sit below the regions later
+    // ones touch (per-frame sizes shrink from stage to stage).
+    struct TrunkState { int cur_id; int ch, cw; int z_id; };   // cur_id 0 = pool, 1 = t0, 2 = t1; z_id -1 / 0 = m0 / 1 = m1
+    auto run_blocks = [&](int s_begin, int s_end, int b0, int nb, TrunkState& st) -> int {
+        auto trunk = [&](int id, size_t per_frame) { return (id == 0 ? m->d_pool : id == 1 ? m->d_t0 : m->d_t1) + (size_t)b0 * per_frame; };
+        auto mid = [&](int id, size_t per_frame) { return (id ? m->d_m1 : m->d_m0) + (size_t)b0 * per_frame; };
+        for (int s = s_begin; s < s_end; ++s) {
+            for (int l = 0; l < a.depths[s]; ++l) {
+                const int bi = m->stage_first[s] + l;
+                const Block& b = m->blocks[bi];
+                const Block* nbk = bi + 1 < (int)m->blocks.size() ? &m->blocks[bi + 1] : nullptr;
+                const int ch = st.ch, cw = st.cw;
+                const int oh = (b.c1.stride == 2) ? down2(ch) : ch, ow = (b.c1.stride == 2) ? down2(cw) : cw;
+                const int C1 = b.c1.Cin, C2 = b.c2.Cout;
+                const f16_t* cur = trunk(st.cur_id, (size_t)ch * cw * b.c0.Cin);
+                const int out_id = st.cur_id == 1 ? 2 : 1;
+                f16_t* out = trunk(out_id, (size_t)oh * ow * C2);
+                const f16_t* res = cur;
+                // first block of stage 1 (64 -> 256 channels, stride 1): the shortcut runs inside the fused tail (kernels_btail.hip, SC)
+                const bool sc_in_tail = b.has_sc && m->fuse_shortcut && m->fuse_btail && b.bias2sc && b.sc.KH == 1 && b.sc.stride == 1 &&
+                                        b.sc.Cin == 64 && b.c1.Cin == 64 && b.c1.stride == 1 && b.c2.Cout == 256 && nbk && nbk->c0.wp &&
+                                        nbk->c0.Cin == 256 && nbk->c0.Cout == 64;
+                if (b.has_sc && !sc_in_tail) {
+                    f16_t* scb = m->d_sc + (size_t)b0 * oh * ow * C2;
+                    RCCHK(run_conv(m, b.sc, cur, nb, ch, cw, oh, ow, scb, false, nullptr));
+                    res = scb;
+                }
+                int x1_id = st.z_id;
+                const f16_t* x1 = nullptr;
+                if (x1_id >= 0) {
+                    x1 = mid(x1_id, (size_t)ch * cw * C1);
+                } else {
+                    x1_id = 0;
+                    f16_t* c0out = mid(0, (size_t)ch * cw * b.c0.Cout);
+                    RCCHK(run_conv(m, b.c0, cur, nb, ch, cw, ch, cw, c0out, true, nullptr));
+                    x1 = c0out;
+                }
+                st.z_id = -1;
+                const bool tail_ok = m->fuse_btail && b.c1.KH == 3 && b.c1.Cout == C1 && b.c2.Cin == C1 && b.c2.Cout == 4 * C1 && b.c2.wp &&
+                                     (size_t)nb * ch * cw * C1 * 2 < 0x7ff00000ull;
+                if (tail_ok && opd_btail_supported(C1, 0)) {
+                    int C3 = 0;
+                    if (nbk && nbk->c0.wp && nbk->c0.Cin == 4 * C1 && opd_btail_supported(C1, nbk->c0.Cout)) C3 = nbk->c0.Cout;
+                    // (a sub-batch pipeline ends with stage 2: its last tail cannot hand z to stage 3 anyway — 256 channels)
+                    BtailParams p{};
+                    p.x1 = x1; p.w1 = b.c1.w; p.b1 = b.c1.bias; p.w2p = b.c2.wp; p.b2 = b.c2.bias; p.res = res; p.y = out;
+                    if (sc_in_tail) { p.res = nullptr; p.xs = cur; p.wsc = b.sc.w; p.b2 = b.bias2sc; }
+                    f16_t* z = mid(1 - x1_id, (size_t)oh * ow * C3);
+                    if (C3) { p.w3p = nbk->c0.wp; p.b3 = nbk->c0.bias; p.z = z; }
+                    p.B = nb; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = nb * oh * ow; p.C1 = C1; p.C3 = C3;
+                    RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));
+                    HIPCHK(opd_launch_btail(p, m->stream));
+                    RCCHK(timed_end(m));
+                    if (C3) st.z_id = 1 - x1_id;
+                } else if (m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nbk && nbk->c0.wp &&
+                           nbk->c0.Cin == 1024 && nbk->c0.Cout == 256 && nbk->c0.KH == 1 && nbk->c0.stride == 1) {
+                    // stage 3: the 3x3 as an implicit GEMM, then ONE kernel for 1x1 expand + residual + ReLU (block output, stored) and the
+                    // next block's 1x1 reduce (kernels_ffn.hip, ETAIL); z takes the buffer the 3x3 has just finished reading
+                    f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
+                    f16_t* z = mid(x1_id, (size_t)oh * ow * 256);
+                    RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr));
+                    FfnParams fp{};
+                    fp.x16 = a1; fp.w1 = b.c2.w; fp.b1 = b.c2.bias; fp.res16 = res; fp.hid16 = out; fp.w2p = nbk->c0.wp; fp.b2 = nbk->c0.bias;
+                    fp.y16 = z; fp.dump = m->d_dump; fp.M = nb * oh * ow; fp.F = 1024; fp.etail = 1;
+                    RCCHK(timed_begin(m, CLS_CONV, 2.0 * fp.M * (256.0 * 1024 + 1024.0 * 256)));
+                    HIPCHK(opd_launch_ffn(fp, m->stream));
+                    RCCHK(timed_end(m));
+                    st.z_id = x1_id;
+                } else {
+                    f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
+                    RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr));
+                    RCCHK(run_conv(m, b.c2, a1, nb, oh, ow, oh, ow, out, true, res));
+                }
+                st.cur_id = out_id; st.ch = oh; st.cw = ow;
             }
-            const f16_t* x1 = z_ready;
-            if (!x1) {
-                RCCHK(run_conv(m, b.c0, cur, B, ch, cw, ch, cw, m->d_m0, true, nullptr));
-                x1 = m->d_m0;
-            }
-            z_ready = nullptr;
-            f16_t* out = (cur == m->d_t0) ? m->d_t1 : m->d_t0;
-            const int C1 = b.c1.Cin;
-            const bool tail_ok = m->fuse_btail && b.c1.KH == 3 && b.c1.Cout == C1 && b.c2.Cin == C1 && b.c2.Cout == 4 * C1 && b.c2.wp &&
-                                 (size_t)B * ch * cw * C1 * 2 < 0x7ff00000ull;
-            if (tail_ok && opd_btail_supported(C1, 0)) {
-                int C3 = 0;
-                if (nb && nb->c0.wp && nb->c0.Cin == 4 * C1 && opd_btail_supported(C1, nb->c0.Cout)) C3 = nb->c0.Cout;
-                BtailParams p{};
-                p.x1 = x1; p.w1 = b.c1.w; p.b1 = b.c1.bias; p.w2p = b.c2.wp; p.b2 = b.c2.bias; p.res = res; p.y = out;
-                if (sc_in_tail) { p.res = nullptr; p.xs = cur; p.wsc = b.sc.w; p.b2 = b.bias2sc; }
-                f16_t* z = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
-                if (C3) { p.w3p = nb->c0.wp; p.b3 = nb->c0.bias; p.z = z; }
-                p.B = B; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = B * oh * ow; p.C1 = C1; p.C3 = C3;
-                RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));
-                HIPCHK(opd_launch_btail(p, m->stream));
-                RCCHK(timed_end(m));
-                if (C3) z_ready = z;
-            } else if (m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nb && nb->c0.wp &&
-                       nb->c0.Cin == 1024 && nb->c0.Cout == 256 && nb->c0.KH == 1 && nb->c0.stride == 1) {
-                // stage 3: the 3x3 as an implicit GEMM, then ONE kernel for 1x1 expand + residual + ReLU (block output, stored) and the
-                // next block's 1x1 reduce (kernels_ffn.hip, ETAIL); z takes the buffer the 3x3 has just finished reading
-                f16_t* a1 = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
-                f16_t* z = (x1 == m->d_m0) ? m->d_m0 : m->d_m1;
-                RCCHK(run_conv(m, b.c1, x1, B, ch, cw, oh, ow, a1, true, nullptr));
-                FfnParams fp{};
-                fp.x16 = a1; fp.w1 = b.c2.w; fp.b1 = b.c2.bias; fp.res16 = res; fp.hid16 = out; fp.w2p = nb->c0.wp; fp.b2 = nb->c0.bias;
-                fp.y16 = z; fp.dump = m->d_dump; fp.M = B * oh * ow; fp.F = 1024; fp.etail = 1;
-                RCCHK(timed_begin(m, CLS_CONV, 2.0 * fp.M * (256.0 * 1024 + 1024.0 * 256)));
-                HIPCHK(opd_launch_ffn(fp, m->stream));
-                RCCHK(timed_end(m));
-                z_ready = z;
-            } else {
-                f16_t* a1 = (x1 == m->d_m0) ? m->d_m1 : m->d_m0;
-                RCCHK(run_conv(m, b.c1, x1, B, ch, cw, oh, ow, a1, true, nullptr));
-                RCCHK(run_conv(m, b.c2, a1, B, oh, ow, oh, ow, out, true, res));
-            }
-            cur = out; ch = oh; cw = ow;
+            if (b0 + nb == B) MARK(2 + s);
         }
-        MARK(2 + s);
+        return OPD_OK;
+    };
+    TrunkState st{0, d.H2, d.W2, -1};
+    {
+        const int sub = (m->trunk_subbatch > 0 && m->trunk_subbatch < B && B % m->trunk_subbatch == 0) ? m->trunk_subbatch : B;
+        TrunkState done = st;
+        for (int b0 = 0; b0 < B; b0 += sub) {
+            TrunkState t = st;
+            RCCHK(run_blocks(0, 2, b0, sub, t));
+            done = t;
+        }
+        st = done;
+        st.z_id = -1;   // (stage 2's last tail has no fused reduce)
+        RCCHK(run_blocks(2, 4, 0, B, st));
     }
+    const f16_t* cur = st.cur_id == 1 ? m->d_t0 : m->d_t1;
+    const int ch = st.ch, cw = st.cw;
     // ---- input projection -> encoder ------------------------------------------------------------------------------
     const int hw = ch * cw, M = B * hw, D = a.d_model, F = a.ffn;
     RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV));
@@ -1174,6 +1210,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     rc = infer_arch(sd, &m->arch, &err);
     if (rc) return fail(rc, err);
     m->cfg = *cfg;
+    if (const char* v = getenv("OPD_TRUNK_SUBBATCH")) m->trunk_subbatch = atoi(v);   // A/B switch for benchmarking
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1214,7 +1251,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch;
     m->d_dump = nullptr;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
