@@ -104,6 +104,7 @@ TEST_API = {
     "opd_test_set_tr_read": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_set_gemm_variant": (C.c_int, [C.c_int]),
     "opd_test_set_gemm_ln_variant": (C.c_int, [C.c_int]),
+    "opd_test_conv_dual": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 13),
     "opd_test_btail_sc": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 3),
     "opd_test_ffn": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 3),
     "opd_test_etail": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3),

@@ -494,7 +494,11 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
 // or rows >= M are expressed by an out-of-range offset, which the descriptor's bounds check turns into zeros.  The
 // flat-pointer form (BUF = false) spends ~25 VALU/SALU instructions per 1-KiB piece on 64-bit address arithmetic and
 // zero-page selects — at 8 pieces per k-step that, not the MFMAs or the memory system, paced the k-loop.
-template <int BN, bool BUF, int MT>
+// DUAL: a K-concatenated GEMM over TWO activation tensors — k-steps below K1 / 64 gather from `x` as usual, the others from `x2`, the
+// input of a 1x1 convolution with its own stride at the same output positions.  Used for the first block of stages 3 and 4: the
+// block's shortcut convolution becomes extra K of its 1x1 expand, y = relu([a1 | xs] . [W2 | Wsc]^T + (b2 + bsc)), instead of a
+// launch of its own that writes a tensor the expand reads back as its residual.
+template <int BN, bool BUF, int MT, bool DUAL = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type and builtins exist only in the gfx950 pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -590,6 +594,26 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         for (int i = 0; i < B_PIECES; ++i)
             woff[i] = (unsigned)((n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
     }
+    __amdgpu_buffer_rsrc_t rsrc_a2 = rsrc_a;
+    unsigned rowoff2[MT];
+    int nk1 = 0x7fffffff;
+    if constexpr (DUAL) {
+        static_assert(BUF, "the dual-source form uses buffer-descriptor staging");
+        nk1 = p.K1 / BK;
+        rsrc_a2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x2), 0, (unsigned)((size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2), 0x00020000);
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m_base + (wave * MT + i) * 8 + lrow;
+            const int mm = m < p.M ? m : 0;
+            const int b = mm / ohw;
+            const int r = mm - b * ohw;
+            const int oh = r / p.OW;
+            const int ow = r - oh * p.OW;
+            rowoff2[i] = m < p.M ? (unsigned)(((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cin2) * 2u + (unsigned)lchunk * 16u
+                                 : 0x80000000u;
+        }
+    }
 
     const int kpc = p.Cin / BK;
     const int nk_all = p.K / BK;
@@ -608,7 +632,12 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
             const int tap = tap_kh * p.KW + tap_kw;
             const int soff_a = stem2 ? tap_c * 16 * p.W   // two padded image rows per k-step
                                      : ((tap_kh * p.W + tap_kw) * p.Cin + tap_c * BK) * 2;  // scalar displacement of this tap / chunk
-            if (!(p.dbg & 8))
+            if (DUAL && ks >= nk1) {   // second source: channels 64 (ks - nk1) .. of the strided 1x1 input
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a2, (__attribute__((address_space(3))) void*)(As + (wave * MT + i) * 1024),
+                                                             16, rowoff2[i], (ks - nk1) * (BK * 2), 0, 0);
+            } else if (!(p.dbg & 8))
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
                 const unsigned vo = ((rowmask[i] >> tap) & 1u) ? rowoff[i] : 0x80000000u;  // out of range -> zeros
@@ -693,13 +722,13 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
 #endif
 }
 
-template <int BN, bool BUF, int MT>
+template <int BN, bool BUF, int MT, bool DUAL = false>
 hipError_t launch_dma_t(const ConvGemmParams& p, hipStream_t stream) {
     constexpr int BMT = 32 * MT;
     constexpr int LDS = 2 * (BMT + BN) * ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF, MT>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF, MT, DUAL>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
@@ -710,7 +739,7 @@ hipError_t launch_dma_t(const ConvGemmParams& p, hipStream_t stream) {
     // a single k-step per workgroup (K = 64 layers, split-K slices of one step) needs no second stage buffer: half the
     // LDS -> three workgroups per CU instead of two, which is what hides the DMA / residual / store round trips there
     const int lds = ((p.K / BK) / splits == 1) ? LDS / 2 : LDS;
-    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT, DUAL>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -749,6 +778,18 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
     // buffer-descriptor staging needs 31-bit byte offsets and <= 32 filter taps; otherwise the flat-pointer form
     const size_t a_bytes = (size_t)p.B * p.H * p.W * p.Cin * 2 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 2;
     const bool buf_ok = g_buffer_staging && a_bytes < 0x7fffff00ull && (size_t)p.N * p.K * 2 < 0x7fffff00ull && p.KH * p.KW <= 32;
+    if (p.x2) {   // dual-source form (validated by opd_launch_conv_gemm): 128-column tiles, buffer staging
+        if constexpr (BN == 128) {
+            if (!buf_ok || (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
+            switch (pick_mt(p.M, p.N, BN, 1)) {
+                case 5: return launch_dma_t<128, true, 5, true>(p, stream);
+                case 6: return launch_dma_t<128, true, 6, true>(p, stream);
+                default: return launch_dma_t<128, true, 4, true>(p, stream);
+            }
+        } else {
+            return hipErrorInvalidValue;
+        }
+    }
     if (!buf_ok) return launch_dma_t<BN, false, 4>(p, stream);
     switch (pick_mt(p.M, p.N, BN, p.split_k > 1 ? p.split_k : 1)) {
         case 5: return launch_dma_t<BN, true, 5>(p, stream);
@@ -1405,6 +1446,13 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
     }
     if (p.stem) {
         if (p.K != 256 || p.KH != 7 || p.KW != 7 || p.stride != 2 || p.pad != 3) return hipErrorInvalidValue;
+    } else if (p.x2) {   // dual source: [primary conv | strided 1x1 of x2], see conv_gemm_dma_kernel<.., DUAL>
+        if ((p.Cin % BK) != 0 || (p.Cin2 % BK) != 0 || p.K1 != p.KH * p.KW * p.Cin || p.K != p.K1 + p.Cin2 || p.stride2 < 1 || p.split_k > 1 ||
+            p.bias_ptrs || (p.N % 128) != 0 || g_gemm_variant < 1 || !p.zero16 || p.H2 < (p.OH - 1) * p.stride2 + 1 ||
+            p.W2 < (p.OW - 1) * p.stride2 + 1)
+            return hipErrorInvalidValue;
+        if ((long long)p.B * p.OH * p.OW != p.M) return hipErrorInvalidValue;
+        return launch_dma<128>(p, stream);
     } else {
         if ((p.Cin % BK) != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
     }

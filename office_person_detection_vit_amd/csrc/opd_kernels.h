@@ -26,6 +26,10 @@ struct ConvGemmParams {
     int stem;            // 0: NHWC conv / linear; 1: stem on a plain NHWC4 image (v1 kernel); 2: stem on the padded NHWC4 image
     int dbg;             // timing ablation for tools (0 = normal; 1 = skip MFMAs, 2 = skip all but the first tile DMA)
     int split_k;         // > 1: K is cut into split_k slices, slice z writes fp32 partials to out + z*M*N (bias in slice 0)
+    // optional second activation source (K-concatenated GEMM): k >= K1 reads x2 [B][H2][W2][Cin2] at (oh*stride2, ow*stride2), i.e. a
+    // 1x1 convolution of x2 added into the same accumulators; w is then [N][K1 + Cin2], K = K1 + Cin2, K1 = KH*KW*Cin
+    const f16_t* x2;
+    int H2, W2, Cin2, stride2, K1;
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 // fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16

@@ -67,6 +67,7 @@ struct Block {
     Conv c0, c1, c2, sc;
     bool has_sc = false;
     float* bias2sc = nullptr;   // c2.bias + sc.bias (fp32): the fused bottleneck tail adds the shortcut GEMM into the expand's accumulators
+    f16_t* w2sc = nullptr;      // [Cout][c2.K + sc.Cin] = [W2 | Wsc] per output channel: the dual-source expand GEMM of stages 3-4
 };
 struct EncLayer {
     f16_t* wqkv = nullptr;  // [768][256] = [Wq; Wk; Wv]
@@ -324,6 +325,18 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
                 HIPCHK(hipMemcpy(bs.data(), b.sc.bias, bs.size() * 4, hipMemcpyDeviceToHost));
                 for (size_t j = 0; j < b2.size(); ++j) b2[j] += bs[j];
                 RCCHK(upload_f32(m, &b.bias2sc, b2));
+                if (b.sc.KH == 1 && b.c2.KH == 1 && b.c2.Cout % 128 == 0 && b.c2.Cin >= 256) {   // stages 3-4: [W2 | Wsc]
+                    const size_t K1 = (size_t)b.c2.K, K2 = (size_t)b.sc.K, N = (size_t)b.c2.Cout;
+                    std::vector<f16_t> h2(N * K1), hs(N * K2), cat(N * (K1 + K2));
+                    HIPCHK(hipMemcpy(h2.data(), b.c2.w, h2.size() * 2, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(hs.data(), b.sc.w, hs.size() * 2, hipMemcpyDeviceToHost));
+                    for (size_t n = 0; n < N; ++n) {
+                        memcpy(&cat[n * (K1 + K2)], &h2[n * K1], K1 * 2);
+                        memcpy(&cat[n * (K1 + K2) + K1], &hs[n * K2], K2 * 2);
+                    }
+                    RCCHK(dalloc(m, &b.w2sc, cat.size(), true));
+                    HIPCHK(hipMemcpy(b.w2sc, cat.data(), cat.size() * 2, hipMemcpyHostToDevice));
+                }
             }
             m->blocks.push_back(b);
         }
@@ -822,7 +835,13 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 const bool sc_in_tail = b.has_sc && m->fuse_shortcut && m->fuse_btail && b.bias2sc && b.sc.KH == 1 && b.sc.stride == 1 &&
                                         b.sc.Cin == 64 && b.c1.Cin == 64 && b.c1.stride == 1 && b.c2.Cout == 256 && nbk && nbk->c0.wp &&
                                         nbk->c0.Cin == 256 && nbk->c0.Cout == 64;
-                if (b.has_sc && !sc_in_tail) {
+                // first block of stages 3 / 4: the shortcut is extra K of the 1x1 expand (conv_gemm_dma_kernel, DUAL)
+                const bool tail_kernel = m->fuse_btail && b.c1.KH == 3 && b.c1.Cout == C1 && b.c2.Cin == C1 && b.c2.Cout == 4 * C1 && b.c2.wp &&
+                                         opd_btail_supported(C1, 0);
+                const bool use_etail = m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nbk && nbk->c0.wp &&
+                                       nbk->c0.Cin == 1024 && nbk->c0.Cout == 256 && nbk->c0.KH == 1 && nbk->c0.stride == 1;
+                const bool sc_in_expand = b.has_sc && m->fuse_shortcut && b.w2sc && !sc_in_tail && !tail_kernel && !use_etail;
+                if (b.has_sc && !sc_in_tail && !sc_in_expand) {
                     f16_t* scb = m->d_sc + (size_t)b0 * oh * ow * C2;
                     RCCHK(run_conv(m, b.sc, cur, nb, ch, cw, oh, ow, scb, false, nullptr));
                     res = scb;
@@ -854,8 +873,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     HIPCHK(opd_launch_btail(p, m->stream));
                     RCCHK(timed_end(m));
                     if (C3) st.z_id = 1 - x1_id;
-                } else if (m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nbk && nbk->c0.wp &&
-                           nbk->c0.Cin == 1024 && nbk->c0.Cout == 256 && nbk->c0.KH == 1 && nbk->c0.stride == 1) {
+                } else if (use_etail) {
                     // stage 3: the 3x3 as an implicit GEMM, then ONE kernel for 1x1 expand + residual + ReLU (block output, stored) and the
                     // next block's 1x1 reduce (kernels_ffn.hip, ETAIL); z takes the buffer the 3x3 has just finished reading
                     f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
@@ -871,7 +889,18 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 } else {
                     f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
                     RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr));
-                    RCCHK(run_conv(m, b.c2, a1, nb, oh, ow, oh, ow, out, true, res));
+                    if (sc_in_expand) {
+                        ConvGemmParams p{};
+                        p.x = a1; p.w = b.w2sc; p.bias = b.bias2sc; p.out = out; p.zero16 = m->zero_bias;
+                        p.B = nb; p.H = oh; p.W = ow; p.Cin = C1; p.OH = oh; p.OW = ow; p.N = C2; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
+                        p.M = nb * oh * ow; p.K1 = C1; p.K = C1 + b.sc.Cin; p.relu = 1;
+                        p.x2 = cur; p.H2 = ch; p.W2 = cw; p.Cin2 = b.sc.Cin; p.stride2 = b.sc.stride;
+                        RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)C2 * p.K));
+                        HIPCHK(opd_launch_conv_gemm(p, m->stream));
+                        RCCHK(timed_end(m));
+                    } else {
+                        RCCHK(run_conv(m, b.c2, a1, nb, oh, ow, oh, ow, out, true, res));
+                    }
                 }
                 st.cur_id = out_id; st.ch = oh; st.cw = ow;
             }

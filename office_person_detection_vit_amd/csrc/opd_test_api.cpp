@@ -72,6 +72,36 @@ int opd_test_conv_gemm(const uint16_t* x, const uint16_t* w, const float* bias, 
     return OPD_OK;
 }
 
+// dual-source GEMM: out = relu( conv(x, w1; KH x KH, stride, pad) + conv1x1(x2, w2; stride2) + bias ): w1 [N][KH*KH*Cin], w2 [N][Cin2]
+// (the hook concatenates them along K), out fp16 [M][N]
+int opd_test_conv_dual(const uint16_t* x, const uint16_t* w1, const uint16_t* x2, const uint16_t* w2, const float* bias, uint16_t* out,
+                       int B, int H, int W, int Cin, int KH, int stride, int pad, int N, int H2, int W2, int Cin2, int stride2, int relu) {
+    DevMem dm;
+    const int OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+    const size_t M = (size_t)B * OH * OW;
+    const int K1 = KH * KH * Cin, K = K1 + Cin2;
+    std::vector<uint16_t> wc((size_t)N * K);
+    for (int n = 0; n < N; ++n) {
+        memcpy(&wc[(size_t)n * K], w1 + (size_t)n * K1, (size_t)K1 * 2);
+        memcpy(&wc[(size_t)n * K + K1], w2 + (size_t)n * Cin2, (size_t)Cin2 * 2);
+    }
+    ConvGemmParams p{};
+    p.x = dm.up(x, (size_t)B * H * W * Cin);
+    p.x2 = dm.up(x2, (size_t)B * H2 * W2 * Cin2);
+    p.w = dm.up(wc.data(), wc.size());
+    p.bias = dm.up(bias, (size_t)N);
+    p.out = dm.up<unsigned char>(nullptr, M * N * 2);
+    const uint32_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    p.zero16 = dm.up(zeros, 8);
+    if (!p.x || !p.x2 || !p.w || !p.bias || !p.out || !p.zero16) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KH; p.stride = stride; p.pad = pad;
+    p.M = (int)M; p.K = K; p.K1 = K1; p.relu = relu; p.H2 = H2; p.W2 = W2; p.Cin2 = Cin2; p.stride2 = stride2;
+    TCHK(opd_launch_conv_gemm(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out, p.out, M * N * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 // split-K linear + fused reduce / residual / LayerNorm: y = LN(x.W^T + bias + res) (gamma == null: no LN), N == 256
 int opd_test_gemm_splitk_ln(const uint16_t* x, const uint16_t* w, const float* bias, const float* res32, const float* gamma,
                             const float* beta, float* y, uint16_t* y16, int M, int K, int splits) {

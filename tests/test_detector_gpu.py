@@ -241,7 +241,8 @@ def test_fused_bottleneck_tail_matches_unfused(weight_cache):
     _capi.check(_capi.load_library().opd_test_set_fuse_btail(C.c_void_p(det.model), 0), "set_fuse_btail")
     lg_u, bx_u, enc_u = det.forward_raw(frames)
     det.close()
-    assert 0 < np.abs(enc_f - enc_s).max() < TOL[1.0][2] and np.abs(bx_f - bx_s).max() < TOL[1.0][0]   # shortcut inside the tail or not
+    # (bit 1 off: the stage-1 shortcut on its own launch AND the stage 3 / 4 shortcuts as separate launches instead of extra K of the expand)
+    assert 0 < np.abs(enc_f - enc_s).max() < TOL[1.0][2] and np.abs(bx_f - bx_s).max() < TOL[1.0][0]
     # (fp16 rounding flips caused by the different fp32 summation order propagate like any other fp16-storage noise:
     #  same bound as against the golden vectors)
     assert np.abs(bx_f - bx_u).max() < TOL[1.0][0] and np.abs(_softmax(lg_f) - _softmax(lg_u)).max() < TOL[1.0][1]

@@ -750,3 +750,54 @@ def test_etail_integer_exact(lib):
     assert want_hid.max() < 2048 and want_z.max() < 2048
     np.testing.assert_array_equal(hid.view(np.float16).astype(np.float32), want_hid)
     np.testing.assert_array_equal(z.view(np.float16).astype(np.float32), want_z)
+
+
+# ---- dual-source GEMM: the shortcut convolution as extra K of the 1x1 expand (conv_gemm_dma_kernel, DUAL) ------------------------
+@pytest.mark.parametrize("B,H,W,Cin,N,Cin2,stride2", [(2, 13, 11, 256, 1024, 512, 2), (1, 25, 42, 512, 2048, 1024, 2), (2, 9, 10, 256, 1024, 512, 1),
+                                                      (8, 50, 84, 256, 1024, 512, 2)])
+def test_conv_dual_source_matches_torch(lib, B, H, W, Cin, N, Cin2, stride2):
+    """out = relu(conv1x1(x, w1) + conv1x1_stride2(x2, w2) + bias) as ONE K-concatenated GEMM vs torch (fp32 on the same fp16 operands;
+    one output rounding).  x2 lives at the resolution BEFORE the stride (odd sizes: the last row / column is not sampled)."""
+    rng = np.random.default_rng(B * H + W + Cin)
+    H2, W2 = (H - 1) * stride2 + 1 + (stride2 - 1), (W - 1) * stride2 + 1
+    x, xb = _h(np.abs(rng.standard_normal((B, H, W, Cin))))
+    x2, x2b = _h(np.abs(rng.standard_normal((B, H2, W2, Cin2))))
+    w1, w1b = _h(rng.standard_normal((N, Cin)) / np.sqrt(Cin))
+    w2, w2b = _h(rng.standard_normal((N, Cin2)) / np.sqrt(Cin2))
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    out = np.empty((B * H * W, N), np.uint16)
+    rc = lib.opd_test_conv_dual(_p(xb), _p(w1b), _p(x2b), _p(w2b), _p(bias), _p(out), B, H, W, Cin, 1, 1, 0, N, H2, W2, Cin2, stride2, 1)
+    _capi.check(rc, "opd_test_conv_dual")
+    want = np.maximum(ref_conv(x, w1[:, :, None, None], bias, 1, 0, False) +
+                      ref_conv(x2, w2[:, :, None, None], np.zeros(N, np.float32), stride2, 0, False)[:, :H, :W], 0)
+    got = out.view(np.float16).astype(np.float32).reshape(B, H, W, N)
+    np.testing.assert_allclose(got, want, atol=4e-3, rtol=2e-3)
+
+
+def test_conv_dual_source_integer_exact(lib):
+    """Integer operands: bit-exact, and identical to the two-launch route (shortcut conv, then expand with that residual)."""
+    rng = np.random.default_rng(3)
+    B, H, W, Cin, N, Cin2 = 2, 7, 9, 256, 1024, 512
+    H2, W2 = 2 * H - 1, 2 * W
+    x = rng.integers(0, 3, (B, H, W, Cin)).astype(np.float32)
+    x2 = rng.integers(0, 3, (B, H2, W2, Cin2)).astype(np.float32)
+    w1 = np.zeros((N, Cin), np.float32)
+    w2 = np.zeros((N, Cin2), np.float32)
+    for n in range(N):
+        w1[n, (n * 7 + 3) % Cin] = 1 + (n % 3)
+        w1[n, (n * 5 + 1) % Cin] -= 1
+        w2[n, (n * 11 + 2) % Cin2] = 2
+        w2[n, (n * 3 + 7) % Cin2] -= 1
+    b1 = rng.integers(-2, 3, N).astype(np.float32)
+    b2 = rng.integers(-2, 3, N).astype(np.float32)
+    _, xb = _h(x); _, x2b = _h(x2); _, w1b = _h(w1); _, w2b = _h(w2)
+    out = np.empty((B * H * W, N), np.uint16)
+    _capi.check(lib.opd_test_conv_dual(_p(xb), _p(w1b), _p(x2b), _p(w2b), _p(b1 + b2), _p(out), B, H, W, Cin, 1, 1, 0, N, H2, W2, Cin2, 2, 1), "dual")
+    sc = ref_conv(x2, w2[:, :, None, None], b2, 2, 0, False)[:, :H, :W]
+    want = np.maximum(ref_conv(x, w1[:, :, None, None], b1, 1, 0, False) + sc, 0)
+    assert np.abs(want).max() < 2048 and np.abs(sc).max() < 2048
+    got = out.view(np.float16).astype(np.float32).reshape(B, H, W, N)
+    np.testing.assert_array_equal(got, want)
+    scu = run_conv(lib, x2, w2[:, :, None, None], b2, 2, 0, False)[:, :H, :W]
+    yu = run_conv(lib, x, w1[:, :, None, None], b1, 1, 0, True, np.ascontiguousarray(scu))
+    np.testing.assert_array_equal(got, yu)
