@@ -202,6 +202,19 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restri
     }
 }
 
+// y[row][:] = c[:] for every row (fp32 and an fp16 copy): the decoder's state after the self-attention block of layer 0, which does
+// not depend on the input (opd_model.cpp::build_weights, "dec0").
+__global__ __launch_bounds__(256) void broadcast_rows256_kernel(const float* __restrict__ c, float* __restrict__ y, f16_t* __restrict__ y16, int rows) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    const float4v v = *reinterpret_cast<const float4v*>(c + lane * 4);
+    *reinterpret_cast<float4v*>(y + (size_t)row * 256 + lane * 4) = v;
+    half4 h;
+    h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+    *reinterpret_cast<half4*>(y16 + (size_t)row * 256 + lane * 4) = h;
+}
+
 // Split-K reduction + residual + LayerNorm: one wave per row of 256, slabs summed in slice order (deterministic).
 __global__ __launch_bounds__(256) void reduce_ln256_kernel(const float* __restrict__ partials, int nsplit, size_t slab_stride,
                                                            const float* __restrict__ residual, const float* __restrict__ gamma,
@@ -268,6 +281,28 @@ __global__ __launch_bounds__(1024) void heads_kernel(HeadParams p) {
     const int kg = threadIdx.x >> 8, t = threadIdx.x & 255;
     if (kg < HEAD_ROWS) h[kg][t] = row0 + kg < p.rows ? p.hs[(size_t)(row0 + kg) * 256 + t] : 0.f;
     __syncthreads();
+    if (p.ln_gamma) {   // the decoder's final LayerNorm (two-pass fp32, like layernorm256_kernel) folded in: thread group kg owns row kg
+        if (kg < HEAD_ROWS) {
+            const int wv = t >> 6;
+            const float x = h[kg][t];
+            const float s = wave_sum(x);
+            if ((t & 63) == 0) part[0][kg][wv] = s;
+        }
+        __syncthreads();
+        float d = 0.f;
+        if (kg < HEAD_ROWS) {
+            const float mean = (part[0][kg][0] + part[0][kg][1] + part[0][kg][2] + part[0][kg][3]) * (1.0f / 256.0f);
+            d = h[kg][t] - mean;
+            const float q = wave_sum(d * d);
+            if ((t & 63) == 0) part[1][kg][t >> 6] = q;
+        }
+        __syncthreads();
+        if (kg < HEAD_ROWS) {
+            const float var = (part[1][kg][0] + part[1][kg][1] + part[1][kg][2] + part[1][kg][3]) * (1.0f / 256.0f);
+            h[kg][t] = d * (1.0f / sqrtf(var + 1e-5f)) * p.ln_gamma[t] + p.ln_beta[t];
+        }
+        __syncthreads();
+    }
     // partial[kg][r][t] = sum over k in [64 kg, 64 kg + 64) of in[r][k] * wt[k][t]
     auto layer = [&](const float (&in)[HEAD_ROWS][256], const float* wt, int ld, bool active) {
         float acc[HEAD_ROWS];
@@ -488,6 +523,12 @@ hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float*
                                 hipStream_t stream) {
     if (rows <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, y16, rows);
+    return hipGetLastError();
+}
+
+hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream) {
+    if (rows <= 0 || !c || !y || !y16) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(broadcast_rows256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, c, y, y16, rows);
     return hipGetLastError();
 }
 

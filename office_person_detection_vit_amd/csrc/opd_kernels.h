@@ -140,6 +140,8 @@ hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float*
 // reduction of split-K GEMM slabs fused with the residual add and the post-LN of the transformer layers.  D == 256.
 hipError_t opd_launch_reduce_ln(const float* partials, int nsplit, size_t slab_stride, const float* residual,
                                 const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream);
+// y[row][0..255] = c[0..255] for every row: fp32 y and its fp16 copy.
+hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream);
 // fp32 -> fp16 cast of n elements (n % 8 == 0 not required).
 hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream);
 // naive fp32 GEMM used once at plan-build time: C[m][n] = sum_k A[m][k]*Wt[n][k] + bias[n]  (Wt fp32 [N][K])
@@ -149,6 +151,7 @@ hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bia
 // passed TRANSPOSED ([in = 256][out]).
 struct HeadParams {
     const float* hs;  // [rows][256]
+    const float *ln_gamma, *ln_beta;  // optional: hs is the decoder state BEFORE its final LayerNorm, applied here first
     const float *wc, *bc, *w1, *b1, *w2, *b2, *w3, *b3;
     float* logits;    // [rows][ncls]
     float* boxes;     // [rows][4]

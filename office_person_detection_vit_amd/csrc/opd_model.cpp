@@ -132,6 +132,8 @@ struct opd_detr {
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;
     f16_t* wkv_all = nullptr;  // [dec_layers*512][256] = per layer [Wk_c; Wv_c]
+    float* dec0_h = nullptr;   // [256]: decoder state after the self-attention block of layer 0 (input independent, see build_weights)
+    int fuse_dec0 = 1;         // use it (0: run that block's four launches on the zero state like every other layer)
     LNp dec_ln;
     float *wc = nullptr, *bc = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     float* zero_bias = nullptr;  // [3072] zeros
@@ -182,6 +184,7 @@ struct opd_detr {
     int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
+    int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
     int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
@@ -325,7 +328,7 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
                 HIPCHK(hipMemcpy(bs.data(), b.sc.bias, bs.size() * 4, hipMemcpyDeviceToHost));
                 for (size_t j = 0; j < b2.size(); ++j) b2[j] += bs[j];
                 RCCHK(upload_f32(m, &b.bias2sc, b2));
-                if (b.sc.KH == 1 && b.c2.KH == 1 && b.c2.Cout % 128 == 0 && b.c2.Cin >= 256) {   // stages 3-4: [W2 | Wsc]
+                if (b.sc.KH == 1 && b.c2.KH == 1 && b.c2.Cout % 128 == 0 && b.c2.Cin >= 128) {   // stages 2-4: [W2 | Wsc]
                     const size_t K1 = (size_t)b.c2.K, K2 = (size_t)b.sc.K, N = (size_t)b.c2.Cout;
                     std::vector<f16_t> h2(N * K1), hs(N * K2), cat(N * (K1 + K2));
                     HIPCHK(hipMemcpy(h2.data(), b.c2.w, h2.size() * 2, hipMemcpyDeviceToHost));
@@ -421,6 +424,31 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln3));
     }
     RCCHK(upload_f16(m, &m->wkv_all, kv_full));
+    {   // The decoder starts from h = 0 (HF:models/detr/modeling_detr.py:1243-1251), so in layer 0 the self-attention values are the
+        // same row for every query, v = 0 . Wv^T + bv, the softmax weights of a row sum to one, and the block's output
+        // LN(0 + Wo . bv + bo) is ONE vector, whatever the frame shows: computed here once in fp32, broadcast at run time instead of
+        // two memsets, the QKV projection, the attention and the output projection + LayerNorm of that layer.
+        const std::string p0 = "model.decoder.layers.0";
+        const auto& bv = T(sd, p0 + ".self_attn.v_proj.bias").data;
+        const auto& wo = T(sd, p0 + ".self_attn.o_proj.weight").data;
+        const auto& bo = T(sd, p0 + ".self_attn.o_proj.bias").data;
+        const auto& g = T(sd, p0 + ".self_attn_layer_norm.weight").data;
+        const auto& be = T(sd, p0 + ".self_attn_layer_norm.bias").data;
+        std::vector<float> x(D), c(D);
+        for (int n = 0; n < D; ++n) {
+            float acc = 0.f;
+            for (int k = 0; k < D; ++k) acc += wo[(size_t)n * D + k] * bv[k];
+            x[n] = acc + bo[n];
+        }
+        float mean = 0.f, var = 0.f;
+        for (int n = 0; n < D; ++n) mean += x[n];
+        mean /= (float)D;
+        for (int n = 0; n < D; ++n) var += (x[n] - mean) * (x[n] - mean);
+        var /= (float)D;
+        const float rstd = 1.0f / sqrtf(var + 1e-5f);
+        for (int n = 0; n < D; ++n) c[n] = (x[n] - mean) * rstd * g[n] + be[n];
+        RCCHK(upload_f32(m, &m->dec0_h, c));
+    }
     RCCHK(make_ln(m, sd, "model.decoder.layernorm", &m->dec_ln));
     auto transposed = [&](const std::string& key) {  // [out][in] -> [in][out] (coalesced reads in heads_kernel)
         const HostTensor& w = T(sd, key);
@@ -836,8 +864,11 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                                         b.sc.Cin == 64 && b.c1.Cin == 64 && b.c1.stride == 1 && b.c2.Cout == 256 && nbk && nbk->c0.wp &&
                                         nbk->c0.Cin == 256 && nbk->c0.Cout == 64;
                 // first block of stages 3 / 4: the shortcut is extra K of the 1x1 expand (conv_gemm_dma_kernel, DUAL)
-                const bool tail_kernel = m->fuse_btail && b.c1.KH == 3 && b.c1.Cout == C1 && b.c2.Cin == C1 && b.c2.Cout == 4 * C1 && b.c2.wp &&
-                                         opd_btail_supported(C1, 0);
+                bool tail_kernel = m->fuse_btail && b.c1.KH == 3 && b.c1.Cout == C1 && b.c2.Cin == C1 && b.c2.Cout == 4 * C1 && b.c2.wp &&
+                                   opd_btail_supported(C1, 0);
+                // first block of stage 2: 3x3 + dual-source expand (+ the next reduce on its own) beats shortcut launch + fused tail
+                // (stage 2: 0.674 -> 0.657 ms; OPD_DUAL_OVER_TAIL=0 restores the tail)
+                if (m->dual_over_tail && tail_kernel && b.has_sc && !sc_in_tail && b.w2sc) tail_kernel = false;
                 const bool use_etail = m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nbk && nbk->c0.wp &&
                                        nbk->c0.Cin == 1024 && nbk->c0.Cout == 256 && nbk->c0.KH == 1 && nbk->c0.stride == 1;
                 const bool sc_in_expand = b.has_sc && m->fuse_shortcut && b.w2sc && !sc_in_tail && !tail_kernel && !use_etail;
@@ -857,9 +888,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     x1 = c0out;
                 }
                 st.z_id = -1;
-                const bool tail_ok = m->fuse_btail && b.c1.KH == 3 && b.c1.Cout == C1 && b.c2.Cin == C1 && b.c2.Cout == 4 * C1 && b.c2.wp &&
-                                     (size_t)nb * ch * cw * C1 * 2 < 0x7ff00000ull;
-                if (tail_ok && opd_btail_supported(C1, 0)) {
+                const bool tail_ok = tail_kernel && (size_t)nb * ch * cw * C1 * 2 < 0x7ff00000ull;
+                if (tail_ok) {
                     int C3 = 0;
                     if (nbk && nbk->c0.wp && nbk->c0.Cin == 4 * C1 && opd_btail_supported(C1, nbk->c0.Cout)) C3 = nbk->c0.Cout;
                     // (a sub-batch pipeline ends with stage 2: its last tail cannot hand z to stage 3 anyway — 256 channels)
@@ -956,11 +986,19 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     // ---- decoder -----------------------------------------------------------------------------------------------
     const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
     RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs));
-    HIPCHK(hipMemsetAsync(m->d_h32, 0, (size_t)Md * D * 4, m->stream));
-    HIPCHK(hipMemsetAsync(m->d_h16, 0, (size_t)Md * D * 2, m->stream));
+    const bool dec0 = m->fuse_dec0 && m->dec0_h && D == 256;
+    if (dec0) {
+        RCCHK(timed_begin(m, CLS_OTHER, 0.0));
+        HIPCHK(opd_launch_broadcast_rows(m->dec0_h, m->d_h32, m->d_h16, Md, m->stream));
+        RCCHK(timed_end(m));
+    } else {
+        HIPCHK(hipMemsetAsync(m->d_h32, 0, (size_t)Md * D * 4, m->stream));
+        HIPCHK(hipMemsetAsync(m->d_h16, 0, (size_t)Md * D * 2, m->stream));
+    }
     for (int i = 0; i < a.dec_layers; ++i) {
         const DecLayer& L = m->dec[i];
         const bool small = m->small_m_gemm && D == 256 && F % 256 == 0 && F / 256 <= 8;
+        if (!(dec0 && i == 0)) {   // (layer 0's self-attention block is the broadcast above)
         if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false));
         else RCCHK(run_gemm(m, m->d_h16, L.wqkv, L.rb_self, Q, Md, 3 * D, D, m->d_qkvd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qkvd16, 3 * D, m->d_qkvd16 + D, 3 * D, m->d_qkvd16 + 2 * D, 3 * D, m->d_attnd16, D, B, Q, Q));
@@ -968,6 +1006,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(run_gemm_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, m->d_h32, L.ln1, m->d_h32, m->d_h16));
         else
             RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, D, 4, m->d_h32, &L.ln1, m->d_h32, m->d_h16, CLS_GEMM));
+        }
         if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false));
         else RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
         RCCHK(run_attn(m, m->d_qd16, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
@@ -984,11 +1023,15 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(run_gemm_splitk_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, D, F, 8, m->d_h32, &L.ln3, m->d_h32, m->d_h16, CLS_GEMM));
         }
     }
-    RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-    HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream));
-    RCCHK(timed_end(m));
     HeadParams hp{};
-    hp.hs = m->d_hs32; hp.wc = m->wc; hp.bc = m->bc; hp.w1 = m->w1; hp.b1 = m->b1; hp.w2 = m->w2; hp.b2 = m->b2;
+    if (m->fuse_gemm_ln) {   // the final LayerNorm runs inside the heads kernel
+        hp.hs = m->d_h32; hp.ln_gamma = m->dec_ln.g; hp.ln_beta = m->dec_ln.b;
+    } else {
+        RCCHK(timed_begin(m, CLS_OTHER, 0.0));
+        HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream));
+        RCCHK(timed_end(m));
+        hp.hs = m->d_hs32;
+    } hp.wc = m->wc; hp.bc = m->bc; hp.w1 = m->w1; hp.b1 = m->b1; hp.w2 = m->w2; hp.b2 = m->b2;
     hp.w3 = m->w3; hp.b3 = m->b3; hp.logits = m->d_logits; hp.boxes = m->d_boxes; hp.rows = Md; hp.ncls = a.ncls;
     RCCHK(timed_begin(m, CLS_OTHER, 2.0 * Md * 256.0 * (a.ncls + 256 + 256 + 4)));
     HIPCHK(opd_launch_heads(hp, m->stream));
@@ -1241,7 +1284,8 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     rc = infer_arch(sd, &m->arch, &err);
     if (rc) return fail(rc, err);
     m->cfg = *cfg;
-    if (const char* v = getenv("OPD_TRUNK_SUBBATCH")) m->trunk_subbatch = atoi(v);   // A/B switch for benchmarking
+    if (const char* v = getenv("OPD_TRUNK_SUBBATCH")) m->trunk_subbatch = atoi(v);   // A/B switches for benchmarking
+    if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1282,7 +1326,8 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail;
+    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     m->d_dump = nullptr;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
@@ -1650,7 +1695,8 @@ int opd_test_set_stem_variant(int v) {
 int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_gemm_ln = on ? 1 : 0;
-    m->small_m_gemm = on ? 1 : 0;   // the switch covers both transformer-side specialisations
+    m->small_m_gemm = on ? 1 : 0;   // the switch covers the transformer-side specialisations
+    m->fuse_dec0 = on ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();
