@@ -54,6 +54,12 @@ __device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+__device__ __forceinline__ int xcd_logical_block_rev(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int x = bid & 7, k = bid >> 3;
+    return (x < r ? x * (q + 1) + q - k : r * (q + 1) + (x - r) * q + q - 1 - k);
+}
+
 __device__ __forceinline__ unsigned pack2h(float a, float b) {
     typedef _Float16 half2v __attribute__((ext_vector_type(2)));
     half2v h;
@@ -117,7 +123,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15;
-    const int m_base = xcd_logical_block(blockIdx.x, gridDim.x) * 128;
+    // p.rev: every XCD walks its range of tiles backwards, so that a kernel starts on the rows its predecessor wrote LAST (the ones still
+    // in the 256-MiB Infinity Cache; a 274-MB tensor written and re-read in the same order never hits)
+    const int m_base = (p.rev ? xcd_logical_block_rev(blockIdx.x, gridDim.x) : xcd_logical_block(blockIdx.x, gridDim.x)) * 128;
     const int wm0 = m_base + wave * 32;        // this wave's 32 pixels
 
     // ---- staging coordinates (see conv_gemm_dma_kernel): piece = 8 tile rows x 128 B, lane -> (row lane>>3, slot lane&7)

@@ -303,7 +303,9 @@ __device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const flo
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
         const int nq = n0 + nt * 16 + g * 4;
-        if (p.bias_period == 0) {
+        // (bias_pcols: only columns with n mod bias_pmod < bias_pcols vary over the period -- the q / k thirds of a fused QKV
+        //  projection; the rows of the table are identical in the other columns, so row 0 serves as a plain bias vector there)
+        if (p.bias_period == 0 || (p.bias_pcols > 0 && (n0 % p.bias_pmod) >= p.bias_pcols)) {
             const float4v b = *reinterpret_cast<const float4v*>(bias + nq);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = b;

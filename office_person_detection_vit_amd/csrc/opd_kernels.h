@@ -23,6 +23,8 @@ struct ConvGemmParams {
     int B, H, W, Cin, OH, OW, N, KH, KW, stride, pad;
     int M, K;
     int relu, bias_period, out_f32;
+    int bias_pmod, bias_pcols;  // bias_pcols > 0: the periodic table varies only in columns n with n mod bias_pmod < bias_pcols (both
+                                // multiples of 256); elsewhere all its rows are equal and the kernel reads row 0 only
     int stem;            // 0: NHWC conv / linear; 1: stem on a plain NHWC4 image (v1 kernel); 2: stem on the padded NHWC4 image
     int dbg;             // timing ablation for tools (0 = normal; 1 = skip MFMAs, 2 = skip all but the first tile DMA)
     int split_k;         // > 1: K is cut into split_k slices, slice z writes fp32 partials to out + z*M*N (bias in slice 0)
@@ -53,6 +55,7 @@ struct BtailParams {
     f16_t* z;          // [M][C3]
     int B, H, W, OH, OW, stride, M, C1, C3;
     int dbg;           // timing ablations for tools (0 = normal): 1 skip the 3x3 loop, 2 skip stores, 4 skip residual, 8 stop after the 3x3
+    int rev;           // 1: each XCD walks its tiles in descending order (results identical; see kernels_btail.hip)
 };
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);

@@ -184,6 +184,7 @@ struct opd_detr {
     int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
+    int tail_rev = 1;        // consecutive fused tails walk their tiles in opposite directions (Infinity Cache reuse of the block output)
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
     int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
@@ -663,9 +664,10 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
 
 // out[M][N] = x16[M][K] . w[N][K]^T + bias (+ res32), as a 1x1 "convolution" over M pixels
 static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
-                    void* out, bool out_f32, bool relu, const float* res32, const float* const* bias_ptrs = nullptr) {
+                    void* out, bool out_f32, bool relu, const float* res32, const float* const* bias_ptrs = nullptr, int bias_pmod = 0,
+                    int bias_pcols = 0) {
     ConvGemmParams p{};
-    p.bias_ptrs = bias_ptrs;
+    p.bias_ptrs = bias_ptrs; p.bias_pmod = bias_pmod; p.bias_pcols = bias_pcols;
     p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0;
@@ -844,6 +846,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     // of the buffer the full batch would use, the finished stage-2 outputs of earlier sub-batches sit below the regions later
     // ones touch (per-frame sizes shrink from stage to stage).
     struct TrunkState { int cur_id; int ch, cw; int z_id; };   // cur_id 0 = pool, 1 = t0, 2 = t1; z_id -1 / 0 = m0 / 1 = m1
+    int tail_no = 0;   // consecutive fused tails walk the tiles in alternating directions (tail_rev)
     auto run_blocks = [&](int s_begin, int s_end, int b0, int nb, TrunkState& st) -> int {
         auto trunk = [&](int id, size_t per_frame) { return (id == 0 ? m->d_pool : id == 1 ? m->d_t0 : m->d_t1) + (size_t)b0 * per_frame; };
         auto mid = [&](int id, size_t per_frame) { return (id ? m->d_m1 : m->d_m0) + (size_t)b0 * per_frame; };
@@ -899,6 +902,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     f16_t* z = mid(1 - x1_id, (size_t)oh * ow * C3);
                     if (C3) { p.w3p = nbk->c0.wp; p.b3 = nbk->c0.bias; p.z = z; }
                     p.B = nb; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = nb * oh * ow; p.C1 = C1; p.C3 = C3;
+                    p.rev = m->tail_rev ? (tail_no++ & 1) : 0;
                     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));
                     HIPCHK(opd_launch_btail(p, m->stream));
                     RCCHK(timed_end(m));
@@ -958,7 +962,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV));
     for (int i = 0; i < a.enc_layers; ++i) {
         const EncLayer& L = m->enc[i];
-        RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i]));
+        RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i], 3 * D, 2 * D));   // (pos enters q and k only)
         RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw, d_keyv, cw));
         if (m->fuse_gemm_ln && D == 256) {
             RCCHK(run_gemm_ln(m, m->d_attn16, L.o.w, L.o.b, M, D, m->d_x32, L.ln1, m->d_x32, m->d_x16));
@@ -985,7 +989,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     MARK(6);
     // ---- decoder -----------------------------------------------------------------------------------------------
     const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
-    RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs));
+    RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs, 2 * D, D));   // (per layer [k | v]: pos enters k only)
     const bool dec0 = m->fuse_dec0 && m->dec0_h && D == 256;
     if (dec0) {
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
@@ -1286,6 +1290,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     m->cfg = *cfg;
     if (const char* v = getenv("OPD_TRUNK_SUBBATCH")) m->trunk_subbatch = atoi(v);   // A/B switches for benchmarking
     if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
+    if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1326,7 +1331,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     m->d_dump = nullptr;
     auto cleanup = [&](int code) {
