@@ -55,6 +55,10 @@ __device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+__device__ __forceinline__ int fdiv(const int m, const FastDiv& f) {   // m >= 0
+    return f.one ? m : (int)(__umulhi((unsigned)m, f.mul) >> f.shift);
+}
+
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint2 ldg8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
 
@@ -313,8 +317,9 @@ __device__ __forceinline__ void init_acc_bias(const ConvGemmParams& p, const flo
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const int m = m0 + mt * 16 + li;
-                const float* brow = p.bias_ptrs && m < p.M ? p.bias_ptrs[m / p.bias_period] : bias;  // per-frame fold (ragged batch)
-                acc[nt][mt] = m < p.M ? *reinterpret_cast<const float4v*>(brow + (size_t)(m % p.bias_period) * p.N + nq)
+                const int fr = fdiv(m, p.fd_period), pr = m - fr * p.bias_period;   // frame, row within the period
+                const float* brow = p.bias_ptrs && m < p.M ? p.bias_ptrs[fr] : bias;  // per-frame fold (ragged batch)
+                acc[nt][mt] = m < p.M ? *reinterpret_cast<const float4v*>(brow + (size_t)pr * p.N + nq)
                                       : float4v{0.f, 0.f, 0.f, 0.f};
             }
         }
@@ -446,7 +451,7 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
                 const int r = r0 + i * RPI;
                 const uint4 v = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ row_swz(r)) << 4));
                 const int m = m0 + g0 * 16 + r;
-                if (m < p.M) *reinterpret_cast<uint4*>(o16 + (size_t)m * p.N + n0 + c * 8) = v;
+                if (m < p.M && !(p.dbg & 64)) *reinterpret_cast<uint4*>(o16 + (size_t)m * p.N + n0 + c * 8) = v;   // (dbg 64: timing ablation)
             }
         }
         return;
@@ -500,10 +505,28 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
 // input of a 1x1 convolution with its own stride at the same output positions.  Used for the first block of stages 3 and 4: the
 // block's shortcut convolution becomes extra K of its 1x1 expand, y = relu([a1 | xs] . [W2 | Wsc]^T + (b2 + bsc)), instead of a
 // launch of its own that writes a tensor the expand reads back as its residual.
-template <int BN, bool BUF, int MT, bool DUAL = false>
+// TRACE (tools only, tools/trace_gemm.py): wave 0 takes a shader-clock stamp at the phase boundaries of the workgroup's life and writes
+// them to p.trace[blockIdx.x][8] when it ends: {100-MHz wall clock at entry, entry, prologue done, first tile landed, k-loop done,
+// epilogue issued, stores retired, HW_ID | XCC_ID << 32}.
+// PW ("pointwise"): linear layers and 1x1 stride-1 convolutions -- a tile row's source is row m of a [M][Cin] matrix, so the prologue
+// needs no (frame, y, x) decomposition, no tap masks and no tap bookkeeping (tools/trace_gemm.py: the general prologue is ~950
+// instructions, 4 400 clocks of a K = 256 workgroup's 19 000).
+template <int BN, bool BUF, int MT, bool DUAL = false, bool TRACE = false, bool PW = false>
 __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)  // the buffer-resource type and builtins exist only in the gfx950 pass
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned long long tstamp[8];
+    auto stamp = [&](const int i) {
+        if constexpr (TRACE) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[i])::"memory");
+    };
+    if constexpr (TRACE) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[0])::"memory");
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        tstamp[7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
+    }
+    stamp(1);
     constexpr int BMT = 32 * MT;       // tile rows: 2 waves along m, MT 16-row MFMA tiles each (128 / 160 / 192)
     constexpr int A_BYTES = BMT * ROW_BYTES;
     constexpr int STAGE_BYTES = A_BYTES + BN * ROW_BYTES;
@@ -518,10 +541,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     const int tiles_n = p.N / BN;
     const int ntiles = tiles_n * ((p.M + BMT - 1) / BMT);
     const int lbid_all = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int zsplit = lbid_all / ntiles;  // split-K slice (0 when split_k <= 1)
+    const int zsplit = p.split_k > 1 ? fdiv(lbid_all, p.fd_ntiles) : 0;  // split-K slice
     const int lbid = lbid_all - zsplit * ntiles;
-    const int tile_n = lbid % tiles_n;
-    const int tile_m = lbid / tiles_n;
+    const int tile_m = fdiv(lbid, p.fd_tilesn);
+    const int tile_n = lbid - tile_m * tiles_n;
     const int m_base = tile_m * BMT;
     const int n_base = tile_n * BN;
     // (kernel arguments are never written: a modified ConvGemmParams would be demoted to scratch memory)
@@ -545,9 +568,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
             const int m = m_base + (wave * MT + i) * 8 + lrow;
             a_ok[i] = m < p.M;
             const int mm = a_ok[i] ? m : 0;
-            const int b = mm / ohw;
+            const int b = fdiv(mm, p.fd_ohw);
             const int r = mm - b * ohw;
-            const int oh = r / p.OW;
+            const int oh = fdiv(r, p.fd_ow);
             const int ow = r - oh * p.OW;
             a_base[i] = (long long)b * p.H * p.W;
             a_ih0[i] = oh * p.stride - p.pad;
@@ -575,10 +598,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         for (int i = 0; i < MT; ++i) {
             const int m = m_base + (wave * MT + i) * 8 + lrow;
             const bool okm = m < p.M;
+            if constexpr (PW) {   // row m of [M][Cin]; rows >= M read zeros through the descriptor's bounds check
+                rowoff[i] = okm ? (unsigned)m * (unsigned)(p.Cin * 2) + (unsigned)lchunk * 16u : 0x80000000u;
+                rowmask[i] = 1u;
+                continue;
+            }
             const int mm = okm ? m : 0;
-            const int b = mm / ohw;
+            const int b = fdiv(mm, p.fd_ohw);
             const int r = mm - b * ohw;
-            const int oh = r / p.OW;
+            const int oh = fdiv(r, p.fd_ow);
             const int ow = r - oh * p.OW;
             // stem == 2: padded NHWC4 image (8 bytes / pixel); a k-step is 2 filter rows x 8 pixels, so the lane's 16-byte
             // chunk sits at (row lchunk>>2, pixel pair lchunk&3) of the window
@@ -608,9 +636,9 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         for (int i = 0; i < MT; ++i) {
             const int m = m_base + (wave * MT + i) * 8 + lrow;
             const int mm = m < p.M ? m : 0;
-            const int b = mm / ohw;
+            const int b = fdiv(mm, p.fd_ohw);
             const int r = mm - b * ohw;
-            const int oh = r / p.OW;
+            const int oh = fdiv(r, p.fd_ow);
             const int ow = r - oh * p.OW;
             rowoff2[i] = m < p.M ? (unsigned)(((b * p.H2 + oh * p.stride2) * p.W2 + ow * p.stride2) * p.Cin2) * 2u + (unsigned)lchunk * 16u
                                  : 0x80000000u;
@@ -624,16 +652,18 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     // (a per-tile rotated k-order was tried to spread L2 channel load: no gain, and it makes a frame's result depend on
     //  its position in the batch through the fp32 summation order — removed; k-steps run in natural order.)
     int ks_cur = ks0;
-    int tap_kh = (ks_cur / kpc) / p.KW, tap_kw = (ks_cur / kpc) % p.KW, tap_c = ks_cur % kpc;
+    int tap_kh = 0, tap_kw = 0, tap_c = ks0;   // PW / single tap: the k-step IS the channel chunk
+    if (!PW && ks0 != 0 && (p.KH | p.KW) != 1) { tap_kh = (ks_cur / kpc) / p.KW; tap_kw = (ks_cur / kpc) % p.KW; tap_c = ks_cur % kpc; }
 
     auto issue = [&](int, int buf) {
         const int ks = ks_cur;
         unsigned char* As = smem + buf * STAGE_BYTES;
         unsigned char* Bs = As + A_BYTES;
         if constexpr (BUF) {
-            const int tap = tap_kh * p.KW + tap_kw;
-            const int soff_a = stem2 ? tap_c * 16 * p.W   // two padded image rows per k-step
-                                     : ((tap_kh * p.W + tap_kw) * p.Cin + tap_c * BK) * 2;  // scalar displacement of this tap / chunk
+            const int tap = PW ? 0 : tap_kh * p.KW + tap_kw;
+            const int soff_a = PW ? ks * (BK * 2)
+                                  : stem2 ? tap_c * 16 * p.W   // two padded image rows per k-step
+                                          : ((tap_kh * p.W + tap_kw) * p.Cin + tap_c * BK) * 2;  // scalar displacement of this tap / chunk
             if (DUAL && ks >= nk1) {   // second source: channels 64 (ks - nk1) .. of the strided 1x1 input
 #pragma unroll
                 for (int i = 0; i < MT; ++i)
@@ -642,7 +672,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
             } else if (!(p.dbg & 8))
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const unsigned vo = ((rowmask[i] >> tap) & 1u) ? rowoff[i] : 0x80000000u;  // out of range -> zeros
+                const unsigned vo = (PW || ((rowmask[i] >> tap) & 1u)) ? rowoff[i] : 0x80000000u;  // out of range -> zeros
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * MT + i) * 1024),
                                                          16, vo, soff_a, 0, 0);
             }
@@ -664,22 +694,29 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
 #pragma unroll
             for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BK, Bs + (wave * B_PIECES + i) * 1024);
         }
-        if (++tap_c == kpc) {
-            tap_c = 0;
-            if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
-        }
-        if (++ks_cur == ks0 + nk) {  // wrap to the first k-step of this slice
-            ks_cur = ks0;
-            tap_kh = (ks0 / kpc) / p.KW; tap_kw = (ks0 / kpc) % p.KW; tap_c = ks0 % kpc;
+        if constexpr (PW) {
+            ++ks_cur;   // (the wrap below only serves the timing ablations that re-issue past the last k-step)
+            if (ks_cur == ks0 + nk) ks_cur = ks0;
+        } else {
+            if (++tap_c == kpc) {
+                tap_c = 0;
+                if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
+            }
+            if (++ks_cur == ks0 + nk) {  // wrap to the first k-step of this slice
+                ks_cur = ks0;
+                tap_kh = (ks0 / kpc) / p.KW; tap_kw = (ks0 / kpc) % p.KW; tap_c = ks0 % kpc;
+            }
         }
     };
 
     const int wm0 = m_base + wm * (MT * 16), wn0 = n_base + wn * (BN / 2);
+    stamp(2);
     issue(0, 0);
     float4v acc[NT][MT];
     init_acc_bias<NT, MT>(p, bias_ptr, acc, wm0, wn0, lane);
     uint4 res[NT][(MT + 1) / 2];
     __syncthreads();  // emits s_waitcnt vmcnt(0) for the DMA in flight, then s_barrier
+    stamp(3);
 
     const int frow = lane & 15;
     const int fchk = lane >> 4;
@@ -709,6 +746,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     }
     prefetch_res16<NT, MT>(p, res, wm0, wn0, lane);  // in flight during the last tile's MFMAs
     compute((nk - 1) & 1);
+    stamp(4);
     // the stage buffer NOT used by the last k-step is free: each wave takes a private quarter of it for the output transpose
     unsigned char* wave_stage = nullptr;
     // (single-k-step launches allocate ONE stage buffer: it is free once every wave has finished its fragment reads)
@@ -721,27 +759,39 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         }
     }
     epilogue_regs<NT, MT>(p, out_ptr, acc, res, wm0, wn0, lane, wave_stage);
+    if constexpr (TRACE) {
+        stamp(5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(6);
+        if (tid == 0 && p.trace) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p.trace[(size_t)blockIdx.x * 8 + i] = tstamp[i];
+        }
+    }
 #endif
 }
 
-template <int BN, bool BUF, int MT, bool DUAL = false>
-hipError_t launch_dma_t(const ConvGemmParams& p, hipStream_t stream) {
+template <int BN, bool BUF, int MT, bool DUAL = false, bool TRACE = false, bool PW = false>
+hipError_t launch_dma_t(const ConvGemmParams& p_in, hipStream_t stream) {
     constexpr int BMT = 32 * MT;
     constexpr int LDS = 2 * (BMT + BN) * ROW_BYTES;
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF, MT, DUAL>),
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF, MT, DUAL, TRACE, PW>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    ConvGemmParams p = p_in;
     const int tiles_m = (p.M + BMT - 1) / BMT;
     const int tiles_n = p.N / BN;
     const int splits = p.split_k > 1 ? p.split_k : 1;
+    p.fd_tilesn = opd_make_fastdiv((unsigned)tiles_n);
+    p.fd_ntiles = opd_make_fastdiv((unsigned)(tiles_m * tiles_n));
     // a single k-step per workgroup (K = 64 layers, split-K slices of one step) needs no second stage buffer: half the
     // LDS -> three workgroups per CU instead of two, which is what hides the DMA / residual / store round trips there
     const int lds = ((p.K / BK) / splits == 1) ? LDS / 2 : LDS;
-    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT, DUAL>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
+    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT, DUAL, TRACE, PW>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
     return hipGetLastError();
 }
 
@@ -793,7 +843,30 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
         }
     }
     if (!buf_ok) return launch_dma_t<BN, false, 4>(p, stream);
-    switch (pick_mt(p.M, p.N, BN, p.split_k > 1 ? p.split_k : 1)) {
+    const bool pw = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1 && p.H == p.OH && p.W == p.OW && !p.stem;
+    const int mt = pick_mt(p.M, p.N, BN, p.split_k > 1 ? p.split_k : 1);
+    if (p.trace) {   // tools/trace_gemm.py
+        if (pw) {
+            switch (mt) {
+                case 5: return launch_dma_t<BN, true, 5, false, true, true>(p, stream);
+                case 6: return launch_dma_t<BN, true, 6, false, true, true>(p, stream);
+                default: return launch_dma_t<BN, true, 4, false, true, true>(p, stream);
+            }
+        }
+        switch (mt) {
+            case 5: return launch_dma_t<BN, true, 5, false, true>(p, stream);
+            case 6: return launch_dma_t<BN, true, 6, false, true>(p, stream);
+            default: return launch_dma_t<BN, true, 4, false, true>(p, stream);
+        }
+    }
+    if (pw) {
+        switch (mt) {
+            case 5: return launch_dma_t<BN, true, 5, false, false, true>(p, stream);
+            case 6: return launch_dma_t<BN, true, 6, false, false, true>(p, stream);
+            default: return launch_dma_t<BN, true, 4, false, false, true>(p, stream);
+        }
+    }
+    switch (mt) {
         case 5: return launch_dma_t<BN, true, 5>(p, stream);
         case 6: return launch_dma_t<BN, true, 6>(p, stream);
         default: return launch_dma_t<BN, true, 4>(p, stream);
@@ -1436,7 +1509,12 @@ hipError_t launch(const ConvGemmParams& p, hipStream_t stream) {
 
 }  // namespace
 
-hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream) {
+hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) {
+    if (p_in.OH <= 0 || p_in.OW <= 0 || p_in.bias_period < 0) return hipErrorInvalidValue;
+    ConvGemmParams p = p_in;   // (+ the launch constants' reciprocals; M < 2^31 is the FastDiv range)
+    p.fd_ohw = opd_make_fastdiv((unsigned)p.OH * (unsigned)p.OW);
+    p.fd_ow = opd_make_fastdiv((unsigned)p.OW);
+    p.fd_period = opd_make_fastdiv((unsigned)(p.bias_period > 0 ? p.bias_period : 1));
     // host-side shape contract of the kernel (checked before every launch: a violated assumption would fault the GPU)
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.N % 64) != 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if (p.stem == 2) {  // padded-NHWC4 stem through the LDS-DMA kernel: [B][H = 2*OH+6][W = 2*OW+6][4], zero borders

@@ -9,6 +9,21 @@ typedef uint16_t f16_t;  // raw IEEE half bits on the host side
 
 // ---- implicit-GEMM convolution / linear layer (kernels_gemm.hip) ---------------------------------------------------
 // out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias + residual ),  m = (b,oh,ow), k = (kh,kw,cin), NHWC fp16 input.
+// Division of a 31-bit unsigned value by a launch constant: q = one ? m : umulhi(m, mul) >> shift, exact for m < 2^31 (mul =
+// ceil(2^(31+s) / d), s = ceil(log2 d), shift = s - 1).  A runtime 32-bit division costs ~40 VALU instructions; the conv / GEMM
+// prologue did ten of them per lane (tools/trace_gemm.py: 5 000 of a workgroup's 20 000 clocks on the K = 256 layers).
+struct FastDiv { unsigned mul, shift, one; };
+inline FastDiv opd_make_fastdiv(unsigned d) {
+    FastDiv f{0u, 0u, 1u};
+    if (d <= 1u) return f;
+    int s = 0;
+    while ((1ull << s) < d) ++s;
+    f.mul = (unsigned)(((1ull << (31 + s)) + d - 1) / d);
+    f.shift = (unsigned)(s - 1);
+    f.one = 0u;
+    return f;
+}
+
 struct ConvGemmParams {
     const f16_t* x;      // [B][H][W][Cin] fp16 (Cin % 64 == 0), or NHWC4 for the stem
     const f16_t* w;      // [N][K] fp16, K = KH*KW*Cin (stem: [N][8][8][4])
@@ -32,6 +47,9 @@ struct ConvGemmParams {
     // 1x1 convolution of x2 added into the same accumulators; w is then [N][K1 + Cin2], K = K1 + Cin2, K1 = KH*KW*Cin
     const f16_t* x2;
     int H2, W2, Cin2, stride2, K1;
+    FastDiv fd_ohw, fd_ow, fd_period;  // filled by opd_launch_conv_gemm: division by OH*OW, OW, bias_period
+    FastDiv fd_tilesn, fd_ntiles;      // filled by the LDS-DMA launcher: column tiles, tiles per split-K slice
+    unsigned long long* trace;  // tools only: per-workgroup phase stamps [grid][8] (conv_gemm_dma_kernel<..., TRACE>); null in the model
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 // fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16

@@ -314,6 +314,42 @@ int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     return OPD_OK;
 }
 
+// One traced launch of a layer shape (after `warm` untraced ones): trace_out [max_wgs][8] receives the per-workgroup phase stamps of
+// conv_gemm_dma_kernel<..., TRACE>, *wgs_out the grid size.
+int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride, int with_res, int dbg, int warm, unsigned long long* trace_out,
+                        int max_wgs, int* wgs_out) {
+    DevMem dm;
+    const int pad = KH / 2, OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
+    const size_t M = (size_t)B * OH * OW, K = (size_t)KH * KH * Cin;
+    ConvGemmParams p{};
+    uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)B * H * W * Cin);
+    uint16_t* w = dm.up<uint16_t>(nullptr, (size_t)N * K);
+    float* bias = dm.up<float>(nullptr, N);
+    uint16_t* res = with_res ? dm.up<uint16_t>(nullptr, M * N) : nullptr;
+    uint16_t* out = dm.up<uint16_t>(nullptr, M * N);
+    float* zero = dm.up<float>(nullptr, 4096);
+    unsigned long long* tr = dm.up<unsigned long long>(nullptr, (size_t)max_wgs * 8);
+    if (!x || !w || !bias || !out || !zero || !tr || (with_res && !res)) return tfail(OPD_ENOMEM, "trace alloc failed");
+    TCHK(hipMemset(x, 0x2c, (size_t)B * H * W * Cin * 2));
+    TCHK(hipMemset(w, 0x1c, (size_t)N * K * 2));
+    TCHK(hipMemset(bias, 0, (size_t)N * 4));
+    TCHK(hipMemset(zero, 0, 4096 * 4));
+    TCHK(hipMemset(tr, 0, (size_t)max_wgs * 64));
+    if (res) TCHK(hipMemset(res, 0x2c, M * N * 2));
+    p.x = x; p.w = w; p.bias = bias; p.res16 = res; p.out = out; p.zero16 = zero;
+    p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KH; p.stride = stride; p.pad = pad;
+    p.M = (int)M; p.K = (int)K; p.relu = 1; p.dbg = dbg;
+    for (int i = 0; i < warm; ++i) TCHK(opd_launch_conv_gemm(p, nullptr));
+    p.trace = tr;
+    TCHK(opd_launch_conv_gemm(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(trace_out, tr, (size_t)max_wgs * 64, hipMemcpyDeviceToHost));
+    const int bn = (N % 128 == 0) ? 128 : 64;   // (the launcher's choice is not exported: the caller reads stamps until the first all-zero row)
+    (void)bn;
+    *wgs_out = max_wgs;
+    return OPD_OK;
+}
+
 // fused bottleneck tail vs. the caller's reference: x1 [B][H][W][C1], w1 [C1][3][3][C1], w2 [4*C1][C1], w3 [C3][4*C1]
 // (plain K order: the hook applies opd_permute_k32), res [M][4*C1] or null; outputs y [M][4*C1], z [M][C3] (C3 > 0).
 int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2,
