@@ -507,7 +507,7 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
 // launch of its own that writes a tensor the expand reads back as its residual.
 // TRACE (tools only, tools/trace_gemm.py): wave 0 takes a shader-clock stamp at the phase boundaries of the workgroup's life and writes
 // them to p.trace[blockIdx.x][8] when it ends: {100-MHz wall clock at entry, entry, prologue done, first tile landed, k-loop done,
-// epilogue issued, stores retired, HW_ID | XCC_ID << 32}.
+// epilogue issued, stores retired, 100-MHz wall clock at the end}.
 // PW ("pointwise"): linear layers and 1x1 stride-1 convolutions -- a tile row's source is row m of a [M][Cin] matrix, so the prologue
 // needs no (frame, y, x) decomposition, no tap masks and no tap bookkeeping (tools/trace_gemm.py: the general prologue is ~950
 // instructions, 4 400 clocks of a K = 256 workgroup's 19 000).
@@ -521,10 +521,6 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     };
     if constexpr (TRACE) {
         asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[0])::"memory");
-        unsigned hw, xcc;
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
-        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-        tstamp[7] = (unsigned long long)hw | ((unsigned long long)xcc << 32);
     }
     stamp(1);
     constexpr int BMT = 32 * MT;       // tile rows: 2 waves along m, MT 16-row MFMA tiles each (128 / 160 / 192)
@@ -612,13 +608,15 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
             // chunk sits at (row lchunk>>2, pixel pair lchunk&3) of the window
             rowoff[i] = stem2 ? (unsigned)((b * p.H + oh * 2) * p.W + ow * 2) * 8u + (unsigned)((lchunk >> 2) * p.W) * 8u + (unsigned)(lchunk & 3) * 16u
                               : (unsigned)(((b * p.H + oh * p.stride) * p.W + ow * p.stride) * p.Cin) * 2u + (unsigned)lchunk * 16u;
-            // separable validity: row bits (kw) replicated for every valid kh
-            unsigned kwmask = 0, mask = 0;
-            for (int kw = 0; kw < p.KW; ++kw)
-                if ((unsigned)(ow * p.stride - p.pad + kw) < (unsigned)p.W) kwmask |= 1u << kw;
-            for (int kh = 0; kh < p.KH; ++kh)
-                if ((unsigned)(oh * p.stride - p.pad + kh) < (unsigned)p.H) mask |= kwmask << (kh * p.KW);
-            rowmask[i] = okm ? mask : 0u;
+            // separable validity in closed form (no loops, no branches): the valid kw form a contiguous range [lo_w, hi_w], likewise kh;
+            // the row bits are replicated to every valid kh by a multiplication with the matching bits of p.tap_rep = sum 1 << kh*KW
+            const int iw0 = ow * p.stride - p.pad, ih0 = oh * p.stride - p.pad;
+            const int lo_w = max(0, -iw0), hi_w = min(p.KW - 1, p.W - 1 - iw0);
+            const int lo_h = max(0, -ih0), hi_h = min(p.KH - 1, p.H - 1 - ih0);
+            auto below = [](const int n) { return n > 0 ? 0xffffffffu >> (32 - n) : 0u; };   // bits [0, n), n <= 32
+            const unsigned kwmask = hi_w >= lo_w ? below(hi_w + 1) & ~below(lo_w) : 0u;
+            const unsigned hsel = hi_h >= lo_h ? below((hi_h + 1) * p.KW) & ~below(lo_h * p.KW) : 0u;
+            rowmask[i] = okm ? kwmask * (p.tap_rep & hsel) : 0u;
         }
 #pragma unroll
         for (int i = 0; i < B_PIECES; ++i)
@@ -763,6 +761,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
         stamp(5);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(6);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[7])::"memory");
         if (tid == 0 && p.trace) {
 #pragma unroll
             for (int i = 0; i < 8; ++i) p.trace[(size_t)blockIdx.x * 8 + i] = tstamp[i];
@@ -792,6 +791,145 @@ hipError_t launch_dma_t(const ConvGemmParams& p_in, hipStream_t stream) {
     // LDS -> three workgroups per CU instead of two, which is what hides the DMA / residual / store round trips there
     const int lds = ((p.K / BK) / splits == 1) ? LDS / 2 : LDS;
     hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT, DUAL, TRACE, PW>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Persistent pointwise form: a workgroup walks several output tiles (static schedule: its j-th tile is logical tile
+// xcd_logical_block(blockIdx.x + j * gridDim.x), so an XCD still owns a contiguous range) and the k-step pipeline runs straight
+// through the tile boundaries -- the first DMA of tile t+1 is issued BEFORE the last MFMAs and the epilogue of tile t.  What the
+// per-workgroup trace (tools/trace_gemm.py) shows for the K = 256 / 512 layers is that a tile's k-loop is less than half of a
+// workgroup's life: ~1 500 clocks of prologue, ~3 500 waiting for the first tile and 5 000 - 6 600 in the epilogue, with both
+// workgroups of a CU going through these phases in lock-step.  Here the prologue is paid once, the first-tile wait once, and an
+// epilogue overlaps the next tile's DMA.  Per-lane DMA offsets are tile independent (row * pitch + chunk) up to the tile's row
+// origin; rows >= M fall outside the buffer descriptor (zeros).  Same per-tile arithmetic, same k order: results are
+// bit-identical to conv_gemm_dma_kernel.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int BN, int MT>
+__global__ __launch_bounds__(256, 2) void gemm_pw_persist_kernel(ConvGemmParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int BMT = 32 * MT;
+    constexpr int A_BYTES = BMT * ROW_BYTES;
+    constexpr int STAGE_BYTES = A_BYTES + BN * ROW_BYTES;
+    constexpr int NT = BN / 32;
+    constexpr int B_PIECES = BN / 32;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = p.N / BN;
+    const int ntiles = tiles_n * ((p.M + BMT - 1) / BMT);
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x), 0, (unsigned)((size_t)p.M * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
+    unsigned rowoff[MT], woff[B_PIECES];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rowoff[i] = (unsigned)(((wave * MT + i) * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
+#pragma unroll
+    for (int i = 0; i < B_PIECES; ++i) woff[i] = (unsigned)(((wave * B_PIECES + i) * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
+    const int nk = p.K / BK;
+    const unsigned pitch = (unsigned)p.K * 2u;
+
+    auto tile_origin = [&](const int seq, int& m_base, int& n_base) {
+        const int lbid = xcd_logical_block(seq, ntiles);
+        const int tile_m = fdiv(lbid, p.fd_tilesn);
+        m_base = tile_m * BMT;
+        n_base = (lbid - tile_m * tiles_n) * BN;
+    };
+    auto issue = [&](const int m_base, const int n_base, const int ks, const int buf) {
+        unsigned char* As = smem + buf * STAGE_BYTES;
+        unsigned char* Bs = As + A_BYTES;
+        // (the tile's row origin goes into the VECTOR offset: only that one is bounds-checked against the descriptor, which is what turns
+        //  rows >= M of the last row tile into zeros; the column origin is always in range and travels as the scalar offset)
+        const unsigned mo = (unsigned)m_base * pitch;
+        const unsigned soff_a = (unsigned)ks * (BK * 2);
+        const unsigned soff_b = (unsigned)n_base * pitch + (unsigned)ks * (BK * 2);
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * MT + i) * 1024), 16, rowoff[i] + mo,
+                                                     soff_a, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_PIECES; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (wave * B_PIECES + i) * 1024), 16, woff[i],
+                                                     soff_b, 0, 0);
+    };
+    const int frow = lane & 15;
+    const int fchk = lane >> 4;
+    float4v acc[NT][MT];
+    auto compute = [&](const int buf) {
+        const unsigned char* As = smem + buf * STAGE_BYTES;
+        const unsigned char* Bs = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[MT], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * (MT * 16) + mt * 16 + frow, kk * 4 + fchk));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    };
+
+    int seq = blockIdx.x;
+    int m_base, n_base;
+    tile_origin(seq, m_base, n_base);
+    int buf = 0;
+    issue(m_base, n_base, 0, buf);
+    while (true) {
+        const int wm0 = m_base + wm * (MT * 16), wn0 = n_base + wn * (BN / 2);
+        init_acc_bias<NT, MT>(p, p.bias, acc, wm0, wn0, lane);
+        uint4 res[NT][(MT + 1) / 2];
+        __syncthreads();   // the tile's first k-step has landed; every wave has left the buffer the next issue overwrites
+        for (int ks = 0; ks + 1 < nk; ++ks) {
+            issue(m_base, n_base, ks + 1, buf ^ 1);
+            compute(buf);
+            __syncthreads();
+            buf ^= 1;
+        }
+        const int seq_next = seq + (int)gridDim.x;
+        const bool more = seq_next < ntiles;
+        int m_next = 0, n_next = 0;
+        if (more) {   // the next tile's first k-step flies during this tile's last MFMAs, residual loads and stores
+            tile_origin(seq_next, m_next, n_next);
+            issue(m_next, n_next, 0, buf ^ 1);
+        }
+        prefetch_res16<NT, MT>(p, res, wm0, wn0, lane);
+        compute(buf);
+        // the buffer of the last k-step becomes the waves' output-transpose area once every wave has read its fragments (a wave's ds_reads
+        // have returned before its MFMAs issue, so a bare s_barrier is enough -- no vmcnt wait: the next tile's DMA and the residual
+        // loads stay in flight); the loop-top barrier of the next tile separates the transposes from the DMA that re-fills this buffer
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        epilogue_regs<NT, MT>(p, p.out, acc, res, wm0, wn0, lane, smem + buf * STAGE_BYTES + wave * (64 * NT * 32));
+        if (!more) break;
+        seq = seq_next; m_base = m_next; n_base = n_next;
+        buf ^= 1;
+    }
+#endif
+}
+
+template <int BN, int MT>
+hipError_t launch_pw_persist_t(const ConvGemmParams& p_in, int grid, hipStream_t stream) {
+    constexpr int LDS = 2 * (32 * MT + BN) * ROW_BYTES;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw_persist_kernel<BN, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    ConvGemmParams p = p_in;
+    p.fd_tilesn = opd_make_fastdiv((unsigned)(p.N / BN));
+    hipLaunchKernelGGL((gemm_pw_persist_kernel<BN, MT>), dim3(grid), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -825,6 +963,10 @@ static inline int pick_mt(int M, int N, int bn, int splits) {
     return best;
 }
 
+static int g_pw_persist = 0;   // persistent pointwise form for multi-round launches: kept under test, OFF by default (opd_set_gemm_variant
+                               // bit 11 turns it on) -- measured equal or slower than one tile per workgroup on every layer it applies to
+                               // (fc1 19.1 vs 18.9 us, stage-3 expand 40.8 vs 41.1, stage-4 expand 32.1 vs 32.2, decoder K/V 26.6 vs 24.1)
+
 template <int BN>
 hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
     // buffer-descriptor staging needs 31-bit byte offsets and <= 32 filter taps; otherwise the flat-pointer form
@@ -857,6 +999,22 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
             case 5: return launch_dma_t<BN, true, 5, false, true>(p, stream);
             case 6: return launch_dma_t<BN, true, 6, false, true>(p, stream);
             default: return launch_dma_t<BN, true, 4, false, true>(p, stream);
+        }
+    }
+    if (pw && g_pw_persist && p.split_k <= 1 && p.K / BK >= 2 && p.dbg == 0 && (size_t)p.M * p.K * 2 < 0x7fffff00ull) {
+        // persistent form when a CU would see more than one round of tiles: tiles per workgroup = ceil(tiles / 512), the grid
+        // the smallest multiple of 8 that covers the tiles at that depth
+        const long long tiles = (long long)((p.M + 32 * mt - 1) / (32 * mt)) * (p.N / BN);
+        const int slots = 256 * dma_blocks_per_cu(BN, mt);
+        if (tiles > slots) {
+            const int depth = (int)((tiles + slots - 1) / slots);
+            int grid = (int)((tiles + depth - 1) / depth);
+            grid = (grid + 7) & ~7;
+            switch (mt) {
+                case 5: return launch_pw_persist_t<BN, 5>(p, grid, stream);
+                case 6: return launch_pw_persist_t<BN, 6>(p, grid, stream);
+                default: return launch_pw_persist_t<BN, 4>(p, grid, stream);
+            }
         }
     }
     if (pw) {
@@ -1515,6 +1673,9 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) 
     p.fd_ohw = opd_make_fastdiv((unsigned)p.OH * (unsigned)p.OW);
     p.fd_ow = opd_make_fastdiv((unsigned)p.OW);
     p.fd_period = opd_make_fastdiv((unsigned)(p.bias_period > 0 ? p.bias_period : 1));
+    p.tap_rep = 0u;
+    if (p.KH >= 1 && p.KW >= 1 && p.KH * p.KW <= 32)
+        for (int kh = 0; kh < p.KH; ++kh) p.tap_rep |= 1u << (kh * p.KW);
     // host-side shape contract of the kernel (checked before every launch: a violated assumption would fault the GPU)
     if (p.M <= 0 || p.N <= 0 || p.K <= 0 || (p.N % 64) != 0 || (p.K % BK) != 0) return hipErrorInvalidValue;
     if (p.stem == 2) {  // padded-NHWC4 stem through the LDS-DMA kernel: [B][H = 2*OH+6][W = 2*OW+6][4], zero borders
@@ -1579,8 +1740,9 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) 
 void opd_set_gemm_variant(int v) {
     g_gemm_variant = v & 15; g_strip3x3 = (v & 16) ? 1 : 0; g_buffer_staging = (v & 32) ? 0 : 1;
     g_tile_mt = (v >> 8) & 7;  // bits 8-10: force m-tiles per wave (4, 5, 6); 0 = automatic
+    g_pw_persist = (v & 0x800) ? 1 : 0;
 }
-int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32) | (g_tile_mt << 8); }
+int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32) | (g_tile_mt << 8) | (g_pw_persist ? 0x800 : 0); }
 
 // x4p: zero-bordered NHWC4 image [B][Hp = 2*OH+6][Wp = 2*OW+6][4]; out: pooled [B][PH][PW][64]
 static int g_stem_variant = 2;  // 2: input-stationary stem_pool2_kernel (default); 1: im2col stem_pool_kernel (cross-check)

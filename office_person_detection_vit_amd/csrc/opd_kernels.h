@@ -48,6 +48,7 @@ struct ConvGemmParams {
     const f16_t* x2;
     int H2, W2, Cin2, stride2, K1;
     FastDiv fd_ohw, fd_ow, fd_period;  // filled by opd_launch_conv_gemm: division by OH*OW, OW, bias_period
+    unsigned tap_rep;                  // filled by opd_launch_conv_gemm: sum over kh of 1 << kh*KW (tap-validity masks)
     FastDiv fd_tilesn, fd_ntiles;      // filled by the LDS-DMA launcher: column tiles, tiles per split-K slice
     unsigned long long* trace;  // tools only: per-workgroup phase stamps [grid][8] (conv_gemm_dma_kernel<..., TRACE>); null in the model
 };

@@ -339,11 +339,19 @@ int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     p.x = x; p.w = w; p.bias = bias; p.res16 = res; p.out = out; p.zero16 = zero;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KH; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.K = (int)K; p.relu = 1; p.dbg = dbg;
-    for (int i = 0; i < warm; ++i) TCHK(opd_launch_conv_gemm(p, nullptr));
+    // `warm` traced launches back to back; the LAST THREE are kept (trace_out [3][max_wgs][8]): the spacing of their wall-clock stamps is
+    // the cost of a launch boundary (drain of one kernel, dispatch of the next) on a busy stream
+    unsigned long long* tr3 = dm.up<unsigned long long>(nullptr, (size_t)3 * max_wgs * 8);
+    if (!tr3) return tfail(OPD_ENOMEM, "trace alloc failed");
+    TCHK(hipMemset(tr3, 0, (size_t)3 * max_wgs * 64));
     p.trace = tr;
-    TCHK(opd_launch_conv_gemm(p, nullptr));
+    for (int i = 0; i < warm; ++i) TCHK(opd_launch_conv_gemm(p, nullptr));
+    for (int i = 0; i < 3; ++i) {
+        p.trace = tr3 + (size_t)i * max_wgs * 8;
+        TCHK(opd_launch_conv_gemm(p, nullptr));
+    }
     TCHK(hipDeviceSynchronize());
-    TCHK(hipMemcpy(trace_out, tr, (size_t)max_wgs * 64, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(trace_out, tr3, (size_t)3 * max_wgs * 64, hipMemcpyDeviceToHost));
     const int bn = (N % 128 == 0) ? 128 : 64;   // (the launcher's choice is not exported: the caller reads stamps until the first all-zero row)
     (void)bn;
     *wgs_out = max_wgs;

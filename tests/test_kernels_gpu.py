@@ -140,6 +140,46 @@ def test_conv_residual_integer_exact(lib, gemm_variant):
     np.testing.assert_array_equal(got, want)
 
 
+@pytest.mark.parametrize("M,K,N,res,period", [
+    (8400, 256, 2048, False, 0),      # encoder fc1 at batch 8: 848 160-row tiles, two per workgroup
+    (33600 + 37, 256, 1024, True, 0),  # stage-3 expand + residual, ragged last row tile, three tiles per workgroup
+    (8400, 256, 3072, False, 1050),   # decoder K/V projection with the row-periodic (position) bias
+    (8400, 512, 2048, True, 0),       # stage-4 expand
+])
+def test_gemm_persistent_pointwise_bit_identical(lib, M, K, N, res, period):
+    """gemm_pw_persist_kernel (variant bit 0x800; off by default, measured no faster): a workgroup walks several tiles and the DMA
+    pipeline runs across the tile boundaries.  Same per-tile arithmetic and k order as conv_gemm_dma_kernel: the outputs must be
+    BIT-identical to the one-tile-per-workgroup form, and exact on integer data."""
+    rng = np.random.default_rng(M + K + N)
+    x, _ = _h(rng.standard_normal((M, 1, 1, K)))
+    w, _ = _h(rng.standard_normal((N, K, 1, 1)) / np.sqrt(K))
+    bias = rng.standard_normal((period, N) if period else N).astype(np.float32)
+    r = _h(rng.standard_normal((M, 1, 1, N)))[0] if res else None
+    outs = []
+    try:
+        for variant in (1, 0x801):
+            lib.opd_test_set_gemm_variant(variant)
+            outs.append(run_conv(lib, x, w, bias, 1, 0, True, r, bias_period=period).reshape(M, N))
+    finally:
+        lib.opd_test_set_gemm_variant(1)
+    np.testing.assert_array_equal(outs[0], outs[1])
+    want = x.reshape(M, K) @ w.reshape(N, K).T + (bias[np.arange(M) % period] if period else bias)
+    if res:
+        want = want + r.reshape(M, N)
+    want = np.maximum(want, 0)
+    np.testing.assert_allclose(outs[0], want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
+    # integer operands through the persistent form: exact, including the rows of the ragged last tile
+    lib.opd_test_set_gemm_variant(0x801)
+    xi = rng.integers(-2, 3, (M, 1, 1, K)).astype(np.float32)
+    wi = rng.integers(-1, 2, (N, K, 1, 1)).astype(np.float32)
+    bi = ((np.arange(N, dtype=np.float32) % 9) - 4)
+    try:
+        got = run_conv(lib, xi, wi, bi, 1, 0, False).reshape(M, N)
+    finally:
+        lib.opd_test_set_gemm_variant(1)
+    np.testing.assert_array_equal(got, xi.reshape(M, K) @ wi.reshape(N, K).T + bi)
+
+
 def test_gemm_rowbias_f32_residual(lib, gemm_variant):
     """Transformer flavour: out_f32 = x.W^T + rowbias[m % period] + res32 (pos-embedding fold, residual stream)."""
     rng = np.random.default_rng(11)

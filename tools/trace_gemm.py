@@ -28,14 +28,18 @@ def main():
     lib = _capi.load_library()
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     MAXW = 8192
-    buf = (C.c_ulonglong * (MAXW * 8))()
+    buf = (C.c_ulonglong * (3 * MAXW * 8))()
     n = C.c_int()
     for name, B, H, W, Cin, N, k, st, res in SHAPES:
         if only and only not in name:
             continue
         _capi.check(lib.opd_test_trace_conv(B, H, W, Cin, N, k, st, res, 0, 3, buf, MAXW, C.byref(n)), "trace")
-        t = np.frombuffer(buf, dtype=np.uint64).reshape(MAXW, 8).astype(np.int64)
-        t = t[t[:, 1] != 0]
+        t3 = np.frombuffer(buf, dtype=np.uint64).reshape(3, MAXW, 8).astype(np.int64)
+        t3 = [x[x[:, 1] != 0] for x in t3]
+        spans = [(x[:, 7].max() - x[:, 0].min()) * 10.0 for x in t3]                       # first entry .. last exit, ns
+        gaps = [(t3[i + 1][:, 0].min() - t3[i][:, 7].max()) * 10.0 for i in range(2)]       # last exit .. next kernel's first entry
+        period = (t3[2][:, 0].min() - t3[0][:, 0].min()) * 10.0 / 2
+        t = t3[1]
         wgs = len(t)
         d = np.diff(t[:, 1:7], axis=1)   # shader clocks per phase
         life = t[:, 6] - t[:, 1]
@@ -53,10 +57,8 @@ def main():
         late = order[order > 1000.0]
         print(f"   starts: {np.sum(order <= 1000.0)} within 1 us of the first, then {len(late)} later"
               + (f" (median +{np.median(late) / 1e3:.1f} us, last +{order[-1] / 1e3:.1f} us)" if len(late) else ""))
-        hw = t[:, 7] & 0xffffffff
-        xcc = (t[:, 7] >> 32) & 0xf
-        cu = ((hw >> 8) & 0xf) | (((hw >> 12) & 1) << 4) | (((hw >> 13) & 7) << 5) | (xcc << 8)
-        print(f"   distinct (xcc, se, sh, cu) ids: {len(np.unique(cu))}; workgroups per id: max {np.bincount(np.unique(cu, return_inverse=True)[1]).max()}", flush=True)
+        print(f"   back-to-back launches: period {period / 1e3:.1f} us = first entry -> last exit {np.mean(spans) / 1e3:.1f} us"
+              f" + last exit -> next kernel's first entry {np.mean(gaps) / 1e3:.1f} us", flush=True)
 
 
 if __name__ == "__main__":
