@@ -54,6 +54,10 @@ __device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
 
+__device__ __forceinline__ int fdiv(const int m, const FastDiv& f) {   // m >= 0
+    return f.one ? m : (int)(__umulhi((unsigned)m, f.mul) >> f.shift);
+}
+
 __device__ __forceinline__ int xcd_logical_block_rev(int bid, int nblocks) {
     const int q = nblocks >> 3, r = nblocks & 7;
     const int x = bid & 7, k = bid >> 3;
@@ -148,9 +152,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             const int m = m_base + (wave * 4 + i) * 8 + lrow;
             const bool okm = m < p.M;
             const int mm = okm ? m : 0;
-            const int b = mm / ohw;
+            const int b = fdiv(mm, p.fd_ohw);   // (host-computed reciprocals: a runtime division is ~40 VALU instructions)
             const int r = mm - b * ohw;
-            const int oh = r / p.OW;
+            const int oh = fdiv(r, p.fd_ow);
             const int ow = r - oh * p.OW;
             rowoff[i] = (unsigned)(((b * p.H + oh * p.stride) * p.W + ow * p.stride) * C1) * 2u + (unsigned)lchunk * 16u;
             unsigned kwmask = 0, mask = 0;
@@ -482,8 +486,11 @@ hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
 
 bool opd_btail_supported(int C1, int C3) { return (C1 == 64 && (C3 == 0 || C3 == 64 || C3 == 128)) || (C1 == 128 && (C3 == 0 || C3 == 128)); }
 
-hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream) {
-    if (!opd_btail_supported(p.C1, p.C3)) return hipErrorInvalidValue;
+hipError_t opd_launch_btail(const BtailParams& p_in, hipStream_t stream) {
+    if (!opd_btail_supported(p_in.C1, p_in.C3) || p_in.OH <= 0 || p_in.OW <= 0) return hipErrorInvalidValue;
+    BtailParams p = p_in;
+    p.fd_ohw = opd_make_fastdiv((unsigned)p.OH * (unsigned)p.OW);
+    p.fd_ow = opd_make_fastdiv((unsigned)p.OW);
     // 31-bit byte offsets in the buffer descriptors
     if ((size_t)p.B * p.H * p.W * p.C1 * 2 + (size_t)(p.W + 1) * p.C1 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
     if ((size_t)p.M * p.C1 * 8 >= 0x7fffff00ull) return hipErrorInvalidValue;

@@ -74,6 +74,7 @@ struct BtailParams {
     f16_t* z;          // [M][C3]
     int B, H, W, OH, OW, stride, M, C1, C3;
     int dbg;           // timing ablations for tools (0 = normal): 1 skip the 3x3 loop, 2 skip stores, 4 skip residual, 8 stop after the 3x3
+    FastDiv fd_ohw, fd_ow;   // filled by opd_launch_btail
     int rev;           // 1: each XCD walks its tiles in descending order (results identical; see kernels_btail.hip)
 };
 bool opd_btail_supported(int C1, int C3);

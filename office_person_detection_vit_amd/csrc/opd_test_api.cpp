@@ -316,8 +316,9 @@ int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
 
 // One traced launch of a layer shape (after `warm` untraced ones): trace_out [max_wgs][8] receives the per-workgroup phase stamps of
 // conv_gemm_dma_kernel<..., TRACE>, *wgs_out the grid size.
-int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride, int with_res, int dbg, int warm, unsigned long long* trace_out,
+int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride, int with_res, int split_k, int warm, unsigned long long* trace_out,
                         int max_wgs, int* wgs_out) {
+    const int dbg = 0;
     DevMem dm;
     const int pad = KH / 2, OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const size_t M = (size_t)B * OH * OW, K = (size_t)KH * KH * Cin;
@@ -326,7 +327,7 @@ int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     uint16_t* w = dm.up<uint16_t>(nullptr, (size_t)N * K);
     float* bias = dm.up<float>(nullptr, N);
     uint16_t* res = with_res ? dm.up<uint16_t>(nullptr, M * N) : nullptr;
-    uint16_t* out = dm.up<uint16_t>(nullptr, M * N);
+    uint16_t* out = dm.up<uint16_t>(nullptr, M * N * (split_k > 1 ? 2 * (size_t)split_k : 1));   // split-K: fp32 slabs
     float* zero = dm.up<float>(nullptr, 4096);
     unsigned long long* tr = dm.up<unsigned long long>(nullptr, (size_t)max_wgs * 8);
     if (!x || !w || !bias || !out || !zero || !tr || (with_res && !res)) return tfail(OPD_ENOMEM, "trace alloc failed");
@@ -339,6 +340,7 @@ int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     p.x = x; p.w = w; p.bias = bias; p.res16 = res; p.out = out; p.zero16 = zero;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KH; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.K = (int)K; p.relu = 1; p.dbg = dbg;
+    if (split_k > 1) { p.split_k = split_k; p.out_f32 = 1; p.relu = 0; }
     // `warm` traced launches back to back; the LAST THREE are kept (trace_out [3][max_wgs][8]): the spacing of their wall-clock stamps is
     // the cost of a launch boundary (drain of one kernel, dispatch of the next) on a busy stream
     unsigned long long* tr3 = dm.up<unsigned long long>(nullptr, (size_t)3 * max_wgs * 8);

@@ -15,6 +15,8 @@ SHAPES = [  # name, B, H, W, Cin, N, k, stride, residual
     ("enc.qkv 256->768", 8400, 1, 1, 256, 768, 1, 1, 0),
     ("enc.fc1 256->2048", 8400, 1, 1, 256, 2048, 1, 1, 0),
     ("enc.fc2 2048->256", 8400, 1, 1, 2048, 256, 1, 1, 0),
+    ("enc.fc2 2048->256 split-K 4", 8400, 1, 1, 2048, 256, 1, 1, -4),
+    ("proj 2048->256 split-K 4", 8400, 1, 1, 2048, 256, 1, 1, -4),
     ("s2.c0 1x1 1024->256", 8, 50, 84, 1024, 256, 1, 1, 0),
     ("s2.c1 3x3 256->256", 8, 50, 84, 256, 256, 3, 1, 0),
     ("s2.c2 1x1 256->1024 +res", 8, 50, 84, 256, 1024, 1, 1, 1),
@@ -33,7 +35,8 @@ def main():
     for name, B, H, W, Cin, N, k, st, res in SHAPES:
         if only and only not in name:
             continue
-        _capi.check(lib.opd_test_trace_conv(B, H, W, Cin, N, k, st, res, 0, 3, buf, MAXW, C.byref(n)), "trace")
+        split = -res if res < 0 else 0   # (negative "residual" column: split-K factor)
+        _capi.check(lib.opd_test_trace_conv(B, H, W, Cin, N, k, st, max(res, 0), split, 3, buf, MAXW, C.byref(n)), "trace")
         t3 = np.frombuffer(buf, dtype=np.uint64).reshape(3, MAXW, 8).astype(np.int64)
         t3 = [x[x[:, 1] != 0] for x in t3]
         spans = [(x[:, 7].max() - x[:, 0].min()) * 10.0 for x in t3]                       # first entry .. last exit, ns
