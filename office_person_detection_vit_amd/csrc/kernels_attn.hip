@@ -12,12 +12,14 @@
 // j>=4 -> S-tile 2kb+1); V^T fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16
 // (hardware transpose), with a scalar-gather cross-check path selectable at run time.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <math.h>
 #include "opd_kernels.h"
 
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef _Float16 half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
+typedef float float2v __attribute__((ext_vector_type(2)));
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 namespace {
@@ -108,9 +110,14 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     store_tile(0);
     __syncthreads();
 
-    for (int t = 0; t < ntiles; ++t) {
+    // One key tile.  LAST (compile time): the tile may hold keys >= Lk; every other tile of an unmasked launch is full and carries no
+    // masking code at all (a run-time "is this the last tile" inside one loop body made the compiler copy all 16 score registers per
+    // tile to merge the two paths).  Packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two scores per instruction) for the
+    // exponent arguments and the row sum; the exponentials themselves are one v_exp_f32 per score.
+    auto tile_step = [&](const int t, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
         const int buf = t & 1;
-        if (t + 1 < ntiles) load_tile(t + 1);
+        if (!LAST) load_tile(t + 1);
         const unsigned char* Kl = lds + buf * TILE_BYTES;
         const unsigned char* Vl = Kl + K_BYTES;
 
@@ -121,7 +128,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             const half8 kf = *reinterpret_cast<const half8*>(Kl + (kt * 16 + li) * LDS_ROW + g * 16);
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        // ---- online softmax (fp32, base-2 domain: p = exp2(s * scale*log2(e) - m), one v_fma + one v_exp per score; the
+        // ---- online softmax (fp32, base-2 domain: p = exp2(s * scale*log2(e) - m), one fma + one v_exp per score; the
         //      running maximum is taken on the RAW scores and scaled once: scale > 0 keeps the order) ----------------------
         float mx = -INFINITY;
         if (MASKED) {
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                     s[kt][r] = ok ? s[kt][r] : -INFINITY;
                     mx = fmaxf(mx, s[kt][r]);
                 }
-        } else if (t + 1 < ntiles) {  // full tile: no key masking needed
+        } else if (!LAST) {  // full tile: no key masking needed
 #pragma unroll
             for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -154,16 +161,21 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx * scale2);  // finite: tile 0 always holds key 0 (the product rounds once, like s*scale2)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        float psum = 0.f;
+        const float2v sc2 = {scale2, scale2}, mneg = {-m_new, -m_new};
+        float2v psum2 = {0.f, 0.f};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kt][r], scale2, -m_new));   // masked: fma(-inf) = -inf -> 0
-                s[kt][r] = e;
-                psum += e;
+            for (int r = 0; r < 4; r += 2) {
+                const float2v a = __builtin_elementwise_fma(float2v{s[kt][r], s[kt][r + 1]}, sc2, mneg);   // masked: fma(-inf) = -inf -> 0
+                float2v e;
+                e[0] = __builtin_amdgcn_exp2f(a[0]);
+                e[1] = __builtin_amdgcn_exp2f(a[1]);
+                s[kt][r] = e[0];
+                s[kt][r + 1] = e[1];
+                psum2 += e;
             }
-        l_run = l_run * alpha + psum;
+        l_run = l_run * alpha + (psum2[0] + psum2[1]);
         m_run = m_new;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
@@ -198,9 +210,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
             }
         }
-        if (t + 1 < ntiles) store_tile(buf ^ 1);
+        if (!LAST) store_tile(buf ^ 1);
         __syncthreads();
-    }
+    };
+    for (int t = 0; t + 1 < ntiles; ++t) tile_step(t, std::false_type{});
+    tile_step(ntiles - 1, std::true_type{});
 
     float l_tot = l_run + __shfl_xor(l_run, 16, 64);
     l_tot += __shfl_xor(l_tot, 32, 64);
