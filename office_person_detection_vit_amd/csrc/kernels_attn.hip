@@ -44,6 +44,18 @@ __device__ __forceinline__ half4 lds_tr16(const unsigned char* p) {
 // MASKED: per-frame key mask of a ragged batch.  Both are compile-time so that the inner loop carries no branches.
 // KT: keys per LDS tile.  64 for the encoder (VALU bound, many workgroups per CU: the smaller tile keeps registers low);
 // 128 for the decoder (<= 128 queries: a handful of workgroups, each a latency chain of per-tile barriers: 14.6 -> 11.8 us).
+// max over lanes {l, l^16, l^32, l^48}: v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers, so
+// each butterfly step is one swap + one v_max in the VALU (ds_bpermute, what __shfl_xor compiles to, is an LDS round trip)
+__device__ __forceinline__ float xmax16_32(const float v) {
+    // (inline asm: given the same value for both operands, hipcc folds max over the two results of __builtin_amdgcn_permlane16_swap to
+    //  the first one, as if they were equal; s_nop 1 = the VALU-write -> permlane-read hazard the compiler would otherwise cover)
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(b));
+    float c = a;
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_max_f32 %0, %0, %1" : "+v"(a), "+v"(c));
+    return a;
+}
+
 template <bool TR, bool MASKED, int KT>
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     constexpr int NKT = KT / 16;              // 16-key score tiles per LDS tile
@@ -157,8 +169,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                     mx = fmaxf(mx, s[kt][r]);
                 }
         }
-        mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+        mx = xmax16_32(mx);   // over the 4 lanes (16 apart) that share the query
         const float m_new = fmaxf(m_run, mx * scale2);  // finite: tile 0 always holds key 0 (the product rounds once, like s*scale2)
         const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
         const float2v sc2 = {scale2, scale2}, mneg = {-m_new, -m_new};
