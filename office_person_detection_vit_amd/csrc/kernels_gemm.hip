@@ -1373,6 +1373,10 @@ struct StemPoolParams {
     f16_t* out;         // pooled [B][PH][PW][64]
     int B, Hp, Wp, OH, OW, PH, PW;
     int tiles_y, tiles_x;
+    // U8 form (stem_pool2_kernel<true>): the raw frames instead of x4p -- pre-processing happens while the input patch is staged
+    const uint8_t* frames;      // [B][H][W][3] uint8 BGR
+    const int32_t* valid_hw;    // nullable [B][2]: frame sizes inside the canvas (ragged batch); outside -> zeros
+    int H, W;
 };
 
 __global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
@@ -1512,6 +1516,18 @@ constexpr int STEM_PROW = 70 * 8;        // bytes per patch row (70 NHWC4 pixels
 constexpr int STEM_PATCH = 9 * 1024;     // 15 rows x 560 B = 8400 B, staged as 9 one-KiB pieces
 constexpr int STEM_W_BYTES = 7 * 64 * 64;
 
+// U8 = true: the kernel reads the uint8 BGR frames itself.  A patch chunk (2 pixels = 6 source bytes at an arbitrary byte address)
+// is fetched one tile ahead as three aligned dwords per chunk, realigned with v_alignbyte and normalised in registers:
+// fp16(fma(v, A_c, -B_c)) with A_c = (1/255) * (1/std_c), B_c = mean_c * (1/std_c) in fp32 gives, for every byte value v = 0..255 and
+// every channel, the same fp16 as preprocess_u8_kernel's (float(v) * (1/255) - mean_c) / std_c (enumerated: tests/test_host_cpu.py;
+// on the device: the bit-identity test against the two-kernel path) -- so the staged patch is bit-identical to what the two-kernel path
+// stages from the materialised NHWC4 image, and that image (69 MB written, 69 MB read at batch 8) and its launch disappear.
+// (A 768-entry look-up table in LDS was the first form: six 2-byte LDS reads per chunk with random bank conflicts cost the
+//  LDS-bound stem +43 us, more than the 34 us the removed launch took.)
+constexpr float STEM_NA[3] = {0.017124755308032036f, 0.017507001757621765f, 0.01742919534444809f};   // RGB: (1/255) / std
+constexpr float STEM_NB[3] = {2.1179039478302f, 2.0357141494750977f, 1.804444432258606f};            // RGB: mean / std
+
+template <bool U8>
 __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1538,8 +1554,12 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
     const int iy0 = 2 * cy0;                     // first padded-image row of the patch
 
     const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x4p), 0, (unsigned)((size_t)p.B * p.Hp * p.Wp * 8), 0x00020000);
+        // (the frames' byte count rounded up to whole dwords: the bounds check works on dwords, and the last one may hold the final
+        //  pixel's bytes next to <= 3 bytes of the allocation's own padding)
+        U8 ? __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(p.frames), 0, (unsigned)(((size_t)p.B * p.H * p.W * 3 + 3) & ~(size_t)3), 0x00020000)
+           : __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x4p), 0, (unsigned)((size_t)p.B * p.Hp * p.Wp * 8), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, 64 * 256 * 2, 0x00020000);
+    const int vh = U8 ? (p.valid_hw ? p.valid_hw[2 * b] : p.H) : 0, vw = U8 ? (p.valid_hw ? p.valid_hw[2 * b + 1] : p.W) : 0;
 
     // ---- weights: 28 pieces of 16 rows x 64 B (piece q: filter row q>>2, output channels 16*(q&3)..+15), 7 per wave ------
     {
@@ -1575,7 +1595,58 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
             }
         }
     };
-    issue_patch(tx_first, 0);
+    // ---- U8: the same 525 chunks through registers.  Chunk c = patch row c / 35, pixel pair c % 35 <-> image pixels (y, x), (y, x + 1)
+    //      with y = iy0 + row - 3, x = ix0 + 2 pair - 3; its 6 source bytes start at byte ((b H + y) W + x) 3 of the frames.
+    unsigned pre[3][3];   // three aligned dwords per chunk, fetched one tile ahead
+    auto load_patch = [&](int tx) {
+        const int ix0 = 2 * (2 * (tx * 15) - 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = wave + 4 * i;
+            pre[i][0] = pre[i][1] = pre[i][2] = 0u;
+            if (q < 9 && prow[i] < 15) {
+                const int y = iy0 + prow[i] - 3, x = ix0 + 2 * pcol[i] - 3;
+                if ((unsigned)y < (unsigned)vh && x + 1 >= 0 && x < vw) {
+                    // (a pair that starts left of the image, x = -1, is fetched from its second pixel: byte addresses never go negative
+                    //  -- hipcc merges the three loads into one dwordx3, and a start before the buffer would zero all of it)
+                    const int a = (((b * p.H + y) * p.W + (x < 0 ? 0 : x)) * 3) & ~3;
+#pragma unroll
+                    for (int d = 0; d < 3; ++d)
+                        pre[i][d] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, (unsigned)(a + 4 * d), 0, 0);   // past the end: zeros
+                }
+            }
+        }
+    };
+    auto store_patch = [&](int tx, int buf) {
+        const int ix0 = 2 * (2 * (tx * 15) - 1);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int q = wave + 4 * i;
+            if (q < 9 && prow[i] < 15) {
+                const int y = iy0 + prow[i] - 3, x = ix0 + 2 * pcol[i] - 3;
+                const bool row_ok = (unsigned)y < (unsigned)vh;
+                const bool ok0 = row_ok && (unsigned)x < (unsigned)vw, ok1 = row_ok && (unsigned)(x + 1) < (unsigned)vw;
+                const bool shifted = x < 0;   // the fetch started at the pair's second pixel
+                const unsigned sh = (unsigned)(((b * p.H + y) * p.W + (shifted ? 0 : x)) * 3) & 3u;
+                unsigned lo = __builtin_amdgcn_alignbyte(pre[i][1], pre[i][0], sh);   // source bytes 0..3: B0 G0 R0 B1
+                unsigned hi = __builtin_amdgcn_alignbyte(pre[i][2], pre[i][1], sh);   // source bytes 4..7: G1 R1 . .
+                if (shifted) { hi = lo >> 8; lo = lo << 24; }                         // bytes 0..2 are B1 G1 R1
+                auto nrm = [&](const int c, const unsigned byte) { return __builtin_fmaf((float)byte, STEM_NA[c], -STEM_NB[c]); };
+                uint4 o;
+                o.x = ok0 ? pack2h(nrm(0, (lo >> 16) & 255u), nrm(1, (lo >> 8) & 255u)) : 0u;   // R0 G0
+                o.y = ok0 ? pack2h(nrm(2, lo & 255u), 0.f) : 0u;                                // B0 0
+                o.z = ok1 ? pack2h(nrm(0, (hi >> 8) & 255u), nrm(1, hi & 255u)) : 0u;           // R1 G1
+                o.w = ok1 ? pack2h(nrm(2, lo >> 24), 0.f) : 0u;                                 // B1 0
+                *reinterpret_cast<uint4*>(Pin + buf * STEM_PATCH + q * 1024 + lane * 16) = o;
+            }
+        }
+    };
+    if constexpr (U8) {
+        load_patch(tx_first);
+        store_patch(tx_first, 0);
+    } else {
+        issue_patch(tx_first, 0);
+    }
 
     float4v bias2[2];
 #pragma unroll
@@ -1584,7 +1655,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
     for (int tx = tx_first; tx < tx_end; ++tx) {
         const int buf = (tx - tx_first) & 1;
         __syncthreads();   // vmcnt(0): this tile's patch (and, first time, the weights) landed; the previous tile's pooling is done
-        if (tx + 1 < tx_end) issue_patch(tx + 1, buf ^ 1);
+        if (tx + 1 < tx_end) {
+            if constexpr (U8) load_patch(tx + 1);
+            else issue_patch(tx + 1, buf ^ 1);
+        }
         const int px0 = tx * 15, cx0 = 2 * px0 - 1;
         float4v acc[2][5];
 #pragma unroll
@@ -1645,6 +1719,10 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
                 *reinterpret_cast<half8*>(p.out + (((size_t)b * p.PH + py) * p.PW + px) * 64 + c8 * 8) = m;
             }
         }
+        // U8: the next tile's patch goes into the buffer this tile did not use (last read in the k-loop of the tile before: every wave
+        // has passed two barriers since); the barrier at the top of the next iteration publishes it
+        if constexpr (U8)
+            if (tx + 1 < tx_end) store_patch(tx + 1, buf ^ 1);
     }
 #endif
 }
@@ -1748,6 +1826,30 @@ int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_
 static int g_stem_variant = 2;  // 2: input-stationary stem_pool2_kernel (default); 1: im2col stem_pool_kernel (cross-check)
 void opd_set_stem_variant(int v) { g_stem_variant = v == 1 ? 1 : 2; }
 
+// Pre-processing + stem + max-pool in one launch: frames [B][H][W][3] uint8 BGR (valid_hw nullable [B][2]), geometry as below with
+// Hp = 2 OH + 6, Wp = 2 OW + 6 the size the materialised padded image would have.
+hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H,
+                                   int W, int OH, int OW, int PH, int PW, hipStream_t stream) {
+    if (B <= 0 || H <= 0 || W <= 0 || OH != (H - 1) / 2 + 1 || OW != (W - 1) / 2 + 1 || PH != (OH - 1) / 2 + 1 || PW != (OW - 1) / 2 + 1 ||
+        (size_t)B * H * W * 3 >= 0x7fffff00ull)
+        return hipErrorInvalidValue;
+    StemPoolParams p{};
+    p.frames = frames; p.valid_hw = valid_hw; p.H = H; p.W = W;
+    p.w = w; p.bias = bias; p.out = out; p.B = B; p.Hp = 2 * OH + 6; p.Wp = 2 * OW + 6; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
+    p.tiles_y = (PH + 1) / 2;
+    p.tiles_x = (PW + 14) / 15;
+    constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
+    static bool attr2 = false;
+    if (!attr2) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+        if (e != hipSuccess) return e;
+        attr2 = true;
+    }
+    const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
+    hipLaunchKernelGGL(stem_pool2_kernel<true>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
+    return hipGetLastError();
+}
+
 hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
                                 int OW, int PH, int PW, hipStream_t stream) {
     if (Hp < 2 * OH + 6 || Wp < 2 * OW + 6 || (Wp & 1) || PH != (OH - 1) / 2 + 1 || PW != (OW - 1) / 2 + 1 ||
@@ -1761,12 +1863,12 @@ hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* b
         constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
         static bool attr2 = false;
         if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
             if (e != hipSuccess) return e;
             attr2 = true;
         }
         const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
-        hipLaunchKernelGGL(stem_pool2_kernel, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
+        hipLaunchKernelGGL(stem_pool2_kernel<false>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
         return hipGetLastError();
     }
     constexpr int LDS = 2 * (160 + 64) * ROW_BYTES;

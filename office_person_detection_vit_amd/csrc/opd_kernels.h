@@ -54,6 +54,8 @@ struct ConvGemmParams {
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 // fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16
+hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H,
+                                   int W, int OH, int OW, int PH, int PW, hipStream_t stream);   // pre-processing inside the stem
 hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
                                 int OW, int PH, int PW, hipStream_t stream);
 // fused bottleneck tail (kernels_btail.hip):  a1 = relu(conv3x3(x1, w1) + b1) ; y = relu(a1*w2 + b2 + res) ; z = relu(y*w3 + b3)

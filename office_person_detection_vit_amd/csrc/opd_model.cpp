@@ -189,6 +189,7 @@ struct opd_detr {
     int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
+    int fuse_prep = 1;       // uint8 frames: pre-processing inside that kernel (0: preprocess_u8_kernel writes the padded NHWC4 image first)
     // kernels_ffn.hip (64-row workgroups, one per CU, each streaming ALL the weights of the pair of GEMMs): built, parity-tested,
     // measured SLOWER than the launches it replaces at every shape of BASELINE.json, so it is OFF by default (DESIGN.md section 2,
     // profiles/r02_bench_ffn.txt): feed-forward block 62 us against 54 us (M = 8400: 132 workgroups, instruction-issue bound with
@@ -815,13 +816,21 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     timed_reset(m);
     MARK(0);
     const int Hp = 2 * d.H1 + 6, Wp = 2 * d.W1 + 6;  // padded image seen by the stem: rows/cols 2*o + k, k = 0..7
-    RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-    if (pixel_format == OPD_PIXELS_U8_BGR_HWC)
-        HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
-    else
-        HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
-    RCCHK(timed_end(m));
-    if (m->fuse_stem_pool) {
+    const bool prep_in_stem = m->fuse_prep && m->fuse_stem_pool && pixel_format == OPD_PIXELS_U8_BGR_HWC;
+    if (!prep_in_stem) {
+        RCCHK(timed_begin(m, CLS_OTHER, 0.0));
+        if (pixel_format == OPD_PIXELS_U8_BGR_HWC)
+            HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
+        else
+            HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
+        RCCHK(timed_end(m));
+    }
+    if (prep_in_stem) {
+        RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
+        HIPCHK(opd_launch_stem_pool_u8(reinterpret_cast<const uint8_t*>(d_pixels), d_valid, m->stem.w, m->stem.bias, m->d_pool, B, H, W, d.H1, d.W1,
+                                       d.H2, d.W2, m->stream));
+        RCCHK(timed_end(m));
+    } else if (m->fuse_stem_pool) {
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
         HIPCHK(opd_launch_stem_pool(m->d_x4, m->stem.w, m->stem.bias, m->d_pool, B, Hp, Wp, d.H1, d.W1, d.H2, d.W2, m->stream));
         RCCHK(timed_end(m));
@@ -1291,6 +1300,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_TRUNK_SUBBATCH")) m->trunk_subbatch = atoi(v);   // A/B switches for benchmarking
     if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
+    if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1331,7 +1341,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     m->d_dump = nullptr;
     auto cleanup = [&](int code) {
@@ -1727,7 +1737,8 @@ int opd_test_set_fuse_btail(opd_detr* m, int on) {   // bit 0: fused bottleneck 
 }
 int opd_test_set_fuse_stem_pool(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->fuse_stem_pool = on ? 1 : 0;
+    m->fuse_stem_pool = (on & 1) ? 1 : 0;   // bit 0: stem + pool in one kernel; bit 1: pre-processing inside it as well
+    m->fuse_prep = (on & 2) ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();

@@ -591,6 +591,29 @@ int opd_test_stem_pool(const uint16_t* x4p, const uint16_t* w, const float* bias
     return OPD_OK;
 }
 
+// Pre-processing + stem + max-pool in one launch against the two-kernel path on the same uint8 frames: out_fused / out_split =
+// pooled [B][PH][PW][64] fp16 (the caller checks bit-equality); valid_hw nullable [B][2]
+int opd_test_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const uint16_t* w, const float* bias, uint16_t* out_fused,
+                          uint16_t* out_split, int B, int H, int W) {
+    DevMem dm;
+    const int OH = (H - 1) / 2 + 1, OW = (W - 1) / 2 + 1, PH = (OH - 1) / 2 + 1, PW = (OW - 1) / 2 + 1, Hp = 2 * OH + 6, Wp = 2 * OW + 6;
+    const uint8_t* df = dm.up(frames, (size_t)B * H * W * 3);
+    const int32_t* dv = valid_hw ? dm.up(valid_hw, (size_t)2 * B) : nullptr;
+    const uint16_t* dw = dm.up(w, (size_t)64 * 256);
+    const float* db = dm.up(bias, 64);
+    uint16_t* dx = dm.up<uint16_t>(nullptr, (size_t)B * Hp * Wp * 4);
+    uint16_t* d1 = dm.up<uint16_t>(nullptr, (size_t)B * PH * PW * 64);
+    uint16_t* d2 = dm.up<uint16_t>(nullptr, (size_t)B * PH * PW * 64);
+    if (!df || !dw || !db || !dx || !d1 || !d2 || (valid_hw && !dv)) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_stem_pool_u8(df, dv, dw, db, d1, B, H, W, OH, OW, PH, PW, nullptr));
+    TCHK(opd_launch_preprocess_u8(df, dx, B, H, W, Hp, Wp, dv, nullptr));
+    TCHK(opd_launch_stem_pool(dx, dw, db, d2, B, Hp, Wp, OH, OW, PH, PW, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out_fused, d1, (size_t)B * PH * PW * 64 * 2, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(out_split, d2, (size_t)B * PH * PW * 64 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 // host-only helpers of the loader, exposed so CPU tests can exercise them without a GPU
 uint16_t opd_test_f32_to_f16(float f) { return opd::f32_to_f16(f); }
 float opd_test_f16_to_f32(uint16_t h) { return opd::f16_to_f32(h); }

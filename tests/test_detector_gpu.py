@@ -252,6 +252,29 @@ def test_fused_bottleneck_tail_matches_unfused(weight_cache):
     assert np.abs(bx_f - bx_u).max() > 0   # the switch really changed the launch sequence
 
 
+def test_preprocessing_inside_the_stem_is_bit_identical(weight_cache):
+    """uint8 frames: pre-processing inside the stem kernel (default) against preprocess_u8_kernel + stem as two launches -- the same
+    fp16 values reach the same MFMAs, so logits, boxes and the encoder map are BIT-identical, for a uniform and for a ragged batch."""
+    path = ensure_weight_file(weight_cache, DetrArch.resnet50(), 0, 1.0, "r50")
+    det = HipDetrDetector(model_path=path, confidence_threshold=0.5, max_batch=2, max_size=(320, 352), resize=False)
+    det.load_model()
+    import ctypes as C
+    from office_person_detection_vit_amd import _capi
+    lib = _capi.load_library()
+    try:
+        for frames in (structured_frames(2, 256, 320, seed=91),
+                       [structured_frames(1, 256, 320, seed=92)[0], structured_frames(1, 224, 288, seed=93)[0]]):
+            _capi.check(lib.opd_test_set_fuse_stem_pool(C.c_void_p(det.model), 3), "set_fuse_stem_pool")
+            a = det.forward_raw(frames)
+            _capi.check(lib.opd_test_set_fuse_stem_pool(C.c_void_p(det.model), 1), "set_fuse_stem_pool")
+            b = det.forward_raw(frames)
+            for x, y in zip(a, b):
+                np.testing.assert_array_equal(x, y)
+    finally:
+        _capi.check(lib.opd_test_set_fuse_stem_pool(C.c_void_p(det.model), 3), "set_fuse_stem_pool")
+        det.close()
+
+
 def test_fused_projection_layernorm_matches_unfused(weight_cache):
     """Attention output projections through kernels_rowln.hip (default) against GEMM -> LayerNorm (encoder) and split-K
     GEMM -> reduce + LayerNorm (decoder): same operands, fp32 statistics; only the fp32 summation order differs."""

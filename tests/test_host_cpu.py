@@ -330,3 +330,22 @@ def test_feature_extractor_matches_reference_fixture(golden_dir):
     assert fe.extract_roi_features(enc, [], (800, 1333)).shape == tuple(g["empty_shape"])
     with pytest.raises(ValueError, match="Expected 3D encoder features"):
         fe.extract_roi_features(enc[0], [], (800, 1333))
+
+
+def test_stem_normalisation_constants_reproduce_the_reference_arithmetic():
+    """stem_pool2_kernel<U8> normalises a pixel byte as fp16(fma(v, A_c, -B_c)) (kernels_gemm.hip: STEM_NA / STEM_NB) where the
+    pre-processing kernel and the oracle compute (float(v) * (1/255) - mean_c) / std_c.  256 x 3 inputs: enumerate -- the fp16 results
+    must agree for every one (the GPU test test_stem_pool_with_preprocessing_inside_is_bit_identical checks the device's own fma)."""
+    import re
+
+    src = open(os.path.join(os.path.dirname(__file__), "..", "office_person_detection_vit_amd", "csrc", "kernels_gemm.hip")).read()
+    na = [np.float32(x) for x in re.search(r"STEM_NA\[3\] = \{([^}]*)\}", src).group(1).replace("f", "").split(",")]
+    nb = [np.float32(x) for x in re.search(r"STEM_NB\[3\] = \{([^}]*)\}", src).group(1).replace("f", "").split(",")]
+    mean = np.array([0.485, 0.456, 0.406], np.float32)
+    std = np.array([0.229, 0.224, 0.225], np.float32)
+    k = np.float32(1.0) / np.float32(255.0)
+    v = np.arange(256, dtype=np.float32)
+    for c in range(3):
+        ref = ((v * k - mean[c]) / std[c]).astype(np.float32).astype(np.float16)
+        fma = (v.astype(np.float64) * np.float64(na[c]) - np.float64(nb[c])).astype(np.float32).astype(np.float16)   # one rounding to fp32
+        np.testing.assert_array_equal(ref.view(np.uint16), fma.view(np.uint16))

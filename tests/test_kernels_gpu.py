@@ -410,6 +410,35 @@ def test_stem_conv_padded_dma(lib, H, W):
     np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
 
 
+@pytest.mark.parametrize("B,H,W,ragged", [(2, 64, 96, False), (2, 61, 83, False), (1, 203, 333, False), (3, 97, 131, True), (2, 800, 1333, False)])
+def test_stem_pool_with_preprocessing_inside_is_bit_identical(lib, B, H, W, ragged):
+    """stem_pool2_kernel<U8>: the uint8 BGR frames go straight into the stem (normalisation by table look-up while the input patch is
+    staged) against preprocess_u8_kernel -> stem_pool2_kernel on the same frames.  The staged patches are the same fp16 values, so the
+    pooled maps must be BIT-identical -- image borders, odd sizes, tiles overhanging the map, and the zero region of a ragged batch."""
+    rng = np.random.default_rng(B * 7919 + H * 31 + W)
+    frames = rng.integers(0, 256, (B, H, W, 3), dtype=np.uint8)
+    frames[0, : min(H, 5), : min(W, 7)] = 255   # extremes of the table next to the border
+    frames[-1, -3:, -5:] = 0
+    frames[-1, -1, -1] = (201, 77, 254)          # the very last bytes of the buffer (its size need not be a multiple of 4)
+    valid = None
+    if ragged:
+        valid = np.asarray([[H, W], [H - 13, W - 29], [H // 2 + 1, W // 3 + 2]][:B], dtype=np.int32)
+    w = (rng.standard_normal((64, 8, 8, 4)) * 0.1).astype(np.float16)
+    w[:, 7, :, :] = 0
+    w[:, :, 7, :] = 0
+    w[:, :, :, 3] = 0
+    bias = (rng.standard_normal(64) * 0.1).astype(np.float32)
+    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
+    PH, PW = (OH - 1) // 2 + 1, (OW - 1) // 2 + 1
+    fused = np.empty((B, PH, PW, 64), np.uint16)
+    split = np.empty((B, PH, PW, 64), np.uint16)
+    rc = lib.opd_test_stem_pool_u8(_p(np.ascontiguousarray(frames)), _p(valid), _p(np.ascontiguousarray(w.view(np.uint16))), _p(bias),
+                                   _p(fused), _p(split), B, H, W)
+    _capi.check(rc, "opd_test_stem_pool_u8")
+    assert np.isfinite(split.view(np.float16).astype(np.float32)).all() and split.any()
+    np.testing.assert_array_equal(fused, split)
+
+
 @pytest.mark.parametrize("variant", [2, 1], ids=["input_stationary", "im2col"])
 @pytest.mark.parametrize("H,W", [(45, 51), (64, 96), (37, 34), (120, 131), (90, 410)])
 def test_fused_stem_pool(lib, H, W, variant):
