@@ -21,7 +21,8 @@ for r in rows:
     n = r["Kernel_Name"]
     name[d] = (n[n.find("::") + 2:] if "::" in n else n).split("(")[0]
     dur[d] = (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
-start = max(d for d in ids if "preprocess_u8" in name[d])   # last forward of the trace
+first = "preprocess_u8" if any("preprocess_u8" in name[d] for d in ids) else "stem_pool"   # (pre-processing inside the stem)
+start = max(d for d in ids if first in name[d])   # last forward of the trace
 agg = collections.OrderedDict()
 for d in ids:
     if d < start:

@@ -20,7 +20,8 @@ GEMM_FAMILY = ("conv_gemm", "btail_kernel", "gemm_ln256", "gemm_k256_kernel", "s
 def per_kernel(path, counter):
     rows = [r for r in csv.DictReader(open(path)) if r["Counter_Name"] == counter]
     rows.sort(key=lambda r: int(r["Dispatch_Id"]))
-    start = max(i for i, r in enumerate(rows) if "preprocess_u8" in r["Kernel_Name"])  # last forward in the trace
+    first = "preprocess_u8" if any("preprocess_u8" in r["Kernel_Name"] for r in rows) else "stem_pool"   # (pre-processing inside the stem)
+    start = max(i for i, r in enumerate(rows) if first in r["Kernel_Name"])  # last forward in the trace
     agg = collections.OrderedDict()
     for r in rows[start:]:
         n = r["Kernel_Name"]

@@ -19,9 +19,10 @@ def short(name):
 def main():
     rows = list(csv.DictReader(open(sys.argv[1])))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    starts = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]]
+    # a forward begins with the pre-processing kernel, or -- uint8 frames, pre-processing inside the stem -- with the stem itself
+    starts = [i for i, r in enumerate(rows) if "preprocess" in r["Kernel_Name"]] or [i for i, r in enumerate(rows) if "stem_pool" in r["Kernel_Name"]]
     if not starts:
-        sys.exit("no preprocess kernel in trace")
+        sys.exit("no forward found in trace (neither a preprocess nor a stem kernel)")
     seg = rows[starts[-1]:]
     # cut at the last postprocess kernel
     ends = [i for i, r in enumerate(seg) if "postprocess" in r["Kernel_Name"]]
