@@ -93,6 +93,7 @@ TEST_API = {
     "opd_test_stem_pool": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7),
     "opd_test_set_stem_variant": (C.c_int, [C.c_int]),
     "opd_test_set_fuse_stem_pool": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_test_set_pos_shadow": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_stem_pool_u8": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3),
     "opd_test_set_fuse_btail": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_set_fuse_gemm_ln": (C.c_int, [C.c_void_p, C.c_int]),

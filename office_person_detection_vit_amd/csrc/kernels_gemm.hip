@@ -587,7 +587,10 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     const bool stem2 = p.stem == 2;
     if constexpr (BUF) {
         const unsigned a_bytes = stem2 ? (unsigned)((size_t)p.B * p.H * p.W * 8) : (unsigned)((size_t)p.B * p.H * p.W * p.Cin * 2) + backoff;
-        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(p.x)) - backoff, 0, a_bytes, 0x00020000);
+        const f16_t* xsrc = p.x;
+        if constexpr (PW)
+            if (p.x_alt && (n_base % p.alt_mod) >= p.alt_cols) xsrc = p.x_alt;   // (workgroup-uniform: a column tile lies in one group)
+        rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(xsrc)) - backoff, 0, a_bytes, 0x00020000);
         rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
         const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -984,8 +987,9 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
             return hipErrorInvalidValue;
         }
     }
-    if (!buf_ok) return launch_dma_t<BN, false, 4>(p, stream);
+    if (!buf_ok) return p.x_alt ? hipErrorInvalidValue : launch_dma_t<BN, false, 4>(p, stream);
     const bool pw = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1 && p.H == p.OH && p.W == p.OW && !p.stem;
+    if (p.x_alt && (!pw || p.alt_mod <= 0 || (p.alt_mod % BN) != 0 || (p.alt_cols % BN) != 0 || g_pw_persist)) return hipErrorInvalidValue;
     const int mt = pick_mt(p.M, p.N, BN, p.split_k > 1 ? p.split_k : 1);
     if (p.trace) {   // tools/trace_gemm.py
         if (pw) {
@@ -1776,6 +1780,7 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) 
         if ((p.Cin % BK) != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
     }
     if ((long long)p.B * p.OH * p.OW != p.M) return hipErrorInvalidValue;
+    if (p.x_alt && (p.split_k > 1 || p.stem || g_gemm_variant != 1 || g_strip3x3 || !p.zero16)) return hipErrorInvalidValue;
     if (p.split_k > 1) {  // split-K: linear fp32 partial slabs only, reduced by opd_launch_reduce_ln
         if (!p.out_f32 || p.relu || p.res16 || p.res32 || p.out16_aux || p.bias_period != 0 || p.stem || g_gemm_variant < 1 ||
             ((p.K / BK) % p.split_k) != 0)

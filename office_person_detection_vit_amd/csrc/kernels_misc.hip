@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256) void broadcast_rows256_kernel(const float* __r
 __global__ __launch_bounds__(256) void reduce_ln256_kernel(const float* __restrict__ partials, int nsplit, size_t slab_stride,
                                                            const float* __restrict__ residual, const float* __restrict__ gamma,
                                                            const float* __restrict__ beta, float* __restrict__ y,
-                                                           f16_t* __restrict__ y16, int rows) {
+                                                           f16_t* __restrict__ y16, int rows, const float* __restrict__ pos,
+                                                           const float* const* __restrict__ pos_ptrs, int period, f16_t* __restrict__ yp16) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -245,6 +246,14 @@ __global__ __launch_bounds__(256) void reduce_ln256_kernel(const float* __restri
         half4 h;
         h[0] = (_Float16)out[0]; h[1] = (_Float16)out[1]; h[2] = (_Float16)out[2]; h[3] = (_Float16)out[3];
         *reinterpret_cast<half4*>(y16 + o) = h;
+    }
+    if (yp16) {   // second fp16 shadow: the row PLUS its position embedding (what the q / k projections read); pos [period][256] per frame
+        const int fr = row / period, pr = row - fr * period;
+        const float* prow = (pos_ptrs ? pos_ptrs[fr] : pos) + (size_t)pr * 256 + lane * 4;
+        const float4v pe = *reinterpret_cast<const float4v*>(prow);
+        half4 h;
+        h[0] = (_Float16)(out[0] + pe[0]); h[1] = (_Float16)(out[1] + pe[1]); h[2] = (_Float16)(out[2] + pe[2]); h[3] = (_Float16)(out[3] + pe[3]);
+        *reinterpret_cast<half4*>(yp16 + o) = h;
     }
 }
 
@@ -534,9 +543,16 @@ hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int r
 
 hipError_t opd_launch_reduce_ln(const float* partials, int nsplit, size_t slab_stride, const float* residual,
                                 const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream) {
-    if (rows <= 0 || nsplit < 1) return hipErrorInvalidValue;
+    return opd_launch_reduce_ln_pos(partials, nsplit, slab_stride, residual, gamma, beta, y, y16, rows, nullptr, nullptr, 0, nullptr, stream);
+}
+
+// ... plus a second fp16 output yp16 = fp16(y + pos[frame][row % period]) (pos: one table, or pos_ptrs: one table per frame)
+hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma,
+                                    const float* beta, float* y, f16_t* y16, int rows, const float* pos, const float* const* pos_ptrs,
+                                    int period, f16_t* yp16, hipStream_t stream) {
+    if (rows <= 0 || nsplit < 1 || (yp16 && (period <= 0 || (!pos && !pos_ptrs)))) return hipErrorInvalidValue;
     hipLaunchKernelGGL(reduce_ln256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, partials, nsplit, slab_stride, residual,
-                       gamma, beta, y, y16, rows);
+                       gamma, beta, y, y16, rows, pos, pos_ptrs, period, yp16);
     return hipGetLastError();
 }
 

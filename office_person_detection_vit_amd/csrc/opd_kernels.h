@@ -48,6 +48,10 @@ struct ConvGemmParams {
     const f16_t* x2;
     int H2, W2, Cin2, stride2, K1;
     FastDiv fd_ohw, fd_ow, fd_period;  // filled by opd_launch_conv_gemm: division by OH*OW, OW, bias_period
+    // pointwise launches only: column tiles n with n mod alt_mod >= alt_cols read x_alt instead of x (same [M][K] shape) -- the fused
+    // QKV projection reads "x + position embedding" for its q / k columns and x for its v columns
+    const f16_t* x_alt;
+    int alt_mod, alt_cols;
     unsigned tap_rep;                  // filled by opd_launch_conv_gemm: sum over kh of 1 << kh*KW (tap-validity masks)
     FastDiv fd_tilesn, fd_ntiles;      // filled by the LDS-DMA launcher: column tiles, tiles per split-K slice
     unsigned long long* trace;  // tools only: per-workgroup phase stamps [grid][8] (conv_gemm_dma_kernel<..., TRACE>); null in the model
@@ -165,6 +169,9 @@ hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float*
 // reduction of split-K GEMM slabs fused with the residual add and the post-LN of the transformer layers.  D == 256.
 hipError_t opd_launch_reduce_ln(const float* partials, int nsplit, size_t slab_stride, const float* residual,
                                 const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream);
+hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma,
+                                    const float* beta, float* y, f16_t* y16, int rows, const float* pos, const float* const* pos_ptrs,
+                                    int period, f16_t* yp16, hipStream_t stream);   // + yp16 = fp16(y + position embedding)
 // y[row][0..255] = c[0..255] for every row: fp32 y and its fp16 copy.
 hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream);
 // fp32 -> fp16 cast of n elements (n % 8 == 0 not required).

@@ -71,6 +71,7 @@ struct Block {
 };
 struct EncLayer {
     f16_t* wqkv = nullptr;  // [768][256] = [Wq; Wk; Wv]
+    float* bqkv = nullptr;  // [768] = [bq; bk; bv] (pos_shadow path: plain bias vector)
     Lin o, fc1, fc2;
     f16_t* fc2p = nullptr;  // fc2 weights K-permuted for the fused feed-forward kernel (opd_permute_k32)
     LNp ln1, ln2;
@@ -89,6 +90,7 @@ struct Plan {  // everything that depends on the feature-map size (h, w)
     int vh = 0, vw = 0;          // valid (unpadded) rows / columns of the feature map this fold was built for (== fh, fw unless ragged)
     std::vector<float*> rb_enc;  // per encoder layer [hw][768]
     float* rb_kv = nullptr;      // [hw][dec_layers*512]
+    float* d_pos = nullptr;      // [hw][256] the sine position embedding itself (pos_shadow path)
 };
 
 struct Dims {
@@ -132,6 +134,7 @@ struct opd_detr {
     std::vector<EncLayer> enc;
     std::vector<DecLayer> dec;
     f16_t* wkv_all = nullptr;  // [dec_layers*512][256] = per layer [Wk_c; Wv_c]
+    float* bkv_all = nullptr;  // [dec_layers*512] = per layer [bk_c; bv_c] (pos_shadow path)
     float* dec0_h = nullptr;   // [256]: decoder state after the self-attention block of layer 0 (input independent, see build_weights)
     int fuse_dec0 = 1;         // use it (0: run that block's four launches on the zero state like every other layer)
     LNp dec_ln;
@@ -148,6 +151,7 @@ struct opd_detr {
     f16_t *d_x4 = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_m0 = nullptr,
           *d_m1 = nullptr, *d_sc = nullptr;
     float *d_x32 = nullptr, *d_y32 = nullptr, *d_slab = nullptr;
+    f16_t* d_xp16 = nullptr;   // fp16(x + position embedding): the q / k projections' input (pos_shadow)
     f16_t *d_x16 = nullptr, *d_qkv16 = nullptr, *d_attn16 = nullptr, *d_ffn16 = nullptr, *d_memkv16 = nullptr;
     float *d_h32 = nullptr, *d_yd32 = nullptr, *d_hs32 = nullptr;
     f16_t *d_h16 = nullptr, *d_qkvd16 = nullptr, *d_qd16 = nullptr, *d_attnd16 = nullptr, *d_ffnd16 = nullptr;
@@ -156,7 +160,7 @@ struct opd_detr {
     int32_t *d_counts = nullptr, *d_orig_hw = nullptr;
     // ragged batches (frames smaller than the canvas): per-frame valid sizes and per-frame bias-fold pointers
     int32_t *d_valid_hw = nullptr, *d_key_valid = nullptr;
-    const float** d_bias_ptrs = nullptr;   // [(enc_layers + 1)][max_batch]
+    const float** d_bias_ptrs = nullptr;   // [(enc_layers + 2)][max_batch]: bias folds per encoder layer, K/V fold, position embeddings
     std::vector<int32_t> h_valid_hw, h_key_valid;
     std::vector<const float*> h_bias_ptrs;
     // asynchronous submissions (opd_detr_detect_async): one completion event per in-flight ticket
@@ -189,6 +193,8 @@ struct opd_detr {
     int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
     int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
+    int pos_shadow = 1;      // q / k projections read a second fp16 shadow "x + position embedding" (written by the producer of x) instead
+                             // of adding a row-periodic fp32 bias table W.pos + b per output tile (0: the table, the round-1 form)
     int fuse_prep = 1;       // uint8 frames: pre-processing inside that kernel (0: preprocess_u8_kernel writes the padded NHWC4 image first)
     // kernels_ffn.hip (64-row workgroups, one per CU, each streaming ALL the weights of the pair of GEMMs): built, parity-tested,
     // measured SLOWER than the launches it replaces at every shape of BASELINE.json, so it is OFF by default (DESIGN.md section 2,
@@ -373,6 +379,7 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         std::vector<float> wfull;
         cat3(p + ".self_attn", &wfull, &m->h_enc_cat_w[i], &m->h_enc_cat_b[i]);
         RCCHK(upload_f16(m, &L.wqkv, wfull));
+        RCCHK(upload_f32(m, &L.bqkv, m->h_enc_cat_b[i]));
         RCCHK(make_lin(m, sd, p + ".self_attn.o_proj", &L.o));
         RCCHK(make_ln(m, sd, p + ".self_attn_layer_norm", &L.ln1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
@@ -426,6 +433,7 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln3));
     }
     RCCHK(upload_f16(m, &m->wkv_all, kv_full));
+    RCCHK(upload_f32(m, &m->bkv_all, m->h_kv_cat_b));
     {   // The decoder starts from h = 0 (HF:models/detr/modeling_detr.py:1243-1251), so in layer 0 the self-attention values are the
         // same row for every query, v = 0 . Wv^T + bv, the softmax weights of a row sum to one, and the block's output
         // LN(0 + Wo . bv + bo) is ONE vector, whatever the frame shows: computed here once in fp32, broadcast at run time instead of
@@ -517,6 +525,7 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_y32, M * D, false));
     RCCHK(dalloc(m, &m->d_slab, std::max(M * D * 4, Md * D * 8), false));
     RCCHK(dalloc(m, &m->d_x16, M * D, false));
+    RCCHK(dalloc(m, &m->d_xp16, M * D, false));
     RCCHK(dalloc(m, &m->d_qkv16, M * 3 * D, false));
     RCCHK(dalloc(m, &m->d_attn16, M * D, false));
     RCCHK(dalloc(m, &m->d_ffn16, M * a.ffn, false));
@@ -536,7 +545,7 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_orig_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_valid_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_key_valid, B * 2, false));
-    RCCHK(dalloc(m, &m->d_bias_ptrs, (size_t)(a.enc_layers + 1) * B, false));
+    RCCHK(dalloc(m, &m->d_bias_ptrs, (size_t)(a.enc_layers + 2) * B, false));
     RCCHK(dalloc(m, &m->d_dump, (size_t)128, false));
     RCCHK(dalloc(m, &m->d_rois, (size_t)128 * 4, false));
     RCCHK(dalloc(m, &m->d_roi_out, (size_t)128 * D, false));
@@ -588,6 +597,7 @@ static int get_plan(opd_detr* m, int fh, int fw, int vh, int vw, Plan** out) {
     sine_pos_embed(fh, fw, vh, vw, D, &pos);
     float* d_pos = nullptr;
     RCCHK(upload_f32(m, &d_pos, pos));
+    p->d_pos = d_pos;
     p->rb_enc.resize(a.enc_layers);
     for (int i = 0; i < a.enc_layers; ++i) {
         float *d_w = nullptr, *d_b = nullptr;
@@ -666,9 +676,10 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
 // out[M][N] = x16[M][K] . w[N][K]^T + bias (+ res32), as a 1x1 "convolution" over M pixels
 static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
                     void* out, bool out_f32, bool relu, const float* res32, const float* const* bias_ptrs = nullptr, int bias_pmod = 0,
-                    int bias_pcols = 0) {
+                    int bias_pcols = 0, const f16_t* x_alt = nullptr, int alt_mod = 0, int alt_cols = 0) {
     ConvGemmParams p{};
     p.bias_ptrs = bias_ptrs; p.bias_pmod = bias_pmod; p.bias_pcols = bias_pcols;
+    p.x_alt = x_alt; p.alt_mod = alt_mod; p.alt_cols = alt_cols;
     p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0;
@@ -680,8 +691,9 @@ static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bi
 
 // Split-K flavour for skinny / deep-K linears: slices write fp32 slabs, then ONE fused kernel reduces them in slice
 // order, adds the residual stream and applies the post-LayerNorm (gamma == nullptr: plain sum, e.g. input_projection).
+struct PosShadow { const float* pos; const float* const* pos_ptrs; int period; f16_t* yp16; };   // second fp16 output of a reduce + LN
 static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int N, int K, int splits,
-                              const float* res32, const LNp* ln, float* y32, f16_t* y16, int cls) {
+                              const float* res32, const LNp* ln, float* y32, f16_t* y16, int cls, const PosShadow* ps = nullptr) {
     ConvGemmParams p{};
     p.x = x; p.w = w; p.bias = bias; p.out = m->d_slab; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
@@ -690,8 +702,8 @@ static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
     RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-    HIPCHK(opd_launch_reduce_ln(m->d_slab, splits, (size_t)M * N, res32, ln ? ln->g : nullptr, ln ? ln->b : nullptr, y32, y16, M,
-                                m->stream));
+    HIPCHK(opd_launch_reduce_ln_pos(m->d_slab, splits, (size_t)M * N, res32, ln ? ln->g : nullptr, ln ? ln->b : nullptr, y32, y16, M,
+                                    ps ? ps->pos : nullptr, ps ? ps->pos_ptrs : nullptr, ps ? ps->period : 0, ps ? ps->yp16 : nullptr, m->stream));
     RCCHK(timed_end(m));
     return OPD_OK;
 }
@@ -784,6 +796,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     Plan* plan = nullptr;
     const float* const* enc_bias_ptrs[16] = {};   // per encoder layer: device array of B per-frame fold pointers (ragged only)
     const float* const* kv_bias_ptrs = nullptr;
+    const float* const* pos_ptrs = nullptr;       // per-frame position embeddings (ragged only)
     const int32_t *d_valid = nullptr, *d_keyv = nullptr;
     if (!ragged) {
         RCCHK(get_plan(m, fh, fw, fh, fw, &plan));
@@ -791,7 +804,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         if (a.enc_layers > 16) return fail(OPD_EINVAL, "ragged batches: at most 16 encoder layers");
         m->h_valid_hw.assign(valid_hw, valid_hw + 2 * B);
         m->h_key_valid.resize((size_t)2 * B);
-        m->h_bias_ptrs.assign((size_t)(a.enc_layers + 1) * B, nullptr);
+        m->h_bias_ptrs.assign((size_t)(a.enc_layers + 2) * B, nullptr);
         for (int b = 0; b < B; ++b) {
             const int vh = valid_hw[2 * b], vw = valid_hw[2 * b + 1];
             if (vh < 1 || vw < 1 || vh > H || vw > W) return fail(OPD_EINVAL, "valid_hw outside the frame canvas");
@@ -803,6 +816,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             if (b == 0) plan = pb;
             for (int i = 0; i < a.enc_layers; ++i) m->h_bias_ptrs[(size_t)i * B + b] = pb->rb_enc[i];
             m->h_bias_ptrs[(size_t)a.enc_layers * B + b] = pb->rb_kv;
+            m->h_bias_ptrs[(size_t)(a.enc_layers + 1) * B + b] = pb->d_pos;
         }
         // (member vectors: they outlive the asynchronous copies; every entry point synchronises before it returns)
         HIPCHK(hipMemcpyAsync(m->d_valid_hw, m->h_valid_hw.data(), (size_t)2 * B * 4, hipMemcpyHostToDevice, m->stream));
@@ -810,6 +824,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         HIPCHK(hipMemcpyAsync(m->d_bias_ptrs, m->h_bias_ptrs.data(), m->h_bias_ptrs.size() * sizeof(float*), hipMemcpyHostToDevice, m->stream));
         for (int i = 0; i < a.enc_layers; ++i) enc_bias_ptrs[i] = m->d_bias_ptrs + (size_t)i * B;
         kv_bias_ptrs = m->d_bias_ptrs + (size_t)a.enc_layers * B;
+        pos_ptrs = m->d_bias_ptrs + (size_t)(a.enc_layers + 1) * B;
         d_valid = m->d_valid_hw;
         d_keyv = m->d_key_valid;
     }
@@ -968,10 +983,20 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     const int ch = st.ch, cw = st.cw;
     // ---- input projection -> encoder ------------------------------------------------------------------------------
     const int hw = ch * cw, M = B * hw, D = a.d_model, F = a.ffn;
-    RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV));
+    // pos_shadow: whoever writes x (input projection, each layer's last LayerNorm) also writes fp16(x + pos); the fused QKV projection
+    // reads that for its q / k column tiles and x for its v tiles, with a plain bias vector -- instead of x everywhere plus a [hw][768]
+    // fp32 table W.pos + b added per output tile (two divisions and 16 dependent table loads per lane in front of the first MFMA:
+    // 14.2 us per launch against 9.4 for the same GEMM with a bias vector; decoder K/V 44.7 against 24-27)
+    const bool shadow = m->pos_shadow && !m->fuse_ffn && D == 256 && (opd_get_gemm_variant() & 0x8ff) == 1 && m->enc[0].bqkv && m->bkv_all;
+    const PosShadow psh{plan->d_pos, pos_ptrs, hw, m->d_xp16};
+    const PosShadow* ps = shadow ? &psh : nullptr;
+    RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV, ps));
     for (int i = 0; i < a.enc_layers; ++i) {
         const EncLayer& L = m->enc[i];
-        RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i], 3 * D, 2 * D));   // (pos enters q and k only)
+        if (shadow)
+            RCCHK(run_gemm(m, m->d_xp16, L.wqkv, L.bqkv, 0, M, 3 * D, D, m->d_qkv16, false, false, nullptr, nullptr, 0, 0, m->d_x16, 3 * D, 2 * D));
+        else
+            RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i], 3 * D, 2 * D));   // (pos enters q and k only)
         RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw, d_keyv, cw));
         if (m->fuse_gemm_ln && D == 256) {
             RCCHK(run_gemm_ln(m, m->d_attn16, L.o.w, L.o.b, M, D, m->d_x32, L.ln1, m->d_x32, m->d_x16));
@@ -992,13 +1017,16 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
             // (fc2 + residual + LayerNorm as ONE row-owner launch — gemm_ln256_kernel with K = 2048 — was measured: encoder 1.05 ms
             //  against 1.00 ms; every 32-row workgroup would stream the whole 1 MiB of fc2 weights)
-            RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM));
+            RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM, ps));
         }
     }
     MARK(6);
     // ---- decoder -----------------------------------------------------------------------------------------------
     const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
-    RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs, 2 * D, D));   // (per layer [k | v]: pos enters k only)
+    if (shadow)
+        RCCHK(run_gemm(m, m->d_xp16, m->wkv_all, m->bkv_all, 0, M, NKV, D, m->d_memkv16, false, false, nullptr, nullptr, 0, 0, m->d_x16, 2 * D, D));
+    else
+        RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs, 2 * D, D));   // (per layer [k | v]: pos enters k only)
     const bool dec0 = m->fuse_dec0 && m->dec0_h && D == 256;
     if (dec0) {
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
@@ -1301,6 +1329,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
+    if (const char* v = getenv("OPD_POS_SHADOW")) m->pos_shadow = atoi(v);
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1336,12 +1365,12 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     // everything build_weights produced: device pointers into the shared WeightSet and the host copies the plans are folded from
     m->weights = src->weights; m->weights_sealed = true; m->weight_bytes = src->weight_bytes;
     m->stem = src->stem; m->blocks = src->blocks; m->stage_first = src->stage_first; m->proj = src->proj;
-    m->enc = src->enc; m->dec = src->dec; m->wkv_all = src->wkv_all; m->dec_ln = src->dec_ln;
+    m->enc = src->enc; m->dec = src->dec; m->wkv_all = src->wkv_all; m->bkv_all = src->bkv_all; m->dec_ln = src->dec_ln;
     m->wc = src->wc; m->bc = src->bc; m->w1 = src->w1; m->b1 = src->b1; m->w2 = src->w2; m->b2 = src->b2; m->w3 = src->w3; m->b3 = src->b3;
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     m->d_dump = nullptr;
     auto cleanup = [&](int code) {
@@ -1730,6 +1759,14 @@ int opd_test_set_fuse_btail(opd_detr* m, int on) {   // bit 0: fused bottleneck 
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_btail = (on & 1) ? 1 : 0;
     m->fuse_shortcut = (on & 2) ? 1 : 0;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+int opd_test_set_pos_shadow(opd_detr* m, int on) {   // 0: row-periodic bias tables W.pos + b (round-1 form) instead of the fp16(x + pos) shadow
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->pos_shadow = on ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();

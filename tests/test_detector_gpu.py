@@ -275,6 +275,31 @@ def test_preprocessing_inside_the_stem_is_bit_identical(weight_cache):
         det.close()
 
 
+def test_position_shadow_matches_bias_tables(weight_cache):
+    """q / k projections on fp16(x + pos) (default) against x plus the row-periodic fp32 table W.pos + b (the round-1 form): the same
+    linear map, with the position term rounded once to fp16 inside the operand instead of being exact in the bias -- one more fp16
+    rounding of the kind every activation already has, so the difference stays inside the golden-vector bounds; uniform and ragged
+    batch (per-frame position tables), and a wrong column split (v reading x + pos, or k reading x) would be far outside."""
+    path = ensure_weight_file(weight_cache, DetrArch.resnet50(), 0, 1.0, "r50")
+    det = HipDetrDetector(model_path=path, confidence_threshold=0.5, max_batch=2, max_size=(320, 352), resize=False)
+    det.load_model()
+    import ctypes as C
+    from office_person_detection_vit_amd import _capi
+    lib = _capi.load_library()
+    try:
+        for frames in (structured_frames(2, 256, 320, seed=95),
+                       [structured_frames(1, 256, 320, seed=96)[0], structured_frames(1, 224, 288, seed=97)[0]]):
+            _capi.check(lib.opd_test_set_pos_shadow(C.c_void_p(det.model), 1), "set_pos_shadow")
+            lg_s, bx_s, enc_s = det.forward_raw(frames)
+            _capi.check(lib.opd_test_set_pos_shadow(C.c_void_p(det.model), 0), "set_pos_shadow")
+            lg_t, bx_t, enc_t = det.forward_raw(frames)
+            assert 0 < np.abs(enc_s - enc_t).max() < TOL[1.0][2]
+            assert np.abs(bx_s - bx_t).max() < TOL[1.0][0] and np.abs(_softmax(lg_s) - _softmax(lg_t)).max() < TOL[1.0][1]
+    finally:
+        _capi.check(lib.opd_test_set_pos_shadow(C.c_void_p(det.model), 1), "set_pos_shadow")
+        det.close()
+
+
 def test_fused_projection_layernorm_matches_unfused(weight_cache):
     """Attention output projections through kernels_rowln.hip (default) against GEMM -> LayerNorm (encoder) and split-K
     GEMM -> reduce + LayerNorm (decoder): same operands, fp32 statistics; only the fp32 summation order differs."""
