@@ -103,9 +103,17 @@ __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory")
 // that a separate launch wrote (274 MB at batch 8) and this kernel read back: the 64 shortcut channels of the wave's 32 pixels sit
 // in 16 VGPRs as B fragments, the 64 x 64 slice of Wsc travels with the W2 / W3 chunk operands.  The shortcut is no longer
 // rounded to fp16 on the way (one rounding fewer than the unfused path; the reference rounds nothing).
-template <int C1, int C3, bool RDMA, bool SC = false>
+// TRACE (tools/trace_btail.py): wave 0 stamps the shader clock at the phase boundaries and writes p.trace[blockIdx.x][16] at the end:
+// {wall clock in, entry, prologue done, 3x3 loop done, chunk 0 .. NCH-1 done, stores retired, ..., [15] wall clock out}.
+template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false>
 __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
+    unsigned long long tstamp[16] = {};
+    auto stamp = [&](const int i) {
+        if constexpr (TRACE) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[i])::"memory");
+    };
+    if constexpr (TRACE) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[0])::"memory");
+    stamp(1);
     static_assert(!RDMA || C1 == 64, "residual staging buffers are budgeted for C1 == 64 (80 KiB of LDS per workgroup)");
     static_assert(!SC || (C1 == 64 && !RDMA), "fused shortcut: 64-channel tails only; it replaces the residual");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -273,6 +281,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             }
         }
     }
+    stamp(2);
     issue_main(ks_first, ks_first & 1);
     float4v acc1[NT1][2];
 #pragma unroll
@@ -317,6 +326,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     else if (counted) wait_vmcnt<8>();           // chunk 0 operands landed (the 8 residual loads may still fly)
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
+    stamp(3);
 
     // ---- a1 = relu(c1) as fp16 B operands: k-block kk <- accumulator tiles 2kk, 2kk+1 -----------------------------------
     half8 a1[2][KK1];
@@ -448,6 +458,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             else wait_vmcnt<4>();
             __builtin_amdgcn_s_barrier();
         }
+        stamp(4 + j);
     }
 
     // ---- z = relu(c0') -----------------------------------------------------------------------------------------------------
@@ -466,19 +477,29 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             if (pr_ok && !(p.dbg & 2)) *reinterpret_cast<uint4*>(p.z + zrow + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
         }
     }
+    if constexpr (TRACE) {
+        stamp(4 + NCH);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5 + NCH);
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[15])::"memory");
+        if (threadIdx.x == 0 && p.trace) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) p.trace[(size_t)blockIdx.x * 16 + i] = tstamp[i];
+        }
+    }
 #endif
 }
 
-template <int C1, int C3, bool RDMA, bool SC = false>
+template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false>
 hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * (128 + C1) * ROW_BYTES + (RDMA ? 2 * 16384 : 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3, RDMA, SC>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3, RDMA, SC, TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA, SC>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA, SC, TRACE>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -497,6 +518,12 @@ hipError_t opd_launch_btail(const BtailParams& p_in, hipStream_t stream) {
     if (p.xs) {   // fused shortcut convolution: stride 1, 64 -> 256 channels next to a 64-channel 3x3 (first block of stage 1)
         if (p.C1 != 64 || p.C3 != 64 || p.stride != 1 || !p.wsc || p.res || (size_t)p.M * 64 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
         return launch_btail_t<64, 64, false, true>(p, stream);
+    }
+    if (p.trace) {   // tools/trace_btail.py: the two shapes that dominate stages 1 and 2
+        if (p.C1 == 64 && p.C3 == 64 && (p.dbg & 16)) return launch_btail_t<64, 64, false, false, true>(p, stream);
+        if (p.C1 == 64 && p.C3 == 64) return launch_btail_t<64, 64, true, false, true>(p, stream);
+        if (p.C1 == 128 && p.C3 == 128) return launch_btail_t<128, 128, false, false, true>(p, stream);
+        return hipErrorInvalidValue;
     }
     if (p.C1 == 64) {
         const bool rdma = !(p.dbg & 16);   // dbg 16: residual through VGPR loads (the first form: cross-check / timing)

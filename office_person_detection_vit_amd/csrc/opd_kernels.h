@@ -81,6 +81,7 @@ struct BtailParams {
     int B, H, W, OH, OW, stride, M, C1, C3;
     int dbg;           // timing ablations for tools (0 = normal): 1 skip the 3x3 loop, 2 skip stores, 4 skip residual, 8 stop after the 3x3
     FastDiv fd_ohw, fd_ow;   // filled by opd_launch_btail
+    unsigned long long* trace;   // tools only: per-workgroup phase stamps [grid][16] (btail_kernel<..., TRACE>); null in the model
     int rev;           // 1: each XCD walks its tiles in descending order (results identical; see kernels_btail.hip)
 };
 bool opd_btail_supported(int C1, int C3);

@@ -426,6 +426,43 @@ int opd_test_btail_sc(const uint16_t* x1, const uint16_t* w1, const float* b1, c
 
 // Times the fused tail (us_out[0]) and the three unfused launches it replaces (us_out[1..3]: c1, c2, c0') on
 // device-resident data of the given shape.
+// Two warm launches, then one traced launch of a fused tail: trace_out [wgs][16] (kernels_btail.hip, TRACE), *wgs_out = grid size
+int opd_test_trace_btail(int B, int H, int W, int C1, int C3, int dbg, unsigned long long* trace_out, int max_wgs, int* wgs_out) {
+    if (!opd_btail_supported(C1, C3)) return tfail(OPD_EINVAL, "btail: unsupported (C1, C3)");
+    DevMem dm;
+    const int C2 = 4 * C1;
+    const size_t M = (size_t)B * H * W;
+    const int wgs = (int)((M + 127) / 128);
+    if (wgs > max_wgs) return tfail(OPD_EINVAL, "trace buffer too small");
+    uint16_t* x1 = dm.up<uint16_t>(nullptr, M * C1);
+    uint16_t* w1 = dm.up<uint16_t>(nullptr, (size_t)C1 * 9 * C1);
+    uint16_t* w2 = dm.up<uint16_t>(nullptr, (size_t)C2 * C1);
+    uint16_t* w3 = dm.up<uint16_t>(nullptr, (size_t)C3 * C2);
+    float* bias = dm.up<float>(nullptr, C2);
+    uint16_t* res = dm.up<uint16_t>(nullptr, M * C2);
+    uint16_t* y = dm.up<uint16_t>(nullptr, M * C2);
+    uint16_t* z = dm.up<uint16_t>(nullptr, M * C3);
+    unsigned long long* tr = dm.up<unsigned long long>(nullptr, (size_t)wgs * 16);
+    if (!x1 || !w1 || !w2 || !w3 || !bias || !res || !y || !z || !tr) return tfail(OPD_ENOMEM, "trace alloc failed");
+    TCHK(hipMemset(x1, 0x2c, M * C1 * 2));
+    TCHK(hipMemset(w1, 0x1c, (size_t)C1 * 9 * C1 * 2));
+    TCHK(hipMemset(w2, 0x1c, (size_t)C2 * C1 * 2));
+    TCHK(hipMemset(w3, 0x1c, (size_t)C3 * C2 * 2));
+    TCHK(hipMemset(bias, 0, (size_t)C2 * 4));
+    TCHK(hipMemset(res, 0x2c, M * C2 * 2));
+    TCHK(hipMemset(tr, 0, (size_t)wgs * 128));
+    BtailParams p{};
+    p.x1 = x1; p.w1 = w1; p.b1 = bias; p.w2p = w2; p.b2 = bias; p.res = res; p.y = y; p.w3p = w3; p.b3 = bias; p.z = z;
+    p.B = B; p.H = H; p.W = W; p.OH = H; p.OW = W; p.stride = 1; p.M = (int)M; p.C1 = C1; p.C3 = C3; p.dbg = dbg;
+    for (int i = 0; i < 2; ++i) TCHK(opd_launch_btail(p, nullptr));
+    p.trace = tr;
+    TCHK(opd_launch_btail(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(trace_out, tr, (size_t)wgs * 128, hipMemcpyDeviceToHost));
+    *wgs_out = wgs;
+    return OPD_OK;
+}
+
 int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int dbg, int iters, float* us_out) {
     if (!opd_btail_supported(C1, C3)) return tfail(OPD_EINVAL, "btail: unsupported (C1, C3)");
     DevMem dm;
