@@ -49,6 +49,16 @@ def launch_ranks(n: int, argv, env=None, script=None) -> int:
     port = s.getsockname()[1]
     s.close()
     procs = []
+
+    def on_signal(signum, _frame):   # the parent is being stopped: take the ranks it started down with it (never orphan GPU children)
+        for pr in procs:
+            if pr.poll() is None:
+                pr.terminate()
+        sys.exit(128 + signum)
+
+    import signal
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        signal.signal(sig, on_signal)
     for r in range(n):
         e = dict(os.environ if env is None else env)
         e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
@@ -214,6 +224,8 @@ def main() -> int:
     g_flat = torch.zeros((world * (NREC + B),), dtype=torch.int32, device=gdev) if world > 1 else None
     hw = np.asarray([[H, W]] * B, dtype=np.int32)
     DetP, I32P = C.POINTER(_capi.OpdDet), C.POINTER(C.c_int32)
+    if not rehearsal:
+        torch.cuda.synchronize()   # the buffers above were filled on torch's stream; the library writes them from its own streams
 
     def collect(buf):
         """records (+ counts) of one finished step -> the orchestrator's host memory (the path's one exchange step for N > 1),
@@ -221,6 +233,10 @@ def main() -> int:
         if world > 1:
             dist.all_gather_into_tensor(g_flat, buf if backend == "nccl" else buf.cpu())
             if rank != 0:
+                # `buf` is a rotating buffer that a later step's post-process kernel rewrites from the LIBRARY's stream, which knows
+                # nothing of torch's / RCCL's streams: host-wait here until the collective has read it (rank 0 waits in .cpu() below)
+                if backend == "nccl":
+                    torch.cuda.current_stream().synchronize()
                 return None
             g = g_flat.cpu().view(world, NREC + B).numpy()
             recs = np.ascontiguousarray(g[:, :NREC]).reshape(world * B * Q, 8)

@@ -114,6 +114,11 @@ TEST_API = {
     "opd_test_etail": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3),
     "opd_test_bench_ffn": (C.c_int, [C.c_int] * 5 + [C.c_void_p]),
     "opd_test_set_fuse_ffn": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_test_set_graph_guard": (C.c_int, [C.c_int]),
+    "opd_test_set_alloc_poison": (C.c_int, [C.c_int]),
+    "opd_test_check_redzones": (C.c_int, [C.c_void_p]),
+    "opd_test_set_taps": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_test_read_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
 }
 
 _lib: Optional[C.CDLL] = None

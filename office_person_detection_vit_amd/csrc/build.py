@@ -30,15 +30,23 @@ def build(verbose: bool = False, force: bool = False) -> str:
     # per-file code-generation options: the attention kernel consumes its S = K.Q^T accumulators with VALU right away, so its
     # MFMAs should write VGPRs (the default AGPR form costs 56 v_accvgpr moves per key tile in a VALU-bound loop)
     extra = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+    jobs = []
     for src in SOURCES:
         sp = os.path.join(HERE, src)
         obj = os.path.join(objdir, os.path.splitext(src)[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
-            cmd = [hipcc] + common + extra.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj]
-            if verbose:
-                print(" ".join(cmd), flush=True)
-            subprocess.run(cmd, check=True)
+            jobs.append([hipcc] + common + extra.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj])
+
+    def compile_one(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True)
+
+    if jobs:   # independent translation units: compile them side by side (bounded by the host's cores)
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
+            list(pool.map(compile_one, jobs))
     if force or _stale(LIB, objs):
         cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
         if verbose:

@@ -556,6 +556,26 @@ hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t sl
     return hipGetLastError();
 }
 
+// Diagnostic tap (opd_test_set_taps): position-weighted 64-bit sum of a buffer's 32-bit words, one partial per block.
+static __global__ void checksum_kernel(const uint32_t* __restrict__ buf, size_t nwords, unsigned long long* __restrict__ slots) {
+    __shared__ unsigned long long part[256];
+    unsigned long long acc = 0ull;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < nwords; i += (size_t)gridDim.x * blockDim.x)
+        acc += (unsigned long long)buf[i] * (unsigned long long)((i * 2654435761ull + 1ull) | 1ull);
+    part[threadIdx.x] = acc;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if ((int)threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) slots[blockIdx.x] = part[0];
+}
+
+hipError_t opd_launch_checksum(const void* buf, size_t bytes, unsigned long long* slots, hipStream_t stream) {
+    hipLaunchKernelGGL(checksum_kernel, dim3(OPD_TAP_BLOCKS), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(buf), bytes / 4, slots);
+    return hipGetLastError();
+}
+
 hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream) {
     hipLaunchKernelGGL(cast_f16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, y, n);
     return hipGetLastError();

@@ -177,6 +177,9 @@ hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t sl
 hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream);
 // fp32 -> fp16 cast of n elements (n % 8 == 0 not required).
 hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream);
+// diagnostic tap: position-weighted 64-bit sums of `bytes / 4` words, OPD_TAP_BLOCKS partials written to slots[0 .. OPD_TAP_BLOCKS)
+#define OPD_TAP_BLOCKS 64
+hipError_t opd_launch_checksum(const void* buf, size_t bytes, unsigned long long* slots, hipStream_t stream);
 // naive fp32 GEMM used once at plan-build time: C[m][n] = sum_k A[m][k]*Wt[n][k] + bias[n]  (Wt fp32 [N][K])
 hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K,
                                int ldc, hipStream_t stream);

@@ -105,8 +105,10 @@ static int down2(int n) { return (n - 1) / 2 + 1; }
 using namespace opd;
 
 // Device buffers of the folded weights: shared (read-only after opd_detr_create) by a handle and its clones, freed with the last one.
+struct RedZoned { void* base; size_t bytes; int poison; };   // a poison-mode allocation: [red zone | bytes | red zone] at base
 struct WeightSet {
     std::vector<void*> allocs;
+    std::vector<RedZoned> zoned;
     int device = 0;
     // per-resolution bias folds (Plan): functions of the weights and the feature-map size only, so clones share them too
     std::mutex plan_mu;
@@ -123,6 +125,7 @@ struct opd_detr {
     int device = 0;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;              // this handle's own buffers: workspace, per-resolution plans
+    std::vector<RedZoned> zoned;            // poison mode only: the same buffers with their red zones
     std::shared_ptr<WeightSet> weights;     // the model's weights (shared with clones)
     bool weights_sealed = false;            // set once the weights are built: later "weight" allocations (plans) are the handle's own
     int64_t weight_bytes = 0, workspace_bytes = 0;
@@ -218,19 +221,40 @@ struct opd_detr {
     float class_ms[4] = {};
     int class_launches[4] = {};
     double class_flops[4] = {};
+
+    // diagnostic taps (opd_test_set_taps): a checksum launch after every launch of the forward, captured into the graph with it
+    int taps = 0;
+    unsigned long long* d_taps = nullptr;   // [OPD_MAX_TAPS][OPD_TAP_BLOCKS]
+    int tap_next = 0;
+    std::vector<std::string> tap_names;
 };
+enum { OPD_MAX_TAPS = 512 };
 
 namespace opd {
+
+// Diagnostic allocation mode (opd_test_set_alloc_poison; -1 = off): every device buffer of handles created afterwards is filled with
+// this byte and sits between two red zones of OPD_REDZONE bytes filled with it as well.  A forward that reads workspace it has not
+// written, or memory next to its buffers, then gives results that depend on the byte: tests/test_detector_gpu.py runs the same
+// batches through handles poisoned with 0x00 / 0xFF (fp16 and fp32 NaN patterns) and an unpoisoned one and demands identical bits.
+static std::atomic<int> g_alloc_poison{-1};
+enum : size_t { OPD_REDZONE = 256 * 1024 };
 
 template <typename T>
 static int dalloc(opd_detr* m, T** p, size_t count, bool weight) {
     void* q = nullptr;
     const size_t bytes = count * sizeof(T);
-    hipError_t e = hipMalloc(&q, bytes ? bytes : 16);
+    const int poison = g_alloc_poison.load();
+    const size_t pad = poison >= 0 ? OPD_REDZONE : 0, total = (bytes ? bytes : 16) + 2 * pad;
+    hipError_t e = hipMalloc(&q, total);
     if (e != hipSuccess) return fail(OPD_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
-    ((weight && !m->weights_sealed && m->weights) ? m->weights->allocs : m->allocs).push_back(q);
+    const bool to_weights = weight && !m->weights_sealed && m->weights;
+    (to_weights ? m->weights->allocs : m->allocs).push_back(q);   // (the base pointer: what hipFree takes)
+    if (poison >= 0) {
+        HIPCHK(hipMemset(q, poison, total));
+        (to_weights ? m->weights->zoned : m->zoned).push_back({q, bytes ? bytes : 16, poison});
+    }
     (weight ? m->weight_bytes : m->workspace_bytes) += (int64_t)bytes;
-    *p = reinterpret_cast<T*>(q);
+    *p = reinterpret_cast<T*>(static_cast<char*>(q) + pad);
     return OPD_OK;
 }
 
@@ -659,6 +683,14 @@ static void timed_collect(opd_detr* m) {
     }
 }
 
+static int tap(opd_detr* m, const char* name, const void* p, size_t bytes) {
+    if (!m->taps || !m->d_taps || m->tap_next >= OPD_MAX_TAPS) return OPD_OK;
+    HIPCHK(opd_launch_checksum(p, bytes, m->d_taps + (size_t)m->tap_next * OPD_TAP_BLOCKS, m->stream));
+    if ((int)m->tap_names.size() <= m->tap_next) m->tap_names.resize(m->tap_next + 1);
+    m->tap_names[m->tap_next++] = name;
+    return OPD_OK;
+}
+
 static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, int W, int OH, int OW, void* out, bool relu,
                     const f16_t* res16) {
     ConvGemmParams p{};
@@ -670,6 +702,7 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)c.Cout * c.KH * c.KW * c.Cin));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, c.KH == 3 ? "conv3x3" : "conv1x1", out, (size_t)p.M * c.Cout * 2));
     return OPD_OK;
 }
 
@@ -686,6 +719,7 @@ static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bi
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, "gemm", out, (size_t)M * N * (out_f32 ? 4 : 2)));
     return OPD_OK;
 }
 
@@ -701,10 +735,12 @@ static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const
     RCCHK(timed_begin(m, cls, 2.0 * M * (double)N * K));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, "splitk_slabs", m->d_slab, (size_t)splits * M * N * 4));
     RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     HIPCHK(opd_launch_reduce_ln_pos(m->d_slab, splits, (size_t)M * N, res32, ln ? ln->g : nullptr, ln ? ln->b : nullptr, y32, y16, M,
                                     ps ? ps->pos : nullptr, ps ? ps->pos_ptrs : nullptr, ps ? ps->period : 0, ps ? ps->yp16 : nullptr, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, "reduce_ln", y32, (size_t)M * N * 4));
     return OPD_OK;
 }
 
@@ -716,6 +752,7 @@ static int run_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float*
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * 256.0 * K));
     HIPCHK(opd_launch_gemm_ln(p, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, "gemm_ln", y32, (size_t)M * 256 * 4));
     return OPD_OK;
 }
 
@@ -729,6 +766,7 @@ static int run_small_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const flo
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
     HIPCHK(opd_launch_gemm_k256(p, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, "gemm_k256", out16, (size_t)M * N * 2));
     return OPD_OK;
 }
 static int run_small_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int K, const float* res32,
@@ -741,6 +779,7 @@ static int run_small_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const 
     RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     HIPCHK(opd_launch_reduce_ln(m->d_slab, p.slices, (size_t)M * 256, res32, ln.g, ln.b, y32, y16, M, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, "small_gemm_ln", y32, (size_t)M * 256 * 4));
     return OPD_OK;
 }
 
@@ -755,6 +794,7 @@ static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ld
     RCCHK(timed_begin(m, CLS_ATTN, 4.0 * B * (double)m->arch.heads * Lq * Lk * 32));
     HIPCHK(opd_launch_attention(p, m->stream));
     RCCHK(timed_end(m));
+    if (ldo == m->arch.d_model) RCCHK(tap(m, "attention", o, (size_t)B * Lq * ldo * 2));
     return OPD_OK;
 }
 
@@ -829,6 +869,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         d_keyv = m->d_key_valid;
     }
     timed_reset(m);
+    m->tap_next = 0;
+    if (pixel_format == OPD_PIXELS_U8_BGR_HWC) RCCHK(tap(m, "pixels_u8", d_pixels, (size_t)B * H * W * 3));
     MARK(0);
     const int Hp = 2 * d.H1 + 6, Wp = 2 * d.W1 + 6;  // padded image seen by the stem: rows/cols 2*o + k, k = 0..7
     const bool prep_in_stem = m->fuse_prep && m->fuse_stem_pool && pixel_format == OPD_PIXELS_U8_BGR_HWC;
@@ -845,6 +887,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         HIPCHK(opd_launch_stem_pool_u8(reinterpret_cast<const uint8_t*>(d_pixels), d_valid, m->stem.w, m->stem.bias, m->d_pool, B, H, W, d.H1, d.W1,
                                        d.H2, d.W2, m->stream));
         RCCHK(timed_end(m));
+        RCCHK(tap(m, "stem_pool_u8", m->d_pool, (size_t)B * d.H2 * d.W2 * 64 * 2));
     } else if (m->fuse_stem_pool) {
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
         HIPCHK(opd_launch_stem_pool(m->d_x4, m->stem.w, m->stem.bias, m->d_pool, B, Hp, Wp, d.H1, d.W1, d.H2, d.W2, m->stream));
@@ -930,6 +973,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));
                     HIPCHK(opd_launch_btail(p, m->stream));
                     RCCHK(timed_end(m));
+                    RCCHK(tap(m, "btail_y", out, (size_t)p.M * 4 * C1 * 2));
+                    if (C3) RCCHK(tap(m, "btail_z", z, (size_t)p.M * C3 * 2));
                     if (C3) st.z_id = 1 - x1_id;
                 } else if (use_etail) {
                     // stage 3: the 3x3 as an implicit GEMM, then ONE kernel for 1x1 expand + residual + ReLU (block output, stored) and the
@@ -956,6 +1001,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                         RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)C2 * p.K));
                         HIPCHK(opd_launch_conv_gemm(p, m->stream));
                         RCCHK(timed_end(m));
+                        RCCHK(tap(m, "dual_expand", out, (size_t)p.M * C2 * 2));
                     } else {
                         RCCHK(run_conv(m, b.c2, a1, nb, oh, ow, oh, ow, out, true, res));
                     }
@@ -1032,6 +1078,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
         HIPCHK(opd_launch_broadcast_rows(m->dec0_h, m->d_h32, m->d_h16, Md, m->stream));
         RCCHK(timed_end(m));
+        RCCHK(tap(m, "dec0_broadcast", m->d_h32, (size_t)Md * D * 4));
     } else {
         HIPCHK(hipMemsetAsync(m->d_h32, 0, (size_t)Md * D * 4, m->stream));
         HIPCHK(hipMemsetAsync(m->d_h16, 0, (size_t)Md * D * 2, m->stream));
@@ -1077,6 +1124,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     RCCHK(timed_begin(m, CLS_OTHER, 2.0 * Md * 256.0 * (a.ncls + 256 + 256 + 4)));
     HIPCHK(opd_launch_heads(hp, m->stream));
     RCCHK(timed_end(m));
+    RCCHK(tap(m, "heads_logits", m->d_logits, (size_t)Md * a.ncls * 4));
     MARK(7);
     m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = ch; m->last_fw = cw;
     return OPD_OK;
@@ -1092,6 +1140,7 @@ static std::shared_mutex g_api_mu;
 // pointer the graph holds belongs to its own, live handle and the same launches issued eagerly stay bit-exact.  Every creation
 // and destruction of a handle therefore bumps this epoch; a graph captured in an older epoch is dropped and captured again.
 static std::atomic<unsigned> g_handle_epoch{0};
+static std::atomic<int> g_graph_guard{1};   // opd_test_set_graph_guard(0): leave stale-epoch graphs alone (diagnosis only)
 static thread_local std::shared_lock<std::shared_mutex>* tl_api_lock = nullptr;
 struct ApiScope {   // first statement of every HIP-calling entry point; entry points calling each other nest harmlessly
     std::shared_lock<std::shared_mutex> lk;
@@ -1124,7 +1173,7 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
         m->graphs.push_back({B, H, W, pixel_format, 0, 0, d_pixels, 0, nullptr, 0u});
         e = &m->graphs.back();
     }
-    if (e->exec && e->epoch != g_handle_epoch.load()) {   // handles came or went since the capture: capture again (see g_handle_epoch)
+    if (e->exec && g_graph_guard.load() && e->epoch != g_handle_epoch.load()) {   // handles came or went since the capture: capture again (see g_handle_epoch)
         (void)hipGraphExecDestroy(e->exec);
         e->exec = nullptr;
         e->uses = 1;
@@ -1780,6 +1829,77 @@ int opd_test_set_fuse_stem_pool(opd_detr* m, int on) {
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();
     return OPD_OK;
+}
+
+int opd_test_set_alloc_poison(int byte) {   // -1: off; 0 .. 255: fill byte for the buffers and red zones of handles created from now on
+    g_alloc_poison = byte < 0 ? -1 : (byte & 255);
+    return OPD_OK;
+}
+// Scans the red zones of a poison-mode handle (its own buffers and its weight set's): returns the number of buffers with a damaged
+// zone (0 = intact) and describes the first one in opd_last_error().
+int opd_test_check_redzones(opd_detr* m) {
+    ApiScope api_scope;
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<unsigned char> h(OPD_REDZONE);
+    int bad = 0;
+    std::string first;
+    auto scan = [&](const std::vector<RedZoned>& v, const char* what) -> int {
+        for (size_t i = 0; i < v.size(); ++i)
+            for (int side = 0; side < 2; ++side) {
+                const char* z = static_cast<const char*>(v[i].base) + (side ? OPD_REDZONE + v[i].bytes : 0);
+                HIPCHK(hipMemcpy(h.data(), z, OPD_REDZONE, hipMemcpyDeviceToHost));
+                size_t lo = OPD_REDZONE, hi = 0;
+                for (size_t k = 0; k < OPD_REDZONE; ++k)
+                    if (h[k] != (unsigned char)v[i].poison) { lo = std::min(lo, k); hi = k; }
+                if (lo <= hi) {
+                    if (!bad++) first = std::string(what) + " buffer #" + std::to_string(i) + " (" + std::to_string(v[i].bytes) + " bytes): " +
+                                        (side ? "zone BEHIND it" : "zone IN FRONT of it") + " overwritten at zone offsets " + std::to_string(lo) + " .. " + std::to_string(hi);
+                }
+            }
+        return OPD_OK;
+    };
+    RCCHK(scan(m->zoned, "handle"));
+    if (m->weights) RCCHK(scan(m->weights->zoned, "weight-set"));
+    if (bad) g_err = first;
+    return bad;
+}
+int opd_test_set_graph_guard(int on) {
+    g_graph_guard = on ? 1 : 0;
+    return OPD_OK;
+}
+// Diagnostic taps: after every launch of the forward a checksum launch of that launch's output (captured into the graph with it).
+int opd_test_set_taps(opd_detr* m, int on) {
+    ApiScope api_scope;
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    HIPCHK(hipSetDevice(m->device));
+    if (on && !m->d_taps) RCCHK(dalloc(m, &m->d_taps, (size_t)OPD_MAX_TAPS * OPD_TAP_BLOCKS, false));
+    m->taps = on ? 1 : 0;
+    for (auto& g : m->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+// sums[i] = checksum of tap i of the last forward, names = '\n'-joined tap names; returns the number of taps
+int opd_test_read_taps(opd_detr* m, unsigned long long* sums, int cap, char* names, int names_cap) {
+    ApiScope api_scope;
+    if (!m || !sums || !m->d_taps) return fail(OPD_EINVAL, "opd_test_read_taps: taps are not enabled");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const int n = std::min(cap, (int)m->tap_names.size());
+    std::vector<unsigned long long> h((size_t)n * OPD_TAP_BLOCKS);
+    if (n) HIPCHK(hipMemcpy(h.data(), m->d_taps, h.size() * 8, hipMemcpyDeviceToHost));
+    std::string all;
+    for (int i = 0; i < n; ++i) {
+        unsigned long long s = 0;
+        for (int j = 0; j < OPD_TAP_BLOCKS; ++j) s += h[(size_t)i * OPD_TAP_BLOCKS + j];
+        sums[i] = s;
+        all += m->tap_names[i];
+        all += '\n';
+    }
+    if (names && names_cap > 0) { strncpy(names, all.c_str(), (size_t)names_cap - 1); names[names_cap - 1] = 0; }
+    return n;
 }
 
 int opd_test_set_tr_read(opd_detr* m, int on) {

@@ -75,11 +75,21 @@ class ShardedDetector:
 
     def detect_batch(self, frames: Sequence[np.ndarray]) -> List[List[Detection]]:
         """Every rank passes the SAME global frame list; every rank returns the full result."""
+        import torch.distributed as dist
+
+        start, stop, _ = shard_bounds(len(frames), dist.get_rank(), dist.get_world_size())
+        return self.detect_shard(list(frames[start:stop]), len(frames))
+
+    def detect_shard(self, local_frames: Sequence[np.ndarray], n_frames: int) -> List[List[Detection]]:
+        """A rank passes ONLY its own frames — global frames ``shard_bounds(n_frames, rank, world)[0:2]`` — plus the global frame
+        count; every rank returns the full result in global frame order (a rank never needs the other ranks' pixels)."""
         import torch
         import torch.distributed as dist
 
         rank, world = dist.get_rank(), dist.get_world_size()
-        start, stop, per = shard_bounds(len(frames), rank, world)
+        start, stop, per = shard_bounds(n_frames, rank, world)
+        if len(local_frames) != stop - start:
+            raise ValueError(f"rank {rank} of {world} owns frames [{start}, {stop}) of {n_frames} but was given {len(local_frames)} frames")
         det = self.detector
         Q = det.num_queries
         nrec = per * Q * 8
@@ -87,13 +97,17 @@ class ShardedDetector:
         # uneven shard.  The collective is latency bound: one launch, not two.
         flat = torch.zeros((nrec + per,), dtype=torch.int32, device=self.device or "cpu")
         flat[nrec:] = -1
+        if flat.is_cuda:
+            # the fills above run on torch's stream, the post-process kernel writes the same tensor from the handle's own
+            # (non-blocking) stream: finish the fills first
+            torch.cuda.current_stream(flat.device).synchronize()
         rec_view, cnt_view = flat[:nrec].view(per, Q, 8), flat[nrec:]
-        for s0 in range(start, stop, det.max_batch):   # the handle's workspace holds max_batch frames
-            s1 = min(stop, s0 + det.max_batch)
-            det.detect_records_into(list(frames[s0:s1]), rec_view[s0 - start:s1 - start], cnt_view[s0 - start:s1 - start])
+        for s0 in range(0, stop - start, det.max_batch):   # the handle's workspace holds max_batch frames
+            s1 = min(stop - start, s0 + det.max_batch)
+            det.detect_records_into(list(local_frames[s0:s1]), rec_view[s0:s1], cnt_view[s0:s1])   # (blocking: returns with the records written)
         gathered = torch.empty((world * flat.shape[0],), dtype=torch.int32, device=flat.device)
         dist.all_gather_into_tensor(gathered, flat)   # concatenated form: accepted by both the RCCL and the gloo backend
         g = gathered.cpu().numpy().reshape(world, flat.shape[0])
         g_rec = np.ascontiguousarray(g[:, :nrec]).reshape(world, per, Q, 8)
         g_cnt = np.ascontiguousarray(g[:, nrec:])
-        return assemble(g_rec, g_cnt, len(frames), nms_threshold=det.nms_threshold, foot=det._get_foot_position)
+        return assemble(g_rec, g_cnt, n_frames, nms_threshold=det.nms_threshold, foot=det._get_foot_position)

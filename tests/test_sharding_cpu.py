@@ -82,7 +82,7 @@ def _sig(frames_dets):
     return [[(round(d.bbox[0], 3), round(d.bbox[2], 3), round(d.confidence, 5), d.query_index, d.camera_coords[1]) for d in f] for f in frames_dets]
 
 
-def _worker(rank, world, port, n_frames, tiled, out_dir):
+def _worker(rank, world, port, n_frames, tiled, out_dir, local_only=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -92,6 +92,11 @@ def _worker(rank, world, port, n_frames, tiled, out_dir):
         if tiled:   # configs[4]: each 4K-like frame -> 2 x 2 overlapping tiles; a frame's tiles straddle the rank boundary
             frames = [np.random.default_rng(50 + i).integers(0, 255, (96, 128, 3), dtype=np.uint8) for i in range(n_frames)]
             dets = TiledDetector(sharded, 2, 2, nms_threshold=0.4).detect_batch(frames)
+        elif local_only:   # a rank holds ONLY its own shard's pixels (the other ranks' frames never reach this process)
+            a, b, _ = shard_bounds(n_frames, rank, world)
+            dets = sharded.detect_shard(_frames(n_frames)[a:b], n_frames)
+            with pytest.raises(ValueError):
+                sharded.detect_shard(_frames(n_frames)[a:b] + _frames(1), n_frames)   # not this rank's shard size
         else:
             dets = sharded.detect_batch(_frames(n_frames))
         a, b, _ = shard_bounds(n_frames * (4 if tiled else 1), rank, world)
@@ -117,6 +122,15 @@ def test_sharded_detect_batch_gloo(tmp_path, world, n_frames):
     for r in range(world):
         assert torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) == want   # every rank holds the full, ordered result
     assert any(len(f) for f in want)
+
+
+@pytest.mark.parametrize("world,n_frames", [(2, 7), (3, 4)])
+def test_sharded_detect_shard_local_frames_only_gloo(tmp_path, world, n_frames):
+    """`detect_shard`: every rank passes only the frames it owns; every rank still returns the full, ordered result."""
+    mp.spawn(_worker, args=(world, _free_port(), n_frames, False, str(tmp_path), True), nprocs=world, join=True)
+    want = _sig(StandInDetector().detect_batch(_frames(n_frames)))
+    for r in range(world):
+        assert torch.load(os.path.join(str(tmp_path), f"rank{r}.pt")) == want
 
 
 @pytest.mark.parametrize("world,n_frames", [(2, 1), (2, 3), (3, 2)])

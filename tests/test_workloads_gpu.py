@@ -1,0 +1,224 @@
+"""BASELINE.json configs[2] and configs[4] as WORKLOADS through the real sharding / tiling code on the one GPU a builder box has
+(world size 1 RCCL group, device-direct exchange), and the memory hygiene of the forward (poisoned buffers, red zones, foreign
+allocations between graph capture and replay).
+
+configs[2]: 64 frames of 800x1333 "sharded 8 ways" = eight chunks of 8 through ``ShardedDetector``: on an 8-GPU node each rank
+runs exactly one of these chunks; here rank 0 of a world-size-1 group runs all eight, through the same ``detect_shard`` code, the
+same exchange buffer in HBM and the same RCCL all-gather.  Sampled frames are checked against the live oracle at 1e-3.
+configs[4]: 8 4K frames -> 32 overlapping 1080p tiles through ``TiledDetector(ShardedDetector)``.
+"""
+
+import ctypes as C
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from office_person_detection_vit_amd import HipDetrDetector, _capi
+from office_person_detection_vit_amd.frames import structured_frames
+from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file, load_safetensors
+from oracle import detr_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def mild_path(weight_cache):
+    return ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+
+
+@pytest.fixture()
+def rccl_world1():
+    import torch.distributed as dist
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    yield dist
+    dist.destroy_process_group()
+
+
+def _sig(frames_dets):
+    return [[(d.bbox, d.confidence, d.query_index) for d in f] for f in frames_dets]
+
+
+def test_config2_64_frames_through_sharded_detector(mild_path, rccl_world1, parity_log):
+    """64 x 800x1333 frames -> ShardedDetector (RCCL, records written by the post-process kernel into the tensor the all-gather
+    reads) = 8 chunks of 8.  Frames repeat with period 16 in a shuffled order, so the workload also checks that a frame's records
+    do not depend on the chunk or slot it travels in; four frames against the live oracle at the north-star tolerance."""
+    from office_person_detection_vit_amd.sharding import ShardedDetector
+    det = HipDetrDetector(model_path=mild_path, max_batch=8, max_size=(800, 1333), resize=False)
+    det.load_model()
+    try:
+        base = structured_frames(16, 800, 1333, seed=6400)
+        order = np.random.default_rng(64).permutation(64) % 16
+        frames = [base[i] for i in order]
+        got = ShardedDetector(det, device="cuda:0").detect_batch(frames)
+        assert len(got) == 64
+        first = {}
+        for pos, i in enumerate(order):     # the same frame gives the same records wherever it sits in the 64
+            first.setdefault(int(i), pos)
+            assert _sig([got[pos]]) == _sig([got[first[int(i)]]])
+        assert sum(len(f) for f in got) > 0
+        w = O.to_torch(load_safetensors(mild_path))
+        compared = 0
+        for pos in (0, 21, 42, 63):
+            fr = frames[pos]
+            pv, pm = O.preprocess([fr])
+            lg, bx, _ = O.forward(w, pv, pm)
+            lg1, bx1, _ = det.forward_raw([fr], want_encoder=False)
+            dbox = float(np.abs(bx1[0] - bx[0].numpy()).max())
+            parity_log(f"configs[2] workload: frame {pos} of 64 (800x1333) vs live oracle", dbox, None, None, 1e-3)
+            assert dbox <= 1e-3
+            want = O.person_detections(O.post_process_object_detection(lg.numpy(), bx.numpy(), 0.5, [(800, 1333)])[0], 0.4)
+            ref_q = {d["query_index"]: d for d in want if abs(d["confidence"] - 0.5) > 4e-3}
+            got_q = {d.query_index: d for d in got[pos] if abs(d.confidence - 0.5) > 4e-3}
+            assert set(ref_q) == set(got_q)
+            compared += len(ref_q)
+            for qi, r in ref_q.items():
+                np.testing.assert_allclose(got_q[qi].bbox, r["bbox"], atol=1e-3 * 1333 * 2)
+        assert compared > 0
+    finally:
+        det.close()
+
+
+def test_config4_eight_4k_frames_as_32_tiles(mild_path, rccl_world1):
+    """8 4K frames -> 32 overlapping 1080p tiles (device resize 1215x2160 -> 750x1333) through TiledDetector(ShardedDetector):
+    equal to the single-process TiledDetector on the same detector, frame for frame."""
+    from office_person_detection_vit_amd.sharding import ShardedDetector
+    from office_person_detection_vit_amd.tiling import TiledDetector
+    det = HipDetrDetector(model_path=mild_path, max_batch=4, max_size=(800, 1333), resize=True)
+    det.load_model()
+    try:
+        frames = structured_frames(8, 2160, 3840, seed=3200)
+        got = TiledDetector(ShardedDetector(det, device="cuda:0"), 2, 2, nms_threshold=0.4).detect_batch(frames)
+        want = TiledDetector(det, 2, 2, nms_threshold=0.4).detect_batch(frames)
+        assert len(got) == 8 and _sig(got) == _sig(want)
+        assert sum(len(f) for f in got) > 0
+        for f in got:
+            for d in f:
+                assert -3840 <= d.bbox[0] <= 3840 and -2160 <= d.bbox[1] <= 2160
+    finally:
+        det.close()
+
+
+def _poisoned(path, poison, **kw):
+    lib = _capi.load_library()
+    lib.opd_test_set_alloc_poison(poison)
+    try:
+        det = HipDetrDetector(model_path=path, **kw)
+        det.load_model()
+    finally:
+        lib.opd_test_set_alloc_poison(-1)
+    return det
+
+
+def test_forward_does_not_depend_on_memory_it_has_not_written(mild_path):
+    """Handles whose every device buffer is pre-filled with 0x00 / 0xFF (fp16 and fp32 NaN patterns) and fenced by 256-KiB red
+    zones of the same byte give bit-identical outputs to an unpoisoned handle — eager, captured and replayed; uniform, ragged, odd
+    and device-resized batches; ROI features — and leave every red zone intact: no kernel consumes workspace it has not written,
+    reads next to a buffer in a way that matters, or writes next to one."""
+    lib = _capi.load_library()
+    uni = structured_frames(2, 256, 320, seed=4321)
+    rag = [structured_frames(1, 256, 320, seed=5)[0], structured_frames(1, 224, 288, seed=6)[0]]
+    odd = structured_frames(1, 203, 333, seed=7)
+    cam = structured_frames(1, 720, 1280, seed=8)
+
+    def run(poison):
+        det = _poisoned(mild_path, poison, max_batch=2, max_size=(800, 1333), resize=True)
+        try:
+            out = []
+            det.resize = False
+            for _ in range(3):
+                out.append(det.forward_raw(uni))
+            out.append(det.forward_raw(rag))
+            out.append(det.forward_raw(odd))
+            det.resize = True
+            for _ in range(2):
+                out.append(det.forward_raw(cam))
+            dets, feats = det.detect_with_features(cam[0])
+            out.append((np.asarray([d.bbox + (d.confidence,) for d in dets], np.float64).reshape(-1, 5), np.asarray(feats, np.float32)))
+            if poison >= 0:
+                bad = lib.opd_test_check_redzones(C.c_void_p(det.model))
+                assert bad == 0, f"poison {poison:#x}: {bad} buffers with a damaged red zone; first: {_capi.last_error()}"
+            return out
+        finally:
+            det.close()
+
+    ref = run(-1)
+    for poison in (0x00, 0xFF):
+        got = run(poison)
+        for k, (a, b) in enumerate(zip(got, ref)):
+            for x, y in zip(a, b):
+                assert not np.isnan(np.asarray(x, np.float64)).any(), f"poison {poison:#x}, step {k}: NaN in the output"
+                np.testing.assert_array_equal(x, y, err_msg=f"poison {poison:#x}, step {k}")
+
+
+def test_batch8_forward_on_poisoned_buffers(mild_path):
+    """The same at the benchmark shape (8 x 800x1333, eager + captured + replayed + detect_batch)."""
+    lib = _capi.load_library()
+    frames = structured_frames(8, 800, 1333, seed=99)
+    outs, sigs = {}, {}
+    for poison in (-1, 0xFF):
+        det = _poisoned(mild_path, poison, max_batch=8, max_size=(800, 1333), resize=False)
+        try:
+            outs[poison] = [det.forward_raw(frames) for _ in range(3)]
+            sigs[poison] = _sig(det.detect_batch(frames))
+            if poison >= 0:
+                assert lib.opd_test_check_redzones(C.c_void_p(det.model)) == 0, _capi.last_error()
+        finally:
+            det.close()
+    assert sigs[0xFF] == sigs[-1] and sum(len(f) for f in sigs[-1]) > 0
+    for k, (a, b) in enumerate(zip(outs[0xFF], outs[-1])):
+        for x, y in zip(a, b):
+            np.testing.assert_array_equal(x, y, err_msg=f"step {k}")
+
+
+def test_graph_replay_survives_foreign_allocations_and_handle_churn(mild_path, weight_cache):
+    """A graph captured BEFORE other users of the device allocate, write and free memory is replayed AFTER it, with the library's
+    own re-capture guard switched off: torch's caching allocator (1 GiB of NaNs allocated, freed back to the driver, 768 MiB
+    allocated again and kept), a world-size-1 RCCL group created and destroyed, another handle created / run / destroyed and a
+    handle with different weights created in the memory it returned.  Replays must stay bit-identical."""
+    import torch.distributed as dist
+    lib = _capi.load_library()
+    sharp = ensure_weight_file(weight_cache, DetrArch(), 0, 2.0, "r50")
+    probe = structured_frames(2, 256, 320, seed=4321)
+    other = structured_frames(2, 256, 320, seed=1234)
+    mk = lambda p: HipDetrDetector(model_path=p, max_batch=2, max_size=(800, 1333), resize=False)
+    lib.opd_test_set_graph_guard(0)
+    A = mk(mild_path)
+    A.load_model()
+    extra = []
+    try:
+        eager = A.forward_raw(probe)
+        A.forward_raw(other)                      # capture + first launch
+        ref = A.forward_raw(probe)                # replay
+        for x, y in zip(ref, eager):
+            np.testing.assert_array_equal(x, y)
+        # (1) torch allocator churn
+        x = torch.full((1 << 28,), float("nan"), device="cuda"); torch.cuda.synchronize(); del x
+        torch.cuda.empty_cache()
+        keep = torch.full((3 << 26,), float("nan"), device="cuda"); torch.cuda.synchronize()
+        for x, y in zip(A.forward_raw(probe), ref):
+            np.testing.assert_array_equal(x, y)
+        # (2) RCCL communicator setup / teardown
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        t = torch.ones(1024, device="cuda"); dist.all_reduce(t); torch.cuda.synchronize()
+        dist.destroy_process_group()
+        for x, y in zip(A.forward_raw(probe), ref):
+            np.testing.assert_array_equal(x, y)
+        # (3) handle churn: the round-2 scenario (tools/graph_churn_probe.py)
+        f = mk(mild_path); f.load_model(); f.forward_raw(probe); f.close()
+        B = mk(sharp); B.load_model(); extra.append(B); B.forward_raw(other)
+        for _ in range(2):
+            for x, y in zip(A.forward_raw(probe), ref):
+                np.testing.assert_array_equal(x, y)
+        del keep
+    finally:
+        lib.opd_test_set_graph_guard(1)
+        A.close()
+        for d in extra:
+            d.close()
