@@ -9,8 +9,25 @@
 //   S^T[key][q]  = mfma_16x16x32(A = K tile rows, B = Q rows)      -> lane holds 4 keys x its query per 16-key tile
 //   O^T[d][q]   += mfma_16x16x32(A = V^T,         B = P^T)         -> lane holds 4 head-dims x its query
 // The P accumulator tile is re-used directly as the B operand of the second product (k-slot j<4 -> S-tile 2kb,
-// j>=4 -> S-tile 2kb+1); V^T fragments come from the row-major V tile in LDS through ds_read_b64_tr_b16
-// (hardware transpose), with a scalar-gather cross-check path selectable at run time.
+// j>=4 -> S-tile 2kb+1); V^T fragments come from the V tile in LDS through ds_read_b64_tr_b16 (hardware transpose).
+//
+// The loop is bound by vector-instruction issue (one v_exp_f32 per score and what surrounds it), not by the matrix pipe or by
+// memory (tools/trace_attn.py: ~520 SIMD cycles per wave and 64-key tile, 160 of them MFMA), so the round-3 form removes
+// instructions from the common tile:
+//  * Lazy rescale.  The exponent reference m_ref of a query is NOT the running maximum: it only moves when a tile holds a score
+//    more than LAZY_T (2^8) above it.  p = exp2(s*c - m_ref) may then exceed 1 (up to 2^8: far inside fp16 / fp32 range), the
+//    softmax ratios are unchanged (a common reference cancels in O = sum p v / sum p), and the common tile carries no cross-lane
+//    maximum, no alpha = exp2(m_old - m_new), no rescale of the accumulators: one wave-uniform branch skips them.
+//  * The row sum comes out of the matrix pipe: a third MFMA per 32 keys with an all-ones A operand accumulates sum_k P[k][q] — of
+//    the fp16-rounded weights the PV product actually uses, so the normalised weights sum to one exactly — instead of eight packed
+//    adds; every lane ends with its query's complete sum, no cross-lane reduction.
+//  * K / V tiles travel HBM -> LDS by LDS-DMA (buffer_load ... lds: 1 KiB = 16 key rows x 64 bytes per wave-instruction): no
+//    staging registers, no ds_write, no predicates (rows past the operand read as zeros through the buffer descriptor).
+//    An LDS-DMA writes lane L's 16 bytes to slot L of its 1-KiB block, so the bank-conflict-free images are made on the SOURCE
+//    side — lane L fetches the (row, 16-byte chunk) cell that belongs in slot L:
+//      K block (ds_read_b128 fragment reads, lane (g, li) takes row li, chunk g):        slot = 16 * chunk + row
+//      V block (ds_read_b64_tr_b16, 32 lanes take 8 rows x 32 bytes):   slot = 32 * (chunk >> 1) + 16 * (row >> 3) + 2 * (row & 7) + (chunk & 1)
+// Encoder launch at batch 8 (1088 workgroups): 30.1 -> 24.0 us; 2040 tokens (r101 at 1066x1920): 91 -> 72 us (profiles/r03_bench_attn.txt).
 #include <hip/hip_runtime.h>
 #include <type_traits>
 #include <math.h>
@@ -24,13 +41,7 @@ typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
 
 namespace {
 
-constexpr int LDS_ROW = 80;  // bytes per K row in LDS (64 payload + 16 pad): 16-byte fragment reads of 16 rows hit 16 distinct slots
-// V rows are read 4 rows x 32 bytes per 16 lanes by ds_read_b64_tr_b16: a 96-byte stride tiles those four pieces over the
-// 128-byte bank line exactly (80 bytes leaves rows 0 and 3 overlapping); measured: attention -1 %, the loop is not LDS bound
-#ifndef OPD_ATTN_V_ROW
-#define OPD_ATTN_V_ROW 96
-#endif
-constexpr int V_ROW = OPD_ATTN_V_ROW;
+constexpr float LAZY_T = 8.0f;   // log2 of the head-room a score may have over its query's exponent reference before the reference moves
 
 __device__ __forceinline__ half4 lds_tr16(const unsigned char* p) {
     short4v t = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
@@ -40,10 +51,6 @@ __device__ __forceinline__ half4 lds_tr16(const unsigned char* p) {
     return r;
 }
 
-// TR: V^T fragments through ds_read_b64_tr_b16 (hardware transpose) or scalar LDS gathers (cross-check path).
-// MASKED: per-frame key mask of a ragged batch.  Both are compile-time so that the inner loop carries no branches.
-// KT: keys per LDS tile.  64 for the encoder (VALU bound, many workgroups per CU: the smaller tile keeps registers low);
-// 128 for the decoder (<= 128 queries: a handful of workgroups, each a latency chain of per-tile barriers: 14.6 -> 11.8 us).
 // max over lanes {l, l^16, l^32, l^48}: v_permlane16_swap / v_permlane32_swap exchange 16- / 32-lane rows between two registers, so
 // each butterfly step is one swap + one v_max in the VALU (ds_bpermute, what __shfl_xor compiles to, is an LDS round trip)
 __device__ __forceinline__ float xmax16_32(const float v) {
@@ -56,14 +63,29 @@ __device__ __forceinline__ float xmax16_32(const float v) {
     return a;
 }
 
-template <bool TR, bool MASKED, int KT>
+// TRACE (tools/trace_attn.py only): wave 0 stamps the shader clock at five points of every key tile and writes the per-phase sums.
+#define ATTN_STAMP(i)                                                                                        \
+    do {                                                                                                     \
+        if constexpr (TRACE) {                                                                               \
+            unsigned long long now_;                                                                         \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                     \
+            tsum[i] += now_ - tlast;                                                                         \
+            tlast = now_;                                                                                    \
+        }                                                                                                    \
+    } while (0)
+
+// MASKED: per-frame key mask of a ragged batch (compile time: the unmasked loop carries no mask arithmetic).
+// KT: keys per LDS tile.  64 for the encoder (many workgroups per CU: the smaller tile keeps registers low); 128 for the decoder's
+// cross-attention (<= 128 queries: a handful of workgroups, each a latency chain of per-tile barriers).
+template <bool MASKED, int KT, bool TRACE = false>
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     constexpr int NKT = KT / 16;              // 16-key score tiles per LDS tile
-    constexpr int K_BYTES = KT * LDS_ROW, TILE_BYTES = KT * (LDS_ROW + V_ROW);   // one buffer = K tile then V tile
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];  // [buf][K|V]
+    constexpr int RPT = KT / 64;              // 1-KiB blocks per wave, operand and tile
+    constexpr int K_BYTES = KT * 64, TILE_BYTES = KT * 128;   // one buffer = K tile then V tile, 64 bytes per key row each
+    __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * TILE_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4;
     const int li = lane & 15;
     // XCD-aware tile map: workgroup L runs on XCD L % 8, so XCD x takes the x-th contiguous eighth of the (frame, head, query
@@ -82,54 +104,54 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) qf[j] = (_Float16)0.f;
     if (q_ok) qf = *reinterpret_cast<const half8*>(p.q + ((size_t)b * p.Lq + q) * p.ldq + h * 32 + g * 8);
-
-    const int skey = tid >> 2, schunk = tid & 3;
-    const f16_t* kbase = p.k + (size_t)b * p.Lk * p.ldk + h * 32 + schunk * 8;
-    const f16_t* vbase = p.v + (size_t)b * p.Lk * p.ldv + h * 32 + schunk * 8;
-    constexpr int RPT = KT / 64;   // key rows per thread and tile (256 threads cover 64 rows x 4 chunks)
-    uint4 rk[RPT], rv[RPT];
-    auto load_tile = [&](int t) {
+    half8 ones;
 #pragma unroll
-        for (int i = 0; i < RPT; ++i) {
-            const int key = t * KT + i * 64 + skey;
-            rk[i] = make_uint4(0u, 0u, 0u, 0u);
-            rv[i] = rk[i];
-            if (key < p.Lk) {
-                rk[i] = *reinterpret_cast<const uint4*>(kbase + (size_t)key * p.ldk);
-                rv[i] = *reinterpret_cast<const uint4*>(vbase + (size_t)key * p.ldv);
-            }
-        }
-    };
-    auto store_tile = [&](int buf) {
+    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.f;
+
+    // LDS-DMA staging: wave w moves key rows 16 w .. 16 w + 15 (+ 64 i) of the tile.  Rows past Lk of the LAST frame fall outside
+    // the descriptor (zeros); of earlier frames they are the next frame's rows: finite, and masked like every key >= Lk.
+    const __amdgpu_buffer_rsrc_t rsrc_k = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.k), 0, (unsigned)((size_t)p.B * p.Lk * p.ldk * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_v = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.v), 0, (unsigned)((size_t)p.B * p.Lk * p.ldv * 2), 0x00020000);
+    const int vr = ((lane >> 4) & 1) * 8 + ((lane >> 1) & 7), vc = (lane >> 5) * 2 + (lane & 1);   // the V cell of this lane's slot
+    const unsigned koff = (unsigned)(((size_t)b * p.Lk + wave * 16 + (lane & 15)) * p.ldk + h * 32 + (lane >> 4) * 8) * 2u;
+    const unsigned voff = (unsigned)(((size_t)b * p.Lk + wave * 16 + vr) * p.ldv + h * 32 + vc * 8) * 2u;
+    auto dma_tile = [&](int t, int buf) {
         unsigned char* base = lds + buf * TILE_BYTES;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
-            *reinterpret_cast<uint4*>(base + (i * 64 + skey) * LDS_ROW + schunk * 16) = rk[i];
-            *reinterpret_cast<uint4*>(base + K_BYTES + (i * 64 + skey) * V_ROW + schunk * 16) = rv[i];
+            const int row0 = t * KT + i * 64;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_k, (__attribute__((address_space(3))) void*)(base + (i * 4 + wave) * 1024), 16, koff,
+                                                     (unsigned)(row0 * p.ldk) * 2u, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_v, (__attribute__((address_space(3))) void*)(base + K_BYTES + (i * 4 + wave) * 1024), 16, voff,
+                                                     (unsigned)(row0 * p.ldv) * 2u, 0, 0);
         }
     };
 
-    float m_run = -INFINITY;  // running max of this lane's query (uniform over the 4 lanes sharing the query)
-    float l_run = 0.f;        // running sum over THIS lane's keys only (combined across the 4 lanes at the end)
+    unsigned long long tsum[5] = {0, 0, 0, 0, 0}, tlast = 0, tbegin = 0, rbegin = 0;
+    if constexpr (TRACE) {
+        asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rbegin)::"memory");   // 100 MHz wall clock
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tbegin)::"memory");
+        tlast = tbegin;
+    }
+    float m_ref = -INFINITY;   // exponent reference of this lane's query (log2 domain, uniform over the 4 lanes that share the query)
     float4v oacc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
+    float4v lacc = float4v{0.f, 0.f, 0.f, 0.f};   // every element: sum over all keys so far of this query's fp16 weights
 
     // ragged batch: keys outside the frame's valid (rows x cols) rectangle of the key map get -inf, like the additive
     // attention mask of the reference (HF:models/detr/modeling_detr.py:402-427, 933-991); key 0 is always valid
     const int kv_rows = MASKED ? p.key_valid[2 * b] : 0, kv_cols = MASKED ? p.key_valid[2 * b + 1] : 0;
     const int ntiles = (p.Lk + KT - 1) / KT;
-    const float scale2 = p.scale * 1.44269504088896340736f;  // scores are kept pre-multiplied by log2(e)
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
+    const float scale2 = p.scale * 1.44269504088896340736f;  // exponents are taken in base 2: scores are multiplied by scale * log2(e)
+    dma_tile(0, 0);
+    __syncthreads();   // (an LDS-DMA in flight is a pending LDS write: the barrier's fence waits for it)
 
     // One key tile.  LAST (compile time): the tile may hold keys >= Lk; every other tile of an unmasked launch is full and carries no
-    // masking code at all (a run-time "is this the last tile" inside one loop body made the compiler copy all 16 score registers per
-    // tile to merge the two paths).  Packed fp32 arithmetic (v_pk_fma_f32 / v_pk_add_f32: two scores per instruction) for the
-    // exponent arguments and the row sum; the exponentials themselves are one v_exp_f32 per score.
+    // masking code at all.
     auto tile_step = [&](const int t, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
         const int buf = t & 1;
-        if (!LAST) load_tile(t + 1);
+        if (!LAST) dma_tile(t + 1, buf ^ 1);
+        ATTN_STAMP(0);
         const unsigned char* Kl = lds + buf * TILE_BYTES;
         const unsigned char* Vl = Kl + K_BYTES;
 
@@ -137,11 +159,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         float4v s[NKT];
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
-            const half8 kf = *reinterpret_cast<const half8*>(Kl + (kt * 16 + li) * LDS_ROW + g * 16);
+            const half8 kf = *reinterpret_cast<const half8*>(Kl + kt * 1024 + lane * 16);
             s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
         }
-        // ---- online softmax (fp32, base-2 domain: p = exp2(s * scale*log2(e) - m), one fma + one v_exp per score; the
-        //      running maximum is taken on the RAW scores and scaled once: scale > 0 keeps the order) ----------------------
         float mx = -INFINITY;
         if (MASKED) {
 #pragma unroll
@@ -169,31 +189,32 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                     mx = fmaxf(mx, s[kt][r]);
                 }
         }
-        mx = xmax16_32(mx);   // over the 4 lanes (16 apart) that share the query
-        const float m_new = fmaxf(m_run, mx * scale2);  // finite: tile 0 always holds key 0 (the product rounds once, like s*scale2)
-        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-        const float2v sc2 = {scale2, scale2}, mneg = {-m_new, -m_new};
-        float2v psum2 = {0.f, 0.f};
+        // ---- does some query of this wave see a score more than 2^LAZY_T above its reference?  (tile 0: m_ref = -inf, always) --
+        if (__any(mx * scale2 > m_ref + LAZY_T)) {
+            const float mq = xmax16_32(mx) * scale2;   // the query's exact tile maximum (uniform over its 4 lanes)
+            const bool up = mq > m_ref + LAZY_T;
+            const float m_new = up ? mq : m_ref;
+            const float alpha = up ? __builtin_amdgcn_exp2f(m_ref - m_new) : 1.0f;   // m_ref = -inf: exp2(-inf) = 0, on sums that are zero
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) lacc[r] *= alpha;
+            m_ref = m_new;
+        }
+        ATTN_STAMP(1);
+        // ---- p = exp2(s * scale * log2(e) - m_ref): one packed fma per two scores, one v_exp_f32 per score ---------------
+        const float2v sc2 = {scale2, scale2}, mneg = {-m_ref, -m_ref};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
             for (int r = 0; r < 4; r += 2) {
-                const float2v a = __builtin_elementwise_fma(float2v{s[kt][r], s[kt][r + 1]}, sc2, mneg);   // masked: fma(-inf) = -inf -> 0
-                float2v e;
-                e[0] = __builtin_amdgcn_exp2f(a[0]);
-                e[1] = __builtin_amdgcn_exp2f(a[1]);
-                s[kt][r] = e[0];
-                s[kt][r + 1] = e[1];
-                psum2 += e;
+                const float2v a = __builtin_elementwise_fma(float2v{s[kt][r], s[kt][r + 1]}, sc2, mneg);   // masked: -inf -> p = 0
+                s[kt][r] = __builtin_amdgcn_exp2f(a[0]);
+                s[kt][r + 1] = __builtin_amdgcn_exp2f(a[1]);
             }
-        l_run = l_run * alpha + (psum2[0] + psum2[1]);
-        m_run = m_new;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) oacc[dt][r] *= alpha;
-
-        // ---- O^T += V^T P^T -------------------------------------------------------------------------------------
+        // ---- O^T += V^T P^T,  l += 1^T P^T ----------------------------------------------------------------------
 #pragma unroll
         for (int kb = 0; kb < NKT / 2; ++kb) {
             half8 pf;
@@ -204,33 +225,42 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
+                // 16 lanes take 4 key rows x 16 head dims: rows kb*32 + g*4 + (li >> 2) (lo) and + 16 (hi: the next 1-KiB block)
+                const unsigned char* a0 = Vl + kb * 2048 + (dt * 32 + (g >> 1) * 16 + ((g & 1) * 4 + (li >> 2)) * 2 + ((li >> 1) & 1)) * 16 + (li & 1) * 8;
+                const half4 lo = lds_tr16(a0);
+                const half4 hi = lds_tr16(a0 + 1024);
                 half8 vf;
-                if (TR) {
-                    const unsigned char* a0 = Vl + (kb * 32 + g * 4 + (li >> 2)) * V_ROW + (dt * 16 + (li & 3) * 4) * 2;
-                    const half4 lo = lds_tr16(a0);
-                    const half4 hi = lds_tr16(a0 + 16 * V_ROW);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const int key = kb * 32 + (j < 4 ? g * 4 + j : 16 + g * 4 + (j - 4));
-                        vf[j] = *reinterpret_cast<const _Float16*>(Vl + key * V_ROW + (dt * 16 + li) * 2);
-                    }
-                }
+                for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
                 oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
             }
+            lacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf, lacc, 0, 0, 0);
         }
-        if (!LAST) store_tile(buf ^ 1);
+        ATTN_STAMP(2);
+        if (TRACE && !LAST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+        ATTN_STAMP(3);
         __syncthreads();
+        ATTN_STAMP(4);
     };
     for (int t = 0; t + 1 < ntiles; ++t) tile_step(t, std::false_type{});
     tile_step(ntiles - 1, std::true_type{});
 
-    float l_tot = l_run + __shfl_xor(l_run, 16, 64);
-    l_tot += __shfl_xor(l_tot, 32, 64);
+    if constexpr (TRACE) {
+        if (tid == 0 && p.trace) {
+            unsigned long long rend;
+            asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(rend)::"memory");
+            unsigned long long* tr = p.trace + (size_t)blockIdx.x * 12;
+            for (int i = 0; i < 5; ++i) tr[i] = tsum[i];
+            tr[5] = 0;
+            tr[6] = tlast - tbegin;
+            tr[7] = (unsigned long long)ntiles;
+            tr[8] = rbegin; tr[9] = rend;
+            tr[10] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID bits 0..3
+            tr[11] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
+        }
+    }
     if (q_ok) {
-        const float inv = 1.0f / l_tot;
+        const float inv = 1.0f / lacc[0];
         f16_t* orow = p.o + ((size_t)b * p.Lq + q) * p.ldo + h * 32 + g * 4;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
@@ -248,21 +278,18 @@ hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Lq <= 0 || p.Lk <= 0) return hipErrorInvalidValue;
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;  // 16-byte row chunks
     if (p.key_valid && p.key_row < 1) return hipErrorInvalidValue;
+    if ((size_t)p.B * p.Lk * p.ldk * 2 >= (1ull << 32) || (size_t)p.B * p.Lk * p.ldv * 2 >= (1ull << 32)) return hipErrorInvalidValue;   // buffer descriptors
     const int total = ((p.Lq + 63) / 64) * p.heads * p.B;
     dim3 grid(8 * ((total + 7) / 8));   // 8 XCDs x their share of the tiles (attention_kernel's tile map)
     const bool wide = p.Lq <= 128 && p.Lk > 128;   // few query tiles, long key loop: decoder cross-attention
-#define OPD_ATTN_LAUNCH(TRV, MV)                                                                             \
-    do {                                                                                                     \
-        if (wide) hipLaunchKernelGGL((attention_kernel<TRV, MV, 128>), grid, dim3(256), 0, stream, p);       \
-        else hipLaunchKernelGGL((attention_kernel<TRV, MV, 64>), grid, dim3(256), 0, stream, p);             \
-    } while (0)
-    if (p.key_valid) {
-        if (p.use_tr_read) OPD_ATTN_LAUNCH(true, true);
-        else OPD_ATTN_LAUNCH(false, true);
+    if (p.trace) {
+        hipLaunchKernelGGL((attention_kernel<false, 64, true>), grid, dim3(256), 0, stream, p);
+    } else if (p.key_valid) {
+        if (wide) hipLaunchKernelGGL((attention_kernel<true, 128>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_kernel<true, 64>), grid, dim3(256), 0, stream, p);
     } else {
-        if (p.use_tr_read) OPD_ATTN_LAUNCH(true, false);
-        else OPD_ATTN_LAUNCH(false, false);
+        if (wide) hipLaunchKernelGGL((attention_kernel<false, 128>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_kernel<false, 64>), grid, dim3(256), 0, stream, p);
     }
-#undef OPD_ATTN_LAUNCH
     return hipGetLastError();
 }

@@ -223,8 +223,8 @@ struct AttnParams {
     int B, heads, Lq, Lk;
     int ldq, ldk, ldv, ldo;
     float scale;
-    int use_tr_read;  // 1: ds_read_b64_tr_b16 for V fragments; 0: scalar LDS gathers (cross-check path)
     const int32_t* key_valid;  // optional (device) [B][2] = (rows, cols) of the valid top-left rectangle of each frame's key map
     int key_row;               // key map row length (key k sits at (k / key_row, k % key_row)); used with key_valid
+    unsigned long long* trace; // tools only (tools/trace_attn.py): per-workgroup phase sums [grid][12]; null in the model
 };
 hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream);

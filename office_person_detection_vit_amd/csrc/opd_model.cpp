@@ -187,7 +187,6 @@ struct opd_detr {
     bool profiling = false;
     hipEvent_t ev[9] = {};
     float stage_ms[8] = {};
-    int use_tr_read = 1;
     int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
@@ -790,7 +789,6 @@ static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ld
     p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.heads = m->arch.heads; p.Lq = Lq; p.Lk = Lk;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
     p.scale = 1.0f / sqrtf((float)(m->arch.d_model / m->arch.heads));
-    p.use_tr_read = m->use_tr_read;
     RCCHK(timed_begin(m, CLS_ATTN, 4.0 * B * (double)m->arch.heads * Lq * Lk * 32));
     HIPCHK(opd_launch_attention(p, m->stream));
     RCCHK(timed_end(m));
@@ -1418,7 +1416,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->wc = src->wc; m->bc = src->bc; m->w1 = src->w1; m->b1 = src->b1; m->w2 = src->w2; m->b2 = src->b2; m->w3 = src->w3; m->b3 = src->b3;
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
-    m->use_tr_read = src->use_tr_read; m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
+    m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     m->d_dump = nullptr;
@@ -1902,10 +1900,6 @@ int opd_test_read_taps(opd_detr* m, unsigned long long* sums, int cap, char* nam
     return n;
 }
 
-int opd_test_set_tr_read(opd_detr* m, int on) {
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->use_tr_read = on ? 1 : 0;
-    return OPD_OK;
-}
+
 
 }  // extern "C"

@@ -517,8 +517,58 @@ int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int db
     return OPD_OK;
 }
 
+// Times `iters` launches of the attention kernel on caller-supplied operands with leading dimension ld (768 = the fused QKV buffer).
+int opd_test_bench_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, int B, int heads, int Lq, int Lk, int ldq, int ldkv,
+                             float scale, int iters, float* us_out) {
+    DevMem dm;
+    AttnParams p{};
+    p.q = dm.up(q, (size_t)B * Lq * ldq);
+    p.k = dm.up(k, (size_t)B * Lk * ldkv);
+    p.v = dm.up(v, (size_t)B * Lk * ldkv);
+    p.o = dm.up<uint16_t>(nullptr, (size_t)B * Lq * heads * 32);
+    if (!p.q || !p.k || !p.v || !p.o) return tfail(OPD_ENOMEM, "bench alloc failed");
+    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = ldq; p.ldk = p.ldv = ldkv; p.ldo = heads * 32; p.scale = scale;
+    hipEvent_t a, b;
+    TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) TCHK(opd_launch_attention(p, nullptr));
+    TCHK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) TCHK(opd_launch_attention(p, nullptr));
+    TCHK(hipEventRecord(b, nullptr));
+    TCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    TCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *us_out = ms * 1000.f / iters;
+    return OPD_OK;
+}
+
+// One traced launch (after 2 untraced ones): trace_out [max_wgs][8] = per-workgroup sums of wave 0's cycles in the five phases of a
+// key tile (loads issued | S + max + branch | exp + PV | wait for the next tile's loads | LDS stores | barrier), total, tiles.
+int opd_test_trace_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, int B, int heads, int Lq, int Lk, int ldq, int ldkv,
+                             float scale, unsigned long long* trace_out, int max_wgs, int* wgs_out) {
+    DevMem dm;
+    AttnParams p{};
+    p.q = dm.up(q, (size_t)B * Lq * ldq);
+    p.k = dm.up(k, (size_t)B * Lk * ldkv);
+    p.v = dm.up(v, (size_t)B * Lk * ldkv);
+    p.o = dm.up<uint16_t>(nullptr, (size_t)B * Lq * heads * 32);
+    const int total = ((Lq + 63) / 64) * heads * B, grid = 8 * ((total + 7) / 8);
+    unsigned long long* tr = dm.up<unsigned long long>(nullptr, (size_t)grid * 12);
+    if (!p.q || !p.k || !p.v || !p.o || !tr) return tfail(OPD_ENOMEM, "trace alloc failed");
+    TCHK(hipMemset(tr, 0, (size_t)grid * 96));
+    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = ldq; p.ldk = p.ldv = ldkv; p.ldo = heads * 32; p.scale = scale;
+    for (int i = 0; i < 2; ++i) TCHK(opd_launch_attention(p, nullptr));
+    p.trace = tr;
+    TCHK(opd_launch_attention(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    const int n = grid < max_wgs ? grid : max_wgs;
+    TCHK(hipMemcpy(trace_out, tr, (size_t)n * 96, hipMemcpyDeviceToHost));
+    *wgs_out = n;
+    return OPD_OK;
+}
+
 int opd_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, uint16_t* o, int B, int heads, int Lq, int Lk,
-                       float scale, int use_tr_read) {
+                       float scale) {
     DevMem dm;
     const int D = heads * 32;
     AttnParams p{};
@@ -527,7 +577,7 @@ int opd_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, 
     p.v = dm.up(v, (size_t)B * Lk * D);
     p.o = dm.up<uint16_t>(nullptr, (size_t)B * Lq * D);
     if (!p.q || !p.k || !p.v || !p.o) return tfail(OPD_ENOMEM, "test alloc failed");
-    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = p.ldk = p.ldv = p.ldo = D; p.scale = scale; p.use_tr_read = use_tr_read;
+    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = p.ldk = p.ldv = p.ldo = D; p.scale = scale;
     TCHK(opd_launch_attention(p, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(o, p.o, (size_t)B * Lq * D * 2, hipMemcpyDeviceToHost));
@@ -546,7 +596,7 @@ int opd_test_attention_masked(const uint16_t* q, const uint16_t* k, const uint16
     p.o = dm.up<uint16_t>(nullptr, (size_t)B * Lq * D);
     p.key_valid = dm.up(key_valid, (size_t)B * 2);
     if (!p.q || !p.k || !p.v || !p.o || !p.key_valid) return tfail(OPD_ENOMEM, "test alloc failed");
-    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = p.ldk = p.ldv = p.ldo = D; p.scale = scale; p.use_tr_read = 1;
+    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = p.ldk = p.ldv = p.ldo = D; p.scale = scale;
     p.key_row = key_row;
     TCHK(opd_launch_attention(p, nullptr));
     TCHK(hipDeviceSynchronize());

@@ -214,8 +214,12 @@ def calibrate_frozen_bn(weights: "OrderedDict[str, np.ndarray]", arch: DetrArch,
 
 
 def synth_weights(arch: DetrArch = DetrArch(), seed: int = 0, attention_gain: float = 2.0,
-                  calibrate: bool = True) -> "OrderedDict[str, np.ndarray]":
+                  calibrate: bool = True, device_exact: bool = True) -> "OrderedDict[str, np.ndarray]":
     """Build the seeded, non-degenerate fp32 weight set (see module docstring).
+
+    ``device_exact=False`` skips ``make_device_exact``: ordinary fp32 tensors, as a real checkpoint has them — the device
+    then rounds every GEMM operand to fp16 itself, and the parity figure includes that weight rounding (the unfavourable case
+    the tests report next to the device-exact one).
 
     One ``default_rng(seed)`` stream drives every tensor in ``param_specs`` order, then FrozenBN statistics are
     calibrated (``calibrate_frozen_bn``), so the result is a pure function of ``(arch, seed, attention_gain)``.
@@ -275,7 +279,8 @@ def synth_weights(arch: DetrArch = DetrArch(), seed: int = 0, attention_gain: fl
         out[name] = np.ascontiguousarray(t, dtype=np.float32)
     if calibrate:
         calibrate_frozen_bn(out, arch)
-    make_device_exact(out)
+    if device_exact:
+        make_device_exact(out)
     return out
 
 
@@ -364,10 +369,13 @@ def rename_4x_key(name: str) -> str:
 
 
 def ensure_weight_file(cache_dir: str, arch: DetrArch = DetrArch(), seed: int = 0, attention_gain: float = 2.0,
-                       tag: str = "r50") -> str:
+                       tag: str = "r50", device_exact: bool = True) -> str:
     """Write (once) and return the path of the safetensors file for a seeded weight set."""
     os.makedirs(cache_dir, exist_ok=True)
-    path = os.path.join(cache_dir, f"detr_{tag}_seed{seed}_ga{attention_gain:g}_v{RECIPE_VERSION}.safetensors")
+    kind = "" if device_exact else "_raw"   # (part of the cache key: the two sets differ in every GEMM weight)
+    path = os.path.join(cache_dir, f"detr_{tag}_seed{seed}_ga{attention_gain:g}_v{RECIPE_VERSION}{kind}.safetensors")
     if not os.path.exists(path):
-        save_safetensors(synth_weights(arch, seed, attention_gain), path)
+        tmp = path + f".tmp{os.getpid()}"
+        save_safetensors(synth_weights(arch, seed, attention_gain, device_exact=device_exact), tmp)
+        os.replace(tmp, path)   # (atomic: several ranks may generate the same file at once)
     return path

@@ -222,3 +222,31 @@ def test_graph_replay_survives_foreign_allocations_and_handle_churn(mild_path, w
         A.close()
         for d in extra:
             d.close()
+
+
+@pytest.mark.parametrize("size,frames_n", [((800, 1333), 2), ((256, 320), 2)])
+def test_parity_on_weights_that_are_not_device_exact(weight_cache, parity_log, size, frames_n):
+    """The unfavourable operating point: the same seeded recipe WITHOUT `make_device_exact`, i.e. ordinary fp32
+    tensors as a real checkpoint has them — the device rounds every folded conv kernel and every linear weight to fp16 itself,
+    the fp32 oracle does not round at all.  Stated bound: 2e-3 on the boxes at 800x1333 (measured 0.9e-3 .. 1.2e-3 in round 3:
+    the fp16 rounding of the WEIGHTS contributes about as much as the fp16 activation storage), 4e-3 at 256x320."""
+    H, W = size
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50", device_exact=False)
+    det = HipDetrDetector(model_path=path, max_batch=2, max_size=(800, 1333), resize=False)
+    det.load_model()
+    try:
+        frames = structured_frames(frames_n, H, W, seed=5150)
+        lg, bx, enc = det.forward_raw(frames)
+    finally:
+        det.close()
+    w = O.to_torch(load_safetensors(path))
+    pv, pm = O.preprocess(frames)
+    lg0, bx0, mem0 = O.forward(w, pv, pm)
+    sm = lambda t: torch.softmax(torch.as_tensor(t), -1).numpy()
+    dbox = float(np.abs(bx - bx0.numpy()).max())
+    dprob = float(np.abs(sm(lg) - sm(lg0.numpy())).max())
+    denc = float(np.abs(enc - mem0.numpy()).max())
+    bound = 2e-3 if H >= 800 else 4e-3
+    parity_log(f"r50 mild {H}x{W}, weights NOT device-exact (raw fp32 checkpoint) vs live oracle", dbox, dprob, denc, bound,
+               "weight rounding included")
+    assert dbox <= bound and dprob <= 2 * bound
