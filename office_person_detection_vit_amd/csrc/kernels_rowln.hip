@@ -281,14 +281,206 @@ __global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Deep-K form (encoder FFN-2: K = 2048): row owners again — a workgroup of 64 rows walks the WHOLE reduction and finishes the
+// LayerNorm itself, so the split-K fp32 slabs (34 MB written and re-read per encoder layer at batch 8) and the reduce launch
+// disappear.  What such a workgroup is bound by is the weight stream: all 256 x K weights (1 MiB) pass through its CU's LDS-DMA
+// path, which moves 21 / 33 / 42 bytes per clock with 32 / 64 / 128 KiB in flight (tools/microbench/ldpath.hip).  Hence a
+// THREE-stage ring of [64 x 64] activation + [256 x 64] weight sub-tiles (40 KiB per stage, two k-steps = 80 KiB in flight
+// while the third is being multiplied), counted vmcnt waits, one barrier per k-step.  The per-workgroup time does not depend on
+// the number of rows (24-32 MFMAs per wave and k-step against ~1100 clocks of staging), so the tile is as tall as the registers
+// allow: M = 8400 gives 132 workgroups, which leaves half the CUs to whatever else is in flight.  Eight waves (two per SIMD, 32
+// columns each) rather than four: more LDS-DMA instructions in flight per CU (31.0 -> 26.7 us at M = 8400; the split-K launch
+// plus its reduce launch take 19.4 + 12.2 us, and move 514 MB of fp32 slabs per forward that this kernel does not).
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int RG_TM = 64;
+constexpr int RG_NS = 3;
+constexpr int RG_NW = 8;                        // waves per workgroup: two per SIMD, each owning 32 of the 256 columns
+constexpr int RG_XSUB = RG_TM * ROW_BYTES;      // 8 KiB
+constexpr int RG_STAGE = RG_XSUB + W_BYTES;     // 40 KiB
+constexpr int RG_LDS = RG_NS * RG_STAGE;
+
+// LN = false (gamma == null: the input projection): no normalisation, y = x . W^T + b (+ res).
+template <bool LN>
+__global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    __shared__ float red[2][RG_NW][RG_TM];       // [pass][wave][row]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int m_base = blockIdx.x * RG_TM;
+    const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    constexpr int NT = 256 / 16 / RG_NW;         // column tiles per wave (2)
+    constexpr int WP = 256 / 8 / RG_NW;          // weight pieces per wave and k-step (4)
+    constexpr int PIECES = WP + 1;               // + one piece of the activation tile
+
+    const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x), 0, (unsigned)((size_t)p.M * p.K * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)256 * p.K * 2), 0x00020000);
+    // per k-step every wave issues exactly PIECES pieces: activation rows 8 wave + lrow (rows >= M fall outside the descriptor: zero
+    // fill) and the WP pieces of its own 32 weight rows
+    const unsigned xoff = (unsigned)((m_base + wave * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
+    const unsigned woff = (unsigned)((wave * (8 * WP) + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
+    const unsigned wstep = (unsigned)(8 * p.K) * 2u;
+    auto issue = [&](int ks) {
+        unsigned char* Xs = smem + (ks % RG_NS) * RG_STAGE;
+        unsigned char* Ws = Xs + RG_XSUB;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(Xs + wave * 1024), 16, xoff, ks * 128, 0, 0);
+#pragma unroll
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Ws + (wave * WP + i) * 1024), 16,
+                                                     woff + (unsigned)i * wstep, ks * 128, 0, 0);
+    };
+    const int nk = p.K / 64;
+    issue(0);
+    if (nk > 1) issue(1);
+    float4v acc[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.bias + (wave * NT + nt) * 16 + g * 4);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = b;
+    }
+    float4v res[NT][4];
+#pragma unroll 1
+    for (int ks = 0; ks < nk; ++ks) {
+        // k-step ks has landed once at most the pieces of k-step ks + 1 are outstanding (vmcnt retires in issue order)
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // everybody's pieces of ks are in LDS; everybody has finished multiplying stage (ks - 1) % 3
+        if (ks + 2 < nk) issue(ks + 2);     // ... which is the stage this goes to
+        // (a second barrier per k-step, so that k-step ks + 2 is issued BEFORE the wait for ks and two whole stages stay in flight, measured
+        //  slower: 30.0 against 26.7 us -- the CU's LDS-DMA path, ~20 bytes per clock here, is the limit, not the bytes in flight)
+        if (ks + 1 == nk) {                 // last k-step: the residual rows travel during its MFMAs
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const int m = m_base + mt * 16 + li;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    res[nt][mt] = float4v{0.f, 0.f, 0.f, 0.f};
+                    if (p.res32 && m < p.M) res[nt][mt] = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + (wave * NT + nt) * 16 + g * 4);
+                }
+            }
+        }
+        const unsigned char* Xs = smem + (ks % RG_NS) * RG_STAGE;
+        const unsigned char* Ws = Xs + RG_XSUB;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[4], wf[NT];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) xf[mt] = *reinterpret_cast<const half8*>(Xs + swz(mt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + swz((wave * NT + nt) * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        }
+    }
+    // ---- + residual, LayerNorm over the 256 columns of each row (as in gemm_ln256_kernel) -----------------------------------
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[nt][mt] += res[nt][mt];
+            sum[mt] += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
+        }
+        if constexpr (LN) {
+            sum[mt] += __shfl_xor(sum[mt], 16);
+            sum[mt] += __shfl_xor(sum[mt], 32);
+            if (g == 0) red[0][wave][mt * 16 + li] = sum[mt];
+        }
+    }
+    if constexpr (LN) __syncthreads();
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; LN && mt < 4; ++mt) {
+        const int r = mt * 16 + li;
+        float mean = 0.f;
+#pragma unroll
+        for (int w = 0; w < RG_NW; ++w) mean += red[0][w][r];
+        mean *= (1.0f / 256.0f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[nt][mt] -= mean;
+            sq[mt] += acc[nt][mt][0] * acc[nt][mt][0] + acc[nt][mt][1] * acc[nt][mt][1] + acc[nt][mt][2] * acc[nt][mt][2] +
+                      acc[nt][mt][3] * acc[nt][mt][3];
+        }
+        sq[mt] += __shfl_xor(sq[mt], 16);
+        sq[mt] += __shfl_xor(sq[mt], 32);
+        if (g == 0) red[1][wave][r] = sq[mt];
+    }
+    if constexpr (LN) __syncthreads();
+    float4v gm[NT], bt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        gm[nt] = LN ? *reinterpret_cast<const float4v*>(p.gamma + (wave * NT + nt) * 16 + g * 4) : float4v{1.f, 1.f, 1.f, 1.f};
+        bt[nt] = LN ? *reinterpret_cast<const float4v*>(p.beta + (wave * NT + nt) * 16 + g * 4) : float4v{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int r = mt * 16 + li;
+        const int m = m_base + r;
+        float var = 0.f;
+#pragma unroll
+        for (int w = 0; LN && w < RG_NW; ++w) var += red[1][w][r];
+        var *= (1.0f / 256.0f);
+        const float rstd = LN ? 1.0f / sqrtf(var + 1e-5f) : 1.0f;
+        const float* pos = nullptr;   // second fp16 shadow y + position embedding (encoder: the next layer's q / k projection input)
+        if (p.yp16 && m < p.M) {
+            const int fr = m / p.pos_period, t = m - fr * p.pos_period;
+            pos = (p.pos_ptrs ? p.pos_ptrs[fr] : p.pos) + (size_t)t * 256;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = (wave * NT + nt) * 16 + g * 4;
+            float4v o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = LN ? acc[nt][mt][q] * rstd * gm[nt][q] + bt[nt][q] : acc[nt][mt][q];
+            if (m < p.M) {
+                if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
+                if (p.y16) {
+                    half4 h;
+                    h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+                    *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
+                }
+                if (pos) {
+                    const float4v pe = *reinterpret_cast<const float4v*>(pos + c);
+                    half4 h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = (_Float16)(o[q] + pe[q]);
+                    *reinterpret_cast<half4*>(p.yp16 + (size_t)m * 256 + c) = h;
+                }
+            }
+        }
+    }
+#endif
+}
+
 }  // namespace
 
 static int g_gemm_ln_variant = 1;   // 1: one-shot kernel for K == 256 (default), 0: the k-loop kernel (cross-check)
 void opd_set_gemm_ln_variant(int v) { g_gemm_ln_variant = v; }
 
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || !p.gamma || !p.beta || !p.bias) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || !p.bias || (!p.deep_k && (!p.gamma || !p.beta)) || (p.gamma && !p.beta)) return hipErrorInvalidValue;
     if ((size_t)p.M * p.K * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;  // 31-bit buffer offsets
+    if (p.deep_k) {   // row-owner ring (the encoder's FFN-2): no split-K slabs, no reduce launch
+        if (p.yp16 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
+        static bool attr_rg = false;
+        if (!attr_rg) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
+            if (e != hipSuccess) return e;
+            attr_rg = true;
+        }
+        if (p.gamma) hipLaunchKernelGGL(gemm_ln256_ring_kernel<true>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
+        else hipLaunchKernelGGL(gemm_ln256_ring_kernel<false>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
+        return hipGetLastError();
+    }
+    if (p.yp16) return hipErrorInvalidValue;   // (the position shadow is written by the deep-K form only)
     if (p.K == 256 && g_gemm_ln_variant == 1) {
         static bool attr_os = false;
         if (!attr_os) {

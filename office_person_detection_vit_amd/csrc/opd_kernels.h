@@ -105,6 +105,13 @@ struct GemmLnParams {
     float* y32;          // [M][256] or null
     f16_t* y16;          // [M][256] or null
     int M, K;
+    int deep_k;          // 1: the row-owner ring kernel for deep reductions (any K % 64 == 0; the encoder's FFN-2, K = 2048)
+    // deep_k only: optional second fp16 output yp16 = fp16(y + pos[row % pos_period]) (pos: one [pos_period][256] table, or pos_ptrs:
+    // one table per frame of pos_period rows) -- the position-embedding shadow the next encoder layer's q / k projection reads
+    const float* pos;
+    const float* const* pos_ptrs;
+    int pos_period;
+    f16_t* yp16;
 };
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream);
 void opd_set_gemm_ln_variant(int v);  // 1 = one-shot kernel for K == 256 (default), 0 = the k-loop kernel everywhere (cross-check)

@@ -189,6 +189,7 @@ struct opd_detr {
     float stage_ms[8] = {};
     int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
+    int deep_fc2 = 1;        // encoder FFN-2 (K = 2048) + residual + LayerNorm as ONE row-owner launch (0: split-K slabs + reduce launch)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int tail_rev = 1;        // consecutive fused tails walk their tiles in opposite directions (Infinity Cache reuse of the block output)
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
@@ -1034,7 +1035,25 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     const bool shadow = m->pos_shadow && !m->fuse_ffn && D == 256 && (opd_get_gemm_variant() & 0x8ff) == 1 && m->enc[0].bqkv && m->bkv_all;
     const PosShadow psh{plan->d_pos, pos_ptrs, hw, m->d_xp16};
     const PosShadow* ps = shadow ? &psh : nullptr;
-    RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV, ps));
+    // Deep-K row-owner launches (kernels_rowln.hip::gemm_ln256_ring_kernel) for the two K = 2048 -> 256 linears of the encoder side:
+    // the input projection (no LayerNorm) and every layer's FFN-2 (+ residual + LayerNorm); both also write the position shadow
+    auto run_deep = [&](const f16_t* x, const Lin* lin, const f16_t* w, const float* bias, int K, const float* res32, const LNp* ln, int cls) -> int {
+        GemmLnParams gp{};
+        gp.x = x; gp.w = w; gp.bias = bias; gp.res32 = res32; gp.gamma = ln ? ln->g : nullptr; gp.beta = ln ? ln->b : nullptr;
+        gp.y32 = m->d_x32; gp.y16 = m->d_x16; gp.M = M; gp.K = K; gp.deep_k = 1;
+        if (ps) { gp.pos = ps->pos; gp.pos_ptrs = ps->pos_ptrs; gp.pos_period = ps->period; gp.yp16 = ps->yp16; }
+        RCCHK(timed_begin(m, cls, 2.0 * M * (double)D * K));
+        HIPCHK(opd_launch_gemm_ln(gp, m->stream));
+        RCCHK(timed_end(m));
+        RCCHK(tap(m, ln ? "fc2_ln_ring" : "input_proj_ring", m->d_x32, (size_t)M * D * 4));
+        (void)lin;
+        return OPD_OK;
+    };
+    const bool deep_ok = m->deep_fc2 && D == 256;
+    if (deep_ok && m->proj.K % 64 == 0 && (size_t)M * m->proj.K * 2 < 0x7fffff00ull)
+        RCCHK(run_deep(cur, nullptr, m->proj.w, m->proj.bias, m->proj.K, nullptr, nullptr, CLS_CONV));
+    else
+        RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV, ps));
     for (int i = 0; i < a.enc_layers; ++i) {
         const EncLayer& L = m->enc[i];
         if (shadow)
@@ -1061,7 +1080,11 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
             // (fc2 + residual + LayerNorm as ONE row-owner launch — gemm_ln256_kernel with K = 2048 — was measured: encoder 1.05 ms
             //  against 1.00 ms; every 32-row workgroup would stream the whole 1 MiB of fc2 weights)
-            RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM, ps));
+            if (deep_ok && F % 64 == 0 && (size_t)M * F * 2 < 0x7fffff00ull) {
+                RCCHK(run_deep(m->d_ffn16, nullptr, L.fc2.w, L.fc2.b, F, m->d_x32, &L.ln2, CLS_GEMM));
+            } else {
+                RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM, ps));
+            }
         }
     }
     MARK(6);
@@ -1377,6 +1400,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
     if (const char* v = getenv("OPD_POS_SHADOW")) m->pos_shadow = atoi(v);
+    if (const char* v = getenv("OPD_DEEP_FC2")) m->deep_fc2 = atoi(v);
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1416,7 +1440,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->wc = src->wc; m->bc = src->bc; m->w1 = src->w1; m->b1 = src->b1; m->w2 = src->w2; m->b2 = src->b2; m->w3 = src->w3; m->b3 = src->b3;
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
-    m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln;
+    m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     m->d_dump = nullptr;
@@ -1787,6 +1811,7 @@ int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_gemm_ln = on ? 1 : 0;
     m->small_m_gemm = on ? 1 : 0;   // the switch covers the transformer-side specialisations
+    m->deep_fc2 = on ? 1 : 0;
     m->fuse_dec0 = on ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);

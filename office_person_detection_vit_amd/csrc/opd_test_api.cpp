@@ -153,6 +153,63 @@ int opd_test_gemm_ln(const uint16_t* x, const uint16_t* w, const float* bias, co
     return OPD_OK;
 }
 
+// deep-K row-owner form (gemm_ln256_ring_kernel) with the optional position shadow: pos [period][256] fp32, yp16 = fp16(y + pos[row % period])
+int opd_test_gemm_ln_deep(const uint16_t* x, const uint16_t* w, const float* bias, const float* res32, const float* gamma, const float* beta,
+                          const float* pos, int period, float* y, uint16_t* y16, uint16_t* yp16, int M, int K, int in_place) {
+    DevMem dm;
+    GemmLnParams p{};
+    p.x = dm.up(x, (size_t)M * K);
+    p.w = dm.up(w, (size_t)256 * K);
+    p.bias = dm.up(bias, 256);
+    float* res = res32 ? dm.up(res32, (size_t)M * 256) : nullptr;
+    p.res32 = res;
+    p.gamma = gamma ? dm.up(gamma, 256) : nullptr;   // null: no LayerNorm (the input projection)
+    p.beta = beta ? dm.up(beta, 256) : nullptr;
+    p.y32 = (in_place && res) ? res : dm.up<float>(nullptr, (size_t)M * 256);   // the model writes the residual stream in place
+    p.y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    p.pos = pos ? dm.up(pos, (size_t)period * 256) : nullptr;
+    p.pos_period = period;
+    p.yp16 = pos ? dm.up<uint16_t>(nullptr, (size_t)M * 256) : nullptr;
+    if (!p.x || !p.w || !p.bias || (gamma && (!p.gamma || !p.beta)) || !p.y32 || !p.y16 || (res32 && !p.res32) || (pos && (!p.pos || !p.yp16)))
+        return tfail(OPD_ENOMEM, "test alloc failed");
+    p.M = M; p.K = K; p.deep_k = 1;
+    TCHK(opd_launch_gemm_ln(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, p.y32, (size_t)M * 256 * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(y16, p.y16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
+    if (pos) TCHK(hipMemcpy(yp16, p.yp16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// Times `iters` launches of Linear(K -> 256) + residual + LayerNorm (deep != 0: the row-owner ring kernel) on M rows of arbitrary data.
+int opd_test_bench_gemm_ln(int M, int K, int deep, int iters, float* us_out) {
+    DevMem dm;
+    GemmLnParams p{};
+    uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)M * K);
+    uint16_t* w = dm.up<uint16_t>(nullptr, (size_t)256 * K);
+    float* f = dm.up<float>(nullptr, 1024);
+    float* res = dm.up<float>(nullptr, (size_t)M * 256);
+    uint16_t* y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    if (!x || !w || !f || !res || !y16) return tfail(OPD_ENOMEM, "bench alloc failed");
+    TCHK(hipMemset(x, 0x2c, (size_t)M * K * 2));
+    TCHK(hipMemset(w, 0x1c, (size_t)256 * K * 2));
+    TCHK(hipMemset(f, 0, 4096));
+    TCHK(hipMemset(res, 0, (size_t)M * 256 * 4));
+    p.x = x; p.w = w; p.bias = f; p.gamma = f + 256; p.beta = f + 512; p.res32 = res; p.y32 = res; p.y16 = y16; p.M = M; p.K = K; p.deep_k = deep;
+    hipEvent_t a, b;
+    TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) TCHK(opd_launch_gemm_ln(p, nullptr));
+    TCHK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) TCHK(opd_launch_gemm_ln(p, nullptr));
+    TCHK(hipEventRecord(b, nullptr));
+    TCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    TCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *us_out = ms * 1000.f / iters;
+    return OPD_OK;
+}
+
 // fused feed-forward block (kernels_ffn.hip): w2 in plain K order [256][F] (the hook applies opd_permute_k32)
 int opd_test_ffn(const uint16_t* x16, const float* res32, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2,
                  const float* gamma, const float* beta, float* y, uint16_t* y16, int M, int F, int in_place) {

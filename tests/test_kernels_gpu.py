@@ -700,6 +700,38 @@ def test_gemm_ln_matches_torch(lib, M, K, use_res, variant):
     np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), want, atol=2e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize("M,K,period,in_place,ln", [(8400, 2048, 1050, True, True), (100, 2048, 0, False, True), (333, 128, 111, True, True),
+                                                     (64, 64, 0, False, True), (1, 192, 0, True, True), (8400, 2048, 1050, False, False),
+                                                     (77, 320, 11, True, False)])
+def test_gemm_ln_deep_matches_torch(lib, M, K, period, in_place, ln):
+    """Row-owner ring kernel (the encoder's FFN-2): y = LN(x W^T + b + res) with the whole reduction walked by one workgroup
+    (three-stage LDS-DMA ring, counted waits), optionally in place on the residual stream and with the position shadow
+    fp16(y + pos[row % period]); K = 64 .. 2048 (1, 2, 3 and many k-steps), ragged last tile."""
+    rng = np.random.default_rng(M * 3 + K)
+    x, xb = _h(rng.standard_normal((M, K)))
+    w, wb = _h(rng.standard_normal((256, K)) / np.sqrt(K))
+    bias = rng.standard_normal(256).astype(np.float32) * 0.1
+    res = rng.standard_normal((M, 256)).astype(np.float32)
+    gamma = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    pos = rng.standard_normal((period, 256)).astype(np.float32) if period else None
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    yp16 = np.empty((M, 256), np.uint16)
+    _capi.check(lib.opd_test_gemm_ln_deep(_p(xb), _p(wb), _p(bias), _p(res), _p(gamma if ln else None), _p(beta if ln else None), _p(pos), period,
+                                          _p(y), _p(y16), _p(yp16), M, K, int(in_place)), "opd_test_gemm_ln_deep")
+    pre = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double() + torch.from_numpy(res).double()
+    if ln:
+        want = F.layer_norm(pre, (256,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5).float().numpy()
+    else:   # gamma == null: the plain linear layer (+ residual), e.g. the input projection
+        want = pre.float().numpy()
+    np.testing.assert_allclose(y, want, atol=3e-5, rtol=1e-5)
+    np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), want, atol=2e-3, rtol=1e-3)
+    if period:
+        wantp = (y + pos[np.arange(M) % period]).astype(np.float16)     # one rounding of the fp32 sum, from the kernel's own fp32 y
+        np.testing.assert_array_equal(yp16.view(np.float16), wantp)
+
+
 # ---- one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel) -------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,period,relu", [(800, 768, 256, 100, False), (800, 256, 256, 100, False), (800, 2048, 256, 0, True),
                                                (800, 256, 2048, 0, False), (37, 64, 256, 0, True), (130, 256, 512, 0, False)])
