@@ -94,7 +94,6 @@ TEST_API = {
     "opd_test_attention_masked": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float, C.c_void_p, C.c_int]),
     "opd_test_stem2": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 5),
     "opd_test_stem_pool": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 7),
-    "opd_test_set_stem_variant": (C.c_int, [C.c_int]),
     "opd_test_set_fuse_stem_pool": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_set_pos_shadow": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_stem_pool_u8": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 3),
@@ -107,16 +106,12 @@ TEST_API = {
     "opd_test_resize_coeffs": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]),
     "opd_test_valid_prefix": (C.c_int, [C.c_int] * 3),
     "opd_test_sine_pos_embed": (C.c_int, [C.c_int] * 5 + [C.c_void_p]),
-    "opd_test_set_gemm_variant": (C.c_int, [C.c_int]),
-    "opd_test_set_gemm_ln_variant": (C.c_int, [C.c_int]),
     "opd_test_conv_dual": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 13),
     "opd_test_btail_sc": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 3),
-    "opd_test_ffn": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 3),
-    "opd_test_etail": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 3),
-    "opd_test_bench_ffn": (C.c_int, [C.c_int] * 5 + [C.c_void_p]),
-    "opd_test_set_fuse_ffn": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_bench_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_int, C.POINTER(C.c_float)]),
     "opd_test_trace_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "opd_test_set_conv_flags": (C.c_int, [C.c_int]),
+    "opd_test_set_gemm_ln_kloop": (C.c_int, [C.c_int]),
     "opd_test_set_graph_guard": (C.c_int, [C.c_int]),
     "opd_test_set_alloc_poison": (C.c_int, [C.c_int]),
     "opd_test_check_redzones": (C.c_int, [C.c_void_p]),

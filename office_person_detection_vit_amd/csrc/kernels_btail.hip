@@ -493,12 +493,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false>
 hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
     constexpr int LDS = 2 * (128 + C1) * ROW_BYTES + (RDMA ? 2 * 16384 : 0);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(btail_kernel<C1, C3, RDMA, SC, TRACE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    OPD_SET_MAX_LDS_ONCE((btail_kernel<C1, C3, RDMA, SC, TRACE>), LDS);
     hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA, SC, TRACE>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }

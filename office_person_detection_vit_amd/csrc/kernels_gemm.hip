@@ -22,11 +22,6 @@
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
-static int g_tile_mt = 0;         // 0: pick 128/160/192-row tiles per layer by wave quantisation; 4/5/6: force
-static int g_buffer_staging = 1;  // tile DMA through buffer descriptors (scalar tap offsets, bounds-check zero fill)
-static int g_strip3x3 = 0;      // 3x3 stride-1 convolutions use the row-strip kernel (0: plain im2col tiles)
-static int g_gemm_variant = 1;  // 0 = v1 register-staged, 1 = v2 LDS-DMA 2-stage (default), 2 = v2 + 3-stage 64-deep ring for deep K, 3 = v2 + 4-stage 32-deep ring
-
 namespace {
 
 constexpr int BM = 128;
@@ -34,16 +29,6 @@ constexpr int BK = 64;           // halfs per k-step = 128 bytes per tile row
 constexpr int ROW_BYTES = BK * 2;
 
 __device__ __forceinline__ int swz(int row, int chunk) { return row * ROW_BYTES + ((chunk ^ (row & 7)) << 4); }
-
-template <int BN>
-struct Smem {
-    static constexpr int A_BYTES = BM * ROW_BYTES;
-    static constexpr int B_BYTES = BN * ROW_BYTES;
-    static constexpr int STAGE = A_BYTES + B_BYTES;
-    static constexpr int LDC = BN + 4;  // fp32 words per row of the epilogue tile
-    static constexpr int C_BYTES = BM * LDC * 4;
-    static constexpr int TOTAL = (2 * STAGE > C_BYTES) ? 2 * STAGE : C_BYTES;
-};
 
 // XCD-aware block -> tile map (cdna_hip_programming.md T1, bijective form).  Workgroups are dealt round-robin over the 8
 // XCDs (blocks b and b+8 share an XCD and its private 4 MiB L2), so hand each XCD a CONTIGUOUS range of logical tile
@@ -61,207 +46,6 @@ __device__ __forceinline__ int fdiv(const int m, const FastDiv& f) {   // m >= 0
 
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ uint2 ldg8(const void* p) { return *reinterpret_cast<const uint2*>(p); }
-
-template <int BN, bool STEM>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(ConvGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    using S = Smem<BN>;
-    constexpr int NT = BN / 32;        // 16-wide n tiles per wave
-    constexpr int B_LOADS = BN / 32;   // 16-byte chunks of the B tile per thread
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int tiles_n = p.N / BN;
-    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int tile_n = lbid % tiles_n;
-    const int tile_m = lbid / tiles_n;
-    const int m_base = tile_m * BM;
-    const int n_base = tile_n * BN;
-
-    // ---- per-thread staging coordinates -------------------------------------------------------------------------
-    const int chunk = tid & 7;     // 16-byte chunk inside the 128-byte tile row
-    const int row0 = tid >> 3;     // rows row0 + 32*i
-    // A rows: decompose m -> (b, oh, ow) once
-    long long a_base[4];           // element offset of pixel (b, 0, 0)
-    int a_ih0[4], a_iw0[4];
-    bool a_ok[4];
-    {
-        const int ohw = p.OH * p.OW;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m_base + row0 + 32 * i;
-            a_ok[i] = m < p.M;
-            const int mm = a_ok[i] ? m : 0;
-            const int b = mm / ohw;
-            const int r = mm - b * ohw;
-            const int oh = r / p.OW;
-            const int ow = r - oh * p.OW;
-            a_base[i] = (long long)b * p.H * p.W;
-            a_ih0[i] = oh * p.stride - p.pad;
-            a_iw0[i] = ow * p.stride - p.pad;
-        }
-    }
-    const f16_t* wrow[B_LOADS];
-#pragma unroll
-    for (int i = 0; i < B_LOADS; ++i) wrow[i] = p.w + (size_t)(n_base + row0 + 32 * i) * p.K + chunk * 8;
-
-    const int nk = p.K / BK;
-    const int kpc = STEM ? 1 : p.Cin / BK;  // k-steps per filter tap
-    int tap_kh = 0, tap_kw = 0, tap_c = 0;  // state of the NEXT k-step to be loaded
-
-    uint4 ra[4], rb[B_LOADS];
-
-    auto load_regs = [&](int ks) {
-        if constexpr (STEM) {
-            // k-step = 2 filter rows x (8 pixels x 4 channels); chunk = 2 pixels of NHWC4 input (8-byte aligned)
-            const int kh = ks * 2 + (chunk >> 2);
-            const int px = (chunk & 3) * 2;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ih = a_ih0[i] + kh;
-                const int iw = a_iw0[i] + px;
-                const bool rowok = a_ok[i] && kh < 7 && (unsigned)ih < (unsigned)p.H;
-                const f16_t* src = p.x + ((a_base[i] + (long long)ih * p.W + iw) << 2);
-                uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
-                if (rowok && (unsigned)iw < (unsigned)p.W) lo = ldg8(src);
-                if (rowok && (unsigned)(iw + 1) < (unsigned)p.W) hi = ldg8(src + 4);
-                ra[i] = make_uint4(lo.x, lo.y, hi.x, hi.y);
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int ih = a_ih0[i] + tap_kh;
-                const int iw = a_iw0[i] + tap_kw;
-                const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-                uint4 v = make_uint4(0u, 0u, 0u, 0u);
-                if (ok) v = ldg16(p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BK + chunk * 8);
-                ra[i] = v;
-            }
-            if (++tap_c == kpc) {
-                tap_c = 0;
-                if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) rb[i] = ldg16(wrow[i] + (size_t)ks * BK);
-    };
-    auto store_lds = [&](int buf) {
-        unsigned char* As = smem + buf * S::STAGE;
-        unsigned char* Bs = As + S::A_BYTES;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<uint4*>(As + swz(row0 + 32 * i, chunk)) = ra[i];
-#pragma unroll
-        for (int i = 0; i < B_LOADS; ++i) *reinterpret_cast<uint4*>(Bs + swz(row0 + 32 * i, chunk)) = rb[i];
-    };
-
-    float4v acc[NT][4];
-#pragma unroll
-    for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) acc[a][b] = float4v{0.f, 0.f, 0.f, 0.f};
-
-    load_regs(0);
-    store_lds(0);
-    __syncthreads();
-
-    const int frow = lane & 15;   // fragment row (m for activations, n for weights)
-    const int fchk = lane >> 4;   // 16-byte k chunk within a 32-wide k sub-step
-
-    for (int ks = 0; ks < nk; ++ks) {
-        const int buf = ks & 1;
-        if (ks + 1 < nk) load_regs(ks + 1);
-        const unsigned char* As = smem + buf * S::STAGE;
-        const unsigned char* Bs = As + S::A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 xf[4], wf[NT];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * 64 + mt * 16 + frow, kk * 4 + fchk));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        }
-        if (ks + 1 < nk) store_lds(buf ^ 1);
-        __syncthreads();
-    }
-
-    // ---- epilogue: accumulators -> LDS (fp32 [m][n]) -> fused bias/residual/ReLU -> 16-byte row-contiguous stores --
-    float* Cs = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = wm * 64 + mt * 16 + (lane & 15);
-            const int n = wn * (BN / 2) + nt * 16 + (lane >> 4) * 4;
-            *reinterpret_cast<float4v*>(Cs + m * S::LDC + n) = acc[nt][mt];
-        }
-    __syncthreads();
-
-    constexpr int CPR = BN / 8;  // 8-wide column groups per tile row
-    for (int idx = tid; idx < BM * CPR; idx += 256) {
-        const int r = idx / CPR;
-        const int c8 = idx - r * CPR;
-        const int m = m_base + r;
-        if (m >= p.M) continue;
-        const int n = n_base + c8 * 8;
-        float v[8];
-        {
-            const float4v lo = *reinterpret_cast<const float4v*>(Cs + r * S::LDC + c8 * 8);
-            const float4v hi = *reinterpret_cast<const float4v*>(Cs + r * S::LDC + c8 * 8 + 4);
-            v[0] = lo[0]; v[1] = lo[1]; v[2] = lo[2]; v[3] = lo[3];
-            v[4] = hi[0]; v[5] = hi[1]; v[6] = hi[2]; v[7] = hi[3];
-        }
-        {
-            const float* bp = p.bias + (p.bias_period > 0 ? (size_t)(m % p.bias_period) * p.N : 0) + n;
-            const float4v b0 = *reinterpret_cast<const float4v*>(bp);
-            const float4v b1 = *reinterpret_cast<const float4v*>(bp + 4);
-            v[0] += b0[0]; v[1] += b0[1]; v[2] += b0[2]; v[3] += b0[3];
-            v[4] += b1[0]; v[5] += b1[1]; v[6] += b1[2]; v[7] += b1[3];
-        }
-        const size_t o = (size_t)m * p.N + n;
-        if (p.res16) {
-            const half8 rr = *reinterpret_cast<const half8*>(p.res16 + o);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] += (float)rr[j];
-        }
-        if (p.res32) {
-            const float4v r0 = *reinterpret_cast<const float4v*>(p.res32 + o);
-            const float4v r1 = *reinterpret_cast<const float4v*>(p.res32 + o + 4);
-            v[0] += r0[0]; v[1] += r0[1]; v[2] += r0[2]; v[3] += r0[3];
-            v[4] += r1[0]; v[5] += r1[1]; v[6] += r1[2]; v[7] += r1[3];
-        }
-        if (p.relu) {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] > 0.f ? v[j] : 0.f;
-        }
-        if (p.out_f32) {
-            float* op = reinterpret_cast<float*>(p.out) + o;
-            *reinterpret_cast<float4v*>(op) = float4v{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<float4v*>(op + 4) = float4v{v[4], v[5], v[6], v[7]};
-            if (p.out16_aux) {
-                half8 h;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
-                *reinterpret_cast<half8*>(p.out16_aux + o) = h;
-            }
-        } else {
-            half8 h;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) h[j] = (_Float16)v[j];
-            *reinterpret_cast<half8*>(reinterpret_cast<f16_t*>(p.out) + o) = h;
-        }
-    }
-}
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // v2: LDS-DMA staging (global_load_lds_dwordx4: HBM/L2 -> LDS without passing through VGPRs or the ds_write path) and
@@ -777,13 +561,7 @@ template <int BN, bool BUF, int MT, bool DUAL = false, bool TRACE = false, bool 
 hipError_t launch_dma_t(const ConvGemmParams& p_in, hipStream_t stream) {
     constexpr int BMT = 32 * MT;
     constexpr int LDS = 2 * (BMT + BN) * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_dma_kernel<BN, BUF, MT, DUAL, TRACE, PW>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    OPD_SET_MAX_LDS_ONCE((conv_gemm_dma_kernel<BN, BUF, MT, DUAL, TRACE, PW>), LDS);
     ConvGemmParams p = p_in;
     const int tiles_m = (p.M + BMT - 1) / BMT;
     const int tiles_n = p.N / BN;
@@ -797,145 +575,6 @@ hipError_t launch_dma_t(const ConvGemmParams& p_in, hipStream_t stream) {
     return hipGetLastError();
 }
 
-// ---------------------------------------------------------------------------------------------------------------------
-// Persistent pointwise form: a workgroup walks several output tiles (static schedule: its j-th tile is logical tile
-// xcd_logical_block(blockIdx.x + j * gridDim.x), so an XCD still owns a contiguous range) and the k-step pipeline runs straight
-// through the tile boundaries -- the first DMA of tile t+1 is issued BEFORE the last MFMAs and the epilogue of tile t.  What the
-// per-workgroup trace (tools/trace_gemm.py) shows for the K = 256 / 512 layers is that a tile's k-loop is less than half of a
-// workgroup's life: ~1 500 clocks of prologue, ~3 500 waiting for the first tile and 5 000 - 6 600 in the epilogue, with both
-// workgroups of a CU going through these phases in lock-step.  Here the prologue is paid once, the first-tile wait once, and an
-// epilogue overlaps the next tile's DMA.  Per-lane DMA offsets are tile independent (row * pitch + chunk) up to the tile's row
-// origin; rows >= M fall outside the buffer descriptor (zeros).  Same per-tile arithmetic, same k order: results are
-// bit-identical to conv_gemm_dma_kernel.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int BN, int MT>
-__global__ __launch_bounds__(256, 2) void gemm_pw_persist_kernel(ConvGemmParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BMT = 32 * MT;
-    constexpr int A_BYTES = BMT * ROW_BYTES;
-    constexpr int STAGE_BYTES = A_BYTES + BN * ROW_BYTES;
-    constexpr int NT = BN / 32;
-    constexpr int B_PIECES = BN / 32;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = p.N / BN;
-    const int ntiles = tiles_n * ((p.M + BMT - 1) / BMT);
-    const int lrow = lane >> 3;
-    const int lchunk = (lane & 7) ^ lrow;
-    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x), 0, (unsigned)((size_t)p.M * p.K * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)((size_t)p.N * p.K * 2), 0x00020000);
-    unsigned rowoff[MT], woff[B_PIECES];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) rowoff[i] = (unsigned)(((wave * MT + i) * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
-#pragma unroll
-    for (int i = 0; i < B_PIECES; ++i) woff[i] = (unsigned)(((wave * B_PIECES + i) * 8 + lrow) * p.K) * 2u + (unsigned)lchunk * 16u;
-    const int nk = p.K / BK;
-    const unsigned pitch = (unsigned)p.K * 2u;
-
-    auto tile_origin = [&](const int seq, int& m_base, int& n_base) {
-        const int lbid = xcd_logical_block(seq, ntiles);
-        const int tile_m = fdiv(lbid, p.fd_tilesn);
-        m_base = tile_m * BMT;
-        n_base = (lbid - tile_m * tiles_n) * BN;
-    };
-    auto issue = [&](const int m_base, const int n_base, const int ks, const int buf) {
-        unsigned char* As = smem + buf * STAGE_BYTES;
-        unsigned char* Bs = As + A_BYTES;
-        // (the tile's row origin goes into the VECTOR offset: only that one is bounds-checked against the descriptor, which is what turns
-        //  rows >= M of the last row tile into zeros; the column origin is always in range and travels as the scalar offset)
-        const unsigned mo = (unsigned)m_base * pitch;
-        const unsigned soff_a = (unsigned)ks * (BK * 2);
-        const unsigned soff_b = (unsigned)n_base * pitch + (unsigned)ks * (BK * 2);
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * MT + i) * 1024), 16, rowoff[i] + mo,
-                                                     soff_a, 0, 0);
-#pragma unroll
-        for (int i = 0; i < B_PIECES; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (wave * B_PIECES + i) * 1024), 16, woff[i],
-                                                     soff_b, 0, 0);
-    };
-    const int frow = lane & 15;
-    const int fchk = lane >> 4;
-    float4v acc[NT][MT];
-    auto compute = [&](const int buf) {
-        const unsigned char* As = smem + buf * STAGE_BYTES;
-        const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 xf[MT], wf[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * (MT * 16) + mt * 16 + frow, kk * 4 + fchk));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        }
-    };
-
-    int seq = blockIdx.x;
-    int m_base, n_base;
-    tile_origin(seq, m_base, n_base);
-    int buf = 0;
-    issue(m_base, n_base, 0, buf);
-    while (true) {
-        const int wm0 = m_base + wm * (MT * 16), wn0 = n_base + wn * (BN / 2);
-        init_acc_bias<NT, MT>(p, p.bias, acc, wm0, wn0, lane);
-        uint4 res[NT][(MT + 1) / 2];
-        __syncthreads();   // the tile's first k-step has landed; every wave has left the buffer the next issue overwrites
-        for (int ks = 0; ks + 1 < nk; ++ks) {
-            issue(m_base, n_base, ks + 1, buf ^ 1);
-            compute(buf);
-            __syncthreads();
-            buf ^= 1;
-        }
-        const int seq_next = seq + (int)gridDim.x;
-        const bool more = seq_next < ntiles;
-        int m_next = 0, n_next = 0;
-        if (more) {   // the next tile's first k-step flies during this tile's last MFMAs, residual loads and stores
-            tile_origin(seq_next, m_next, n_next);
-            issue(m_next, n_next, 0, buf ^ 1);
-        }
-        prefetch_res16<NT, MT>(p, res, wm0, wn0, lane);
-        compute(buf);
-        // the buffer of the last k-step becomes the waves' output-transpose area once every wave has read its fragments (a wave's ds_reads
-        // have returned before its MFMAs issue, so a bare s_barrier is enough -- no vmcnt wait: the next tile's DMA and the residual
-        // loads stay in flight); the loop-top barrier of the next tile separates the transposes from the DMA that re-fills this buffer
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        epilogue_regs<NT, MT>(p, p.out, acc, res, wm0, wn0, lane, smem + buf * STAGE_BYTES + wave * (64 * NT * 32));
-        if (!more) break;
-        seq = seq_next; m_base = m_next; n_base = n_next;
-        buf ^= 1;
-    }
-#endif
-}
-
-template <int BN, int MT>
-hipError_t launch_pw_persist_t(const ConvGemmParams& p_in, int grid, hipStream_t stream) {
-    constexpr int LDS = 2 * (32 * MT + BN) * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_pw_persist_kernel<BN, MT>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    ConvGemmParams p = p_in;
-    p.fd_tilesn = opd_make_fastdiv((unsigned)(p.N / BN));
-    hipLaunchKernelGGL((gemm_pw_persist_kernel<BN, MT>), dim3(grid), dim3(256), LDS, stream, p);
-    return hipGetLastError();
-}
-
 // Workgroups per CU that the LDS footprint of a <BN, MT> tile admits (160 KiB per CU), capped by the 2-waves/SIMD bound.
 static inline int dma_blocks_per_cu(int bn, int mt) {
     const int lds = 2 * (32 * mt + bn) * ROW_BYTES;
@@ -946,8 +585,8 @@ static inline int dma_blocks_per_cu(int bn, int mt) {
 // Tile height by wave quantisation: with T tiles on S = 256 CUs x blocks/CU slots the launch takes ceil(T/S) rounds, and a
 // round lasts ~ (rows + cols) of the tile (DMA-throughput bound).  E.g. M = 33 600, N = 256: 128-row tiles give 526
 // workgroups on 512 slots (2 rounds), 160-row tiles 420 (1 round).
-static inline int pick_mt(int M, int N, int bn, int splits) {
-    if (g_tile_mt) return g_tile_mt;
+static inline int pick_mt(int M, int N, int bn, int splits, int force_mt) {
+    if (force_mt >= 4 && force_mt <= 6) return force_mt;   // (tools/sweep_tiles.py)
     {   // many rounds: quantisation is noise, keep the 128-row tile (tools/sweep_tiles.py: up to ~8 rounds the taller
         // tiles still win, e.g. the strided stage-2/3 shortcuts: 74 -> 65 us, 53 -> 47 us)
         const long long tiles128 = (long long)((M + 127) / 128) * (N / bn) * splits;
@@ -966,19 +605,15 @@ static inline int pick_mt(int M, int N, int bn, int splits) {
     return best;
 }
 
-static int g_pw_persist = 0;   // persistent pointwise form for multi-round launches: kept under test, OFF by default (opd_set_gemm_variant
-                               // bit 11 turns it on) -- measured equal or slower than one tile per workgroup on every layer it applies to
-                               // (fc1 19.1 vs 18.9 us, stage-3 expand 40.8 vs 41.1, stage-4 expand 32.1 vs 32.2, decoder K/V 26.6 vs 24.1)
-
 template <int BN>
 hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
     // buffer-descriptor staging needs 31-bit byte offsets and <= 32 filter taps; otherwise the flat-pointer form
     const size_t a_bytes = (size_t)p.B * p.H * p.W * p.Cin * 2 + (size_t)(p.pad * p.W + p.pad) * p.Cin * 2;
-    const bool buf_ok = g_buffer_staging && a_bytes < 0x7fffff00ull && (size_t)p.N * p.K * 2 < 0x7fffff00ull && p.KH * p.KW <= 32;
+    const bool buf_ok = !p.flat_staging && a_bytes < 0x7fffff00ull && (size_t)p.N * p.K * 2 < 0x7fffff00ull && p.KH * p.KW <= 32;
     if (p.x2) {   // dual-source form (validated by opd_launch_conv_gemm): 128-column tiles, buffer staging
         if constexpr (BN == 128) {
             if (!buf_ok || (size_t)p.B * p.H2 * p.W2 * p.Cin2 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
-            switch (pick_mt(p.M, p.N, BN, 1)) {
+            switch (pick_mt(p.M, p.N, BN, 1, p.force_mt)) {
                 case 5: return launch_dma_t<128, true, 5, true>(p, stream);
                 case 6: return launch_dma_t<128, true, 6, true>(p, stream);
                 default: return launch_dma_t<128, true, 4, true>(p, stream);
@@ -989,8 +624,8 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
     }
     if (!buf_ok) return p.x_alt ? hipErrorInvalidValue : launch_dma_t<BN, false, 4>(p, stream);
     const bool pw = p.KH == 1 && p.KW == 1 && p.pad == 0 && p.stride == 1 && p.H == p.OH && p.W == p.OW && !p.stem;
-    if (p.x_alt && (!pw || p.alt_mod <= 0 || (p.alt_mod % BN) != 0 || (p.alt_cols % BN) != 0 || g_pw_persist)) return hipErrorInvalidValue;
-    const int mt = pick_mt(p.M, p.N, BN, p.split_k > 1 ? p.split_k : 1);
+    if (p.x_alt && (!pw || p.alt_mod <= 0 || (p.alt_mod % BN) != 0 || (p.alt_cols % BN) != 0)) return hipErrorInvalidValue;
+    const int mt = pick_mt(p.M, p.N, BN, p.split_k > 1 ? p.split_k : 1, p.force_mt);
     if (p.trace) {   // tools/trace_gemm.py
         if (pw) {
             switch (mt) {
@@ -1005,22 +640,6 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
             default: return launch_dma_t<BN, true, 4, false, true>(p, stream);
         }
     }
-    if (pw && g_pw_persist && p.split_k <= 1 && p.K / BK >= 2 && p.dbg == 0 && (size_t)p.M * p.K * 2 < 0x7fffff00ull) {
-        // persistent form when a CU would see more than one round of tiles: tiles per workgroup = ceil(tiles / 512), the grid
-        // the smallest multiple of 8 that covers the tiles at that depth
-        const long long tiles = (long long)((p.M + 32 * mt - 1) / (32 * mt)) * (p.N / BN);
-        const int slots = 256 * dma_blocks_per_cu(BN, mt);
-        if (tiles > slots) {
-            const int depth = (int)((tiles + slots - 1) / slots);
-            int grid = (int)((tiles + depth - 1) / depth);
-            grid = (grid + 7) & ~7;
-            switch (mt) {
-                case 5: return launch_pw_persist_t<BN, 5>(p, grid, stream);
-                case 6: return launch_pw_persist_t<BN, 6>(p, grid, stream);
-                default: return launch_pw_persist_t<BN, 4>(p, grid, stream);
-            }
-        }
-    }
     if (pw) {
         switch (mt) {
             case 5: return launch_dma_t<BN, true, 5, false, false, true>(p, stream);
@@ -1033,331 +652,6 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
         case 6: return launch_dma_t<BN, true, 6>(p, stream);
         default: return launch_dma_t<BN, true, 4>(p, stream);
     }
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// v3: 3-stage LDS-DMA pipeline with counted vmcnt and ONE raw s_barrier per k-step (cdna_hip_programming.md T3/T4).
-// v2's k-step is {issue next tile; compute; vmcnt(0); barrier}: with 2 workgroups per CU at most one tile per
-// workgroup is in flight and every k-step exposes (load latency - compute time).  Here the DMA of tile ks+2 is issued
-// right after the barrier that retires tile ks, so two tiles stay in flight across barriers and the wait at the top of
-// a k-step (s_waitcnt vmcnt(PER_STAGE): "all but the newest tile's pieces have landed") normally finds the data there.
-//   order per k-step:  s_waitcnt vmcnt(N) -> s_barrier -> issue DMA(ks+2) into the buffer read at ks-1 -> MFMAs(ks)
-//   RAW: every wave waits for its own pieces of tile ks, then the barrier makes all waves' pieces visible.
-//   WAR: the buffer of tile ks+2 was last read during k-step ks-1; all waves have left it once they pass the barrier.
-// Tile = (WM*64) x BN x 64 with WM*2 waves (WM = 4: 256-row tiles, 512 threads; WM = 2: 128-row tiles).
-// ---------------------------------------------------------------------------------------------------------------------
-template <int N_OUTSTANDING>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N_OUTSTANDING >= 0 && N_OUTSTANDING <= 63, "vmcnt range");
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_OUTSTANDING) : "memory");
-}
-
-// Generalised ring: tile (WM*64) x BN x BKT, NSTAGE LDS buffers, NSTAGE-1 tiles of DMA in flight across barriers.
-//   <4,128,64,3> / <4,64,64,3> / <2,128,64,3>: the 256- or 128-row 3-stage form, one workgroup per CU;
-//   <2,128,32,4> / <2,64,32,4>: 128-row tiles with 32-deep k-steps and a 4-deep ring — 64 / 48 KiB of LDS, so TWO (three)
-//   workgroups stay resident per CU and ~96 KiB of tile data is continuously in flight per CU.
-// LDS rows are BKT*2 bytes; the 16-byte-chunk XOR swizzle keeps ds_read_b128 fragment reads conflict free:
-//   128-byte rows: chunk ^= row & 7;   64-byte rows: chunk ^= (-(row >> 2)) & 3   (4 tile rows share a 256-byte bank row).
-template <int BKT>
-__device__ __forceinline__ int swz_t(int row, int chunk) {
-    if constexpr (BKT == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
-    else return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
-}
-
-template <int WM, int BN, int BKT, int NSTAGE>
-__global__ __launch_bounds__(WM * 128, (BKT == 32) ? ((NSTAGE == 3 && BN <= 128) ? 3 : 2) : 1) void conv_gemm_ring_kernel(ConvGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int BMT = WM * 64;
-    constexpr int NWAVES = WM * 2;
-    constexpr int ROWB = BKT * 2;          // bytes per tile row
-    constexpr int RPP = 1024 / ROWB;       // tile rows per 1-KiB DMA piece
-    constexpr int CPR = ROWB / 16;         // 16-byte chunks per tile row
-    constexpr int A_BYTES = BMT * ROWB;
-    constexpr int B_BYTES = BN * ROWB;
-    constexpr int STAGE = A_BYTES + B_BYTES;
-    constexpr int NT = BN / 32;
-    constexpr int A_PIECES = (BMT / RPP) / NWAVES;
-    constexpr int B_PIECES = (BN / RPP) / NWAVES;
-    constexpr int PER_STAGE = A_PIECES + B_PIECES;
-    constexpr int KK = BKT / 32;
-    static_assert(A_PIECES >= 1 && B_PIECES >= 1 && NSTAGE >= 3 && NSTAGE <= 4, "ring geometry");
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    const int tiles_n = p.N / BN;
-    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int tile_n = lbid % tiles_n;
-    const int tile_m = lbid / tiles_n;
-    const int m_base = tile_m * BMT;
-    const int n_base = tile_n * BN;
-
-    const int lrow = lane / CPR;
-    const int lslot = lane % CPR;
-    const int lchunk = (BKT == 64) ? (lslot ^ (lrow & 7)) : (lslot ^ ((0 - (lrow >> 2)) & 3));
-    long long a_base[A_PIECES];
-    int a_ih0[A_PIECES], a_iw0[A_PIECES];
-    bool a_ok[A_PIECES];
-    {
-        const int ohw = p.OH * p.OW;
-#pragma unroll
-        for (int i = 0; i < A_PIECES; ++i) {
-            const int m = m_base + (wave * A_PIECES + i) * RPP + lrow;
-            a_ok[i] = m < p.M;
-            const int mm = a_ok[i] ? m : 0;
-            const int b = mm / ohw;
-            const int r = mm - b * ohw;
-            const int oh = r / p.OW;
-            const int ow = r - oh * p.OW;
-            a_base[i] = (long long)b * p.H * p.W;
-            a_ih0[i] = oh * p.stride - p.pad;
-            a_iw0[i] = ow * p.stride - p.pad;
-        }
-    }
-    const f16_t* wrow[B_PIECES];
-#pragma unroll
-    for (int i = 0; i < B_PIECES; ++i)
-        wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * RPP + lrow) * p.K + lchunk * 8;
-
-    const int nk = p.K / BKT;
-    const int kpc = p.Cin / BKT;
-    int tap_kh = 0, tap_kw = 0, tap_c = 0;
-
-    auto issue = [&](int ks, int buf) {
-        unsigned char* As = smem + buf * STAGE;
-        unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < A_PIECES; ++i) {
-            const int ih = a_ih0[i] + tap_kh;
-            const int iw = a_iw0[i] + tap_kw;
-            const bool ok = a_ok[i] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
-            const f16_t* src = ok ? p.x + (a_base[i] + (long long)ih * p.W + iw) * p.Cin + tap_c * BKT + lchunk * 8
-                                  : reinterpret_cast<const f16_t*>(p.zero16);
-            dma16(src, As + (wave * A_PIECES + i) * 1024);
-        }
-#pragma unroll
-        for (int i = 0; i < B_PIECES; ++i) dma16(wrow[i] + (size_t)ks * BKT, Bs + (wave * B_PIECES + i) * 1024);
-        if (++tap_c == kpc) {
-            tap_c = 0;
-            if (++tap_kw == p.KW) { tap_kw = 0; ++tap_kh; }
-        }
-    };
-
-#pragma unroll
-    for (int st = 0; st < NSTAGE - 1; ++st)
-        if (st < nk) issue(st, st);
-    float4v acc[NT][4];
-    init_acc_bias<NT>(p, p.bias, acc, m_base + wm * 64, n_base + wn * (BN / 2), lane);
-    uint4 res[NT][2];
-
-    const int frow = lane & 15;
-    const int fchk = lane >> 4;
-    int buf = 0, buf_issue = NSTAGE - 1;
-    for (int ks = 0; ks < nk; ++ks) {
-        // tiles ks+1 .. ks+NSTAGE-2 may still be in flight; tile ks must have landed
-        const int ahead = nk - 1 - ks;  // tiles issued after tile ks
-        if (ahead >= NSTAGE - 2) wait_vmcnt<(NSTAGE - 2) * PER_STAGE>();
-        else if (NSTAGE == 4 && ahead == 1) wait_vmcnt<PER_STAGE>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-        if (ks + NSTAGE - 1 < nk && (p.dbg & 3) != 2) issue(ks + NSTAGE - 1, buf_issue);
-        if (ks + 1 == nk) prefetch_res16<NT>(p, res, m_base + wm * 64, n_base + wn * (BN / 2), lane);
-        const unsigned char* As = smem + buf * STAGE;
-        const unsigned char* Bs = As + A_BYTES;
-        if ((p.dbg & 3) != 1)
-#pragma unroll
-        for (int kk = 0; kk < KK; ++kk) {
-            half8 xf[4], wf[NT];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
-                xf[mt] = *reinterpret_cast<const half8*>(As + swz_t<BKT>(wm * 64 + mt * 16 + frow, kk * 4 + fchk));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz_t<BKT>(wn * (BN / 2) + nt * 16 + frow, kk * 4 + fchk));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        }
-        buf = (buf == NSTAGE - 1) ? 0 : buf + 1;
-        buf_issue = (buf_issue == NSTAGE - 1) ? 0 : buf_issue + 1;
-    }
-
-    epilogue_regs<NT>(p, p.out, acc, res, m_base + wm * 64, n_base + wn * (BN / 2), lane);
-}
-
-template <int WM, int BN, int BKT, int NSTAGE>
-hipError_t launch_ring(const ConvGemmParams& p, hipStream_t stream) {
-    constexpr int LDS = NSTAGE * (WM * 64 + BN) * BKT * 2;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_ring_kernel<WM, BN, BKT, NSTAGE>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int tiles_m = (p.M + WM * 64 - 1) / (WM * 64);
-    const int tiles_n = p.N / BN;
-    hipLaunchKernelGGL((conv_gemm_ring_kernel<WM, BN, BKT, NSTAGE>), dim3(tiles_m * tiles_n), dim3(WM * 128), LDS, stream, p);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------------
-// 3x3 stride-1 "row strip" kernel.  In flattened NHWC order the im2col tile of filter tap (kh, kw+1) is the tile of
-// tap (kh, kw) shifted by ONE row, so instead of staging a fresh 128-row tile per tap (v2: 9 activation tiles per 64
-// channels) a strip of 128+2 consecutive pixels is staged once per (kh, 64-channel chunk) and the three kw taps read
-// it at row offsets 0/1/2.  Pixels that wrap over an image-row or image boundary are zeroed per lane when the
-// fragment is read (the zero padding of the convolution).  Activation staging traffic drops 3x — it is the part that
-// comes from beyond L2 (DESIGN.md "what bounds the GEMM"); weight tiles still stream per tap (L2-resident).
-// k-step order: (kh, cin-chunk, kw) with kw fastest; weights keep the [n][kh][kw][cin] layout.
-// ---------------------------------------------------------------------------------------------------------------------
-template <int BN>
-__global__ __launch_bounds__(256, 2) void conv3x3s1_strip_kernel(ConvGemmParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int NT = BN / 32;
-    constexpr int B_PIECES = BN / 32;
-    constexpr int A_ROWS = 136;                 // 17 DMA pieces: 128 + 2 halo rows, rounded up to whole pieces
-    constexpr int A_BYTES = A_ROWS * ROW_BYTES;
-    constexpr int B_BYTES = BN * ROW_BYTES;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int g4 = lane >> 4, li = lane & 15;
-
-    const int tiles_n = p.N / BN;
-    const int lbid = xcd_logical_block(blockIdx.x, gridDim.x);
-    const int tile_n = lbid % tiles_n;
-    const int tile_m = lbid / tiles_n;
-    const int m_base = tile_m * BM;
-    const int n_base = tile_n * BN;
-
-    unsigned char* Abuf = smem;
-    unsigned char* Bbuf = smem + 2 * A_BYTES;
-
-    const int lrow = lane >> 3;
-    const int lchunk = (lane & 7) ^ lrow;
-    const long long total_px = (long long)p.B * p.H * p.W;
-    const f16_t* wrow[B_PIECES];
-#pragma unroll
-    for (int i = 0; i < B_PIECES; ++i)
-        wrow[i] = p.w + (size_t)(n_base + (wave * B_PIECES + i) * 8 + lrow) * p.K + lchunk * 8;
-
-    // per-lane validity of the 9 taps for the 4 output pixels this lane feeds (bit kh*3+kw)
-    int okmask[4];
-    {
-        const int ohw = p.H * p.W;
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
-            const int m = m_base + wm * 64 + mt * 16 + li;
-            int mask = 0;
-            if (m < p.M) {
-                const int r = m % ohw;
-                const int oh = r / p.W, ow = r - oh * p.W;
-#pragma unroll
-                for (int kh = 0; kh < 3; ++kh)
-#pragma unroll
-                    for (int kw = 0; kw < 3; ++kw)
-                        if ((unsigned)(oh + kh - 1) < (unsigned)p.H && (unsigned)(ow + kw - 1) < (unsigned)p.W) mask |= 1 << (kh * 3 + kw);
-            }
-            okmask[mt] = mask;
-        }
-    }
-
-    const int kpc = p.Cin / BK;
-    const int nk = 9 * kpc;
-
-    auto issue = [&](int s) {
-        const int kw = s % 3, grp = s / 3;
-        const int kh = grp / kpc, cc = grp - kh * kpc;
-        unsigned char* Bs = Bbuf + (s & 1) * B_BYTES;
-#pragma unroll
-        for (int i = 0; i < B_PIECES; ++i)
-            dma16(wrow[i] + (size_t)((kh * 3 + kw) * p.Cin + cc * BK), Bs + (wave * B_PIECES + i) * 1024);
-        if (kw == 0) {  // new strip: input pixels m_base-1 .. m_base+134 shifted by (kh-1) image rows
-            unsigned char* As = Abuf + (grp & 1) * A_BYTES;
-            const long long pix0 = (long long)m_base - 1 + (long long)(kh - 1) * p.W + lrow;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int q = wave + 4 * i;
-                const long long pix = pix0 + q * 8;
-                const f16_t* src = (pix >= 0 && pix < total_px) ? p.x + pix * p.Cin + cc * BK + lchunk * 8
-                                                                : reinterpret_cast<const f16_t*>(p.zero16);
-                dma16(src, As + q * 1024);
-            }
-            if (wave == 0) {
-                const long long pix = pix0 + 16 * 8;
-                const f16_t* src = (pix >= 0 && pix < total_px) ? p.x + pix * p.Cin + cc * BK + lchunk * 8
-                                                                : reinterpret_cast<const f16_t*>(p.zero16);
-                dma16(src, As + 16 * 1024);
-            }
-        }
-    };
-
-    const int wm0 = m_base + wm * 64, wn0 = n_base + wn * (BN / 2);
-    issue(0);
-    float4v acc[NT][4];
-    init_acc_bias<NT>(p, p.bias, acc, wm0, wn0, lane);
-    uint4 res[NT][2];
-    __syncthreads();
-
-    auto compute = [&](int s) {
-        const int kw = s % 3, grp = s / 3;
-        const int tapbit = (grp / kpc) * 3 + kw;
-        const unsigned char* As = Abuf + (grp & 1) * A_BYTES;
-        const unsigned char* Bs = Bbuf + (s & 1) * B_BYTES;
-        bool ok[4];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) ok[mt] = (okmask[mt] >> tapbit) & 1;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 xf[4], wf[NT];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) {
-                const half8 v = *reinterpret_cast<const half8*>(As + swz(wm * 64 + mt * 16 + li + kw, kk * 4 + g4));
-                half8 z;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) z[j] = ok[mt] ? v[j] : (_Float16)0.f;
-                xf[mt] = z;
-            }
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * (BN / 2) + nt * 16 + li, kk * 4 + g4));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        }
-    };
-    for (int s = 0; s + 1 < nk; ++s) {
-        issue(s + 1);
-        compute(s);
-        __syncthreads();
-    }
-    prefetch_res16<NT>(p, res, wm0, wn0, lane);
-    compute(nk - 1);
-    epilogue_regs<NT>(p, p.out, acc, res, wm0, wn0, lane);
-}
-
-template <int BN>
-hipError_t launch_strip(const ConvGemmParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * 136 * ROW_BYTES + 2 * BN * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3s1_strip_kernel<BN>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int tiles_m = (p.M + BM - 1) / BM;
-    hipLaunchKernelGGL((conv3x3s1_strip_kernel<BN>), dim3(tiles_m * (p.N / BN)), dim3(256), LDS, stream, p);
-    return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1383,137 +677,26 @@ struct StemPoolParams {
     int H, W;
 };
 
-__global__ __launch_bounds__(256, 2) void stem_pool_kernel(StemPoolParams p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    constexpr int MT = 5, NT = 2, BMT = 160;
-    constexpr int A_BYTES = BMT * ROW_BYTES, STAGE_BYTES = A_BYTES + 64 * ROW_BYTES;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int g = lane >> 4, li = lane & 15;
-
-    const int tiles_per_img = p.tiles_y * p.tiles_x;
-    const int b = blockIdx.x / tiles_per_img;
-    const int t = blockIdx.x - b * tiles_per_img;
-    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
-    const int py0 = ty * 2, px0 = tx * 15;            // first pooled pixel of this tile
-    const int cy0 = 2 * py0 - 1, cx0 = 2 * px0 - 1;   // first convolution-output pixel (may be -1)
-
-    const int lrow = lane >> 3;
-    const int lchunk = (lane & 7) ^ lrow;
-    const __amdgpu_buffer_rsrc_t rsrc_a =
-        __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x4p), 0, (unsigned)((size_t)p.B * p.Hp * p.Wp * 8), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_b = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, 64 * 256 * 2, 0x00020000);
-    unsigned rowoff[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int r = (wave * MT + i) * 8 + lrow;
-        const int cy = cy0 + (r >> 5), cx = cx0 + (r & 31);
-        const bool ok = (unsigned)cy < (unsigned)p.OH && (unsigned)cx < (unsigned)p.OW;
-        rowoff[i] = ok ? (unsigned)((b * p.Hp + cy * 2) * p.Wp + cx * 2) * 8u + (unsigned)((lchunk >> 2) * p.Wp) * 8u + (unsigned)(lchunk & 3) * 16u
-                       : 0x80000000u;  // out of range -> the descriptor returns zeros
-    }
-    unsigned woff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) woff[i] = (unsigned)(((wave * 2 + i) * 8 + lrow) * 256) * 2u + (unsigned)lchunk * 16u;
-
-    auto issue = [&](int ks, int buf) {
-        unsigned char* As = smem + buf * STAGE_BYTES;
-        unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * MT + i) * 1024), 16,
-                                                     rowoff[i], ks * 16 * p.Wp, 0, 0);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)(Bs + (wave * 2 + i) * 1024), 16,
-                                                     woff[i], ks * (BK * 2), 0, 0);
-    };
-
-    issue(0, 0);
-    float4v acc[NT][MT];
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        const float4v bv = *reinterpret_cast<const float4v*>(p.bias + wn * 32 + nt * 16 + g * 4);
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[nt][mt] = bv;
-    }
-    __syncthreads();
-    for (int ks = 0; ks < 4; ++ks) {
-        if (ks + 1 < 4) issue(ks + 1, (ks & 1) ^ 1);
-        const unsigned char* As = smem + (ks & 1) * STAGE_BYTES;
-        const unsigned char* Bs = As + A_BYTES;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            half8 xf[MT], wf[NT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-                xf[mt] = *reinterpret_cast<const half8*>(As + swz(wm * 80 + mt * 16 + li, kk * 4 + g));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-                wf[nt] = *reinterpret_cast<const half8*>(Bs + swz(wn * 32 + nt * 16 + li, kk * 4 + g));
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    // ---- ReLU -> fp16 patch [160 pixels][64 ch] in stage buffer 0 (free: the last k-step read buffer 1) ----------------
-    unsigned char* patch = smem;
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const int r = wm * 80 + mt * 16 + li;
-            const int cy = cy0 + (r >> 5), cx = cx0 + (r & 31);
-            const bool ok = (unsigned)cy < (unsigned)p.OH && (unsigned)cx < (unsigned)p.OW;
-            float4v v = acc[nt][mt];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = ok ? (v[j] > 0.f ? v[j] : 0.f) : -65504.f;
-            const int cb = wn * 64 + nt * 32 + g * 8;  // byte offset of the quad in the 128-byte pixel row
-            const int off = r * 128 + ((((cb >> 4) ^ (r & 7)) << 4) | (cb & 8));
-            *reinterpret_cast<uint2*>(patch + off) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
-        }
-    __syncthreads();
-    // ---- 3x3 s2 max over the patch: thread -> (pooled pixel 0..29, 8-channel group 0..7) -----------------------------------
-    if (tid < 240) {
-        const int c8 = tid & 7, pp = tid >> 3;
-        const int ly = pp / 15, lx = pp - ly * 15;
-        const int py = py0 + ly, px = px0 + lx;
-        if (py < p.PH && px < p.PW) {
-            half8 m;
-#pragma unroll
-            for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.f);
-#pragma unroll
-            for (int dy = 0; dy < 3; ++dy)
-#pragma unroll
-                for (int dx = 0; dx < 3; ++dx) {
-                    const int r = (2 * ly + dy) * 32 + 2 * lx + dx;
-                    const half8 v = *reinterpret_cast<const half8*>(patch + r * 128 + ((c8 ^ (r & 7)) << 4));
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
-                }
-            *reinterpret_cast<half8*>(p.out + (((size_t)b * p.PH + py) * p.PW + px) * 64 + c8 * 8) = m;
-        }
-    }
-#endif
+// 16-byte-chunk XOR swizzle that keeps ds_read_b128 fragment reads conflict free for rows of BKT halfs:
+//   128-byte rows: chunk ^= row & 7;   64-byte rows: chunk ^= (-(row >> 2)) & 3   (4 tile rows share a 256-byte bank row).
+template <int BKT>
+__device__ __forceinline__ int swz_t(int row, int chunk) {
+    if constexpr (BKT == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
+    else return row * 64 + ((chunk ^ ((0 - (row >> 2)) & 3)) << 4);
 }
 
-
 // ---------------------------------------------------------------------------------------------------------------------
-// Input-stationary stem + max-pool (the default).  stem_pool_kernel above stages the im2col matrix: every input pixel goes
-// through the LDS-DMA path up to 16 times and the 64 x 256 weight tile once per 160 output pixels (112 KiB per tile).  The
+// Input-stationary stem + max-pool.  An im2col formulation (round 1: the LDS-DMA GEMM on a 2-D row map) sends every input pixel
+// through the LDS-DMA path up to 16 times and the 64 x 256 weight tile once per 160 output pixels (112 KiB per tile); its
 // k-loop is LDS-bandwidth bound, so this form stages what is unique instead:
 //   * the folded weights without the all-zero eighth filter row ([7 kh][64 n][32 k] = 28 KiB) ONCE per workgroup, which
 //     then walks up to STEM_TPW tiles along x;
 //   * per tile the INPUT PATCH (15 rows x 70 NHWC4 pixels = 8.4 KiB, double buffered) instead of the 80 KiB im2col tile:
 //     the B fragment of output pixel (r, c), filter row kh, column pair g is the 16 bytes at patch[(2r + kh)][2c + 2g], so
 //     the 7 k-steps (K = 7 x 32 = 224 instead of 256) run straight from LDS without a barrier between them.
-// Tile, pooling and output are those of stem_pool_kernel (5 x 32 convolution outputs -> 2 x 15 pooled pixels).
+// Tile: 5 x 32 convolution outputs -> 2 x 15 pooled pixels (+1 halo row / column recomputed by the neighbours: 1.33x the stem
+// FLOPs, which are 2.5 % of the model).  Epilogue: bias + ReLU -> fp16 patch in LDS (out-of-map pixels = -65504 so the max ignores
+// them, which is exactly MaxPool2d's implicit -inf padding) -> barrier -> 240 threads each reduce one (pooled pixel, 8 channels).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int STEM_TPW = 6;              // tiles per workgroup
 constexpr int STEM_PROW = 70 * 8;        // bytes per patch row (70 NHWC4 pixels)
@@ -1731,22 +914,6 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 #endif
 }
 
-template <int BN, bool STEM>
-hipError_t launch(const ConvGemmParams& p, hipStream_t stream) {
-    using S = Smem<BN>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(conv_gemm_kernel<BN, STEM>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, S::TOTAL);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    const int tiles_m = (p.M + BM - 1) / BM;
-    const int tiles_n = p.N / BN;
-    hipLaunchKernelGGL((conv_gemm_kernel<BN, STEM>), dim3(tiles_m * tiles_n), dim3(256), S::TOTAL, stream, p);
-    return hipGetLastError();
-}
-
 }  // namespace
 
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) {
@@ -1771,7 +938,7 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) 
         if (p.K != 256 || p.KH != 7 || p.KW != 7 || p.stride != 2 || p.pad != 3) return hipErrorInvalidValue;
     } else if (p.x2) {   // dual source: [primary conv | strided 1x1 of x2], see conv_gemm_dma_kernel<.., DUAL>
         if ((p.Cin % BK) != 0 || (p.Cin2 % BK) != 0 || p.K1 != p.KH * p.KW * p.Cin || p.K != p.K1 + p.Cin2 || p.stride2 < 1 || p.split_k > 1 ||
-            p.bias_ptrs || (p.N % 128) != 0 || g_gemm_variant < 1 || !p.zero16 || p.H2 < (p.OH - 1) * p.stride2 + 1 ||
+            p.bias_ptrs || (p.N % 128) != 0 || !p.zero16 || p.H2 < (p.OH - 1) * p.stride2 + 1 ||
             p.W2 < (p.OW - 1) * p.stride2 + 1)
             return hipErrorInvalidValue;
         if ((long long)p.B * p.OH * p.OW != p.M) return hipErrorInvalidValue;
@@ -1780,9 +947,9 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) 
         if ((p.Cin % BK) != 0 || p.K != p.KH * p.KW * p.Cin) return hipErrorInvalidValue;
     }
     if ((long long)p.B * p.OH * p.OW != p.M) return hipErrorInvalidValue;
-    if (p.x_alt && (p.split_k > 1 || p.stem || g_gemm_variant != 1 || g_strip3x3 || !p.zero16)) return hipErrorInvalidValue;
+    if (p.x_alt && (p.split_k > 1 || p.stem || !p.zero16)) return hipErrorInvalidValue;
     if (p.split_k > 1) {  // split-K: linear fp32 partial slabs only, reduced by opd_launch_reduce_ln
-        if (!p.out_f32 || p.relu || p.res16 || p.res32 || p.out16_aux || p.bias_period != 0 || p.stem || g_gemm_variant < 1 ||
+        if (!p.out_f32 || p.relu || p.res16 || p.res32 || p.out16_aux || p.bias_period != 0 || p.stem ||
             ((p.K / BK) % p.split_k) != 0)
             return hipErrorInvalidValue;
         if (!p.zero16) return hipErrorInvalidValue;
@@ -1795,41 +962,11 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) 
         if (p.bias_period <= 0 || p.stem || !p.zero16) return hipErrorInvalidValue;
         return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);
     }
-    if (p.stem) return launch<64, true>(p, stream);
-    if (g_gemm_variant >= 1) {
-        if (!p.zero16) return hipErrorInvalidValue;
-        const int nk = p.K / BK;
-        if (g_strip3x3 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W && p.dbg == 0)
-            return wide ? launch_strip<128>(p, stream) : launch_strip<64>(p, stream);
-        if (g_gemm_variant == 2 && nk >= 3) {  // 3-stage 64-deep ring, one workgroup per CU
-            const bool n128 = (p.N % 128) == 0;
-            const long long blocks256 = (long long)((p.M + 255) / 256) * (p.N / (n128 ? 128 : 64));
-            if (blocks256 >= 200) return n128 ? launch_ring<4, 128, 64, 3>(p, stream) : launch_ring<4, 64, 64, 3>(p, stream);
-            return n128 ? launch_ring<2, 128, 64, 3>(p, stream) : launch_ring<2, 64, 64, 3>(p, stream);
-        }
-        if (g_gemm_variant == 3 && nk >= 2) {  // 4-stage 32-deep ring, two / three workgroups per CU
-            return wide ? launch_ring<2, 128, 32, 4>(p, stream) : launch_ring<2, 64, 32, 4>(p, stream);
-        }
-        if (g_gemm_variant == 5 && nk >= 2 && (p.N % 256) == 0)  // 128 x 256 tiles: 25 % less L2->LDS traffic per FLOP
-            return launch_ring<2, 256, 32, 3>(p, stream);
-        if (g_gemm_variant == 4 && nk >= 2) {  // 3-stage 32-deep ring, three / four workgroups per CU
-            return wide ? launch_ring<2, 128, 32, 3>(p, stream) : launch_ring<2, 64, 32, 3>(p, stream);
-        }
-        return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);
-    }
-    return wide ? launch<128, false>(p, stream) : launch<64, false>(p, stream);
+    if (p.stem || !p.zero16) return hipErrorInvalidValue;   // (the 7x7 stem runs in stem_pool2_kernel, or as stem == 2 above)
+    return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);
 }
-
-void opd_set_gemm_variant(int v) {
-    g_gemm_variant = v & 15; g_strip3x3 = (v & 16) ? 1 : 0; g_buffer_staging = (v & 32) ? 0 : 1;
-    g_tile_mt = (v >> 8) & 7;  // bits 8-10: force m-tiles per wave (4, 5, 6); 0 = automatic
-    g_pw_persist = (v & 0x800) ? 1 : 0;
-}
-int opd_get_gemm_variant() { return g_gemm_variant | (g_strip3x3 ? 16 : 0) | (g_buffer_staging ? 0 : 32) | (g_tile_mt << 8) | (g_pw_persist ? 0x800 : 0); }
 
 // x4p: zero-bordered NHWC4 image [B][Hp = 2*OH+6][Wp = 2*OW+6][4]; out: pooled [B][PH][PW][64]
-static int g_stem_variant = 2;  // 2: input-stationary stem_pool2_kernel (default); 1: im2col stem_pool_kernel (cross-check)
-void opd_set_stem_variant(int v) { g_stem_variant = v == 1 ? 1 : 2; }
 
 // Pre-processing + stem + max-pool in one launch: frames [B][H][W][3] uint8 BGR (valid_hw nullable [B][2]), geometry as below with
 // Hp = 2 OH + 6, Wp = 2 OW + 6 the size the materialised padded image would have.
@@ -1844,12 +981,7 @@ hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_h
     p.tiles_y = (PH + 1) / 2;
     p.tiles_x = (PW + 14) / 15;
     constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
-    static bool attr2 = false;
-    if (!attr2) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-        if (e != hipSuccess) return e;
-        attr2 = true;
-    }
+    OPD_SET_MAX_LDS_ONCE(stem_pool2_kernel<true>, LDS2);
     const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
     hipLaunchKernelGGL(stem_pool2_kernel<true>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
     return hipGetLastError();
@@ -1864,25 +996,9 @@ hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* b
     p.x4p = x4p; p.w = w; p.bias = bias; p.out = out; p.B = B; p.Hp = Hp; p.Wp = Wp; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
     p.tiles_y = (PH + 1) / 2;
     p.tiles_x = (PW + 14) / 15;
-    if (g_stem_variant == 2) {
-        constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
-        static bool attr2 = false;
-        if (!attr2) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS2);
-            if (e != hipSuccess) return e;
-            attr2 = true;
-        }
-        const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
-        hipLaunchKernelGGL(stem_pool2_kernel<false>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
-        return hipGetLastError();
-    }
-    constexpr int LDS = 2 * (160 + 64) * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(stem_pool_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(stem_pool_kernel, dim3(B * p.tiles_y * p.tiles_x), dim3(256), LDS, stream, p);
+    constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
+    OPD_SET_MAX_LDS_ONCE(stem_pool2_kernel<false>, LDS2);
+    const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
+    hipLaunchKernelGGL(stem_pool2_kernel<false>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
     return hipGetLastError();
 }

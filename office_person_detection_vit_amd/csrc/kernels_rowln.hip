@@ -461,43 +461,25 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
 
 }  // namespace
 
-static int g_gemm_ln_variant = 1;   // 1: one-shot kernel for K == 256 (default), 0: the k-loop kernel (cross-check)
-void opd_set_gemm_ln_variant(int v) { g_gemm_ln_variant = v; }
-
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || !p.bias || (!p.deep_k && (!p.gamma || !p.beta)) || (p.gamma && !p.beta)) return hipErrorInvalidValue;
     if ((size_t)p.M * p.K * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;  // 31-bit buffer offsets
     if (p.deep_k) {   // row-owner ring (the encoder's FFN-2): no split-K slabs, no reduce launch
         if (p.yp16 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
-        static bool attr_rg = false;
-        if (!attr_rg) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_ring_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
-            if (e == hipSuccess) e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_ring_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);
-            if (e != hipSuccess) return e;
-            attr_rg = true;
-        }
+        OPD_SET_MAX_LDS_ONCE(gemm_ln256_ring_kernel<true>, RG_LDS);
+        OPD_SET_MAX_LDS_ONCE(gemm_ln256_ring_kernel<false>, RG_LDS);
         if (p.gamma) hipLaunchKernelGGL(gemm_ln256_ring_kernel<true>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
         else hipLaunchKernelGGL(gemm_ln256_ring_kernel<false>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
         return hipGetLastError();
     }
     if (p.yp16) return hipErrorInvalidValue;   // (the position shadow is written by the deep-K form only)
-    if (p.K == 256 && g_gemm_ln_variant == 1) {
-        static bool attr_os = false;
-        if (!attr_os) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_os_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, OS_LDS);
-            if (e != hipSuccess) return e;
-            attr_os = true;
-        }
+    if (p.K == 256 && !p.kloop) {
+        OPD_SET_MAX_LDS_ONCE(gemm_ln256_os_kernel, OS_LDS);
         hipLaunchKernelGGL(gemm_ln256_os_kernel, dim3((p.M + OS_TM - 1) / OS_TM), dim3(256), OS_LDS, stream, p);
         return hipGetLastError();
     }
     constexpr int LDS = 2 * STAGE_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_ln256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    OPD_SET_MAX_LDS_ONCE(gemm_ln256_kernel, LDS);
     hipLaunchKernelGGL(gemm_ln256_kernel, dim3((p.M + TM - 1) / TM), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
@@ -603,12 +585,7 @@ hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream) {
     if (p.ldx < 256 * p.slices || p.ldw < 256 * p.slices) return hipErrorInvalidValue;
     if ((size_t)p.M * p.ldx * 2 >= 0x7fffff00ull || (size_t)p.N * p.ldw * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
     constexpr int LDS = 8 * 64 * ROW_BYTES;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_k256_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
+    OPD_SET_MAX_LDS_ONCE(gemm_k256_kernel, LDS);
     hipLaunchKernelGGL(gemm_k256_kernel, dim3(p.N / 64, (p.M + 63) / 64, p.slices), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }

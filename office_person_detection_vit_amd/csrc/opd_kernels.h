@@ -7,6 +7,20 @@
 
 typedef uint16_t f16_t;  // raw IEEE half bits on the host side
 
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instantiation and device, from whichever thread launches it first
+// (HipDetrDetector(streams = N) drives several handles from worker threads); used by the launchers in kernels_*.hip.
+#include <mutex>
+#define OPD_SET_MAX_LDS_ONCE(kernel, bytes)                                                                                  \
+    do {                                                                                                                     \
+        static std::once_flag once_[16];                                                                                     \
+        static hipError_t err_[16];                                                                                          \
+        int dev_ = 0;                                                                                                        \
+        (void)hipGetDevice(&dev_);                                                                                           \
+        dev_ &= 15;                                                                                                          \
+        std::call_once(once_[dev_], [&] { err_[dev_] = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); }); \
+        if (err_[dev_] != hipSuccess) return err_[dev_];                                                                     \
+    } while (0)
+
 // ---- implicit-GEMM convolution / linear layer (kernels_gemm.hip) ---------------------------------------------------
 // out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias + residual ),  m = (b,oh,ow), k = (kh,kw,cin), NHWC fp16 input.
 // Division of a 31-bit unsigned value by a launch constant: q = one ? m : umulhi(m, mul) >> shift, exact for m < 2^31 (mul =
@@ -55,6 +69,8 @@ struct ConvGemmParams {
     unsigned tap_rep;                  // filled by opd_launch_conv_gemm: sum over kh of 1 << kh*KW (tap-validity masks)
     FastDiv fd_tilesn, fd_ntiles;      // filled by the LDS-DMA launcher: column tiles, tiles per split-K slice
     unsigned long long* trace;  // tools only: per-workgroup phase stamps [grid][8] (conv_gemm_dma_kernel<..., TRACE>); null in the model
+    int force_mt;        // tools only (tools/sweep_tiles.py): 4 / 5 / 6 = tile height 128 / 160 / 192 rows instead of the quantisation-aware choice
+    int flat_staging;    // tools / tests: 1 = stage tiles through flat global addresses (the path tensors beyond 2 GiB take) instead of buffer descriptors
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 // fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16
@@ -87,10 +103,6 @@ struct BtailParams {
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);
 void opd_permute_k32(const f16_t* w, f16_t* out, int rows, int K);  // host
-void opd_set_stem_variant(int v);  // 2 = input-stationary fused stem (default), 1 = im2col fused stem (cross-check)
-void opd_set_gemm_variant(int v);  // low 4 bits: 0 = register-staged v1, 1 = LDS-DMA v2 (default), 2/3 = ring variants;
-                                   // +16 enables the experimental 3x3 row-strip kernel, +32 disables buffer-descriptor staging
-int opd_get_gemm_variant();
 
 // ---- Linear(K -> 256) + bias + residual + LayerNorm in one kernel (kernels_rowln.hip) ---------------------------------
 // y = LayerNorm(x . W^T + bias + res32) * gamma + beta over rows of 256; writes fp32 y and/or an fp16 copy.  y32 may alias
@@ -105,6 +117,7 @@ struct GemmLnParams {
     float* y32;          // [M][256] or null
     f16_t* y16;          // [M][256] or null
     int M, K;
+    int kloop;           // tests only: 1 = the k-loop kernel also for K == 256 (default there: the one-shot kernel)
     int deep_k;          // 1: the row-owner ring kernel for deep reductions (any K % 64 == 0; the encoder's FFN-2, K = 2048)
     // deep_k only: optional second fp16 output yp16 = fp16(y + pos[row % pos_period]) (pos: one [pos_period][256] table, or pos_ptrs:
     // one table per frame of pos_period rows) -- the position-embedding shadow the next encoder layer's q / k projection reads
@@ -114,7 +127,6 @@ struct GemmLnParams {
     f16_t* yp16;
 };
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream);
-void opd_set_gemm_ln_variant(int v);  // 1 = one-shot kernel for K == 256 (default), 0 = the k-loop kernel everywhere (cross-check)
 // Small-M linear layer, reduction cut into 256-wide slices: slice z computes x[:, 256z : 256z+256] . w[:, 256z : 256z+256]^T.
 // slices == 1: out = act(. + bias) as fp16 (out16) or fp32 (out32).  slices > 1: fp32 slabs out32[z][M][N], bias in slab 0
 // (summed by opd_launch_reduce_ln).  bias_period > 0: row-periodic bias [period][N].
@@ -127,32 +139,6 @@ struct GemmK256Params {
     int M, N, ldx, ldw, slices, bias_period, relu;
 };
 hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream);
-
-// ---- two chained 1x1 GEMMs through a wide hidden layer in one kernel (kernels_ffn.hip) ------------------------------------
-// etail == 0 (transformer feed-forward block):  y = LayerNorm(res32 + W_b . relu(W_a . x16 + b1) + b2) over rows of 256; the
-//     hidden activations never reach HBM.  y32 may alias res32 and y16 may alias x16 (a workgroup reads its own rows first).
-// etail == 1 (stage-3 bottleneck tail):  hid16 = relu(W_a . x16 + b1 + res16)  (the block output, [M][F] fp16, stored);
-//     y16 = relu(W_b . hid16 + b2)  (the next block's 1x1 reduce, [M][256] fp16).  hid16 may alias res16.
-struct FfnParams {
-    const f16_t* x16;    // [M][256] fp16 (GEMM operand)
-    const float* res32;  // FFN: [M][256] fp32 residual stream
-    const f16_t* w1;     // W_a [F][256] fp16 (fc1 / 1x1 expand)
-    const float* b1;     // [F]
-    const f16_t* w2p;    // W_b [256][F] fp16 (fc2 / next 1x1 reduce), K-permuted with opd_permute_k32
-    const float* b2;     // [256]
-    const float* gamma;  // FFN: [256]
-    const float* beta;   // FFN: [256]
-    float* y32;          // FFN: [M][256] or null
-    f16_t* y16;          // [M][256] (FFN: or null)
-    const f16_t* res16;  // ETAIL: [M][F] fp16 residual
-    f16_t* hid16;        // ETAIL: [M][F] fp16 hidden output
-    f16_t* dump;         // ETAIL: >= 16 writable bytes on the device (rows >= M of the last workgroup store here)
-    int M, F;            // F % 64 == 0
-    int etail;
-    int dbg;             // timing ablations for tools (0 = normal): 1 skip ds_reads + MFMAs, 2 stage only chunks 0 and 1, 4 all 16 staging
-                         // pieces of a step in front of its MFMAs, 8 all of them during GEMM a (two per k-step)
-};
-hipError_t opd_launch_ffn(const FfnParams& p, hipStream_t stream);
 
 // ---- element-wise / small kernels (kernels_misc.hip) ----------------------------------------------------------------
 // uint8 BGR HWC frames -> normalised fp16 NHWC4 (channel 3 = 0): (x/255 - mean)/std, RGB order, written into a

@@ -73,7 +73,6 @@ struct EncLayer {
     f16_t* wqkv = nullptr;  // [768][256] = [Wq; Wk; Wv]
     float* bqkv = nullptr;  // [768] = [bq; bk; bv] (pos_shadow path: plain bias vector)
     Lin o, fc1, fc2;
-    f16_t* fc2p = nullptr;  // fc2 weights K-permuted for the fused feed-forward kernel (opd_permute_k32)
     LNp ln1, ln2;
 };
 struct DecLayer {
@@ -199,15 +198,6 @@ struct opd_detr {
     int pos_shadow = 1;      // q / k projections read a second fp16 shadow "x + position embedding" (written by the producer of x) instead
                              // of adding a row-periodic fp32 bias table W.pos + b per output tile (0: the table, the round-1 form)
     int fuse_prep = 1;       // uint8 frames: pre-processing inside that kernel (0: preprocess_u8_kernel writes the padded NHWC4 image first)
-    // kernels_ffn.hip (64-row workgroups, one per CU, each streaming ALL the weights of the pair of GEMMs): built, parity-tested,
-    // measured SLOWER than the launches it replaces at every shape of BASELINE.json, so it is OFF by default (DESIGN.md section 2,
-    // profiles/r02_bench_ffn.txt): feed-forward block 62 us against 54 us (M = 8400: 132 workgroups, instruction-issue bound with
-    // one wave per SIMD), stage-3 tail 100-110 us against 74 us (M = 33600: 525 workgroups = 2.05 rounds on 256 CUs); with r101 at
-    // 1066x1920 (M = 16320 / 64320) the forward is 11.2 ms either way.  Not switched by size: a frame's low-order bits would then
-    // depend on the batch it travels in (fp32 summation order), which the batch-invariance tests forbid.
-    int fuse_ffn = 0;        // encoder feed-forward block in one kernel (0: fc1, split-K fc2, reduce + LayerNorm)
-    int fuse_etail = 0;      // stage 3: 1x1 expand + residual -> next block's 1x1 reduce in one kernel (0: two launches)
-    f16_t* d_dump = nullptr; // 256 bytes nobody reads (out-of-range rows of kernels_ffn.hip's last workgroup store here)
 
     // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
     struct GraphEntry { int B, H, W, fmt, fh, fw; const void* pixels; int uses; hipGraphExec_t exec; unsigned epoch; };
@@ -309,7 +299,7 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
                             w.data[(((size_t)o * Cin + ci) * KH + kh) * KW + kw] * scale[o];
     }
     RCCHK(upload_f16(m, &c->w, wt));
-    if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 1024) {  // operands of kernels_btail.hip (stages 1-2) / kernels_ffn.hip (stage 3)
+    if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 512) {  // operands of kernels_btail.hip (stages 1-2)
         std::vector<float> wp(wt.size());
         for (int o = 0; o < Cout; ++o)
             for (int b = 0; b < Cin; b += 32)
@@ -408,14 +398,6 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_ln(m, sd, p + ".self_attn_layer_norm", &L.ln1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
-        if (L.fc2.K % 64 == 0 && L.fc2.N == 256) {   // operand of kernels_ffn.hip
-            const HostTensor& w2 = T(sd, p + ".mlp.fc2.weight");
-            std::vector<f16_t> h(w2.data.size()), hp(w2.data.size());
-            for (size_t j = 0; j < h.size(); ++j) h[j] = f32_to_f16(w2.data[j]);
-            opd_permute_k32(h.data(), hp.data(), L.fc2.N, L.fc2.K);
-            RCCHK(dalloc(m, &L.fc2p, hp.size(), true));
-            HIPCHK(hipMemcpy(L.fc2p, hp.data(), hp.size() * 2, hipMemcpyHostToDevice));
-        }
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln2));
     }
     // decoder: query-position folds are resolution independent -> build them now with the fp32 plan GEMM
@@ -570,7 +552,6 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_valid_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_key_valid, B * 2, false));
     RCCHK(dalloc(m, &m->d_bias_ptrs, (size_t)(a.enc_layers + 2) * B, false));
-    RCCHK(dalloc(m, &m->d_dump, (size_t)128, false));
     RCCHK(dalloc(m, &m->d_rois, (size_t)128 * 4, false));
     RCCHK(dalloc(m, &m->d_roi_out, (size_t)128 * D, false));
     return OPD_OK;
@@ -938,9 +919,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 // first block of stage 2: 3x3 + dual-source expand (+ the next reduce on its own) beats shortcut launch + fused tail
                 // (stage 2: 0.674 -> 0.657 ms; OPD_DUAL_OVER_TAIL=0 restores the tail)
                 if (m->dual_over_tail && tail_kernel && b.has_sc && !sc_in_tail && b.w2sc) tail_kernel = false;
-                const bool use_etail = m->fuse_etail && b.c1.KH == 3 && b.c1.Cout == 256 && b.c2.Cin == 256 && b.c2.Cout == 1024 && nbk && nbk->c0.wp &&
-                                       nbk->c0.Cin == 1024 && nbk->c0.Cout == 256 && nbk->c0.KH == 1 && nbk->c0.stride == 1;
-                const bool sc_in_expand = b.has_sc && m->fuse_shortcut && b.w2sc && !sc_in_tail && !tail_kernel && !use_etail;
+                const bool sc_in_expand = b.has_sc && m->fuse_shortcut && b.w2sc && !sc_in_tail && !tail_kernel;
                 if (b.has_sc && !sc_in_tail && !sc_in_expand) {
                     f16_t* scb = m->d_sc + (size_t)b0 * oh * ow * C2;
                     RCCHK(run_conv(m, b.sc, cur, nb, ch, cw, oh, ow, scb, false, nullptr));
@@ -975,19 +954,6 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     RCCHK(tap(m, "btail_y", out, (size_t)p.M * 4 * C1 * 2));
                     if (C3) RCCHK(tap(m, "btail_z", z, (size_t)p.M * C3 * 2));
                     if (C3) st.z_id = 1 - x1_id;
-                } else if (use_etail) {
-                    // stage 3: the 3x3 as an implicit GEMM, then ONE kernel for 1x1 expand + residual + ReLU (block output, stored) and the
-                    // next block's 1x1 reduce (kernels_ffn.hip, ETAIL); z takes the buffer the 3x3 has just finished reading
-                    f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
-                    f16_t* z = mid(x1_id, (size_t)oh * ow * 256);
-                    RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr));
-                    FfnParams fp{};
-                    fp.x16 = a1; fp.w1 = b.c2.w; fp.b1 = b.c2.bias; fp.res16 = res; fp.hid16 = out; fp.w2p = nbk->c0.wp; fp.b2 = nbk->c0.bias;
-                    fp.y16 = z; fp.dump = m->d_dump; fp.M = nb * oh * ow; fp.F = 1024; fp.etail = 1;
-                    RCCHK(timed_begin(m, CLS_CONV, 2.0 * fp.M * (256.0 * 1024 + 1024.0 * 256)));
-                    HIPCHK(opd_launch_ffn(fp, m->stream));
-                    RCCHK(timed_end(m));
-                    st.z_id = x1_id;
                 } else {
                     f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
                     RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr));
@@ -1032,7 +998,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     // reads that for its q / k column tiles and x for its v tiles, with a plain bias vector -- instead of x everywhere plus a [hw][768]
     // fp32 table W.pos + b added per output tile (two divisions and 16 dependent table loads per lane in front of the first MFMA:
     // 14.2 us per launch against 9.4 for the same GEMM with a bias vector; decoder K/V 44.7 against 24-27)
-    const bool shadow = m->pos_shadow && !m->fuse_ffn && D == 256 && (opd_get_gemm_variant() & 0x8ff) == 1 && m->enc[0].bqkv && m->bkv_all;
+    const bool shadow = m->pos_shadow && D == 256 && m->enc[0].bqkv && m->bkv_all;
     const PosShadow psh{plan->d_pos, pos_ptrs, hw, m->d_xp16};
     const PosShadow* ps = shadow ? &psh : nullptr;
     // Deep-K row-owner launches (kernels_rowln.hip::gemm_ln256_ring_kernel) for the two K = 2048 -> 256 linears of the encoder side:
@@ -1069,14 +1035,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
             RCCHK(timed_end(m));
         }
-        if (m->fuse_ffn && L.fc2p && D == 256) {
-            FfnParams fp{};
-            fp.x16 = m->d_x16; fp.res32 = m->d_x32; fp.w1 = L.fc1.w; fp.b1 = L.fc1.b; fp.w2p = L.fc2p; fp.b2 = L.fc2.b;
-            fp.gamma = L.ln2.g; fp.beta = L.ln2.b; fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F;
-            RCCHK(timed_begin(m, CLS_GEMM, 4.0 * M * (double)D * F));
-            HIPCHK(opd_launch_ffn(fp, m->stream));
-            RCCHK(timed_end(m));
-        } else {
+        {
             RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
             // (fc2 + residual + LayerNorm as ONE row-owner launch — gemm_ln256_kernel with K = 2048 — was measured: encoder 1.05 ms
             //  against 1.00 ms; every 32-row workgroup would stream the whole 1 MiB of fc2 weights)
@@ -1386,7 +1345,6 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (cfg->struct_size != (int32_t)sizeof(opd_config)) return fail(OPD_EINVAL, "opd_config.struct_size mismatch");
     if (cfg->max_batch < 1 || cfg->max_height < 32 || cfg->max_width < 32) return fail(OPD_EINVAL, "opd_config maxima must be >= 1 x 32 x 32");
     *out = nullptr;
-    if (const char* v = getenv("OPD_GEMM_VARIANT")) opd_set_gemm_variant(atoi(v));  // A/B switch for benchmarking
     StateDict sd;
     std::string err;
     int rc = load_safetensors(weights_path, &sd, &err);
@@ -1441,9 +1399,8 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->fuse_ffn = src->fuse_ffn; m->fuse_etail = src->fuse_etail; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
-    m->d_dump = nullptr;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         if (m->stream) (void)hipStreamDestroy(m->stream);
@@ -1775,11 +1732,6 @@ int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, dou
 }
 
 // ---- test / diagnostic hooks (not part of include/opd_detr.h; used by tests/test_kernels_gpu.py) ----------------------
-int opd_test_set_gemm_variant(int v) {
-    opd_set_gemm_variant(v);
-    return opd_get_gemm_variant();
-}
-
 // Pillow coefficient tables of the device resize (host only): bounds [out][2], coeffs [out][ksize]; returns ksize
 int opd_test_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int coeffs_capacity) {
     std::vector<int32_t> b, k;
@@ -1799,29 +1751,12 @@ int opd_test_sine_pos_embed(int h, int w, int vh, int vw, int D, float* out) {
     memcpy(out, pos.data(), pos.size() * sizeof(float));
     return OPD_OK;
 }
-int opd_test_set_gemm_ln_variant(int v) {
-    opd_set_gemm_ln_variant(v);
-    return OPD_OK;
-}
-int opd_test_set_stem_variant(int v) {
-    opd_set_stem_variant(v);
-    return OPD_OK;
-}
 int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     m->fuse_gemm_ln = on ? 1 : 0;
     m->small_m_gemm = on ? 1 : 0;   // the switch covers the transformer-side specialisations
     m->deep_fc2 = on ? 1 : 0;
     m->fuse_dec0 = on ? 1 : 0;
-    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    m->graphs.clear();
-    return OPD_OK;
-}
-int opd_test_set_fuse_ffn(opd_detr* m, int on) {   // bit 0: encoder feed-forward kernel, bit 1: stage-3 expand tail kernel
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->fuse_ffn = (on & 1) ? 1 : 0;
-    m->fuse_etail = (on & 2) ? 1 : 0;
     for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
     m->graphs.clear();

@@ -42,6 +42,17 @@ struct DevMem {
 
 extern "C" {
 
+// Launch options of the hooks below (test infrastructure only; the kernel tests are single-threaded): bits 8-10 = forced tile height
+// (4 / 5 / 6 x 32 rows), bit 5 = flat-address tile staging (the path tensors beyond 2 GiB take), bit 0 of the second word = k-loop
+// gemm + LayerNorm kernel also for K == 256.
+static int g_conv_flags = 0, g_gemm_ln_kloop = 0;
+int opd_test_set_conv_flags(int flags) { g_conv_flags = flags; return OPD_OK; }
+int opd_test_set_gemm_ln_kloop(int on) { g_gemm_ln_kloop = on ? 1 : 0; return OPD_OK; }
+static void apply_conv_flags(ConvGemmParams& p, int flags) {
+    p.force_mt = (flags >> 8) & 7;
+    p.flat_staging = (flags >> 5) & 1;
+}
+
 // x: NHWC fp16 bits [B][H][W][Cin] (stem: NHWC4); w: [N][K] fp16 bits; bias fp32 [N] (or [period][N]);
 // res16/res32 optional; out fp16 bits or fp32 [M][N].
 int opd_test_conv_gemm(const uint16_t* x, const uint16_t* w, const float* bias, const uint16_t* res16, const float* res32,
@@ -66,6 +77,7 @@ int opd_test_conv_gemm(const uint16_t* x, const uint16_t* w, const float* bias, 
     if (!p.zero16 || !p.x || !p.w || !p.bias || !p.out || (res16 && !p.res16) || (res32 && !p.res32)) return tfail(OPD_ENOMEM, "test alloc failed");
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.K = K; p.relu = relu; p.bias_period = bias_period; p.out_f32 = out_f32; p.stem = stem;
+    apply_conv_flags(p, g_conv_flags);
     TCHK(opd_launch_conv_gemm(p, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(out, p.out, obytes, hipMemcpyDeviceToHost));
@@ -145,7 +157,7 @@ int opd_test_gemm_ln(const uint16_t* x, const uint16_t* w, const float* bias, co
     p.y32 = dm.up<float>(nullptr, (size_t)M * 256);
     p.y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
     if (!p.x || !p.w || !p.bias || !p.gamma || !p.beta || !p.y32 || !p.y16 || (res32 && !p.res32)) return tfail(OPD_ENOMEM, "test alloc failed");
-    p.M = M; p.K = K;
+    p.M = M; p.K = K; p.kloop = g_gemm_ln_kloop;
     TCHK(opd_launch_gemm_ln(p, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(y, p.y32, (size_t)M * 256 * 4, hipMemcpyDeviceToHost));
@@ -210,102 +222,6 @@ int opd_test_bench_gemm_ln(int M, int K, int deep, int iters, float* us_out) {
     return OPD_OK;
 }
 
-// fused feed-forward block (kernels_ffn.hip): w2 in plain K order [256][F] (the hook applies opd_permute_k32)
-int opd_test_ffn(const uint16_t* x16, const float* res32, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2,
-                 const float* gamma, const float* beta, float* y, uint16_t* y16, int M, int F, int in_place) {
-    DevMem dm;
-    std::vector<uint16_t> w2p((size_t)256 * F);
-    opd_permute_k32(w2, w2p.data(), 256, F);
-    FfnParams p{};
-    uint16_t* dx = dm.up(x16, (size_t)M * 256);
-    float* dres = dm.up(res32, (size_t)M * 256);
-    p.x16 = dx; p.res32 = dres;
-    p.w1 = dm.up(w1, (size_t)F * 256);
-    p.b1 = dm.up(b1, (size_t)F);
-    p.w2p = dm.up(w2p.data(), w2p.size());
-    p.b2 = dm.up(b2, 256);
-    p.gamma = dm.up(gamma, 256);
-    p.beta = dm.up(beta, 256);
-    p.y32 = in_place ? dres : dm.up<float>(nullptr, (size_t)M * 256);
-    p.y16 = in_place ? dx : dm.up<uint16_t>(nullptr, (size_t)M * 256);
-    if (!p.x16 || !p.res32 || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.gamma || !p.beta || !p.y32 || !p.y16) return tfail(OPD_ENOMEM, "test alloc failed");
-    p.M = M; p.F = F;
-    TCHK(opd_launch_ffn(p, nullptr));
-    TCHK(hipDeviceSynchronize());
-    TCHK(hipMemcpy(y, p.y32, (size_t)M * 256 * 4, hipMemcpyDeviceToHost));
-    TCHK(hipMemcpy(y16, p.y16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
-    return OPD_OK;
-}
-
-// stage-3 expand tail (kernels_ffn.hip, ETAIL): hid = relu(a1 W_a^T + b1 + res) [M][F], z = relu(hid W_b^T + b2) [M][256];
-// wb in plain K order [256][F] (the hook applies opd_permute_k32)
-int opd_test_etail(const uint16_t* a1, const uint16_t* res16, const uint16_t* wa, const float* b1, const uint16_t* wb, const float* b2,
-                   uint16_t* hid, uint16_t* z, int M, int F, int in_place) {
-    DevMem dm;
-    std::vector<uint16_t> wbp((size_t)256 * F);
-    opd_permute_k32(wb, wbp.data(), 256, F);
-    FfnParams p{};
-    p.x16 = dm.up(a1, (size_t)M * 256);
-    uint16_t* dres = dm.up(res16, (size_t)M * F);
-    p.res16 = dres;
-    p.w1 = dm.up(wa, (size_t)F * 256);
-    p.b1 = dm.up(b1, (size_t)F);
-    p.w2p = dm.up(wbp.data(), wbp.size());
-    p.b2 = dm.up(b2, 256);
-    p.hid16 = in_place ? dres : dm.up<uint16_t>(nullptr, (size_t)M * F);
-    p.y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
-    p.dump = dm.up<uint16_t>(nullptr, 64);
-    if (!p.x16 || !p.res16 || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.hid16 || !p.y16 || !p.dump) return tfail(OPD_ENOMEM, "test alloc failed");
-    p.M = M; p.F = F; p.etail = 1;
-    TCHK(opd_launch_ffn(p, nullptr));
-    TCHK(hipDeviceSynchronize());
-    TCHK(hipMemcpy(hid, p.hid16, (size_t)M * F * 2, hipMemcpyDeviceToHost));
-    TCHK(hipMemcpy(z, p.y16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
-    return OPD_OK;
-}
-
-// timing of kernels_ffn.hip on zero-filled weights / random-free buffers (tools/bench_ffn.py): average us over `iters` launches
-int opd_test_bench_ffn(int M, int F, int etail, int dbg, int iters, float* us_out) {
-    DevMem dm;
-    FfnParams p{};
-    std::vector<uint16_t> hx((size_t)M * 256), hw((size_t)F * 256);
-    for (size_t i = 0; i < hx.size(); ++i) hx[i] = opd::f32_to_f16((float)((i * 2654435761u >> 20) & 255) / 256.0f - 0.5f);
-    for (size_t i = 0; i < hw.size(); ++i) hw[i] = opd::f32_to_f16(((float)((i * 40503u >> 7) & 255) / 256.0f - 0.5f) / 16.0f);
-    std::vector<float> hb((size_t)F, 0.01f), ones(256, 1.0f);
-    p.x16 = dm.up(hx.data(), hx.size());
-    p.w1 = dm.up(hw.data(), hw.size());
-    p.w2p = dm.up(hw.data(), hw.size());
-    p.b1 = dm.up(hb.data(), (size_t)F);
-    p.b2 = dm.up(hb.data(), 256);
-    p.gamma = dm.up(ones.data(), 256);
-    p.beta = dm.up(hb.data(), 256);
-    float* r32 = dm.up<float>(nullptr, (size_t)M * 256);
-    uint16_t* r16 = dm.up<uint16_t>(nullptr, (size_t)M * F);
-    uint16_t* hid = dm.up<uint16_t>(nullptr, (size_t)M * F);
-    p.res32 = r32; p.res16 = r16; p.hid16 = hid;
-    p.y32 = dm.up<float>(nullptr, (size_t)M * 256);
-    p.y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
-    p.dump = dm.up<uint16_t>(nullptr, 64);
-    if (!p.x16 || !p.w1 || !p.w2p || !p.b1 || !p.b2 || !r32 || !r16 || !hid || !p.y32 || !p.y16 || !p.dump) return tfail(OPD_ENOMEM, "test alloc failed");
-    TCHK(hipMemset(r32, 0, (size_t)M * 256 * 4));
-    TCHK(hipMemset(r16, 0, (size_t)M * F * 2));
-    p.M = M; p.F = F; p.etail = etail; p.dbg = dbg;
-    hipEvent_t a, b;
-    TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) TCHK(opd_launch_ffn(p, nullptr));
-    TCHK(hipEventRecord(a, nullptr));
-    for (int i = 0; i < iters; ++i) TCHK(opd_launch_ffn(p, nullptr));
-    TCHK(hipEventRecord(b, nullptr));
-    TCHK(hipEventSynchronize(b));
-    float ms = 0.f;
-    TCHK(hipEventElapsedTime(&ms, a, b));
-    *us_out = 1e3f * ms / (float)iters;
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    return OPD_OK;
-}
-
-// one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel): slices == 1 -> fp16 out; slices > 1 -> the fp32
-// slabs are summed by reduce_ln256 without LayerNorm (gamma == null) into out32
 int opd_test_gemm_k256(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* out16, float* out32, int M, int N,
                        int K, int bias_period, int relu) {
     DevMem dm;
@@ -354,8 +270,7 @@ int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     p.x = x; p.w = w; p.bias = bias; p.res16 = res; p.out = out; p.zero16 = zero;
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KH; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.K = (int)K; p.relu = 1; p.dbg = dbg;
-    const int old = opd_get_gemm_variant();
-    opd_set_gemm_variant(variant);
+    apply_conv_flags(p, variant);   // (`variant`: the flag word of opd_test_set_conv_flags)
     hipEvent_t a, b;
     TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
     for (int i = 0; i < 2; ++i) TCHK(opd_launch_conv_gemm(p, nullptr));
@@ -365,7 +280,6 @@ int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     TCHK(hipEventSynchronize(b));
     float ms = 0.f;
     TCHK(hipEventElapsedTime(&ms, a, b));
-    opd_set_gemm_variant(old);
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *us_out = ms * 1000.f / iters;
     return OPD_OK;

@@ -23,15 +23,13 @@ def lib():
     return _capi.load_library()
 
 
-@pytest.fixture(params=[1, 0x501, 0x601, 33, 17, 3, 2, 0],
-                ids=["gemm_v2_bufdma_auto", "gemm_v2_160rows", "gemm_v2_192rows", "gemm_v2_flatdma", "gemm_v2+strip3x3", "gemm_ring4x32",
-                     "gemm_ring3x64", "gemm_v1_regstage"])
+@pytest.fixture(params=[0, 0x400, 0x500, 0x600, 0x20], ids=["auto_tiles", "128rows", "160rows", "192rows", "flat_staging"])
 def gemm_variant(request, lib):
-    """Every generation of the implicit-GEMM kernel stays under test: the default dispatch (v3 3-stage LDS-DMA pipeline
-    for deep K, v2 2-stage LDS-DMA otherwise), v2 alone, and v1 (register-staged, LDS epilogue)."""
-    lib.opd_test_set_gemm_variant(request.param)
+    """Every instantiation of the implicit-GEMM kernel the dispatcher can pick: the quantisation-aware tile height, each height
+    forced, and the flat-address staging path that tensors beyond 2 GiB take (opd_test_set_conv_flags)."""
+    lib.opd_test_set_conv_flags(request.param)
     yield request.param
-    lib.opd_test_set_gemm_variant(1)
+    lib.opd_test_set_conv_flags(0)
 
 
 def _h(a):
@@ -140,46 +138,6 @@ def test_conv_residual_integer_exact(lib, gemm_variant):
     np.testing.assert_array_equal(got, want)
 
 
-@pytest.mark.parametrize("M,K,N,res,period", [
-    (8400, 256, 2048, False, 0),      # encoder fc1 at batch 8: 848 160-row tiles, two per workgroup
-    (33600 + 37, 256, 1024, True, 0),  # stage-3 expand + residual, ragged last row tile, three tiles per workgroup
-    (8400, 256, 3072, False, 1050),   # decoder K/V projection with the row-periodic (position) bias
-    (8400, 512, 2048, True, 0),       # stage-4 expand
-])
-def test_gemm_persistent_pointwise_bit_identical(lib, M, K, N, res, period):
-    """gemm_pw_persist_kernel (variant bit 0x800; off by default, measured no faster): a workgroup walks several tiles and the DMA
-    pipeline runs across the tile boundaries.  Same per-tile arithmetic and k order as conv_gemm_dma_kernel: the outputs must be
-    BIT-identical to the one-tile-per-workgroup form, and exact on integer data."""
-    rng = np.random.default_rng(M + K + N)
-    x, _ = _h(rng.standard_normal((M, 1, 1, K)))
-    w, _ = _h(rng.standard_normal((N, K, 1, 1)) / np.sqrt(K))
-    bias = rng.standard_normal((period, N) if period else N).astype(np.float32)
-    r = _h(rng.standard_normal((M, 1, 1, N)))[0] if res else None
-    outs = []
-    try:
-        for variant in (1, 0x801):
-            lib.opd_test_set_gemm_variant(variant)
-            outs.append(run_conv(lib, x, w, bias, 1, 0, True, r, bias_period=period).reshape(M, N))
-    finally:
-        lib.opd_test_set_gemm_variant(1)
-    np.testing.assert_array_equal(outs[0], outs[1])
-    want = x.reshape(M, K) @ w.reshape(N, K).T + (bias[np.arange(M) % period] if period else bias)
-    if res:
-        want = want + r.reshape(M, N)
-    want = np.maximum(want, 0)
-    np.testing.assert_allclose(outs[0], want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
-    # integer operands through the persistent form: exact, including the rows of the ragged last tile
-    lib.opd_test_set_gemm_variant(0x801)
-    xi = rng.integers(-2, 3, (M, 1, 1, K)).astype(np.float32)
-    wi = rng.integers(-1, 2, (N, K, 1, 1)).astype(np.float32)
-    bi = ((np.arange(N, dtype=np.float32) % 9) - 4)
-    try:
-        got = run_conv(lib, xi, wi, bi, 1, 0, False).reshape(M, N)
-    finally:
-        lib.opd_test_set_gemm_variant(1)
-    np.testing.assert_array_equal(got, xi.reshape(M, K) @ wi.reshape(N, K).T + bi)
-
-
 def test_gemm_rowbias_f32_residual(lib, gemm_variant):
     """Transformer flavour: out_f32 = x.W^T + rowbias[m % period] + res32 (pos-embedding fold, residual stream)."""
     rng = np.random.default_rng(11)
@@ -216,27 +174,6 @@ def test_gemm_splitk_reduce_ln(lib, M, K, splits, ln):
     y2 = np.empty_like(y)
     lib.opd_test_gemm_splitk_ln(_p(xb), _p(wb), _p(bias), _p(res), _p(g) if ln else None, _p(b) if ln else None, _p(y2), _p(y16), M, K, splits)
     np.testing.assert_array_equal(y, y2)
-
-
-def test_stem_conv(lib):
-    """7x7 s2 p3 stem on the NHWC4 image, odd sizes."""
-    rng = np.random.default_rng(3)
-    B, H, W, N = 2, 45, 51, 64
-    x, _ = _h(rng.standard_normal((B, H, W, 3)))
-    w, _ = _h(rng.standard_normal((N, 3, 7, 7)) * 0.1)
-    bias = rng.standard_normal(N).astype(np.float32) * 0.1
-    x4 = np.zeros((B, H, W, 4), np.float16)
-    x4[..., :3] = x
-    wt = np.zeros((N, 8, 8, 4), np.float16)
-    wt[:, :7, :7, :3] = w.transpose(0, 2, 3, 1)
-    OH, OW = (H - 1) // 2 + 1, (W - 1) // 2 + 1
-    out = np.empty((B * OH * OW, N), np.uint16)
-    rc = lib.opd_test_conv_gemm(_p(np.ascontiguousarray(x4.view(np.uint16))), _p(np.ascontiguousarray(wt.view(np.uint16))),
-                                _p(bias), None, None, _p(out), B, H, W, 3, OH, OW, N, 7, 7, 2, 3, 1, 0, 0, 1)
-    _capi.check(rc, "opd_test_conv_gemm(stem)")
-    got = out.view(np.float16).astype(np.float32).reshape(B, OH, OW, N)
-    want = ref_conv(x, w, bias, 2, 3, True)
-    np.testing.assert_allclose(got, want, atol=1.5e-3 * float(np.abs(want).max()), rtol=1e-3)
 
 
 def _ref_attention(q, k, v, heads, scale):
@@ -463,13 +400,10 @@ def test_stem_pool_with_preprocessing_inside_is_bit_identical(lib, B, H, W, ragg
     np.testing.assert_array_equal(fused, split)
 
 
-@pytest.mark.parametrize("variant", [2, 1], ids=["input_stationary", "im2col"])
 @pytest.mark.parametrize("H,W", [(45, 51), (64, 96), (37, 34), (120, 131), (90, 410)])
-def test_fused_stem_pool(lib, H, W, variant):
+def test_fused_stem_pool(lib, H, W):
     """Stem conv + FrozenBN/ReLU + 3x3 s2 max-pool in ONE kernel vs conv2d -> relu -> max_pool2d (odd / even sizes, tiles
-    that overhang the map on every side; the last case makes a workgroup of the input-stationary kernel walk 6 tiles and
-    the next one the remaining one).  Both generations: input patch in LDS (default) and im2col staging."""
-    lib.opd_test_set_stem_variant(variant)
+    that overhang the map on every side; the last case makes a workgroup walk 6 tiles and the next one the remaining one)."""
     rng = np.random.default_rng(H * 1000 + W)
     B, N = 2, 64
     x, _ = _h(rng.standard_normal((B, H, W, 3)))
@@ -485,7 +419,6 @@ def test_fused_stem_pool(lib, H, W, variant):
     out = np.empty((B, PH, PW, N), np.uint16)
     rc = lib.opd_test_stem_pool(_p(np.ascontiguousarray(x4p.view(np.uint16))), _p(np.ascontiguousarray(wt.view(np.uint16))), _p(bias),
                                 _p(out), B, Hp, Wp, OH, OW, PH, PW)
-    lib.opd_test_set_stem_variant(2)
     _capi.check(rc, "opd_test_stem_pool")
     got = out.view(np.float16).astype(np.float32)
     conv = torch.from_numpy(ref_conv(x, w, bias, 2, 3, True)).permute(0, 3, 1, 2)
@@ -686,11 +619,11 @@ def test_gemm_ln_matches_torch(lib, M, K, use_res, variant):
     beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
     y = np.empty((M, 256), np.float32)
     y16 = np.empty((M, 256), np.uint16)
-    lib.opd_test_set_gemm_ln_variant(variant)
+    lib.opd_test_set_gemm_ln_kloop(1 - variant)
     try:
         rc = lib.opd_test_gemm_ln(_p(xb), _p(wb), _p(bias), _p(res), _p(gamma), _p(beta), _p(y), _p(y16), M, K)
     finally:
-        lib.opd_test_set_gemm_ln_variant(1)
+        lib.opd_test_set_gemm_ln_kloop(0)
     _capi.check(rc, "opd_test_gemm_ln")
     pre = torch.from_numpy(x).double() @ torch.from_numpy(w).double().T + torch.from_numpy(bias).double()
     if use_res:
@@ -768,113 +701,6 @@ def test_gemm_k256_integer_exact(lib):
     rc = lib.opd_test_gemm_k256(_p(_h(x)[1]), _p(_h(w)[1]), _p(bias), _p(out16), None, M, N, K, 0, 0)
     _capi.check(rc, "opd_test_gemm_k256")
     np.testing.assert_array_equal(out16.view(np.float16).astype(np.float32), x @ w.T + bias)
-
-
-# ---- feed-forward block in one kernel (kernels_ffn.hip) -------------------------------------------------------------------------
-@pytest.mark.parametrize("M,F,in_place", [(8400, 2048, True), (800, 2048, False), (64, 64, False), (37, 128, True), (129, 192, False)])
-def test_ffn_matches_torch(lib, M, F, in_place):
-    """y = LN(res + fc2(relu(fc1 x + b1)) + b2): fp16 operands, the hidden activations rounded to fp16 once (as the unfused path
-    stored them), fp32 accumulate / statistics.  The reference applies exactly that rounding in fp64 arithmetic, so the bound
-    is fp32 summation order (3e-5 abs on O(1) outputs) + the cases where fp32-vs-fp64 accumulation flips the fp16 rounding of
-    a hidden value (each worth <= 2^-11 x |h| x |w2|, a few of them per row at F = 2048: 5e-4 abs covers it; the mean stays 5e-6).  Partial last workgroups (M % 64 != 0), one chunk
-    (F = 64), in-place outputs (y aliasing x / the residual, as the encoder uses it)."""
-    rng = np.random.default_rng(M * 3 + F)
-    x, xb = _h(rng.standard_normal((M, 256)))
-    res = (x + 0.01 * rng.standard_normal((M, 256))).astype(np.float32)
-    w1, w1b = _h(rng.standard_normal((F, 256)) * np.sqrt(2.0 / 256))
-    w2, w2b = _h(rng.standard_normal((256, F)) / np.sqrt(F))
-    b1 = (0.1 * rng.standard_normal(F)).astype(np.float32)
-    b2 = (0.1 * rng.standard_normal(256)).astype(np.float32)
-    gamma = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
-    beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
-    y = np.empty((M, 256), np.float32)
-    y16 = np.empty((M, 256), np.uint16)
-    rc = lib.opd_test_ffn(_p(xb), _p(res), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(gamma), _p(beta), _p(y), _p(y16), M, F, int(in_place))
-    _capi.check(rc, "opd_test_ffn")
-    t = lambda a: torch.from_numpy(a).double()
-    hid = torch.relu(t(x) @ t(w1).T + t(b1)).to(torch.float16).double()
-    pre = t(res) + hid @ t(w2).T + t(b2)
-    want = F_.layer_norm(pre, (256,), t(gamma), t(beta), 1e-5).float().numpy()
-    np.testing.assert_allclose(y, want, atol=5e-4, rtol=1e-5)
-    assert float(np.abs(y - want).mean()) < 5e-6
-    np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), want, atol=2e-3, rtol=1e-3)
-
-
-def test_ffn_integer_exact(lib):
-    """Small-integer operands: every product and partial sum is exactly representable, so fc1 / ReLU / fc2 / residual must be
-    bit exact whatever the summation order — this pins the lane maps (x B-fragments, the accumulator-as-operand k permutation
-    of W2, the split of each chunk over two waves and the exchange of their partial sums).  LayerNorm is taken out by
-    comparing pre-norm sums: gamma = 1, beta = 0 and rows engineered to mean 0 / unit variance are not needed — instead the
-    check inverts nothing: it compares LN(kernel) with LN(exact pre-norm) at 1e-6, and the pre-norm sums differ per channel
-    by construction (asymmetric weights), so a swapped row / channel / feature cannot cancel."""
-    rng = np.random.default_rng(5)
-    M, F = 150, 256
-    x = rng.integers(-3, 4, (M, 256)).astype(np.float32)
-    w1 = rng.integers(-2, 3, (F, 256)).astype(np.float32)
-    w2 = rng.integers(-2, 3, (256, F)).astype(np.float32)
-    w1[np.arange(F), np.arange(F) % 256] += 7          # asymmetric: feature f looks at input channel f
-    w2[np.arange(256), (3 * np.arange(256) + 1) % F] += 5
-    b1 = rng.integers(-4, 5, F).astype(np.float32)
-    b2 = rng.integers(-4, 5, 256).astype(np.float32)
-    res = rng.integers(-8, 9, (M, 256)).astype(np.float32)
-    gamma, beta = np.ones(256, np.float32), np.zeros(256, np.float32)
-    _, xb = _h(x); _, w1b = _h(w1); _, w2b = _h(w2)
-    y = np.empty((M, 256), np.float32)
-    y16 = np.empty((M, 256), np.uint16)
-    _capi.check(lib.opd_test_ffn(_p(xb), _p(res), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(gamma), _p(beta), _p(y), _p(y16), M, F, 0), "opd_test_ffn")
-    hid = np.maximum(x.astype(np.float64) @ w1.T.astype(np.float64) + b1, 0.0)
-    assert hid.max() < 2048                                 # integers below 2^11: exact in fp16
-    pre = res + hid @ w2.T.astype(np.float64) + b2
-    want = (pre - pre.mean(1, keepdims=True)) / np.sqrt(pre.var(1, keepdims=True) + 1e-5)
-    np.testing.assert_allclose(y, want, atol=2e-6, rtol=2e-6)
-
-
-# ---- stage-3 expand tail: 1x1 expand + residual + ReLU -> next 1x1 reduce in one kernel (kernels_ffn.hip, ETAIL) -----------------
-@pytest.mark.parametrize("M,F,in_place", [(33600, 1024, True), (4200, 1024, False), (64, 128, False), (101, 256, True)])
-def test_etail_matches_torch(lib, M, F, in_place):
-    """hid = relu(a1 W_a^T + b_a + res) (fp16, one rounding), z = relu(hid W_b^T + b_b): both against fp64 arithmetic on the same
-    fp16 operands; z from the kernel's OWN rounded hid (the B operand it really used) within fp32 summation order + one fp16
-    rounding.  Partial last workgroup (M % 64 != 0: rows >= M store to the dump slot), hid written over the residual."""
-    rng = np.random.default_rng(M + F)
-    a1, a1b = _h(np.abs(rng.standard_normal((M, 256))))
-    res, resb = _h(np.abs(rng.standard_normal((M, F))))
-    wa, wab = _h(rng.standard_normal((F, 256)) / 16)
-    wb, wbb = _h(rng.standard_normal((256, F)) / np.sqrt(F))
-    ba = (0.1 * rng.standard_normal(F)).astype(np.float32)
-    bb = (0.1 * rng.standard_normal(256)).astype(np.float32)
-    hid = np.empty((M, F), np.uint16)
-    z = np.empty((M, 256), np.uint16)
-    _capi.check(lib.opd_test_etail(_p(a1b), _p(resb), _p(wab), _p(ba), _p(wbb), _p(bb), _p(hid), _p(z), M, F, int(in_place)), "opd_test_etail")
-    t = lambda a: torch.from_numpy(a).double()
-    want_hid = torch.relu(t(a1) @ t(wa).T + t(ba) + t(res)).numpy()
-    got_hid = hid.view(np.float16).astype(np.float64)
-    np.testing.assert_allclose(got_hid, want_hid, atol=2e-3, rtol=1.1e-3)           # one fp16 rounding of O(1..8) values
-    want_z = torch.relu(torch.from_numpy(got_hid) @ t(wb).T + t(bb)).numpy()
-    np.testing.assert_allclose(z.view(np.float16).astype(np.float64), want_z, atol=2e-3, rtol=1.1e-3)
-
-
-def test_etail_integer_exact(lib):
-    """Small integers: every sum is exact in fp32 and every stored value exact in fp16 -> bit-exact hid and z, pinning the lane
-    maps (paired-layout residual loads and y stores, the k permutation of W_b, the channel-half exchange of the z epilogue)."""
-    rng = np.random.default_rng(9)
-    M, F = 200, 256
-    a1 = rng.integers(0, 4, (M, 256)).astype(np.float32)
-    wa = rng.integers(-1, 2, (F, 256)).astype(np.float32)
-    wa[np.arange(F), (5 * np.arange(F) + 2) % 256] += 3
-    res = rng.integers(0, 9, (M, F)).astype(np.float32)
-    ba = rng.integers(-3, 4, F).astype(np.float32)
-    wb = (rng.integers(-1, 2, (256, F)) * (rng.random((256, F)) < 0.1)).astype(np.float32)
-    wb[np.arange(256), (7 * np.arange(256) + 3) % F] += 1
-    bb = rng.integers(-3, 4, 256).astype(np.float32)
-    _, a1b = _h(a1); _, resb = _h(res); _, wab = _h(wa); _, wbb = _h(wb)
-    hid = np.empty((M, F), np.uint16)
-    z = np.empty((M, 256), np.uint16)
-    _capi.check(lib.opd_test_etail(_p(a1b), _p(resb), _p(wab), _p(ba), _p(wbb), _p(bb), _p(hid), _p(z), M, F, 0), "opd_test_etail")
-    want_hid = np.maximum(a1 @ wa.T + ba + res, 0)
-    want_z = np.maximum(want_hid @ wb.T + bb, 0)
-    assert want_hid.max() < 2048 and want_z.max() < 2048
-    np.testing.assert_array_equal(hid.view(np.float16).astype(np.float32), want_hid)
-    np.testing.assert_array_equal(z.view(np.float16).astype(np.float32), want_z)
 
 
 # ---- dual-source GEMM: the shortcut convolution as extra K of the 1x1 expand (conv_gemm_dma_kernel, DUAL) ------------------------

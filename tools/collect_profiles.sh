@@ -15,7 +15,6 @@ tail -n 1 $O/bench_gloo2.json > $P/${R}_bench_gloo2_selflaunch_rehearsal.json
 tail -n 1 $O/bench_r101_1066x1920.json > $P/${R}_bench_r101_1066x1920.json
 tail -n 1 $O/bench_r50_tile1080p_b4.json > $P/${R}_bench_r50_tile1080p_b4.json
 cp $O/host_rate.txt $P/${R}_host_boundary_rate.txt
-cp $O/bench_ffn.txt $P/${R}_bench_ffn.txt
 cp $O/trace_gemm.txt $P/${R}_trace_gemm.txt
 cp $O/bench_layers.txt $P/${R}_bench_layers.txt
 cp $O/bench_btail.txt $P/${R}_bench_btail.txt

@@ -33,8 +33,7 @@ def main():
                                   ("stage-2 first block through the fused tail", {"OPD_DUAL_OVER_TAIL": "0"}, ()),
                                   ("shortcut fusions off", {}, (("opd_test_set_fuse_btail", 1),)),
                                   ("tails + shortcut fusions off", {}, (("opd_test_set_fuse_btail", 0),)),
-                                  ("projection+LN, dec0 constant, heads LN off", {}, (("opd_test_set_fuse_gemm_ln", 0),)),
-                                  ("fused FFN + expand tails on", {}, (("opd_test_set_fuse_ffn", 3),))):
+                                  ("projection+LN, deep-K FFN-2, dec0 constant, heads LN off", {}, (("opd_test_set_fuse_gemm_ln", 0),))):
             for k, v in env.items():
                 os.environ[k] = v
             det = HipDetrDetector(model_path=path, confidence_threshold=0.5, max_batch=len(frames), max_size=(800, 1333), resize=False)

@@ -22,7 +22,6 @@ OPD_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --wa
 timeout -k 10 300 python tools/host_rate.py 96 > $O/host_rate.txt 2>&1 && timeout -k 10 300 python tools/host_rate.py 96 720 1280 >> $O/host_rate.txt 2>&1 && cat $O/host_rate.txt &&
 timeout -k 10 300 python bench.py --arch r101 --height 1066 --width 1920 --no-cpu-baseline > $O/bench_r101_1066x1920.json 2> $O/bench_r101.err && cut -c1-200 $O/bench_r101_1066x1920.json &&
 timeout -k 10 300 python bench.py --height 1080 --width 1920 --batch 4 --no-cpu-baseline > $O/bench_r50_tile1080p_b4.json 2> $O/bench_tile.err && cut -c1-200 $O/bench_r50_tile1080p_b4.json &&
-timeout -k 10 120 python tools/bench_ffn.py > $O/bench_ffn.txt 2>&1 &&
 timeout -k 10 120 python tools/trace_gemm.py > $O/trace_gemm.txt 2>&1 &&
 timeout -k 10 300 python tools/bench_layers.py 1 > $O/bench_layers.txt 2>&1 &&
 timeout -k 10 300 python tools/bench_btail.py --ablate > $O/bench_btail.txt 2>&1 &&

@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from office_person_detection_vit_amd import _capi
 a = [int(v) for v in sys.argv[1:9]]
-variant = int(sys.argv[9]) if len(sys.argv) > 9 else 1
+variant = int(sys.argv[9], 0) if len(sys.argv) > 9 else 0   # flag word of opd_test_set_conv_flags
 dbg = int(sys.argv[10]) if len(sys.argv) > 10 else 0
 lib = _capi.load_library()
 us = C.c_float()

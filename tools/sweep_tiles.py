@@ -36,7 +36,7 @@ for name, B, H, W, Cin, N, k, st, res in SHAPES:
     OH, OW = (H + 2 * pad - k) // st + 1, (W + 2 * pad - k) // st + 1
     fl = 2.0 * B * OH * OW * N * k * k * Cin
     t = []
-    for v in (1, 0x401, 0x501, 0x601):
+    for v in (0, 0x400, 0x500, 0x600):   # flag word of opd_test_set_conv_flags: bits 8-10 force the tile height
         _capi.check(lib.opd_test_bench_conv(B, H, W, Cin, N, k, st, res, v, 0, 20, C.byref(us)), "bench_conv")
         t.append(us.value)
     print(f"{name:26s} {t[0]:8.1f} {t[1]:8.1f} {t[2]:8.1f} {t[3]:8.1f}   {fl / min(t) / 1e6:7.1f}", flush=True)
