@@ -110,6 +110,9 @@ TEST_API = {
     "opd_test_btail_sc": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 3),
     "opd_test_bench_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_int, C.POINTER(C.c_float)]),
     "opd_test_trace_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "opd_test_heads": (C.c_int, [C.c_void_p] * 13 + [C.c_int] * 2),
+    "opd_test_postprocess": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_float, C.c_void_p, C.c_void_p]),
+    "opd_test_roi_features": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 3 + [C.c_void_p]),
     "opd_test_set_conv_flags": (C.c_int, [C.c_int]),
     "opd_test_set_gemm_ln_kloop": (C.c_int, [C.c_int]),
     "opd_test_set_graph_guard": (C.c_int, [C.c_int]),

@@ -275,89 +275,112 @@ __global__ void gemm_f32_kernel(const float* __restrict__ A, const float* __rest
     C[(size_t)m * ldc + n] = acc + (bias ? bias[n] : 0.f);
 }
 
-// Heads: one 1024-thread block per HEAD_ROWS decoder rows; fp32 throughout (0.03 GFLOP/frame).  Weights are stored
-// TRANSPOSED ([in][out]) so that thread (kg, o) reads wt[k*N + o]: consecutive lanes touch consecutive addresses.
-// The kernel is a latency chain (3 dependent layers, every weight comes from L2), so the reduction dimension is split
-// over 4 thread groups (64 k each, 16 independent loads in flight per thread) and each weight feeds HEAD_ROWS FMA chains;
-// partial sums meet in LDS in a fixed order.  (One block per row: 43 us at batch 8, re-reading 620 KB of weights per row;
-// 4 rows per 256-thread block with a 256-deep serial k-loop: 54 us, pure load latency.)
-constexpr int HEAD_ROWS = 4;
-__global__ __launch_bounds__(1024) void heads_kernel(HeadParams p) {
-    __shared__ float h[HEAD_ROWS][256];
-    __shared__ float t1[HEAD_ROWS][256];
-    __shared__ float part[4][HEAD_ROWS][256];
+// Heads (HF:models/detr/modeling_detr.py:1284-1300, 1317-1322, 1410-1411): class logits and the box MLP + sigmoid for the decoder
+// states, fp32 throughout — on the matrix pipe: v_mfma_f32_16x16x4_f32 is an exact fp32 fma chain (k-ordered, one rounding per
+// product) at the fp32 vector rate, without the vector pipe's loads-per-FMA problem.  One 512-thread workgroup per 16 decoder rows
+// (the MFMA's 16 columns); a wave owns 16-channel output tiles (weights = A operand straight from L2: [in][out] storage gives
+// lane (k, n) a coalesced read; rows = B operand from LDS) and chains the 64 MFMAs of a tile's K = 256 on one accumulator, two tiles
+// interleaved per wave.  The decoder's final LayerNorm (two-pass fp32, as layernorm256_kernel) runs on the rows first when
+// ln_gamma is given.  Batch 8 (800 rows, 50 workgroups): 30 us, against 35 us for the VALU form of rounds 1-2 (4 rows per
+// 1024-thread block, every weight loaded once per 4 rows); what remains is six L2 round trips for the weights.
+constexpr int HEAD_ROWS = 16;
+constexpr int HEAD_LD = 260;   // fp32 words per LDS row (256 + 4: rows 8 apart do not share a bank)
+typedef float float4m __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void heads_kernel(HeadParams p) {
+    __shared__ float h[HEAD_ROWS][HEAD_LD];
+    __shared__ float t1[HEAD_ROWS][HEAD_LD];
+    __shared__ float part[8][64];
     const int row0 = blockIdx.x * HEAD_ROWS;
-    const int kg = threadIdx.x >> 8, t = threadIdx.x & 255;
-    if (kg < HEAD_ROWS) h[kg][t] = row0 + kg < p.rows ? p.hs[(size_t)(row0 + kg) * 256 + t] : 0.f;
-    __syncthreads();
-    if (p.ln_gamma) {   // the decoder's final LayerNorm (two-pass fp32, like layernorm256_kernel) folded in: thread group kg owns row kg
-        if (kg < HEAD_ROWS) {
-            const int wv = t >> 6;
-            const float x = h[kg][t];
-            const float s = wave_sum(x);
-            if ((t & 63) == 0) part[0][kg][wv] = s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    {   // rows -> LDS: 32 threads per row, 8 consecutive columns each; optional LayerNorm by the same 32 threads
+        const int r = tid >> 5, c0 = (tid & 31) * 8;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = row0 + r < p.rows ? p.hs[(size_t)(row0 + r) * 256 + c0 + j] : 0.f;
+        if (p.ln_gamma) {
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += v[j];
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const float mean = s * (1.0f / 256.0f);
+            float q = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { v[j] -= mean; q += v[j] * v[j]; }
+#pragma unroll
+            for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
+            const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * p.ln_gamma[c0 + j] + p.ln_beta[c0 + j];
         }
-        __syncthreads();
-        float d = 0.f;
-        if (kg < HEAD_ROWS) {
-            const float mean = (part[0][kg][0] + part[0][kg][1] + part[0][kg][2] + part[0][kg][3]) * (1.0f / 256.0f);
-            d = h[kg][t] - mean;
-            const float q = wave_sum(d * d);
-            if ((t & 63) == 0) part[1][kg][t >> 6] = q;
-        }
-        __syncthreads();
-        if (kg < HEAD_ROWS) {
-            const float var = (part[1][kg][0] + part[1][kg][1] + part[1][kg][2] + part[1][kg][3]) * (1.0f / 256.0f);
-            h[kg][t] = d * (1.0f / sqrtf(var + 1e-5f)) * p.ln_gamma[t] + p.ln_beta[t];
-        }
-        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) h[r][c0 + j] = v[j];
     }
-    // partial[kg][r][t] = sum over k in [64 kg, 64 kg + 64) of in[r][k] * wt[k][t]
-    auto layer = [&](const float (&in)[HEAD_ROWS][256], const float* wt, int ld, bool active) {
-        float acc[HEAD_ROWS];
+    __syncthreads();
+    // out[m][n] = act(sum_k in[m][k] * wt[k][n] + bias[n]) for the workgroup's 16 rows m: D[row = channel][col = m] per 16-channel
+    // tile; lane (kq = lane >> 4, i = lane & 15) feeds A[i][kq] = wt[k0 + kq][n0 + i] and B[kq][i] = in[i][k0 + kq], and receives
+    // channels n0 + 4 kq + r of row i.
+    const int kq = lane >> 4, li = lane & 15;
+    auto layer = [&](const float (*in)[HEAD_LD], const float* __restrict__ wt, const int N, const int ntiles, auto&& emit) {
+        for (int nt = wave; nt < ntiles; nt += 16) {   // this wave's tiles nt and nt + 8, interleaved (two accumulator chains)
+            const int nA = nt * 16 + li, nB = (nt + 8) * 16 + li;
+            const bool okA = nA < N, okB = nt + 8 < ntiles && nB < N;
+            float4m accA = {0.f, 0.f, 0.f, 0.f}, accB = {0.f, 0.f, 0.f, 0.f};
+            // 2 x 32 weight operands (half the reduction of the tile pair) are requested before their first MFMA: the kernel is a
+            // latency chain (every weight comes from L2, ~1 us away), so two round trips per tile pair instead of sixteen (46 us)
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                float a[32], b2[32];
 #pragma unroll
-        for (int r = 0; r < HEAD_ROWS; ++r) acc[r] = 0.f;
-        if (active) {
-#pragma unroll 16
-            for (int kk = 0; kk < 64; ++kk) {
-                const int k = kg * 64 + kk;
-                const float w = wt[k * ld + t];
+                for (int u = 0; u < 32; ++u) {
+                    const int k = (half * 32 + u) * 4 + kq;
+                    a[u] = okA ? wt[(size_t)k * N + nA] : 0.f;
+                    b2[u] = okB ? wt[(size_t)k * N + nB] : 0.f;
+                }
 #pragma unroll
-                for (int r = 0; r < HEAD_ROWS; ++r) acc[r] = fmaf(in[r][k], w, acc[r]);
+                for (int u = 0; u < 32; ++u) {
+                    const float x = in[li][(half * 32 + u) * 4 + kq];
+                    accA = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], x, accA, 0, 0, 0);
+                    accB = __builtin_amdgcn_mfma_f32_16x16x4f32(b2[u], x, accB, 0, 0, 0);
+                }
             }
+            emit(nt * 16 + kq * 4, accA);
+            if (nt + 8 < ntiles) emit((nt + 8) * 16 + kq * 4, accB);
         }
-#pragma unroll
-        for (int r = 0; r < HEAD_ROWS; ++r) part[kg][r][t] = acc[r];
     };
-    auto total = [&](int r, int o) { return ((part[0][r][o] + part[1][r][o]) + part[2][r][o]) + part[3][r][o]; };
-    // class logits
-    layer(h, p.wc, p.ncls, t < p.ncls);
+    // class logits: lane holds channels n .. n + 3 of row li
+    layer(h, p.wc, p.ncls, (p.ncls + 15) / 16, [&](const int n, const float4m acc) {
+        if (row0 + li < p.rows)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.ncls) p.logits[(size_t)(row0 + li) * p.ncls + n + r] = acc[r] + p.bc[n + r];
+    });
+    // box MLP: 256 -> 256 -> 256 -> 4, ReLU between, sigmoid at the end
+    layer(h, p.w1, 256, 16, [&](const int n, const float4m acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = acc[r] + p.b1[n + r]; t1[li][n + r] = v > 0.f ? v : 0.f; }
+    });
+    __syncthreads();   // t1 complete; every wave is done reading h
+    layer(t1, p.w2, 256, 16, [&](const int n, const float4m acc) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float v = acc[r] + p.b2[n + r]; h[li][n + r] = v > 0.f ? v : 0.f; }   // h is free: second hidden layer
+    });
     __syncthreads();
-    if (t < p.ncls && kg < HEAD_ROWS && row0 + kg < p.rows) p.logits[(size_t)(row0 + kg) * p.ncls + t] = total(kg, t) + p.bc[t];
-    __syncthreads();
-    // box MLP
-    layer(h, p.w1, 256, true);
-    __syncthreads();
-    if (kg < HEAD_ROWS) {
-        const float v = total(kg, t) + p.b1[t];
-        t1[kg][t] = v > 0.f ? v : 0.f;
-    }
-    __syncthreads();
-    layer(t1, p.w2, 256, true);
-    __syncthreads();
-    if (kg < HEAD_ROWS) {
-        const float v = total(kg, t) + p.b2[t];
-        h[kg][t] = v > 0.f ? v : 0.f;   // h is free: reuse it for the second hidden layer
-    }
-    __syncthreads();
-    if (threadIdx.x < 64 * HEAD_ROWS) {  // one wave per row: lane -> (coordinate lane&3, k-slice lane>>2 of 16)
-        const int r = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 3, ks = lane >> 2;
+    {   // last layer: 64 outputs (row = lane >> 2, coordinate = lane & 3), the reduction split over the 8 waves (32 k each), summed in order
+        const int r = lane >> 2, c = lane & 3;
         float a = 0.f;
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) a = fmaf(h[r][wave * 32 + kk], p.w3[(wave * 32 + kk) * 4 + c], a);
+        part[wave][lane] = a;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        const int r = tid >> 2, c = tid & 3;
+        float a = part[0][tid];
 #pragma unroll
-        for (int kk = 0; kk < 16; ++kk) a = fmaf(h[r][ks * 16 + kk], p.w3[(ks * 16 + kk) * 4 + c], a);
-#pragma unroll
-        for (int o = 4; o < 64; o <<= 1) a += __shfl_xor(a, o);
-        if (lane < 4 && row0 + r < p.rows) p.boxes[(size_t)(row0 + r) * 4 + c] = 1.0f / (1.0f + expf(-(a + p.b3[c])));
+        for (int w = 1; w < 8; ++w) a += part[w][tid];
+        if (row0 + r < p.rows) p.boxes[(size_t)(row0 + r) * 4 + c] = 1.0f / (1.0f + expf(-(a + p.b3[c])));
     }
 }
 
@@ -589,7 +612,7 @@ hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bia
 
 hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
     if (p.ncls > 256 || p.rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(1024), 0, stream, p);
+    hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -672,6 +672,69 @@ int opd_test_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const 
     return OPD_OK;
 }
 
+// heads_kernel alone: hs [rows][256] fp32 (+ optional final LayerNorm), weights in the reference's [out][in] layout (the hook
+// transposes them as opd_model.cpp does); logits [rows][ncls], boxes [rows][4]
+int opd_test_heads(const float* hs, const float* ln_g, const float* ln_b, const float* wc, const float* bc, const float* w1, const float* b1,
+                   const float* w2, const float* b2, const float* w3, const float* b3, float* logits, float* boxes, int rows, int ncls) {
+    DevMem dm;
+    auto tr = [&](const float* w, int O, int I) -> const float* {
+        std::vector<float> t((size_t)O * I);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i) t[(size_t)i * O + o] = w[(size_t)o * I + i];
+        return dm.up(t.data(), t.size());
+    };
+    HeadParams p{};
+    p.hs = dm.up(hs, (size_t)rows * 256);
+    p.ln_gamma = ln_g ? dm.up(ln_g, 256) : nullptr;
+    p.ln_beta = ln_b ? dm.up(ln_b, 256) : nullptr;
+    p.wc = tr(wc, ncls, 256); p.bc = dm.up(bc, ncls);
+    p.w1 = tr(w1, 256, 256); p.b1 = dm.up(b1, 256);
+    p.w2 = tr(w2, 256, 256); p.b2 = dm.up(b2, 256);
+    p.w3 = tr(w3, 4, 256); p.b3 = dm.up(b3, 4);
+    p.logits = dm.up<float>(nullptr, (size_t)rows * ncls);
+    p.boxes = dm.up<float>(nullptr, (size_t)rows * 4);
+    if (!p.hs || !p.wc || !p.bc || !p.w1 || !p.b1 || !p.w2 || !p.b2 || !p.w3 || !p.b3 || !p.logits || !p.boxes) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.rows = rows; p.ncls = ncls;
+    TCHK(opd_launch_heads(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(logits, p.logits, (size_t)rows * ncls * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(boxes, p.boxes, (size_t)rows * 4 * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// postprocess_kernel alone: logits [B][Q][ncls], boxes [B][Q][4] cxcywh, orig_hw [B][2] -> records [B][Q] (compacted) + counts [B]
+int opd_test_postprocess(const float* logits, const float* boxes, const int32_t* orig_hw, int B, int Q, int ncls, float threshold,
+                         opd_det* records, int32_t* counts) {
+    DevMem dm;
+    PostParams p{};
+    p.logits = dm.up(logits, (size_t)B * Q * ncls);
+    p.boxes = dm.up(boxes, (size_t)B * Q * 4);
+    p.orig_hw = dm.up(orig_hw, (size_t)B * 2);
+    opd_det* rec = dm.up<opd_det>(nullptr, (size_t)B * Q);
+    p.counts = dm.up<int32_t>(nullptr, B);
+    if (!p.logits || !p.boxes || !p.orig_hw || !rec || !p.counts) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(hipMemset(rec, 0, (size_t)B * Q * sizeof(opd_det)));
+    p.records = rec; p.B = B; p.Q = Q; p.ncls = ncls; p.threshold = threshold;
+    TCHK(opd_launch_postprocess(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(records, rec, (size_t)B * Q * sizeof(opd_det), hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(counts, p.counts, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// roi_features_kernel alone: enc [h][w][256] fp32, rois [n][4] = (x0, y0, x1, y1) in map cells -> out [n][256]
+int opd_test_roi_features(const float* enc, const int32_t* rois, int n, int h, int w, float* out) {
+    DevMem dm;
+    const float* d_enc = dm.up(enc, (size_t)h * w * 256);
+    const int32_t* d_rois = dm.up(rois, (size_t)n * 4);
+    float* d_out = dm.up<float>(nullptr, (size_t)n * 256);
+    if (!d_enc || !d_rois || !d_out) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_roi_features(d_enc, d_rois, d_out, n, h, w, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(out, d_out, (size_t)n * 256 * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
 // host-only helpers of the loader, exposed so CPU tests can exercise them without a GPU
 uint16_t opd_test_f32_to_f16(float f) { return opd::f32_to_f16(f); }
 float opd_test_f16_to_f32(uint16_t h) { return opd::f16_to_f32(h); }

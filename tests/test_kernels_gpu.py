@@ -32,6 +32,10 @@ def gemm_variant(request, lib):
     lib.opd_test_set_conv_flags(0)
 
 
+DET = np.dtype([("x1", "<f4"), ("y1", "<f4"), ("x2", "<f4"), ("y2", "<f4"), ("score", "<f4"), ("label", "<i4"), ("query_index", "<i4"),
+                ("frame", "<i4")])   # opd_det (include/opd_detr.h)
+
+
 def _h(a):
     """fp32 array -> (fp16-rounded fp32 array, uint16 bit pattern)."""
     h = np.ascontiguousarray(a, dtype=np.float32).astype(np.float16)
@@ -752,3 +756,90 @@ def test_conv_dual_source_integer_exact(lib):
     scu = run_conv(lib, x2, w2[:, :, None, None], b2, 2, 0, False)[:, :H, :W]
     yu = run_conv(lib, x, w1[:, :, None, None], b1, 1, 0, True, np.ascontiguousarray(scu))
     np.testing.assert_array_equal(got, yu)
+
+
+# ---- output kernels in isolation (kernels_misc.hip): heads, post-process, ROI features ---------------------------------------------
+@pytest.mark.parametrize("rows,ln", [(800, True), (100, False), (37, True), (1, True)])
+def test_heads_kernel_matches_torch(lib, rows, ln):
+    """class_labels_classifier + DetrMLPPredictionHead + sigmoid (HF:models/detr/modeling_detr.py:1284-1300, 1410-1411), with and
+    without the decoder's final LayerNorm inside; fp32 on the matrix pipe (exact fp32 fma chains) against float64 torch."""
+    rng = np.random.default_rng(rows)
+    hs = rng.standard_normal((rows, 256)).astype(np.float32) * 1.5
+    g = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    b = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    wc = (rng.standard_normal((92, 256)) / 16 * 2).astype(np.float32); bc = rng.standard_normal(92).astype(np.float32)
+    w1 = (rng.standard_normal((256, 256)) / 11).astype(np.float32); b1 = rng.standard_normal(256).astype(np.float32) * 0.1
+    w2 = (rng.standard_normal((256, 256)) / 11).astype(np.float32); b2 = rng.standard_normal(256).astype(np.float32) * 0.1
+    w3 = (rng.standard_normal((4, 256)) / 8).astype(np.float32); b3 = rng.standard_normal(4).astype(np.float32) * 0.1
+    logits = np.empty((rows, 92), np.float32)
+    boxes = np.empty((rows, 4), np.float32)
+    _capi.check(lib.opd_test_heads(_p(hs), _p(g if ln else None), _p(b if ln else None), _p(wc), _p(bc), _p(w1), _p(b1), _p(w2), _p(b2), _p(w3),
+                                   _p(b3), _p(logits), _p(boxes), rows, 92), "opd_test_heads")
+    t = lambda a: torch.from_numpy(a).double()
+    x = t(hs)
+    if ln:
+        x = F.layer_norm(x, (256,), t(g), t(b), 1e-5)
+    want_logits = x @ t(wc).T + t(bc)
+    y = F.relu(x @ t(w1).T + t(b1))
+    y = F.relu(y @ t(w2).T + t(b2))
+    want_boxes = torch.sigmoid(y @ t(w3).T + t(b3))
+    np.testing.assert_allclose(logits, want_logits.numpy(), atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(boxes, want_boxes.numpy(), atol=2e-6)
+
+
+def test_postprocess_kernel_matches_oracle(lib):
+    """softmax / max over the first C classes / cxcywh -> xyxy x (W, H) / threshold / compaction in query order against the oracle's
+    restatement of HF's post_process_object_detection, incl. ties between classes (lowest index wins, like torch.max), a frame with
+    no survivor and a frame where every query survives."""
+    from oracle import detr_oracle as O
+    rng = np.random.default_rng(5)
+    B, Q, C1 = 4, 100, 92
+    logits = rng.standard_normal((B, Q, C1)).astype(np.float32) * 2.0
+    logits[0, :, 1] += 4.0                       # frame 0: person wins often
+    logits[1, :, :] = 0.0                        # frame 1: all classes tie -> score 1/92 < threshold, nothing kept
+    logits[2, :, 17] = 30.0                      # frame 2: everything kept, label 17
+    logits[3, 10, 5] = logits[3, 10, 6] = 9.0    # frame 3, query 10: two classes tie for the maximum -> label 5
+    boxes = rng.uniform(0.05, 0.95, (B, Q, 4)).astype(np.float32)
+    hw = np.asarray([[720, 1280], [800, 1333], [333, 203], [1080, 1920]], np.int32)
+    recs = np.zeros((B, Q), DET)
+    counts = np.zeros(B, np.int32)
+    thr = 0.3   # (a two-way tie scores just under 0.5)
+    _capi.check(lib.opd_test_postprocess(_p(logits), _p(boxes), _p(hw), B, Q, C1, thr, _p(recs), _p(counts)), "opd_test_postprocess")
+    want = O.post_process_object_detection(logits, boxes, thr, [tuple(int(v) for v in r) for r in hw])
+    assert counts.tolist() == [len(w["scores"]) for w in want] and counts[1] == 0 and counts[2] == Q
+    for b in range(B):
+        n = counts[b]
+        np.testing.assert_array_equal(recs[b, :n]["query_index"], want[b]["query_index"])
+        np.testing.assert_array_equal(recs[b, :n]["label"], want[b]["labels"])
+        assert (recs[b, :n]["frame"] == b).all()
+        np.testing.assert_allclose(recs[b, :n]["score"], want[b]["scores"], rtol=2e-6, atol=1e-7)
+        got_xyxy = np.stack([recs[b, :n][k] for k in ("x1", "y1", "x2", "y2")], -1) if n else np.zeros((0, 4), np.float32)
+        np.testing.assert_allclose(got_xyxy, want[b]["boxes"], rtol=1e-6, atol=1e-3)
+    q10 = np.flatnonzero(recs[3, :counts[3]]["query_index"] == 10)
+    assert len(q10) == 1 and recs[3, q10[0]]["label"] == 5
+
+
+def test_roi_features_kernel_matches_oracle(lib):
+    """ROI mean-pool + L2 normalisation on the encoder map (src/tracking/feature_extractor.py:39-88) against the oracle for boxes
+    given in map cells: single cell, full map, thin rows / columns."""
+    from oracle import detr_oracle as O
+    rng = np.random.default_rng(6)
+    h, w = 25, 42
+    enc = rng.standard_normal((h, w, 256)).astype(np.float32)
+    rois = np.asarray([[0, 0, 1, 1], [0, 0, 42, 25], [41, 24, 42, 25], [3, 7, 30, 8], [10, 2, 11, 20], [5, 5, 17, 19]], np.int32)
+    out = np.empty((len(rois), 256), np.float32)
+    _capi.check(lib.opd_test_roi_features(_p(enc), _p(rois), len(rois), h, w, _p(out)), "opd_test_roi_features")
+    want = []
+    for x0, y0, x1, y1 in rois:
+        f = enc[y0:y1, x0:x1].astype(np.float64).mean(axis=(0, 1))
+        want.append(f / (np.linalg.norm(f) + 1e-8))
+    np.testing.assert_allclose(out, np.asarray(want), atol=2e-6)
+    # and through the oracle's own box -> cell arithmetic on an image-space box
+    img = (800, 1333)
+    box = (100.0, 200.0, 400.0, 300.0)
+    x0, y0 = int(box[0] / img[1] * w), int(box[1] / img[0] * h)
+    x1, y1 = int((box[0] + box[2]) / img[1] * w), int((box[1] + box[3]) / img[0] * h)
+    r1 = np.asarray([[x0, y0, max(x0 + 1, min(x1, w)), max(y0 + 1, min(y1, h))]], np.int32)
+    o1 = np.empty((1, 256), np.float32)
+    _capi.check(lib.opd_test_roi_features(_p(enc), _p(r1), 1, h, w, _p(o1)), "opd_test_roi_features")
+    np.testing.assert_allclose(o1, O.roi_features(enc, [box], img), atol=2e-6)
