@@ -506,43 +506,6 @@ hipError_t opd_launch_resize_u8(const uint8_t* in, uint8_t* out, int B, int h, i
     return hipGetLastError();
 }
 
-// Pillow's precompute_coeffs + normalize_coeffs_8bpc for the bilinear (triangle, support 1) filter over the whole axis
-// (box = [0, in_size)): per output position the first source index, the tap count, and the 22-bit fixed-point taps.
-void opd_resize_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs, int* ksize_out) {
-    const double scale = (double)in_size / out_size;
-    const double filterscale = scale < 1.0 ? 1.0 : scale;
-    const double support = 1.0 * filterscale;
-    const int ksize = (int)ceil(support) * 2 + 1;
-    bounds->assign((size_t)out_size * 2, 0);
-    coeffs->assign((size_t)out_size * ksize, 0);
-    std::vector<double> k(ksize);
-    for (int xx = 0; xx < out_size; ++xx) {
-        const double center = 0.0 + (xx + 0.5) * scale;
-        double ww = 0.0;
-        const double ss = 1.0 / filterscale;
-        int xmin = (int)(center - support + 0.5);
-        if (xmin < 0) xmin = 0;
-        int xmax = (int)(center + support + 0.5);
-        if (xmax > in_size) xmax = in_size;
-        xmax -= xmin;
-        for (int x = 0; x < xmax; ++x) {
-            double a = (x + xmin - center + 0.5) * ss;
-            if (a < 0.0) a = -a;
-            const double wgt = a < 1.0 ? 1.0 - a : 0.0;
-            k[x] = wgt;
-            ww += wgt;
-        }
-        for (int x = 0; x < xmax; ++x) {
-            if (ww != 0.0) k[x] /= ww;
-            const double v = k[x] * (double)(1 << 22);
-            (*coeffs)[(size_t)xx * ksize + x] = k[x] < 0 ? (int)(-0.5 + v) : (int)(0.5 + v);
-        }
-        (*bounds)[2 * xx] = xmin;
-        (*bounds)[2 * xx + 1] = xmax;
-    }
-    *ksize_out = ksize;
-}
-
 hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW,
                               hipStream_t stream) {
     if (C % 8 != 0) return hipErrorInvalidValue;

@@ -23,15 +23,11 @@
 #include "../../include/opd_detr.h"
 #include "opd_kernels.h"
 #include "opd_loader.h"
+#include "opd_host.h"
 
 namespace opd {
 
-thread_local std::string g_err;
-
-static int fail(int code, const std::string& msg) {
-    g_err = msg;
-    return code;
-}
+// (g_err / fail: opd_host.cpp)
 
 #define HIPCHK(expr)                                                                                           \
     do {                                                                                                       \
@@ -557,31 +553,6 @@ static int build_workspace(opd_detr* m) {
     return OPD_OK;
 }
 
-// DetrSinePositionEmbedding (HF:models/detr/modeling_detr.py:294-368), fp32 like the reference, for a mask that is a
-// top-left rectangle of vh x vw valid positions inside the h x w map (vh == h, vw == w: all-ones mask):
-//   y_embed = cumsum(mask, rows) = min(y+1, vh) in valid columns, 0 in padded columns; normalised by its last row (+eps);
-//   x_embed = cumsum(mask, cols) = min(x+1, vw) in valid rows, 0 in padded rows; normalised by its last column (+eps).
-static void sine_pos_embed(int h, int w, int vh, int vw, int D, std::vector<float>* pos) {
-    const int npf = D / 2;
-    pos->assign((size_t)h * w * D, 0.f);
-    const float scale = 6.283185307179586f, eps = 1e-6f;
-    std::vector<float> dim_t(npf);
-    for (int i = 0; i < npf; ++i) dim_t[i] = powf(10000.0f, (2.0f * (float)(i / 2)) / (float)npf);
-    for (int y = 0; y < h; ++y)
-        for (int x = 0; x < w; ++x) {
-            const float yc = x < vw ? (float)std::min(y + 1, vh) : 0.f, ylast = x < vw ? (float)vh : 0.f;
-            const float xc = y < vh ? (float)std::min(x + 1, vw) : 0.f, xlast = y < vh ? (float)vw : 0.f;
-            const float ye = yc / (ylast + eps) * scale;
-            const float xe = xc / (xlast + eps) * scale;
-            float* p = pos->data() + ((size_t)y * w + x) * D;
-            for (int i = 0; i < npf; ++i) {
-                const float py = ye / dim_t[i], px = xe / dim_t[i];
-                p[i] = (i & 1) ? cosf(py) : sinf(py);
-                p[npf + i] = (i & 1) ? cosf(px) : sinf(px);
-            }
-        }
-}
-
 static int get_plan(opd_detr* m, int fh, int fw, int vh, int vw, Plan** out) {
     // the cache lives with the weights; a fold is built once, on the calling handle's stream, and is complete (stream
     // synchronised) before the lock is released.  Its buffers belong to the WeightSet: they may outlive this handle.
@@ -790,20 +761,6 @@ static bool is_ragged(const int32_t* valid_hw, int B, int H, int W) {
     for (int b = 0; b < B; ++b)
         if (valid_hw[2 * b] != H || valid_hw[2 * b + 1] != W) return true;
     return false;
-}
-
-// Valid extent of a frame on the feature map: the reference down-samples the pixel mask with nearest-neighbour
-// interpolation (HF:models/detr/modeling_detr.py:283-289: F.interpolate(mask, size=feature_map.shape[-2:])), i.e. feature
-// position i looks at pixel floor(i * in / out) (float32 scale, like ATen's nearest kernel); the mask is a top-left
-// rectangle, so the valid feature positions are a prefix.
-static int valid_prefix(int valid, int in, int out) {
-    const float scale = (float)in / (float)out;
-    int n = 0;
-    for (int i = 0; i < out; ++i) {
-        const int src = std::min((int)floorf((float)i * scale), in - 1);
-        if (src < valid) ++n;
-    }
-    return n;
 }
 
 // `valid_hw` (host, nullable): [B][2] = (h, w) of each frame inside the H x W canvas.
@@ -1327,7 +1284,6 @@ static int guarded(const char* what, F&& body) {
 }
 extern "C" {
 
-const char* opd_last_error(void) { return opd::g_err.c_str(); }
 const char* opd_version(void) { return "opd_hip 0.1 gfx950 (fp16 MFMA, fp32 accumulate)"; }
 
 int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out) {
@@ -1604,48 +1560,6 @@ int opd_host_alloc(size_t bytes, void** out) {
 void opd_host_free(void* p) {
     ApiScope api_scope;
     if (p) (void)hipHostFree(p);
-}
-
-int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold) {
-    if (n < 0 || (n > 0 && !dets)) return fail(OPD_EINVAL, "opd_person_nms: bad arguments");
-    std::vector<int> idx;
-    for (int i = 0; i < n; ++i)
-        if (person_label < 0 || dets[i].label == person_label) idx.push_back(i);
-    // stable sort by descending score (ties keep query order), as the oracle's person_detections
-    for (size_t i = 1; i < idx.size(); ++i) {
-        const int v = idx[i];
-        size_t j = i;
-        while (j > 0 && dets[idx[j - 1]].score < dets[v].score) { idx[j] = idx[j - 1]; --j; }
-        idx[j] = v;
-    }
-    auto iou = [](const opd_det& a, const opd_det& b) {
-        const float ix1 = fmaxf(a.x1, b.x1), iy1 = fmaxf(a.y1, b.y1), ix2 = fminf(a.x2, b.x2), iy2 = fminf(a.y2, b.y2);
-        const float iw = fmaxf(0.f, ix2 - ix1), ih = fmaxf(0.f, iy2 - iy1), inter = iw * ih;
-        const float ua = fmaxf(0.f, a.x2 - a.x1) * fmaxf(0.f, a.y2 - a.y1) + fmaxf(0.f, b.x2 - b.x1) * fmaxf(0.f, b.y2 - b.y1) - inter;
-        return ua > 0.f ? inter / ua : 0.f;
-    };
-    std::vector<opd_det> kept;
-    for (int i : idx) {
-        bool ok = true;
-        if (nms_threshold < 1.0f)
-            for (const auto& k : kept)
-                if (iou(dets[i], k) > nms_threshold) { ok = false; break; }
-        if (ok) kept.push_back(dets[i]);
-    }
-    for (size_t i = 0; i < kept.size(); ++i) dets[i] = kept[i];
-    return (int)kept.size();
-}
-
-int opd_person_nms_batch(opd_det* dets, int32_t* counts, int n_frames, int stride, int person_label, float nms_threshold) {
-    if (n_frames < 0 || stride < 0 || (n_frames > 0 && (!dets || !counts))) return fail(OPD_EINVAL, "opd_person_nms_batch: bad arguments");
-    for (int f = 0; f < n_frames; ++f) {
-        if (counts[f] < 0) continue;
-        if (counts[f] > stride) return fail(OPD_EINVAL, "opd_person_nms_batch: a frame holds more records than its slots");
-        const int kept = opd_person_nms(dets + (size_t)f * stride, counts[f], person_label, nms_threshold);
-        if (kept < 0) return kept;
-        counts[f] = kept;
-    }
-    return OPD_OK;
 }
 
 int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* boxes1, const uint8_t* has1, int n1,
