@@ -124,7 +124,8 @@ def cpu_baseline(path: str, H: int, W: int, batch: int = 4, iters: int = 3) -> d
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)   # 0.55 s timed; 20 steps carry ~4 % of pipeline fill / drain
+    ap.add_argument("--steps", type=int, default=1000)  # 2.8 s timed.  A 200-step window (0.1-0.6 s after the load starts) sits in the
+                                                        # power-management transient and reads ~4 % low: profiles/r03_clock_vs_window.txt
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=800)
@@ -346,12 +347,12 @@ def main() -> int:
         # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
         # in separate runs, gfx950 x2 fetch correction: tools/pmc_traffic.py) — valid for the default 8 x 800x1333 workload
         traffic = None
-        for name in ("r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333) and args.arch == "r50":
                 traffic = round(json.load(open(tpath))["conv_gemm_family"]["bytes_per_launch"])
                 break
-        roof = {"bound": "mfma", "kernel": "implicit-GEMM family (conv_gemm_dma_kernel, btail_kernel, ffn_kernel, gemm_ln256_kernel, gemm_k256_kernel, stem_pool2_kernel)",
+        roof = {"bound": "mfma", "kernel": "implicit-GEMM family (conv_gemm_dma_kernel, btail_kernel, gemm_ln256_ring/os_kernel, gemm_k256_kernel, stem_pool2_kernel)",
                 "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": k_n, "avg_launch_us": round(1e3 * k_ms / max(k_n, 1), 2),
@@ -360,6 +361,26 @@ def main() -> int:
                 "kernel_ms_per_step": round(float(ms_avg.sum()), 4),   # every launch of a serial forward + post-process
                 "by_class_ms": {"conv": round(float(ms_avg[0]), 4), "linear": round(float(ms_avg[1]), 4),
                                 "attention": round(float(ms_avg[2]), 4), "other": round(float(ms_avg[3]), 4)}}
+        if (B, H, W) == (8, 800, 1333) and args.arch == "r50":
+            # achieved HBM GB/s of the convolution stages: SURVEY.md section 8(d)'s unfused per-layer minimum bytes of each stage (MB per
+            # frame, bf16/fp16) x 8 frames / the stage's duration measured live with HIP events on the library's stream (profiling mode:
+            # eager launches, so the few-us gaps between a stage's launches are included)
+            stage_mb = {"stem+pool": 40.6, "stage1": 17.1 + 51.5 + 171.0 + 85.6, "stage2": 51.4 + 21.7 + 86.0 + 51.6 + 64.5 + 26.5,
+                        "stage3": 25.9 + 11.9 + 67.7 + 26.8 + 56.4 + 27.4, "stage4": 14.0 + 10.1 + 22.4 + 17.1 + 15.0 + 13.7}
+            roof["conv_stages_hbm"] = [
+                {"stage": name, "ms": stage_ms[1 + i], "algorithmic_GB": round(mb * B / 1e3, 3),
+                 "GB_per_s": round(mb * B / 1e3 / (stage_ms[1 + i] * 1e-3), 1) if stage_ms[1 + i] > 0 else None,
+                 "frac_of_peak": round(mb * B / 1e3 / (stage_ms[1 + i] * 1e-3) / PEAK_HBM_GBS, 3) if stage_ms[1 + i] > 0 else None}
+                for i, (name, mb) in enumerate(stage_mb.items())]
+            # MFMA-pipe utilisation of the attention / linear kernels from the committed SQ counter pass of the same build
+            sq_path = os.path.join(ROOT, "profiles", "r03_pmc_sq.json")
+            if os.path.exists(sq_path):
+                sq = json.load(open(sq_path))
+                pick = lambda sub: {k: v["mfma_busy_pct"] for k, v in sq["kernels"].items() if sub in k}
+                roof["mfma_busy_pct"] = {"source": "profiles/r03_pmc_sq.json (rocprofv3 --pmc SQ pass, one serial forward)",
+                                         "whole_forward": sq["whole_forward_mfma_busy_pct"], "attention": pick("attention_kernel"),
+                                         "row_owner_linears": pick("gemm_ln256"), "implicit_gemm": pick("conv_gemm_dma_kernel"),
+                                         "fused_tails": pick("btail_kernel")}
 
     total_frames = B * world * args.steps
     fps = total_frames / elapsed

@@ -8,7 +8,7 @@ MFMA pipe utilisation, what the waves do with their cycles, LDS bank conflicts.
 Units (MI355X_MICROARCH.md): SQ_BUSY_CYCLES is summed over the 32 shader engines, SQ_VALU_MFMA_BUSY_CYCLES over the 1024 SIMDs
 (cycles), the wave counters are quad-cycles summed over waves.  MFMA utilisation = MFMA_BUSY / (1024 x kernel cycles) with
 kernel cycles = SQ_BUSY_CYCLES / 32.
-usage: pmc_mfma.py <counter_collection.csv>"""
+usage: pmc_mfma.py <counter_collection.csv> [summary.json]"""
 import collections, csv, sys
 
 rows = list(csv.DictReader(open(sys.argv[1])))
@@ -42,3 +42,11 @@ for k, a in agg.items():
     print(f"{k:40s} {int(a['n']):3d} {a['us']:8.1f} {100 * util:8.1f}% {100 * a['SQ_ACTIVE_INST_ANY'] / wc:6.1f}% {100 * a['SQ_WAIT_ANY'] / wc:5.1f}% "
           f"{100 * a['SQ_WAIT_INST_ANY'] / wc:10.1f}% {100 * lds:25.1f}%")
 print(f"whole forward: MFMA pipes busy {100 * tot_mfma / (1024.0 * tot_cyc):.1f} % of the kernel cycles")
+if len(sys.argv) > 2:   # machine-readable form for bench.py's roofline object
+    import json
+    out = {"note": "rocprofv3 --pmc SQ_* pass over one serial forward (tools/pmc_mfma.sh); MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x kernel cycles)",
+           "whole_forward_mfma_busy_pct": round(100 * tot_mfma / (1024.0 * tot_cyc), 2), "kernels": {}}
+    for k, a in agg.items():
+        cyc = a["SQ_BUSY_CYCLES"] / 32.0
+        out["kernels"][k] = {"launches": int(a["n"]), "us": round(a["us"], 1), "mfma_busy_pct": round(100 * a["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc), 2) if cyc else 0.0}
+    json.dump(out, open(sys.argv[2], "w"), indent=1)
