@@ -85,16 +85,18 @@ def test_full_resolution_matches_golden(detectors, golden_dir, parity_log):
 
 
 def test_r101_matches_golden(detectors, golden_dir, parity_log):
-    """r101 (33 bottlenecks) at 256x320: 3e-3 -- the maximum over 400 coordinates moves between 1.2e-3 and 2.0e-3 with the
-    fp32 summation order alone (six launch sequences, tools/drift_toggles.py -> profiles/r02_drift_toggles.txt); at its BASELINE
-    resolution the 1e-3 bound holds (test_config4_r101_1080p_batch8).  tools/drift_split.py, DESIGN.md section 3."""
+    """r101 (33 bottlenecks) at 256x320.  The MAXIMUM over the 400 box coordinates is a noisy statistic here: it moves between 1.2e-3
+    and 2.1e-3 with the fp32 summation order alone (six launch sequences, tools/drift_toggles.py -> profiles/r02_drift_toggles.txt), so
+    the assertion is on statistics whose spread is small — mean <= 6e-4 (measured 3.4e-4 .. 4.2e-4) and 99th percentile <= 1.6e-3 — plus
+    the maximum at 3e-3; at its BASELINE resolution the plain 1e-3 bound holds (test_config4_r101_1080p_batch8)."""
     g = np.load(os.path.join(golden_dir, "r101_mild_256x320.npz"))
     det = detectors(depths=(3, 4, 23, 3), ga=1.0)
     logits, boxes, enc = det.forward_raw(_golden_frames(g))
-    dbox = float(np.abs(boxes - g["pred_boxes"]).max())
+    d = np.abs(boxes - g["pred_boxes"]).ravel()
+    dbox, mean, p99 = float(d.max()), float(d.mean()), float(np.percentile(d, 99))
     dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
-    parity_log("r101 mild 256x320 vs HF golden", dbox, dprob, None, 3e-3, "small frame")
-    assert dbox <= 3e-3 and dprob <= 4e-3
+    parity_log("r101 mild 256x320 vs HF golden", dbox, dprob, None, 3e-3, f"small frame; mean {mean:.2e}, p99 {p99:.2e}")
+    assert mean <= 6e-4 and p99 <= 1.6e-3 and dbox <= 3e-3 and dprob <= 4e-3
 
 
 def test_matches_live_oracle_and_postprocess(detectors, weight_cache):
