@@ -156,10 +156,12 @@ constexpr int OS_XSUB = OS_TM * ROW_BYTES;   // one [48 rows][64 k] activation s
 constexpr int OS_WSUB = 256 * ROW_BYTES;     // one [256 rows][64 k] weight sub-tile: 32 KiB
 constexpr int OS_LDS = 4 * (OS_XSUB + OS_WSUB);
 
-__global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
+constexpr int OS_NW = 8;   // waves per workgroup: 32 columns each; twice the LDS-DMA instructions in flight of a 4-wave workgroup
+
+__global__ __launch_bounds__(64 * OS_NW, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float red[2][4][OS_TM];       // [pass][wave][row]
+    __shared__ float red[2][OS_NW][OS_TM];   // [pass][wave][row]
     unsigned char* const Xs = smem;                   // 4 sub-tiles
     unsigned char* const Ws = smem + 4 * OS_XSUB;     // 4 sub-tiles
     const int tid = threadIdx.x;
@@ -168,41 +170,43 @@ __global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
     const int g = lane >> 4, li = lane & 15;
     const int m_base = blockIdx.x * OS_TM;
     const int lrow = lane >> 3, lchunk = (lane & 7) ^ lrow;
+    constexpr int NT = 256 / 16 / OS_NW;     // column tiles per wave (2)
+    constexpr int WP = 256 / 8 / OS_NW;      // weight pieces per wave and sub-tile (4)
 
     const __amdgpu_buffer_rsrc_t rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.x), 0, (unsigned)((size_t)p.M * 256 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w), 0, (unsigned)(256 * 256 * 2), 0x00020000);
-    // weights: wave w stages its own 64 rows (8 pieces) of each of the 4 sub-tiles; activations: 6 pieces per sub-tile, 24 in all,
-    // 6 per wave (piece q = 6 wave + i -> sub-tile q / 6, rows 8 (q % 6) ..); rows >= M are outside the descriptor: zero fill
+    // weights: wave w stages its own 32 rows (4 pieces) of each of the 4 sub-tiles; activations: 6 pieces per sub-tile, 24 in all,
+    // 3 per wave (piece q = 3 wave + i -> sub-tile q / 6, rows 8 (q % 6) ..); rows >= M are outside the descriptor: zero fill
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Ws + t * OS_WSUB + (wave * 8 + i) * 1024), 16,
-                                                     (unsigned)((wave * 64 + i * 8 + lrow) * 256) * 2u + (unsigned)lchunk * 16u, t * 128, 0, 0);
+        for (int i = 0; i < WP; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w, (__attribute__((address_space(3))) void*)(Ws + t * OS_WSUB + (wave * WP + i) * 1024), 16,
+                                                     (unsigned)((wave * (8 * WP) + i * 8 + lrow) * 256) * 2u + (unsigned)lchunk * 16u, t * 128, 0, 0);
     }
 #pragma unroll
-    for (int i = 0; i < 6; ++i) {
-        const int q = wave * 6 + i, t = q / 6, r = (q % 6) * 8 + lrow;   // (t == wave)
+    for (int i = 0; i < 3; ++i) {
+        const int q = wave * 3 + i, t = q / 6, r = (q % 6) * 8 + lrow;
         const int m = m_base + r;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_x, (__attribute__((address_space(3))) void*)(Xs + t * OS_XSUB + (q % 6) * 1024), 16,
                                                  m < p.M ? (unsigned)(m * 256) * 2u + (unsigned)lchunk * 16u : 0x80000000u, t * 128, 0, 0);
     }
-    float4v acc[4][3];
+    float4v acc[NT][3];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        const float4v b = *reinterpret_cast<const float4v*>(p.bias + wave * 64 + nt * 16 + g * 4);
+    for (int nt = 0; nt < NT; ++nt) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.bias + (wave * NT + nt) * 16 + g * 4);
 #pragma unroll
         for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = b;
     }
-    // residual rows in flight during the MFMAs: lane (g, li) holds, for row mt*16 + li, columns 64 wave + nt*16 + 4g + r
-    float4v res[4][3];
+    // residual rows in flight during the MFMAs: lane (g, li) holds, for row mt*16 + li, columns 32 wave + nt*16 + 4g + r
+    float4v res[NT][3];
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
         const int m = m_base + mt * 16 + li;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             res[nt][mt] = float4v{0.f, 0.f, 0.f, 0.f};
-            if (p.res32 && m < p.M) res[nt][mt] = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + wave * 64 + nt * 16 + g * 4);
+            if (p.res32 && m < p.M) res[nt][mt] = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + (wave * NT + nt) * 16 + g * 4);
         }
     }
     __syncthreads();   // vmcnt(0) + barrier: everything is in LDS
@@ -210,13 +214,13 @@ __global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk) {
-            half8 xf[3], wf[4];
+            half8 xf[3], wf[NT];
 #pragma unroll
             for (int mt = 0; mt < 3; ++mt) xf[mt] = *reinterpret_cast<const half8*>(Xs + t * OS_XSUB + swz(mt * 16 + li, kk * 4 + g));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + t * OS_WSUB + swz(wave * 64 + nt * 16 + li, kk * 4 + g));
+            for (int nt = 0; nt < NT; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + t * OS_WSUB + swz((wave * NT + nt) * 16 + li, kk * 4 + g));
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt)
+            for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
         }
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int nt = 0; nt < NT; ++nt) {
             acc[nt][mt] += res[nt][mt];
             sum[mt] += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
         }
@@ -238,9 +242,12 @@ __global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
         const int r = mt * 16 + li;
-        const float mean = (red[0][0][r] + red[0][1][r] + red[0][2][r] + red[0][3][r]) * (1.0f / 256.0f);
+        float mean = 0.f;
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
+        for (int w = 0; w < OS_NW; ++w) mean += red[0][w][r];
+        mean *= (1.0f / 256.0f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
             acc[nt][mt] -= mean;
             sq[mt] += acc[nt][mt][0] * acc[nt][mt][0] + acc[nt][mt][1] * acc[nt][mt][1] + acc[nt][mt][2] * acc[nt][mt][2] +
                       acc[nt][mt][3] * acc[nt][mt][3];
@@ -250,21 +257,24 @@ __global__ __launch_bounds__(256, 1) void gemm_ln256_os_kernel(GemmLnParams p) {
         if (g == 0) red[1][wave][r] = sq[mt];
     }
     __syncthreads();
-    float4v gm[4], bt[4];
+    float4v gm[NT], bt[NT];
 #pragma unroll
-    for (int nt = 0; nt < 4; ++nt) {
-        gm[nt] = *reinterpret_cast<const float4v*>(p.gamma + wave * 64 + nt * 16 + g * 4);
-        bt[nt] = *reinterpret_cast<const float4v*>(p.beta + wave * 64 + nt * 16 + g * 4);
+    for (int nt = 0; nt < NT; ++nt) {
+        gm[nt] = *reinterpret_cast<const float4v*>(p.gamma + (wave * NT + nt) * 16 + g * 4);
+        bt[nt] = *reinterpret_cast<const float4v*>(p.beta + (wave * NT + nt) * 16 + g * 4);
     }
 #pragma unroll
     for (int mt = 0; mt < 3; ++mt) {
         const int r = mt * 16 + li;
         const int m = m_base + r;
-        const float var = (red[1][0][r] + red[1][1][r] + red[1][2][r] + red[1][3][r]) * (1.0f / 256.0f);
+        float var = 0.f;
+#pragma unroll
+        for (int w = 0; w < OS_NW; ++w) var += red[1][w][r];
+        var *= (1.0f / 256.0f);
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            const int c = wave * 64 + nt * 16 + g * 4;
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = (wave * NT + nt) * 16 + g * 4;
             float4v o;
 #pragma unroll
             for (int q = 0; q < 4; ++q) o[q] = acc[nt][mt][q] * rstd * gm[nt][q] + bt[nt][q];
@@ -475,7 +485,7 @@ hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream) {
     if (p.yp16) return hipErrorInvalidValue;   // (the position shadow is written by the deep-K form only)
     if (p.K == 256 && !p.kloop) {
         OPD_SET_MAX_LDS_ONCE(gemm_ln256_os_kernel, OS_LDS);
-        hipLaunchKernelGGL(gemm_ln256_os_kernel, dim3((p.M + OS_TM - 1) / OS_TM), dim3(256), OS_LDS, stream, p);
+        hipLaunchKernelGGL(gemm_ln256_os_kernel, dim3((p.M + OS_TM - 1) / OS_TM), dim3(64 * OS_NW), OS_LDS, stream, p);
         return hipGetLastError();
     }
     constexpr int LDS = 2 * STAGE_BYTES;
