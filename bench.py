@@ -368,9 +368,9 @@ def main() -> int:
             stage_mb = {"stem+pool": 40.6, "stage1": 17.1 + 51.5 + 171.0 + 85.6, "stage2": 51.4 + 21.7 + 86.0 + 51.6 + 64.5 + 26.5,
                         "stage3": 25.9 + 11.9 + 67.7 + 26.8 + 56.4 + 27.4, "stage4": 14.0 + 10.1 + 22.4 + 17.1 + 15.0 + 13.7}
             roof["conv_stages_hbm"] = [
-                {"stage": name, "ms": stage_ms[1 + i], "algorithmic_GB": round(mb * B / 1e3, 3),
-                 "GB_per_s": round(mb * B / 1e3 / (stage_ms[1 + i] * 1e-3), 1) if stage_ms[1 + i] > 0 else None,
-                 "frac_of_peak": round(mb * B / 1e3 / (stage_ms[1 + i] * 1e-3) / PEAK_HBM_GBS, 3) if stage_ms[1 + i] > 0 else None}
+                {"stage": name, "ms": stage_ms[i], "algorithmic_GB": round(mb * B / 1e3, 3),   # stage_ms[0] = stem + pool, [1..4] = stages 1-4
+                 "GB_per_s": round(mb * B / 1e3 / (stage_ms[i] * 1e-3), 1) if stage_ms[i] > 0 else None,
+                 "frac_of_peak": round(mb * B / 1e3 / (stage_ms[i] * 1e-3) / PEAK_HBM_GBS, 3) if stage_ms[i] > 0 else None}
                 for i, (name, mb) in enumerate(stage_mb.items())]
             # MFMA-pipe utilisation of the attention / linear kernels from the committed SQ counter pass of the same build
             sq_path = os.path.join(ROOT, "profiles", "r03_pmc_sq.json")

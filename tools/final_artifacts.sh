@@ -1,13 +1,16 @@
 #!/bin/bash
-# Round-end evidence run on the GPU box (from the repo root): full GPU test suite, the default bench line with the CPU
-# baseline, rocprofv3 kernel traces of the default command and of the one-batch-in-flight form, the two HBM-traffic PMC
-# passes, the self-launched 2-rank gloo rehearsal of the sharded bench path, the other BASELINE shapes.  Everything lands
-# under gpurun_out/final/; tools/collect_profiles.sh copies the summaries into profiles/.
+# Round-end evidence run on the GPU box (from the repo root), in two parts (a gpurun call lasts at most 20 minutes):
+#   part 1: full GPU test suite, smoke, the default bench line with the CPU baseline, the driver's K = 20 form, rocprofv3 kernel
+#           traces of the default command and of the one-batch-in-flight form, the HBM-traffic and SQ counter passes
+#   part 2: the 2-rank gloo rehearsal of the self-launched bench, the other BASELINE shapes, host-boundary rates, kernel microbenches
+# Everything lands under gpurun_out/final/; tools/collect_profiles.sh copies the summaries into profiles/.
 set -o pipefail
 R=$PWD
 O=$R/gpurun_out/final
 mkdir -p $O
 export TMPDIR=/tmp
+part=${1:-1}
+if [ "$part" = 1 ]; then
 timeout -k 10 900 python -m pytest tests -x -q -m gpu > $O/tests_gpu.log 2>&1 && tail -2 $O/tests_gpu.log &&
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.log 2>&1 && cat $O/smoke.log &&
 timeout -k 10 400 python bench.py > $O/bench.json 2> $O/bench.err && cat $O/bench.json &&
@@ -17,13 +20,19 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_streams1 -- python3 $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --streams 1 --serial-steps 0 > $O/prof_streams1.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 --serial-steps 0 > $O/pmc_fetch.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 --serial-steps 0 > $O/pmc_write.log 2>&1 &&
-cd $R &&
+timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --serial-steps 0 > $O/pmc_sq.log 2>&1 &&
+cd $R && find $O -name "*.csv" | head -30 && du -sh $O
+else
 OPD_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err && tail -1 $O/bench_gloo2.json | cut -c1-300 &&
 timeout -k 10 300 python tools/host_rate.py 96 > $O/host_rate.txt 2>&1 && timeout -k 10 300 python tools/host_rate.py 96 720 1280 >> $O/host_rate.txt 2>&1 && cat $O/host_rate.txt &&
-timeout -k 10 300 python bench.py --arch r101 --height 1066 --width 1920 --no-cpu-baseline > $O/bench_r101_1066x1920.json 2> $O/bench_r101.err && cut -c1-200 $O/bench_r101_1066x1920.json &&
-timeout -k 10 300 python bench.py --height 1080 --width 1920 --batch 4 --no-cpu-baseline > $O/bench_r50_tile1080p_b4.json 2> $O/bench_tile.err && cut -c1-200 $O/bench_r50_tile1080p_b4.json &&
+timeout -k 10 300 python bench.py --arch r101 --height 1066 --width 1920 --no-cpu-baseline --steps 300 > $O/bench_r101_1066x1920.json 2> $O/bench_r101.err && cut -c1-200 $O/bench_r101_1066x1920.json &&
+timeout -k 10 300 python bench.py --height 1080 --width 1920 --batch 4 --no-cpu-baseline --steps 300 > $O/bench_r50_tile1080p_b4.json 2> $O/bench_tile.err && cut -c1-200 $O/bench_r50_tile1080p_b4.json &&
+timeout -k 10 120 python tools/bench_attn.py > $O/bench_attn.txt 2>&1 &&
+timeout -k 10 120 python tools/trace_attn.py > $O/trace_attn.txt 2>&1 &&
+timeout -k 10 120 python tools/bench_gemm_ln.py > $O/bench_gemm_ln.txt 2>&1 &&
 timeout -k 10 120 python tools/trace_gemm.py > $O/trace_gemm.txt 2>&1 &&
-timeout -k 10 300 python tools/bench_layers.py 1 > $O/bench_layers.txt 2>&1 &&
+timeout -k 10 300 python tools/bench_layers.py 0 > $O/bench_layers.txt 2>&1 &&
 timeout -k 10 300 python tools/bench_btail.py --ablate > $O/bench_btail.txt 2>&1 &&
-timeout -k 10 300 python tools/drift_toggles.py $O/drift_toggles.txt &&
-find $O -name "*.csv" | head -30 && du -sh $O
+timeout -k 10 300 python tools/clock_vs_window.py 20 200 1000 > $O/clock_vs_window.txt 2>&1 &&
+du -sh $O
+fi
