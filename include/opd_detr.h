@@ -196,6 +196,14 @@ int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* 
 int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n, int orig_h, int orig_w,
                           float* features);
 
+/* Replaces `get_attention_map` / `_extract_attention_map` (deleted vit_detector.py 392-446, `coverage.json:1`; the surviving stand-in
+ * returns None, `src/detection/yolov8_detector.py:243-254`; consumer: `Visualizer.draw_attention_map`, `src/visualization/visualizer.py:148-200`,
+ * which takes a 1-D or 2-D array in [0, 1]).  The DETR-era source is gone, so the definition is this build's: the decoder's
+ * cross-attention weights of layer `layer` (negative: counted from the last) of the LAST forward's frame `frame`, averaged over the
+ * heads and over the `n_queries` query indices in `queries` (n_queries == 0: all queries).  `out` = host [fh * fw] f32, row-major over
+ * the feature map, summing to 1; runs on the device from the q / k operands the forward left there. */
+int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* queries, int n_queries, float* out);
+
 /* Device time (ms) of the last forward/detect per stage, measured with HIP events on the handle's stream:
  * [0] preprocess+stem+pool, [1] stage1, [2] stage2, [3] stage3, [4] stage4, [5] projection+encoder, [6] decoder+heads,
  * [7] post-process.  Only filled when profiling was enabled with opd_detr_set_profiling(m, 1). */

@@ -67,6 +67,7 @@ API = {
     "opd_similarity_matrix": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "opd_detr_roi_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "opd_detr_attention_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_detr_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "opd_detr_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),

@@ -476,9 +476,79 @@ __global__ __launch_bounds__(256) void roi_features_kernel(const float* __restri
     out[(size_t)r * 256 + c] = mean / (norm + 1e-8f);
 }
 
+// Cross-attention map (get_attention_map): mean over heads and over the selected queries of softmax(q . k^T * scale) for ONE frame and
+// ONE decoder layer, fp32 arithmetic on the fp16 q / k the forward left on the device.  Pass 1: one wave per (selected query, head) row
+// -> row maximum and sum of exponentials.  Pass 2: one thread per key sums the normalised weights over the rows in a fixed order.
+__global__ __launch_bounds__(256) void attn_map_rowstat_kernel(const f16_t* __restrict__ q, int ldq, const f16_t* __restrict__ k, int ldk,
+                                                               const int32_t* __restrict__ sel, int nsel, int heads, int Lk, float scale,
+                                                               const int32_t* __restrict__ key_valid2, int key_row, float2* __restrict__ stat) {
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);   // row = selected query x head
+    if (row >= nsel * heads) return;
+    const int lane = threadIdx.x & 63, h = row % heads, qi = sel[row / heads];
+    float qv[32];
+#pragma unroll
+    for (int d = 0; d < 32; ++d) qv[d] = (float)reinterpret_cast<const _Float16*>(q)[(size_t)qi * ldq + h * 32 + d];
+    const int vr = key_valid2 ? key_valid2[0] : 0x7fffffff, vc = key_valid2 ? key_valid2[1] : 0x7fffffff;
+    float mx = -INFINITY;
+    for (int key = lane; key < Lk; key += 64) {
+        const int kr = key / key_row, kc = key - kr * key_row;
+        if (kr >= vr || kc >= vc) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s = fmaf(qv[d], (float)reinterpret_cast<const _Float16*>(k)[(size_t)key * ldk + h * 32 + d], s);
+        mx = fmaxf(mx, s * scale);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float sum = 0.f;
+    for (int key = lane; key < Lk; key += 64) {
+        const int kr = key / key_row, kc = key - kr * key_row;
+        if (kr >= vr || kc >= vc) continue;
+        float s = 0.f;
+#pragma unroll
+        for (int d = 0; d < 32; ++d) s = fmaf(qv[d], (float)reinterpret_cast<const _Float16*>(k)[(size_t)key * ldk + h * 32 + d], s);
+        sum += expf(s * scale - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) stat[row] = make_float2(mx, sum);
+}
+__global__ __launch_bounds__(256) void attn_map_mean_kernel(const f16_t* __restrict__ q, int ldq, const f16_t* __restrict__ k, int ldk,
+                                                            const int32_t* __restrict__ sel, int nsel, int heads, int Lk, float scale,
+                                                            const int32_t* __restrict__ key_valid2, int key_row, const float2* __restrict__ stat,
+                                                            float* __restrict__ out) {
+    const int key = blockIdx.x * 256 + threadIdx.x;
+    if (key >= Lk) return;
+    const int vr = key_valid2 ? key_valid2[0] : 0x7fffffff, vc = key_valid2 ? key_valid2[1] : 0x7fffffff;
+    const int kr = key / key_row, kc = key - kr * key_row;
+    float acc = 0.f;
+    if (kr < vr && kc < vc) {
+        for (int row = 0; row < nsel * heads; ++row) {
+            const int h = row % heads, qi = sel[row / heads];
+            float s = 0.f;
+#pragma unroll
+            for (int d = 0; d < 32; ++d)
+                s = fmaf((float)reinterpret_cast<const _Float16*>(q)[(size_t)qi * ldq + h * 32 + d],
+                         (float)reinterpret_cast<const _Float16*>(k)[(size_t)key * ldk + h * 32 + d], s);
+            const float2 st = stat[row];
+            acc += expf(s * scale - st.x) / st.y;
+        }
+    }
+    out[key] = acc / (float)(nsel * heads);
+}
+
 inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + threads - 1) / threads); }
 
 }  // namespace
+
+hipError_t opd_launch_attention_map(const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,
+                                    const int32_t* key_valid2, int key_row, void* stat, float* out, hipStream_t stream) {
+    if (nsel <= 0 || heads <= 0 || Lk <= 0 || key_row <= 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_map_rowstat_kernel, dim3((nsel * heads + 3) / 4), dim3(256), 0, stream, q, ldq, k, ldk, sel, nsel, heads, Lk, scale,
+                       key_valid2, key_row, reinterpret_cast<float2*>(stat));
+    hipLaunchKernelGGL(attn_map_mean_kernel, dim3((Lk + 255) / 256), dim3(256), 0, stream, q, ldq, k, ldk, sel, nsel, heads, Lk, scale, key_valid2,
+                       key_row, reinterpret_cast<const float2*>(stat), out);
+    return hipGetLastError();
+}
 
 hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
                                     hipStream_t stream) {

@@ -202,6 +202,12 @@ hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream);
 hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois /*[n][4] x0,y0,x1,y1 map coords*/, float* out,
                                    int n, int h, int w, hipStream_t stream);
 
+// cross-attention map of one frame and one decoder layer: mean over heads and the `nsel` selected queries of the softmax rows, fp32;
+// q rows [query][ldq] (this frame's), k rows [key][ldk] (this frame's, this layer's), stat: >= nsel * heads * 8 bytes of scratch,
+// key_valid2 (device, nullable): (rows, cols) of the frame's valid key rectangle; out [Lk]
+hipError_t opd_launch_attention_map(const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,
+                                    const int32_t* key_valid2, int key_row, void* stat, float* out, hipStream_t stream);
+
 // tracker cost matrix: similarity (or 1 - similarity) of n1 x n2 (features [n][D] nullable, xywh boxes [n][4], per-row feature flags)
 hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const uint8_t* has1, int n1, const float* f2, const float* b2,
                                         const uint8_t* has2, int n2, int D, double aw, double mw, int as_distance, float* out,

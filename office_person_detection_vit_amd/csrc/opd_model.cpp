@@ -173,6 +173,9 @@ struct opd_detr {
     size_t src_bytes = 0;
     struct ResizeTab { int h, w, oh, ow, ksh, ksv; int32_t *bh, *kh, *bv, *kv; };
     std::vector<ResizeTab> resize_tabs;
+    float *d_amap = nullptr, *d_amap_stat = nullptr;   // opd_detr_attention_map: output [hw], row statistics
+    int32_t* d_amap_sel = nullptr;
+    bool last_ragged = false;
     int32_t* d_rois = nullptr;
     float* d_roi_out = nullptr;
     std::vector<int32_t> h_orig_hw;
@@ -537,7 +540,10 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_hs32, Md * D, false));
     RCCHK(dalloc(m, &m->d_h16, Md * D, false));
     RCCHK(dalloc(m, &m->d_qkvd16, Md * 3 * D, false));
-    RCCHK(dalloc(m, &m->d_qd16, Md * D, false));
+    RCCHK(dalloc(m, &m->d_qd16, Md * D * a.dec_layers, false));   // (every layer's cross-attention queries stay: opd_detr_attention_map)
+    RCCHK(dalloc(m, &m->d_amap, (size_t)lvl[5] + 64, false));
+    RCCHK(dalloc(m, &m->d_amap_stat, (size_t)a.queries * a.heads * 2, false));
+    RCCHK(dalloc(m, &m->d_amap_sel, (size_t)a.queries, false));
     RCCHK(dalloc(m, &m->d_attnd16, Md * D, false));
     RCCHK(dalloc(m, &m->d_ffnd16, Md * a.ffn, false));
     RCCHK(dalloc(m, &m->d_logits, Md * a.ncls, false));
@@ -1032,9 +1038,10 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         else
             RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, D, 4, m->d_h32, &L.ln1, m->d_h32, m->d_h16, CLS_GEMM));
         }
-        if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false));
-        else RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, m->d_qd16, false, false, nullptr));
-        RCCHK(run_attn(m, m->d_qd16, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
+        f16_t* qd = m->d_qd16 + (size_t)i * Md * D;
+        if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, qd, false));
+        else RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, qd, false, false, nullptr));
+        RCCHK(run_attn(m, qd, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
                        m->d_attnd16, D, B, Q, hw, d_keyv, cw));
         if (m->fuse_gemm_ln && D == 256)
             RCCHK(run_gemm_ln(m, m->d_attnd16, L.co.w, L.co.b, Md, D, m->d_h32, L.ln2, m->d_h32, m->d_h16));
@@ -1064,6 +1071,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     RCCHK(tap(m, "heads_logits", m->d_logits, (size_t)Md * a.ncls * 4));
     MARK(7);
     m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = ch; m->last_fw = cw;
+    m->last_ragged = ragged;
     return OPD_OK;
 }
 
@@ -1127,7 +1135,7 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
     }
     if (e->exec) {
         HIPCHK(hipGraphLaunch(e->exec, m->stream));
-        m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = e->fh; m->last_fw = e->fw;
+        m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = e->fh; m->last_fw = e->fw; m->last_ragged = false;
         return OPD_OK;
     }
     if (e->uses++ == 0) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
@@ -1631,6 +1639,33 @@ int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n
     const float* enc = m->d_x32 + (size_t)frame * h * w * m->arch.d_model;
     HIPCHK(opd_launch_roi_features(enc, m->d_rois, m->d_roi_out, n, h, w, m->stream));
     HIPCHK(hipMemcpyAsync(features, m->d_roi_out, (size_t)n * m->arch.d_model * 4, hipMemcpyDeviceToHost, m->stream));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return OPD_OK;
+}
+
+int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* queries, int n_queries, float* out) {
+    ApiScope api_scope;
+    if (!m || !out) return fail(OPD_EINVAL, "opd_detr_attention_map: null argument");
+    if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_attention_map called before any forward");
+    const int L = m->arch.dec_layers, Q = m->arch.queries, D = m->arch.d_model;
+    if (layer < 0) layer += L;
+    if (frame < 0 || frame >= m->last_B || layer < 0 || layer >= L || n_queries < 0 || n_queries > Q || (n_queries > 0 && !queries))
+        return fail(OPD_EINVAL, "opd_detr_attention_map: frame / layer / queries out of range");
+    std::vector<int32_t> sel;
+    if (n_queries == 0) { sel.resize(Q); for (int i = 0; i < Q; ++i) sel[i] = i; }
+    else {
+        sel.assign(queries, queries + n_queries);
+        for (int q : sel) if (q < 0 || q >= Q) return fail(OPD_EINVAL, "opd_detr_attention_map: query index out of range");
+    }
+    HIPCHK(hipSetDevice(m->device));
+    const int hw = m->last_fh * m->last_fw, NKV = L * 2 * D, Md = m->last_B * Q;
+    HIPCHK(hipMemcpyAsync(m->d_amap_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, m->stream));
+    const f16_t* q = m->d_qd16 + (size_t)layer * Md * D + (size_t)frame * Q * D;
+    const f16_t* k = m->d_memkv16 + (size_t)frame * hw * NKV + (size_t)layer * 2 * D;
+    const float scale = 1.0f / sqrtf((float)(D / m->arch.heads));
+    HIPCHK(opd_launch_attention_map(q, D, k, NKV, m->d_amap_sel, (int)sel.size(), m->arch.heads, hw, scale,
+                                    m->last_ragged ? m->d_key_valid + 2 * frame : nullptr, m->last_fw, m->d_amap_stat, m->d_amap, m->stream));
+    HIPCHK(hipMemcpyAsync(out, m->d_amap, (size_t)hw * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return OPD_OK;
 }

@@ -433,11 +433,28 @@ class HipDetrDetector:
         x, y, w, h = bbox
         return (x + w / 2, y + h)
 
-    def get_attention_map(self, _frame: np.ndarray, _layer_index: int = -1) -> Optional[np.ndarray]:
-        """Attention scores are never materialised by the fused attention kernel; like the YOLO stand-in
-        (``yolov8_detector.py:243-254``) this returns None."""
-        logger.warning("Attention map is not available from the fused HIP attention kernel")
-        return None
+    def get_attention_map(self, frame: np.ndarray, layer_index: int = -1) -> Optional[np.ndarray]:
+        """Attention map for visualisation (deleted vit_detector.py 392-446; ``Visualizer.draw_attention_map``,
+        ``src/visualization/visualizer.py:148-200``, takes a 1-D or 2-D array in [0, 1]).  The DETR-era source is gone, so the
+        definition is this build's: detect on ``frame``, then the decoder's cross-attention weights of layer ``layer_index``,
+        averaged over the heads and over the queries of the kept person detections (all queries when there is none), as a
+        ``(feature_h, feature_w)`` float32 array scaled so that its maximum is 1."""
+        self._require_model()
+        dets = self.detect(frame)
+        fh, fw = (_feature_hw(s) for s in self._model_hw(frame))
+        q = np.asarray(sorted({d.query_index for d in dets if d.query_index is not None}), dtype=np.int32)
+        out = np.empty((fh * fw,), np.float32)
+        rc = self._lib.opd_detr_attention_map(C.c_void_p(self.model), 0, int(layer_index), q.ctypes.data_as(C.c_void_p) if len(q) else None,
+                                              len(q), out.ctypes.data_as(C.c_void_p))
+        _capi.check(rc, "opd_detr_attention_map")
+        mx = float(out.max())
+        return (out / mx if mx > 0 else out).reshape(fh, fw)
+
+    def _model_hw(self, frame: np.ndarray) -> Tuple[int, int]:
+        """Model-input size of a frame under this detector's resize policy."""
+        if self.resize:
+            return model_input_size(frame.shape[0], frame.shape[1], self.max_size[0], self.max_size[1])
+        return int(frame.shape[0]), int(frame.shape[1])
 
     # ------------------------------------------------------------------------------------------------------------
     def set_profiling(self, enabled: bool) -> None:

@@ -149,7 +149,7 @@ def _lin(x, w, prefix):
     return F.linear(x, w[prefix + ".weight"], w[prefix + ".bias"])
 
 
-def _mha(w, prefix, q_in, k_in, v_in, heads, key_mask_add=None, q=None):
+def _mha(w, prefix, q_in, k_in, v_in, heads, key_mask_add=None, q=None, probs_out=None):
     """softmax(Q K^T / sqrt(dh) + mask) V, then o_proj.  *_in: [B, L, D]."""
     B, Lq, D = q_in.shape
     Lk = k_in.shape[1]
@@ -166,6 +166,8 @@ def _mha(w, prefix, q_in, k_in, v_in, heads, key_mask_add=None, q=None):
     if key_mask_add is not None:
         s = s + key_mask_add
     p = F.softmax(s, dim=-1)
+    if probs_out is not None:
+        probs_out.append(p)   # [B, heads, Lq, Lk]
     if q is not None:
         p = q(p)
     o = torch.matmul(p, V).transpose(1, 2).reshape(B, Lq, D)
@@ -210,7 +212,10 @@ def decoder(w, memory, pos, n_layers, heads, key_mask_add=None, taps=None, q=Non
         qk = ident(h + qpos)
         a = _mha(w, p + ".self_attn", qk, qk, ident(h), heads, None, q)
         h = _ln(h + a, w, p + ".self_attn_layer_norm")
-        a = _mha(w, p + ".encoder_attn", ident(h + qpos), ident(memory + pos), ident(memory), heads, key_mask_add, q)
+        cross = [] if taps is not None else None
+        a = _mha(w, p + ".encoder_attn", ident(h + qpos), ident(memory + pos), ident(memory), heads, key_mask_add, q, cross)
+        if taps is not None:
+            taps[f"dec{i}_cross_probs"] = cross[0]
         h = _ln(h + a, w, p + ".encoder_attn_layer_norm")
         h = _ln(h + _mlp(h, w, p + ".mlp", q), w, p + ".final_layer_norm")
         if taps is not None:
@@ -308,6 +313,18 @@ def forward(weights: Dict[str, torch.Tensor], pixel_values: torch.Tensor, pixel_
 # ------------------------------------------------------------------------------------------------
 # a14-a16 — post-process
 # ------------------------------------------------------------------------------------------------
+
+def cross_attention_map(taps: dict, frame: int, layer: int, queries=None) -> np.ndarray:
+    """Attention map of ``get_attention_map`` (the reference's DETR-era method is deleted: ``coverage.json:1`` src 392-446 keeps only its
+    line numbers, so the definition is this build's): the decoder's cross-attention weights of layer ``layer`` (negative: from the end),
+    averaged over the heads and over ``queries`` (all queries when None) -> [h*w] float32, summing to 1.  ``taps`` is the dict that
+    ``forward(..., taps=taps)`` filled."""
+    n = sum(1 for k in taps if k.endswith("_cross_probs"))
+    p = taps[f"dec{layer % n}_cross_probs"][frame]          # [heads, Q, hw]
+    if queries is not None:
+        p = p[:, list(queries), :]
+    return p.mean(dim=(0, 1)).numpy().astype(np.float32)
+
 
 def post_process_object_detection(logits: np.ndarray, boxes: np.ndarray, threshold: float,
                                   target_sizes: Sequence[Tuple[int, int]]) -> List[dict]:

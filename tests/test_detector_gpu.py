@@ -334,10 +334,64 @@ def test_detector_surface(detectors):
         assert d.bbox[2] > 0 and d.bbox[3] > 0
     assert det.extract_features(frame, []).size == 0
     assert det._get_foot_position((100.0, 200.0, 50.0, 100.0)) == (125.0, 300.0)
-    assert det.get_attention_map(frame) is None
+    amap = det.get_attention_map(frame)
+    assert amap.shape == (8, 10) and amap.dtype == np.float32 and float(amap.max()) == pytest.approx(1.0) and float(amap.min()) >= 0.0
     assert det.detect_batch([]) == []
     with pytest.raises(ValueError):
         det.detect(np.zeros((64, 64), np.uint8))
+
+
+def test_attention_map_matches_oracle(detectors):
+    """``opd_detr_attention_map`` (the DETR-era ``get_attention_map``): the decoder's cross-attention weights, head- and query-averaged,
+    against the fp32 oracle's softmax rows (``detr_oracle.cross_attention_map``) for two frames of one batch, the last and an inner
+    layer, all queries and a subset.  A row of the map sums to 1; entries are ~1e-2, the stated bound is 2e-4 absolute (measured
+    <= 4e-5: fp16 q / k operands, fp32 softmax)."""
+    import ctypes as C
+
+    from office_person_detection_vit_amd import _capi
+    det = detectors(ga=1.0)
+    frames = structured_frames(2, 256, 320, seed=77)
+    det.forward_raw(frames, want_encoder=False)
+    w = O.to_torch(load_safetensors(det.model_path))
+    pv, pm = O.preprocess(frames)
+    taps = {}
+    O.forward(w, pv, pm, taps=taps)
+    lib = _capi.load_library()
+    out = np.empty(80, np.float32)
+    for frame, layer, queries in ((0, -1, None), (1, -1, [3, 17, 64]), (1, 2, None), (0, 0, [99])):
+        q = None if queries is None else np.asarray(queries, np.int32)
+        rc = lib.opd_detr_attention_map(C.c_void_p(det.model), frame, layer, None if q is None else q.ctypes.data_as(C.c_void_p),
+                                        0 if q is None else len(q), out.ctypes.data_as(C.c_void_p))
+        _capi.check(rc, "opd_detr_attention_map")
+        ref = O.cross_attention_map(taps, frame, layer, queries)
+        assert abs(float(out.sum()) - 1.0) < 1e-4
+        assert float(np.abs(out - ref).max()) <= 2e-4, (frame, layer, queries, float(np.abs(out - ref).max()))
+    # argument errors are reported, not executed
+    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 2, -1, None, 0, out.ctypes.data_as(C.c_void_p)) != 0
+    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 0, 6, None, 0, out.ctypes.data_as(C.c_void_p)) != 0
+    bad = np.asarray([100], np.int32)
+    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 0, -1, bad.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)) != 0
+
+
+def test_attention_map_ragged_batch_ignores_padding(detectors):
+    """Ragged batch: the keys of the padded area carry no weight (the key mask of HF:models/detr/modeling_detr.py:402-427), and the map of
+    the smaller frame matches the oracle run on the same padded batch."""
+    import ctypes as C
+
+    from office_person_detection_vit_amd import _capi
+    det = detectors(ga=1.0)
+    frames = [structured_frames(1, 256, 320, seed=5)[0], structured_frames(1, 192, 256, seed=6)[0]]
+    det.forward_raw(frames, want_encoder=False)
+    w = O.to_torch(load_safetensors(det.model_path))
+    pv, pm = O.preprocess(frames)
+    taps = {}
+    O.forward(w, pv, pm, taps=taps)
+    out = np.empty(80, np.float32)
+    _capi.check(_capi.load_library().opd_detr_attention_map(C.c_void_p(det.model), 1, -1, None, 0, out.ctypes.data_as(C.c_void_p)), "attention_map")
+    ref = O.cross_attention_map(taps, 1, -1, None)
+    assert float(np.abs(out - ref).max()) <= 2e-4
+    m = out.reshape(8, 10)
+    assert float(m[6:, :].sum()) == 0.0 and float(m[:, 8:].sum()) == 0.0 and abs(float(m.sum()) - 1.0) < 1e-4
 
 
 def test_roi_features_match_reference_formula(detectors):
