@@ -8,7 +8,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_test_api.cpp"]
+SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_test_api.cpp"]
 HEADERS = ["opd_kernels.h", "opd_loader.h", "opd_host.h", os.path.join("..", "..", "include", "opd_detr.h")]
 LIB = os.path.join(PKG, "libopd_hip.so")
 

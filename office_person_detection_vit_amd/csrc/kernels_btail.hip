@@ -500,7 +500,9 @@ hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
 
 }  // namespace
 
-bool opd_btail_supported(int C1, int C3) { return (C1 == 64 && (C3 == 0 || C3 == 64 || C3 == 128)) || (C1 == 128 && (C3 == 0 || C3 == 128)); }
+bool opd_btail_supported(int C1, int C3) {
+    return (C1 == 64 && (C3 == 0 || C3 == 64 || C3 == 128)) || (C1 == 128 && (C3 == 0 || C3 == 128)) || opd_btail256_supported(C1, C3);
+}
 
 hipError_t opd_launch_btail(const BtailParams& p_in, hipStream_t stream) {
     if (!opd_btail_supported(p_in.C1, p_in.C3) || p_in.OH <= 0 || p_in.OW <= 0) return hipErrorInvalidValue;
@@ -510,6 +512,7 @@ hipError_t opd_launch_btail(const BtailParams& p_in, hipStream_t stream) {
     // 31-bit byte offsets in the buffer descriptors
     if ((size_t)p.B * p.H * p.W * p.C1 * 2 + (size_t)(p.W + 1) * p.C1 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
     if ((size_t)p.M * p.C1 * 8 >= 0x7fffff00ull) return hipErrorInvalidValue;
+    if (p.C1 == 256) return opd_launch_btail256(p, stream);   // stage 3: kernels_btail3.hip
     if (p.xs) {   // fused shortcut convolution: stride 1, 64 -> 256 channels next to a 64-channel 3x3 (first block of stage 1)
         if (p.C1 != 64 || p.C3 != 64 || p.stride != 1 || !p.wsc || p.res || (size_t)p.M * 64 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
         return launch_btail_t<64, 64, false, true>(p, stream);

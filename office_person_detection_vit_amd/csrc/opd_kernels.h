@@ -103,6 +103,9 @@ struct BtailParams {
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);
 void opd_permute_k32(const f16_t* w, f16_t* out, int rows, int K);  // host
+// 256-channel blocks (stage 3): eight-wave form, kernels_btail3.hip; reached through opd_launch_btail
+bool opd_btail256_supported(int C1, int C3);
+hipError_t opd_launch_btail256(const BtailParams& p, hipStream_t stream);
 
 // ---- Linear(K -> 256) + bias + residual + LayerNorm in one kernel (kernels_rowln.hip) ---------------------------------
 // y = LayerNorm(x . W^T + bias + res32) * gamma + beta over rows of 256; writes fp32 y and/or an fp16 copy.  y32 may alias

@@ -190,6 +190,7 @@ struct opd_detr {
     int deep_fc2 = 1;        // encoder FFN-2 (K = 2048) + residual + LayerNorm as ONE row-owner launch (0: split-K slabs + reduce launch)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int tail_rev = 1;        // consecutive fused tails walk their tiles in opposite directions (Infinity Cache reuse of the block output)
+    int tail3 = 1;           // stage 3 (256-channel blocks) through the eight-wave fused tail (kernels_btail3.hip); 0: three launches per block
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
     int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
@@ -298,7 +299,7 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
                             w.data[(((size_t)o * Cin + ci) * KH + kh) * KW + kw] * scale[o];
     }
     RCCHK(upload_f16(m, &c->w, wt));
-    if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 512) {  // operands of kernels_btail.hip (stages 1-2)
+    if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 1024) {  // operands of kernels_btail.hip / kernels_btail3.hip (stages 1-3)
         std::vector<float> wp(wt.size());
         for (int o = 0; o < Cout; ++o)
             for (int b = 0; b < Cin; b += 32)
@@ -882,6 +883,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 // first block of stage 2: 3x3 + dual-source expand (+ the next reduce on its own) beats shortcut launch + fused tail
                 // (stage 2: 0.674 -> 0.657 ms; OPD_DUAL_OVER_TAIL=0 restores the tail)
                 if (m->dual_over_tail && tail_kernel && b.has_sc && !sc_in_tail && b.w2sc) tail_kernel = false;
+                if (C1 == 256 && !m->tail3) tail_kernel = false;
                 const bool sc_in_expand = b.has_sc && m->fuse_shortcut && b.w2sc && !sc_in_tail && !tail_kernel;
                 if (b.has_sc && !sc_in_tail && !sc_in_expand) {
                     f16_t* scb = m->d_sc + (size_t)b0 * oh * ow * C2;
@@ -1330,6 +1332,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_TRUNK_SUBBATCH")) m->trunk_subbatch = atoi(v);   // A/B switches for benchmarking
     if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
+    if (const char* v = getenv("OPD_TAIL3")) m->tail3 = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
     if (const char* v = getenv("OPD_POS_SHADOW")) m->pos_shadow = atoi(v);
     if (const char* v = getenv("OPD_DEEP_FC2")) m->deep_fc2 = atoi(v);
@@ -1373,7 +1376,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);

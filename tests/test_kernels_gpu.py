@@ -471,6 +471,11 @@ BTAIL_CASES = [
     (2, 15, 13, 128, 128, 2, True),   # stage-2 first block: stride-2 3x3, odd sizes
     (1, 18, 23, 128, 128, 1, True),   # stage-2 block
     (3, 11, 7, 128, 0, 1, True),      # images narrower than the tile; no fused reduce
+    # stage 3 (kernels_btail3.hip: eight waves, wave pairs exchange B operands through LDS)
+    (2, 13, 17, 256, 256, 1, True),   # stage-3 block -> next block's reduce, ragged M (442 rows)
+    (1, 16, 16, 256, 0, 1, True),     # last stage-3 block (no fused reduce), M a multiple of 128
+    (1, 9, 11, 256, 256, 1, False),   # no residual, one partial tile
+    (2, 15, 13, 256, 256, 2, True),   # stride-2 3x3, odd sizes
 ]
 
 
@@ -496,7 +501,7 @@ def test_btail_matches_torch(lib, case):
         np.testing.assert_allclose(z, zr, atol=2e-3 * float(np.abs(zr).max()), rtol=2e-3)
 
 
-@pytest.mark.parametrize("C1,C3", [(64, 64), (64, 128), (128, 128)])
+@pytest.mark.parametrize("C1,C3", [(64, 64), (64, 128), (128, 128), (256, 256)])
 def test_btail_integer_exact_and_equals_unfused(lib, C1, C3):
     """Small-integer operands: all three GEMMs are exact, so the fused kernel must be BIT-identical to the torch
     reference and to the three unfused conv_gemm launches; asymmetric one-hot-ish weights catch a wrong k-permutation."""

@@ -15,7 +15,12 @@ SHAPES = [  # B, H, W, C1, C3, stride
     (8, 200, 334, 128, 128, 2),   # s1b0 tail (stride-2 3x3)
     (8, 100, 167, 128, 128, 1),   # s1b1 / s1b2 tails
     (8, 100, 167, 128, 0, 1),     # s1b3 tail
+    (8, 50, 84, 256, 256, 1),     # stage-3 tails (kernels_btail3.hip)
+    (8, 50, 84, 256, 0, 1),       # last stage-3 tail
+    (8, 67, 120, 256, 256, 1),    # r101 at 1066x1920 (configs[3]): 22 of these
 ]
+if "--s3" in sys.argv:
+    SHAPES = SHAPES[-3:]
 print(f"{'shape':>28s} {'fused us':>9s} {'c1':>7s} {'c2':>7s} {'c0n':>7s} {'unfused':>8s} {'TB/s fused':>10s}")
 for s in SHAPES:
     B, H, W, C1, C3, st = s
