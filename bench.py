@@ -198,7 +198,9 @@ def main() -> int:
         if world > 1:
             dist.barrier()
         path = ensure_weight_file(cache, arch, 0, 1.0, args.arch)
-        cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
+        # several handles keep batches in flight: the library may choose kernels for throughput (include/opd_detr.h, OPD_FLAG_MULTI_STREAM)
+        cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W,
+                              flags=_capi.OPD_FLAG_MULTI_STREAM if args.streams > 1 else 0)
         handle = C.c_void_p()
         _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), device_index, C.byref(handle)), "opd_detr_create")
         info = _capi.OpdModelInfo()
@@ -312,13 +314,20 @@ def main() -> int:
     roof = serial = stage_ms = None
     if rank == 0 and not rehearsal:
         handle = handles[0]
-        # serial cross-check: ONE handle, one blocking call per step (forward + post-process + records to host + NMS)
+        # serial cross-check: ONE handle, one blocking call per step (forward + post-process + records to host + NMS).  It is a handle of
+        # its own, configured the way a single-stream caller would (no OPD_FLAG_MULTI_STREAM), not one of the handles of the timed leg.
         if args.serial_steps > 0:
-            detect_blocking(handle, d_flats[0])
+            shandle = handle
+            if args.streams > 1:
+                scfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
+                shandle = C.c_void_p()
+                _capi.check(lib.opd_detr_create(C.byref(scfg), path.encode(), device_index, C.byref(shandle)), "opd_detr_create")
+                handles.append(shandle)   # (destroyed with the others)
+            detect_blocking(shandle, d_flats[0])
             torch.cuda.synchronize()
             ts = time.perf_counter()
             for _ in range(args.serial_steps):
-                detect_blocking(handle, d_flats[0])
+                detect_blocking(shandle, d_flats[0])
                 h = d_flats[0].cpu().numpy()
                 recs, cnts = h[:NREC].reshape(B * Q, 8), h[NREC:]
                 lib.opd_person_nms_batch(recs.ctypes.data_as(DetP), cnts.ctypes.data_as(I32P), B, Q, 1, 0.4)
@@ -352,7 +361,7 @@ def main() -> int:
             if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333) and args.arch == "r50":
                 traffic = round(json.load(open(tpath))["conv_gemm_family"]["bytes_per_launch"])
                 break
-        roof = {"bound": "mfma", "kernel": "implicit-GEMM family (conv_gemm_dma_kernel, btail_kernel, gemm_ln256_ring/os_kernel, gemm_k256_kernel, stem_pool2_kernel)",
+        roof = {"bound": "mfma", "kernel": "implicit-GEMM family (conv_gemm_dma_kernel, btail_kernel, btail256_kernel, gemm_ln256_ring/os_kernel, gemm_k256_kernel, stem_pool2_kernel)",
                 "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": k_n, "avg_launch_us": round(1e3 * k_ms / max(k_n, 1), 2),

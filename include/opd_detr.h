@@ -61,6 +61,8 @@ typedef struct opd_config {
 } opd_config;
 
 #define OPD_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define OPD_FLAG_MULTI_STREAM 2 /* this handle is one of several that keep batches in flight on one GPU: kernel choices are made for
+                                 * throughput (a launch's last, partly filled round overlaps other handles' work) rather than for latency */
 
 /* One detection record (32 bytes).  Boxes are (x1,y1,x2,y2) in pixels of the ORIGINAL frame, as produced by
  * HF `post_process_object_detection` (HF:models/detr/image_processing_detr.py:805-856). */

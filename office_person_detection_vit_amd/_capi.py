@@ -19,6 +19,7 @@ OPD_MEM_HOST = 0
 OPD_MEM_DEVICE = 1
 OPD_MEM_HOST_PIXELS_DEVICE_OUT = 2
 OPD_FLAG_NO_GRAPH = 1
+OPD_FLAG_MULTI_STREAM = 2
 
 
 class OpdConfig(C.Structure):

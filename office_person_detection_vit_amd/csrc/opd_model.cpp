@@ -190,7 +190,9 @@ struct opd_detr {
     int deep_fc2 = 1;        // encoder FFN-2 (K = 2048) + residual + LayerNorm as ONE row-owner launch (0: split-K slabs + reduce launch)
     int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
     int tail_rev = 1;        // consecutive fused tails walk their tiles in opposite directions (Infinity Cache reuse of the block output)
-    int tail3 = 1;           // stage 3 (256-channel blocks) through the eight-wave fused tail (kernels_btail3.hip); 0: three launches per block
+    int tail3 = 1;           // stage 3 (256-channel blocks) through the eight-wave fused tail (kernels_btail3.hip) where it pays (see run_blocks);
+                             // 0: never (three launches per block), 2: always
+    int num_cus = 256;
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
     int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
@@ -883,7 +885,16 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 // first block of stage 2: 3x3 + dual-source expand (+ the next reduce on its own) beats shortcut launch + fused tail
                 // (stage 2: 0.674 -> 0.657 ms; OPD_DUAL_OVER_TAIL=0 restores the tail)
                 if (m->dual_over_tail && tail_kernel && b.has_sc && !sc_in_tail && b.w2sc) tail_kernel = false;
-                if (C1 == 256 && !m->tail3) tail_kernel = false;
+                // Stage 3: the eight-wave tail holds one 160-KiB workgroup per CU, so a launch costs whole ROUNDS of ~70 us: 263 tiles (batch 8 at
+                // 800x1333) take two rounds = more than the three launches they replace, 503 tiles (r101 at 1066x1920) take two full ones = 25 %
+                // less.  The choice is made from the handle's configuration (max_batch and the frame size), never from the batch at hand: a
+                // frame's low-order bits must not depend on the batch it travels in.  Several batches in flight (OPD_FLAG_MULTI_STREAM, set by
+                // the shim for streams > 1) fill a launch's last round with other streams' work: always fused there.
+                if (C1 == 256 && tail_kernel) {
+                    const long long tiles = ((long long)m->cfg.max_batch * oh * ow + 127) / 128, rounds = (tiles + m->num_cus - 1) / m->num_cus;
+                    const bool fills = tiles * 10 >= rounds * m->num_cus * 7;   // >= 70 % of the rounds it pays for
+                    if (m->tail3 == 0 || (m->tail3 == 1 && !fills && !(m->cfg.flags & OPD_FLAG_MULTI_STREAM))) tail_kernel = false;
+                }
                 const bool sc_in_expand = b.has_sc && m->fuse_shortcut && b.w2sc && !sc_in_tail && !tail_kernel;
                 if (b.has_sc && !sc_in_tail && !sc_in_expand) {
                     f16_t* scb = m->d_sc + (size_t)b0 * oh * ow * C2;
@@ -1350,6 +1361,8 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
         hipError_t e = hipSetDevice(device_ordinal);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
         if (e != hipSuccess) return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e));
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) m->num_cus = cus;
     }
     m->weights = std::make_shared<WeightSet>();
     m->weights->device = device_ordinal;
@@ -1376,7 +1389,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);

@@ -155,7 +155,8 @@ class HipDetrDetector:
             path = self._resolve_weights()
             cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=self.max_batch,
                                   max_height=self.max_size[0], max_width=self.max_size[1],
-                                  flags=0 if self.use_graph else _capi.OPD_FLAG_NO_GRAPH)
+                                  flags=(0 if self.use_graph else _capi.OPD_FLAG_NO_GRAPH) |
+                                        (_capi.OPD_FLAG_MULTI_STREAM if self.streams > 1 else 0))
             self._lib = lib
             handle = C.c_void_p()
             rc = lib.opd_detr_create(C.byref(cfg), path.encode("utf-8"), self.device_ordinal, C.byref(handle))

@@ -71,6 +71,27 @@ def test_forward_matches_hf_golden(detectors, golden_dir, tag, parity_log):
     assert dbox <= tb and dprob <= tp and denc <= te
 
 
+@pytest.mark.parametrize("tag", ["r50_mild_256x320", "r50_mild_800x1333"])
+def test_stage3_fused_tail_forward_matches_golden(weight_cache, golden_dir, parity_log, monkeypatch, tag):
+    """Stage 3 through the eight-wave fused tail (kernels_btail3.hip) whatever the launch-cost model says (OPD_TAIL3=2; the default takes
+    it for r101 at 1066x1920 and for multi-stream handles): same golden vectors, same bounds as the three-launch path."""
+    monkeypatch.setenv("OPD_TAIL3", "2")
+    g = np.load(os.path.join(golden_dir, tag + ".npz"))
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    det = HipDetrDetector(model_path=path, confidence_threshold=0.5, max_batch=2, max_size=(800, 1333), resize=False)
+    det.load_model()
+    try:
+        logits, boxes, enc = det.forward_raw(_golden_frames(g))
+    finally:
+        det.close()
+    full = tag.endswith("800x1333")
+    tb, tp, _ = (1e-3, 2e-3, 0) if full else TOL[1.0]
+    dbox = float(np.abs(boxes - g["pred_boxes"]).max())
+    dprob = float(np.abs(_softmax(logits) - _softmax(g["logits"])).max())
+    parity_log(f"{tag} vs HF golden, stage 3 through the fused tail", dbox, dprob, None, tb)
+    assert dbox <= tb and dprob <= tp
+
+
 def test_full_resolution_matches_golden(detectors, golden_dir, parity_log):
     """One 800x1333 frame (BASELINE config resolution) against the HF golden logits / boxes, at the north-star tolerance:
     boxes within 1e-3 (normalised cxcywh = 1.3 px at width 1333)."""
@@ -558,10 +579,14 @@ def test_async_host_buffers_equal_blocking_detect(detectors):
             np.testing.assert_array_equal(got[b, :counts[b]], want[i][1][b, :counts[b]])
 
 
-def test_multi_handle_detect_batch_equals_serial(weight_cache):
+def test_multi_handle_detect_batch_equals_serial(weight_cache, monkeypatch):
     """HipDetrDetector(streams=3): chunks of one detect_batch call overlap on three handles (worker threads, own HIP streams)
     and return exactly the serial detector's detections, frame for frame, for both the canvas and the device-resize path
-    (the serial one stacks into pageable numpy memory, the other into the page-locked staging of ``opd_host_alloc``)."""
+    (the serial one stacks into pageable numpy memory, the other into the page-locked staging of ``opd_host_alloc``).
+    A multi-stream detector may run stage 3 through other kernels than a single-stream one (OPD_FLAG_MULTI_STREAM: same arithmetic,
+    another summation order inside one MFMA, i.e. last-bit differences); this test is about the plumbing, so both detectors are
+    pinned to the same choice."""
+    monkeypatch.setenv("OPD_TAIL3", "0")
     path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
     serial = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=True, pinned_staging=False)
     multi = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=True, streams=3)
