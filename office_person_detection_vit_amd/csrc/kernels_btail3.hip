@@ -236,17 +236,24 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
             for (int nt = 0; nt < 8; ++nt) wf[kk][nt] = *reinterpret_cast<const half8*>(Ws + swz(half * 128 + nt * 16 + li, kk * 4 + g));
         }
     };
-    auto mfma_phase = [&]() {
+    auto mfma_phase = [&](auto&& between) {   // `between(slot)`: after every eighth MFMA (slots 0 .. 3)
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int nt = 0; nt < 8; ++nt)
+            for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][nt], xf[kk][mt], acc1[nt][mt], 0, 0, 0);
+                if ((nt & 3) == 3) {
+                    __builtin_amdgcn_sched_barrier(0);
+                    between(kk * 2 + (nt >> 2));
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         __builtin_amdgcn_s_setprio(0);
         lds_barrier();
     };
+    auto no_issue = [](int) {};
     static_assert(nk % 3 == 0, "stage bookkeeping below assumes the last k-step sits in stage 2");
     wait_vmcnt<6>();   // stage 0
     lds_barrier();
@@ -256,12 +263,15 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
     for (int ks = 0; ks + 2 < nk; ++ks) {
         read_frags(st_cur);
         compiler_fence();
+        // requests of k-step ks+2: two pieces here, four between the MFMAs of M(ks) (an LDS-DMA request costs its wave 60-185 clocks of
+        // issue; all six in P1 made P1 twice as long as M).  The wait retires stage ks+1 (requested in P1(ks-1) and M(ks-1)): the 2 pieces
+        // just issued may fly.  WAR of the late pieces: they go out after B_2k (group 0) at the earliest, later than the early ones.
         begin_issue(ks + 2);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) issue_piece(i, st_next2);
-        wait_vmcnt<6>();
+        for (int i = 0; i < 2; ++i) issue_piece(i, st_next2);
+        wait_vmcnt<2>();
         lds_barrier();
-        mfma_phase();
+        mfma_phase([&](int slot) { issue_piece(2 + slot, st_next2); });   // (measured per k-step: 6 + 0: 1900 clocks, 3 + 3: 1680, 2 + 4: 1630, 0 + 6: 1740)
         st_cur = st_cur == 2 * STAGE_BYTES ? 0 : st_cur + STAGE_BYTES;
         st_next2 = st_next2 == 2 * STAGE_BYTES ? 0 : st_next2 + STAGE_BYTES;
     }
@@ -280,7 +290,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
     for (int i = 0; i < 4; ++i) issue_w2_piece(0, i);
     wait_vmcnt<4>();   // retires stage nk-1
     lds_barrier();
-    mfma_phase();
+    mfma_phase(no_issue);
     // k-step nk-1 (stage 2): [0, 96K) is free -> W2 of chunk 1, W3 of chunk 0, the first biases and residuals
     read_frags(2 * STAGE_BYTES);
     compiler_fence();
@@ -299,7 +309,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
     load_res(1, res[1]);
     compiler_fence();
     lds_barrier();
-    mfma_phase();
+    mfma_phase(no_issue);
     if (group == 0) lds_barrier();   // the groups are aligned again: every wave has passed the same number of barriers
     wait_vmcnt<0>();
     if constexpr (C3 > 0) {
@@ -364,6 +374,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
             for (int t = 0; t < 2; ++t)
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) ring[t][nt] = w2frag(t, nt);
+            __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 if (t + 2 < 8) {
@@ -376,6 +387,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
                     for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t % 3][nt], a1[mt][t], acc2[nt][mt], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            __builtin_amdgcn_s_setprio(0);
         }
         // residual (paired layout -> accumulator layout), ReLU, fp16; store y; the fp16 values are this wave's k-block of the chunk
         uint4v (&res_cur)[2] = res[j % 3];
