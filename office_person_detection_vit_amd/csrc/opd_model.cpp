@@ -119,6 +119,8 @@ struct opd_detr {
     opd_config cfg{};
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;   // second branch of the forward (stage-3 frame split, see enqueue_forward); joins the capture of `stream`
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     std::vector<void*> allocs;              // this handle's own buffers: workspace, per-resolution plans
     std::vector<RedZoned> zoned;            // poison mode only: the same buffers with their red zones
     std::shared_ptr<WeightSet> weights;     // the model's weights (shared with clones)
@@ -193,6 +195,7 @@ struct opd_detr {
     int tail3 = 1;           // stage 3 (256-channel blocks) through the eight-wave fused tail (kernels_btail3.hip) where it pays (see run_blocks);
                              // 0: never (three launches per block), 2: always
     int num_cus = 256;
+    int tail3_split = 1;     // stage 3: frames beyond whole rounds of the fused tail run as a second chain on `stream2` (0: one launch per tail)
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
     int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
     int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
@@ -860,11 +863,11 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     // ones touch (per-frame sizes shrink from stage to stage).
     struct TrunkState { int cur_id; int ch, cw; int z_id; };   // cur_id 0 = pool, 1 = t0, 2 = t1; z_id -1 / 0 = m0 / 1 = m1
     int tail_no = 0;   // consecutive fused tails walk the tiles in alternating directions (tail_rev)
-    auto run_blocks = [&](int s_begin, int s_end, int b0, int nb, TrunkState& st) -> int {
+    auto run_blocks = [&](int s_begin, int s_end, int b0, int nb, TrunkState& st, int l_begin = 0, int l_end = 1 << 30) -> int {
         auto trunk = [&](int id, size_t per_frame) { return (id == 0 ? m->d_pool : id == 1 ? m->d_t0 : m->d_t1) + (size_t)b0 * per_frame; };
         auto mid = [&](int id, size_t per_frame) { return (id ? m->d_m1 : m->d_m0) + (size_t)b0 * per_frame; };
         for (int s = s_begin; s < s_end; ++s) {
-            for (int l = 0; l < a.depths[s]; ++l) {
+            for (int l = l_begin; l < a.depths[s] && l < l_end; ++l) {   // (a block range only makes sense with s_end == s_begin + 1)
                 const int bi = m->stage_first[s] + l;
                 const Block& b = m->blocks[bi];
                 const Block* nbk = bi + 1 < (int)m->blocks.size() ? &m->blocks[bi + 1] : nullptr;
@@ -885,15 +888,16 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 // first block of stage 2: 3x3 + dual-source expand (+ the next reduce on its own) beats shortcut launch + fused tail
                 // (stage 2: 0.674 -> 0.657 ms; OPD_DUAL_OVER_TAIL=0 restores the tail)
                 if (m->dual_over_tail && tail_kernel && b.has_sc && !sc_in_tail && b.w2sc) tail_kernel = false;
-                // Stage 3: the eight-wave tail holds one 160-KiB workgroup per CU, so a launch costs whole ROUNDS of ~70 us: 263 tiles (batch 8 at
-                // 800x1333) take two rounds = more than the three launches they replace, 503 tiles (r101 at 1066x1920) take two full ones = 25 %
-                // less.  The choice is made from the handle's configuration (max_batch and the frame size), never from the batch at hand: a
-                // frame's low-order bits must not depend on the batch it travels in.  Several batches in flight (OPD_FLAG_MULTI_STREAM, set by
-                // the shim for streams > 1) fill a launch's last round with other streams' work: always fused there.
+                // Stage 3: the eight-wave tail holds one 160-KiB workgroup per CU, so a launch costs whole ROUNDS of ~70 us whatever they hold.
+                // Rounds that are only partly filled because the batch does not divide into them are dealt with by the frame split below; what
+                // remains is the case of too few tiles for even one round (small frames / batches: the three launches win there).  The choice is
+                // made from the handle's configuration (max_batch and the frame size), never from the batch at hand: the two paths differ in
+                // the last bit (kernels_btail3.hip), and a frame's low-order bits must not depend on the batch it travels in.  Handles that
+                // keep several batches in flight (OPD_FLAG_MULTI_STREAM) always take the fused tail: other streams fill its idle CUs.
                 if (C1 == 256 && tail_kernel) {
-                    const long long tiles = ((long long)m->cfg.max_batch * oh * ow + 127) / 128, rounds = (tiles + m->num_cus - 1) / m->num_cus;
-                    const bool fills = tiles * 10 >= rounds * m->num_cus * 7;   // >= 70 % of the rounds it pays for
-                    if (m->tail3 == 0 || (m->tail3 == 1 && !fills && !(m->cfg.flags & OPD_FLAG_MULTI_STREAM))) tail_kernel = false;
+                    const long long tiles = ((long long)m->cfg.max_batch * oh * ow + 127) / 128;
+                    const bool pays = tiles * 10 >= (long long)m->num_cus * 6;
+                    if (m->tail3 == 0 || (m->tail3 == 1 && !pays && !(m->cfg.flags & OPD_FLAG_MULTI_STREAM))) tail_kernel = false;
                 }
                 const bool sc_in_expand = b.has_sc && m->fuse_shortcut && b.w2sc && !sc_in_tail && !tail_kernel;
                 if (b.has_sc && !sc_in_tail && !sc_in_expand) {
@@ -949,7 +953,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 }
                 st.cur_id = out_id; st.ch = oh; st.cw = ow;
             }
-            if (b0 + nb == B) MARK(2 + s);
+            if (b0 + nb == B && l_end >= a.depths[s]) MARK(2 + s);
         }
         return OPD_OK;
     };
@@ -964,7 +968,53 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         }
         st = done;
         st.z_id = -1;   // (stage 2's last tail has no fused reduce)
-        RCCHK(run_blocks(2, 4, 0, B, st));
+        // Stage 3.  Frame split: with the fused tails a launch of T tiles costs ceil(T / CUs) rounds, and batch 8 at 800x1333 is 263 tiles on
+        // 256 CUs.  Frames are independent, so blocks 1 .. n-1 of the stage (all tensors there have one per-frame size, the buffers of the
+        // two chains never overlap) run as TWO chains on two streams -- frames [0, nbA) = whole rounds, the rest on `stream2` -- whose
+        // workgroups the hardware packs onto whatever CU is free: 5 tails of 263 workgroup-lives take ~5.3 rounds instead of 10.  Per-row
+        // arithmetic does not depend on the tiling, so this is invisible in the results (any batch, any split).  Captured into the graph
+        // as a fork / join; not under profiling (event pairs on one stream) or diagnostic taps, and not for handles that keep several batches
+        // in flight (there other handles' kernels fill the idle CUs; measured on one box, 1000 steps x 2: three streams 2841 frames/s with
+        // one launch per tail, 2783 with the split, 2793 unfused; one stream 2045 / 2112 / 2090).
+        int nbA = B;
+        {
+            const Block& b1 = m->blocks[m->stage_first[2] + (a.depths[2] > 1 ? 1 : 0)];
+            const int oh3 = down2(st.ch), ow3 = down2(st.cw);
+            const bool fused3 = m->fuse_btail && a.depths[2] > 2 && b1.c1.Cin == 256 && opd_btail_supported(256, 0) && b1.c2.wp && !m->profiling && !m->taps &&
+                                m->stream2 && m->tail3_split && !(m->cfg.flags & OPD_FLAG_MULTI_STREAM) && B >= 2 && [&] {   // the policy of run_blocks, evaluated for this stage
+                                    const long long tiles = ((long long)m->cfg.max_batch * oh3 * ow3 + 127) / 128;
+                                    return m->tail3 == 2 || (m->tail3 == 1 && (tiles * 10 >= (long long)m->num_cus * 6 || (m->cfg.flags & OPD_FLAG_MULTI_STREAM)));
+                                }();
+            if (fused3) {
+                auto tiles_of = [&](int frames) { return ((long long)frames * oh3 * ow3 + 127) / 128; };
+                const long long total = tiles_of(B), cus = m->num_cus, last = total % cus;
+                if (total > cus && last > 0 && last < cus / 2) {
+                    const long long whole = (total / cus) * cus;
+                    int bA = B - 1;
+                    while (bA > 1 && tiles_of(bA) > whole) --bA;
+                    if (tiles_of(bA) <= whole) nbA = bA;
+                }
+            }
+        }
+        RCCHK(run_blocks(2, 3, 0, B, st, 0, 1));   // first block (stride 2, shortcut): whole batch
+        if (nbA < B) {
+            TrunkState ta = st, tb = st;
+            HIPCHK(hipEventRecord(m->ev_fork, m->stream));
+            HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
+            RCCHK(run_blocks(2, 3, 0, nbA, ta, 1));
+            hipStream_t main_stream = m->stream;
+            m->stream = m->stream2;
+            const int rc_b = run_blocks(2, 3, nbA, B - nbA, tb, 1);
+            const hipError_t ej = hipEventRecord(m->ev_join, m->stream);
+            m->stream = main_stream;
+            RCCHK(rc_b);
+            HIPCHK(ej);
+            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+            st = ta;
+        } else {
+            RCCHK(run_blocks(2, 3, 0, B, st, 1));
+        }
+        RCCHK(run_blocks(3, 4, 0, B, st));
     }
     const f16_t* cur = st.cur_id == 1 ? m->d_t0 : m->d_t1;
     const int ch = st.ch, cw = st.cw;
@@ -1297,6 +1347,21 @@ static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kin
 // C-ABI
 // =====================================================================================================================
 // No C++ exception may cross the C-ABI: creation parses an untrusted file and allocates, so its body runs under a catch-all.
+// second branch of the forward (stage-3 frame split): a stream and two untimed events per handle
+static hipError_t make_branch_stream(opd_detr* m) {
+    hipError_t e = hipStreamCreateWithFlags(&m->stream2, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_fork, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&m->ev_join, hipEventDisableTiming);
+    return e;
+}
+static void drop_streams(opd_detr* m) {
+    if (m->ev_fork) (void)hipEventDestroy(m->ev_fork);
+    if (m->ev_join) (void)hipEventDestroy(m->ev_join);
+    if (m->stream2) (void)hipStreamDestroy(m->stream2);
+    if (m->stream) (void)hipStreamDestroy(m->stream);
+    m->ev_fork = m->ev_join = nullptr; m->stream2 = m->stream = nullptr;
+}
+
 static int create_impl(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out);
 static int clone_impl(const opd_detr* src, opd_detr** out);
 template <typename F>
@@ -1344,6 +1409,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
     if (const char* v = getenv("OPD_TAIL3")) m->tail3 = atoi(v);
+    if (const char* v = getenv("OPD_TAIL3_SPLIT")) m->tail3_split = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
     if (const char* v = getenv("OPD_POS_SHADOW")) m->pos_shadow = atoi(v);
     if (const char* v = getenv("OPD_DEEP_FC2")) m->deep_fc2 = atoi(v);
@@ -1354,13 +1420,14 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (device_ordinal < 0 || device_ordinal >= ndev) return fail(OPD_EINVAL, "device_ordinal out of range");
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
-        if (m->stream) (void)hipStreamDestroy(m->stream);
+        drop_streams(m.get());
         return code;
     };
     {
         hipError_t e = hipSetDevice(device_ordinal);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e));
+        if (e == hipSuccess) e = make_branch_stream(m.get());
+        if (e != hipSuccess) { drop_streams(m.get()); return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e)); }
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_ordinal) == hipSuccess && cus > 0) m->num_cus = cus;
     }
@@ -1389,17 +1456,18 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
-    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus;
+    m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
-        if (m->stream) (void)hipStreamDestroy(m->stream);
+        drop_streams(m.get());
         return code;
     };
     {
         hipError_t e = hipSetDevice(m->device);
         if (e == hipSuccess) e = hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking);
-        if (e != hipSuccess) return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e));
+        if (e == hipSuccess) e = make_branch_stream(m.get());
+        if (e != hipSuccess) { drop_streams(m.get()); return fail(OPD_EHIP, std::string("device/stream setup failed: ") + hipGetErrorString(e)); }
     }
     int rc;
     if ((rc = build_workspace(m.get()))) return cleanup(rc);
@@ -1426,7 +1494,7 @@ void opd_detr_destroy(opd_detr* m) {
     for (auto& e : m->event_pool) (void)hipEventDestroy(e);
     for (auto& g : m->graphs)
         if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    if (m->stream) (void)hipStreamDestroy(m->stream);
+    drop_streams(m);
     delete m;
     ++g_handle_epoch;
 }

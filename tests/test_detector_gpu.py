@@ -603,6 +603,24 @@ def test_multi_handle_detect_batch_equals_serial(weight_cache, monkeypatch):
         serial.close(); multi.close()
 
 
+def test_multi_stream_kernel_choice_stays_within_the_parity_bounds(weight_cache):
+    """Without pinning: a ``streams=2`` detector (OPD_FLAG_MULTI_STREAM: stage 3 through the fused tail) against a single-stream one
+    (three launches per block at this size).  The two differ like any two summation orders do (last bits of fp16 activations,
+    amplified by the network): raw outputs within the small-frame parity bounds of each other, and not bit-identical."""
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    serial = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=False)
+    multi = HipDetrDetector(model_path=path, max_batch=2, max_size=(256, 320), resize=False, streams=2)
+    serial.load_model(); multi.load_model()
+    try:
+        frames = structured_frames(2, 256, 320, seed=4711)
+        lg_s, bx_s, _ = serial.forward_raw(frames, want_encoder=False)
+        lg_m, bx_m, _ = multi.forward_raw(frames, want_encoder=False)
+        assert float(np.abs(bx_s - bx_m).max()) <= TOL[1.0][0] and float(np.abs(_softmax(lg_s) - _softmax(lg_m)).max()) <= TOL[1.0][1]
+        assert float(np.abs(bx_s - bx_m).max()) > 0   # the flag really changed the launch sequence
+    finally:
+        serial.close(); multi.close()
+
+
 def test_clone_shares_weights_and_outlives_its_source(weight_cache):
     """opd_detr_clone: a second handle on the same weights gives bit-identical records, reports the same weight bytes, and keeps
     working after the handle it was cloned from has been destroyed (shared ownership of the device buffers)."""
