@@ -389,7 +389,7 @@ def main() -> int:
                 roof["mfma_busy_pct"] = {"source": "profiles/r03_pmc_sq.json (rocprofv3 --pmc SQ pass, one serial forward)",
                                          "whole_forward": sq["whole_forward_mfma_busy_pct"], "attention": pick("attention_kernel"),
                                          "row_owner_linears": pick("gemm_ln256"), "implicit_gemm": pick("conv_gemm_dma_kernel"),
-                                         "fused_tails": pick("btail_kernel")}
+                                         "fused_tails": {**pick("btail_kernel"), **pick("btail256_kernel")}}
 
     total_frames = B * world * args.steps
     fps = total_frames / elapsed

@@ -7,11 +7,11 @@ O=gpurun_out/final
 P=profiles
 tail -n 1 $O/bench.json > $P/${R}_bench_default_k1000.json
 tail -n 1 $O/bench_k20.json > $P/${R}_bench_default_k20.json
-cp $(ls $O/prof_default/*/*_kernel_stats.csv | tail -n 1) $P/${R}_bench_default_kernel_stats.csv
-cp $(ls $O/prof_streams1/*/*_kernel_stats.csv | tail -n 1) $P/${R}_bench_streams1_kernel_stats.csv
-python tools/timeline.py $(ls $O/prof_streams1/*/*_kernel_trace.csv | tail -n 1) --all > $P/${R}_bench_streams1_timeline.txt
-python tools/pmc_traffic.py $(ls $O/pmc_fetch/*/*_counter_collection.csv | tail -n 1) $(ls $O/pmc_write/*/*_counter_collection.csv | tail -n 1) $P/${R}_pmc_traffic.json
-python tools/pmc_mfma.py $(ls $O/pmc_sq/*/*_counter_collection.csv | tail -n 1) $P/${R}_pmc_sq.json > $P/${R}_pmc_sq_per_kernel.txt
+cp $(ls -t $O/prof_default/*/*_kernel_stats.csv | head -n 1) $P/${R}_bench_default_kernel_stats.csv
+cp $(ls -t $O/prof_streams1/*/*_kernel_stats.csv | head -n 1) $P/${R}_bench_streams1_kernel_stats.csv
+python tools/timeline.py $(ls -t $O/prof_streams1/*/*_kernel_trace.csv | head -n 1) --all > $P/${R}_bench_streams1_timeline.txt
+python tools/pmc_traffic.py $(ls -t $O/pmc_fetch/*/*_counter_collection.csv | head -n 1) $(ls -t $O/pmc_write/*/*_counter_collection.csv | head -n 1) $P/${R}_pmc_traffic.json
+python tools/pmc_mfma.py $(ls -t $O/pmc_sq/*/*_counter_collection.csv | head -n 1) $P/${R}_pmc_sq.json > $P/${R}_pmc_sq_per_kernel.txt
 for f in bench_gloo2:bench_gloo2_selflaunch_rehearsal bench_r101_1066x1920:bench_r101_1066x1920 bench_r50_tile1080p_b4:bench_r50_tile1080p_b4; do
   [ -f $O/${f%%:*}.json ] && tail -n 1 $O/${f%%:*}.json > $P/${R}_${f##*:}.json
 done
