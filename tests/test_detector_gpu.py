@@ -71,10 +71,11 @@ def test_forward_matches_hf_golden(detectors, golden_dir, tag, parity_log):
     assert dbox <= tb and dprob <= tp and denc <= te
 
 
-@pytest.mark.parametrize("tag", ["r50_mild_256x320", "r50_mild_800x1333"])
+@pytest.mark.parametrize("tag", ["r50_mild_256x320", "r50_mild_800x1333", "r50_mild_ragged"])
 def test_stage3_fused_tail_forward_matches_golden(weight_cache, golden_dir, parity_log, monkeypatch, tag):
     """Stage 3 through the eight-wave fused tail (kernels_btail3.hip) whatever the launch-cost model says (OPD_TAIL3=2; the default takes
-    it for r101 at 1066x1920 and for multi-stream handles): same golden vectors, same bounds as the three-launch path."""
+    it for r101 at 1066x1920 and for multi-stream handles): same golden vectors, same bounds as the three-launch path; also a ragged
+    batch (zero canvas + padding mask)."""
     monkeypatch.setenv("OPD_TAIL3", "2")
     g = np.load(os.path.join(golden_dir, tag + ".npz"))
     path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
