@@ -89,6 +89,7 @@ TEST_API = {
     "opd_test_trace_conv": (C.c_int, [C.c_int] * 10 + [C.POINTER(C.c_ulonglong), C.c_int, C.POINTER(C.c_int)]),
     "opd_test_btail": (C.c_int, [C.c_void_p] * 10 + [C.c_int] * 6),
     "opd_test_bench_btail": (C.c_int, [C.c_int] * 8 + [C.POINTER(C.c_float)]),
+    "opd_test_btail_repeat": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 6 + [C.POINTER(C.c_int)]),
     "opd_test_attention": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_float]),
     "opd_test_layernorm": (C.c_int, [C.c_void_p] * 5 + [C.c_int]),
     "opd_test_maxpool": (C.c_int, [C.c_void_p] * 2 + [C.c_int] * 6),

@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <string>
+#include <cstring>
 #include <vector>
 
 #include "../../include/opd_detr.h"
@@ -361,6 +362,50 @@ int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, cons
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(y, p.y, M * C2 * 2, hipMemcpyDeviceToHost));
     if (C3) TCHK(hipMemcpy(z, p.z, M * C3 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// Race screen for the fused tails (the stage-3 kernel reads LDS-DMA data by counted waits and raw barriers: a misplaced wait shows as a
+// rare wrong tile that comes and goes with timing): `reps` launches on the same device-resident operands, position-weighted checksums of
+// y and z after each, *n_diff = number of launches whose checksums differ from the first launch's.  A second stream keeps the memory system
+// busy meanwhile (a 256-MiB device-to-device copy per launch) so that DMA latencies vary between launches.
+int opd_test_btail_repeat(const uint16_t* x1, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const uint16_t* res,
+                          const uint16_t* w3, const float* b3, int B, int H, int W, int C1, int C3, int reps, int* n_diff) {
+    if (!opd_btail_supported(C1, C3) || !C3 || reps < 2 || !n_diff) return tfail(OPD_EINVAL, "btail_repeat: bad arguments");
+    DevMem dm;
+    const int C2 = 4 * C1;
+    const size_t M = (size_t)B * H * W;
+    std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)C3 * C2);
+    opd_permute_k32(w2, w2p.data(), C2, C1);
+    opd_permute_k32(w3, w3p.data(), C3, C2);
+    BtailParams p{};
+    p.x1 = dm.up(x1, M * C1); p.w1 = dm.up(w1, (size_t)C1 * 9 * C1); p.b1 = dm.up(b1, C1); p.w2p = dm.up(w2p.data(), w2p.size());
+    p.b2 = dm.up(b2, C2); p.res = dm.up(res, M * C2); p.y = dm.up<uint16_t>(nullptr, M * C2); p.w3p = dm.up(w3p.data(), w3p.size());
+    p.b3 = dm.up(b3, C3); p.z = dm.up<uint16_t>(nullptr, M * C3);
+    const size_t noise_bytes = (size_t)256 << 20;
+    unsigned char* noise = dm.up<unsigned char>(nullptr, 2 * noise_bytes);
+    unsigned long long* sums = dm.up<unsigned long long>(nullptr, (size_t)reps * 2 * OPD_TAP_BLOCKS);
+    if (!p.x1 || !p.w1 || !p.b1 || !p.w2p || !p.b2 || !p.res || !p.y || !p.w3p || !p.b3 || !p.z || !noise || !sums) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.H = H; p.W = W; p.OH = H; p.OW = W; p.stride = 1; p.M = (int)M; p.C1 = C1; p.C3 = C3;
+    hipStream_t side = nullptr;
+    TCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    for (int r = 0; r < reps; ++r) {
+        p.rev = r & 1;
+        (void)hipMemcpyAsync(noise + ((r & 1) ? noise_bytes : 0), noise + ((r & 1) ? 0 : noise_bytes), noise_bytes, hipMemcpyDeviceToDevice, side);
+        TCHK(hipMemsetAsync(p.y, 0xff, M * C2 * 2, nullptr));
+        TCHK(hipMemsetAsync(p.z, 0xff, M * C3 * 2, nullptr));
+        TCHK(opd_launch_btail(p, nullptr));
+        TCHK(opd_launch_checksum(p.y, M * C2 * 2, sums + (size_t)(2 * r) * OPD_TAP_BLOCKS, nullptr));
+        TCHK(opd_launch_checksum(p.z, M * C3 * 2, sums + (size_t)(2 * r + 1) * OPD_TAP_BLOCKS, nullptr));
+    }
+    TCHK(hipDeviceSynchronize());
+    (void)hipStreamDestroy(side);
+    std::vector<unsigned long long> h((size_t)reps * 2 * OPD_TAP_BLOCKS);
+    TCHK(hipMemcpy(h.data(), sums, h.size() * 8, hipMemcpyDeviceToHost));
+    int diff = 0;
+    for (int r = 1; r < reps; ++r)
+        if (memcmp(h.data() + (size_t)(2 * r) * OPD_TAP_BLOCKS, h.data(), 2 * OPD_TAP_BLOCKS * 8) != 0) ++diff;
+    *n_diff = diff;
     return OPD_OK;
 }
 

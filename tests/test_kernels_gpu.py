@@ -537,6 +537,29 @@ def test_btail_integer_exact_and_equals_unfused(lib, C1, C3):
     np.testing.assert_array_equal(z, zu)
 
 
+@pytest.mark.parametrize("C1,C3,B,H,W", [(256, 256, 6, 50, 84), (128, 128, 3, 100, 167), (64, 64, 1, 200, 334)])
+def test_btail_repeated_launches_are_bit_identical(lib, C1, C3, B, H, W):
+    """Race screen: 40 launches of a fused tail on the same random operands (hundreds of workgroups, alternating tile walk direction, a
+    256-MiB copy on a second stream per launch to vary the memory latencies) must give 40 identical y and z tensors.  The stage-3 kernel
+    orders its LDS-DMA traffic by counted waits and raw barriers only: a wait that is one count short passes every reference check
+    whenever the data happens to land in time."""
+    rng = np.random.default_rng(C1 + B)
+    C2 = 4 * C1
+    f16 = lambda a: np.ascontiguousarray(a.astype(np.float16).view(np.uint16))
+    x1 = f16(np.abs(rng.standard_normal((B, H, W, C1))))
+    w1 = f16((rng.standard_normal((C1, C1, 3, 3)) * np.sqrt(2.0 / (9 * C1))).transpose(0, 2, 3, 1).reshape(C1, 9 * C1))
+    w2 = f16(rng.standard_normal((C2, C1)) * np.sqrt(2.0 / C1))
+    w3 = f16(rng.standard_normal((C3, C2)) * np.sqrt(2.0 / C2))
+    res = f16(rng.standard_normal((B * H * W, C2)))
+    b1 = (rng.standard_normal(C1) * 0.1).astype(np.float32)
+    b2 = (rng.standard_normal(C2) * 0.1).astype(np.float32)
+    b3 = (rng.standard_normal(C3) * 0.1).astype(np.float32)
+    n_diff = C.c_int(-1)
+    rc = lib.opd_test_btail_repeat(_p(x1), _p(w1), _p(b1), _p(w2), _p(b2), _p(res), _p(w3), _p(b3), B, H, W, C1, C3, 40, C.byref(n_diff))
+    _capi.check(rc, "opd_test_btail_repeat")
+    assert n_diff.value == 0
+
+
 def run_btail_sc(lib, x1, w1, b1, w2, b2sc, xs, wsc, w3, b3):
     """fused tail with the block's shortcut convolution inside: xs [B,H,W,64], wsc [256,64]; stride 1, C1 = C3 = 64."""
     B, H, W, C1 = x1.shape
