@@ -357,8 +357,10 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
     if (p.dbg & 8) return;
 
     // ---- chunk steps: 64 channels of y each; this wave computes 32 of them (2 tiles) for the pair's 32 pixels; all eight waves in step, one
-    // barrier per chunk.  (A two-phase form with the wave groups staggered as in the 3x3 loop -- Y(c) | barrier | Z(c) | barrier, one group an
-    // interval behind -- was built and measured: 8000 clocks per two chunks against 7500 for this loop; removed.)
+    // barrier per chunk.  (Two de-synchronised forms were built and measured against this loop's 7500 clocks per two chunks, and removed:
+    // Y(c) | barrier | Z(c) | barrier with the wave groups one interval apart as in the 3x3 loop: 8000; Z one chunk behind Y, one barrier
+    // per chunk, the two groups running {Y(c), Z(c-1)} in opposite order: 8400-9100.  What holds the chunk step at 1.8 x its MFMA time is
+    // not the waves of a SIMD being in the same phase.)
 #pragma unroll
     for (int j = 0; j < NCH; ++j) {
         const unsigned char* W2s = smem + W2BUF + (j & 1) * 32768;
