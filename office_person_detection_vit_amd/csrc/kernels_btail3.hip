@@ -463,7 +463,8 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
                 for (int mt = 0; mt < 2; ++mt) accz[idx & 7][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, yf[idx >> 3][mt], accz[idx & 7][mt], 0, 0, 0);
                 if (idx + 4 < 16) ring[idx & 3] = w3frag(idx + 4);
                 __builtin_amdgcn_sched_barrier(0);
-                if (idx < 4) { if (j + 1 < NCH) issue_w3_piece(j + 1, idx); }
+                if (p.dbg & 16) {}   // timing ablation: no weight requests in the chunk loop (tools only)
+                else if (idx < 4) { if (j + 1 < NCH) issue_w3_piece(j + 1, idx); }
                 else if (idx < 8) { if (j + 2 < NCH) issue_w2_piece(j + 2, idx - 4); }
                 else if (idx == 8) { if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]); }
                 __builtin_amdgcn_sched_barrier(0);

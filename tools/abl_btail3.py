@@ -7,8 +7,8 @@ lib = _capi.load_library()
 for s in [(8, 50, 84, 256, 256, 1), (8, 67, 120, 256, 256, 1), (7, 50, 84, 256, 256, 1)]:
     B, H, W, C1, C3, st = s
     t = []
-    for dbg in (0, 8, 2, 4, 6):
+    for dbg in (0, 8, 2, 4, 6, 16, 22):
         us = (C.c_float * 4)()
         _capi.check(lib.opd_test_bench_btail(B, H, W, C1, C3, st, dbg, 20, us), "bench_btail")
         t.append(us[0])
-    print(s, "full | 3x3 + a1 exchange only | no stores | no residual | neither:", " ".join(f"{v:8.1f}" for v in t), flush=True)
+    print(s, "full | 3x3 + a1 exchange only | no stores | no residual | neither | no chunk DMA | no chunk DMA, stores, residual:", " ".join(f"{v:8.1f}" for v in t), flush=True)
