@@ -149,8 +149,9 @@ def _lin(x, w, prefix):
     return F.linear(x, w[prefix + ".weight"], w[prefix + ".bias"])
 
 
-def _mha(w, prefix, q_in, k_in, v_in, heads, key_mask_add=None, q=None, probs_out=None):
-    """softmax(Q K^T / sqrt(dh) + mask) V, then o_proj.  *_in: [B, L, D]."""
+def _mha(w, prefix, q_in, k_in, v_in, heads, key_mask_add=None, q=None, probs_out=None, site="attn"):
+    """softmax(Q K^T / sqrt(dh) + mask) V, then o_proj.  *_in: [B, L, D].  `q` (storage emulation) is applied at the named
+    rounding sites `site`.q / .kv / .p / .o (see _SiteQuant)."""
     B, Lq, D = q_in.shape
     Lk = k_in.shape[1]
     dh = D // heads
@@ -158,7 +159,7 @@ def _mha(w, prefix, q_in, k_in, v_in, heads, key_mask_add=None, q=None, probs_ou
     K = _lin(k_in, w, prefix + ".k_proj")
     V = _lin(v_in, w, prefix + ".v_proj")
     if q is not None:
-        Q, K, V = q(Q), q(K), q(V)
+        Q, K, V = q(Q, site + ".q"), q(K, site + ".kv"), q(V, site + ".kv")
     Q = Q.view(B, Lq, heads, dh).transpose(1, 2)
     K = K.view(B, Lk, heads, dh).transpose(1, 2)
     V = V.view(B, Lk, heads, dh).transpose(1, 2)
@@ -169,10 +170,10 @@ def _mha(w, prefix, q_in, k_in, v_in, heads, key_mask_add=None, q=None, probs_ou
     if probs_out is not None:
         probs_out.append(p)   # [B, heads, Lq, Lk]
     if q is not None:
-        p = q(p)
+        p = q(p, site + ".p")
     o = torch.matmul(p, V).transpose(1, 2).reshape(B, Lq, D)
     if q is not None:
-        o = q(o)
+        o = q(o, site + ".o")
     return _lin(o, w, prefix + ".o_proj")
 
 
@@ -180,10 +181,10 @@ def _ln(x, w, prefix):
     return F.layer_norm(x, (x.shape[-1],), w[prefix + ".weight"], w[prefix + ".bias"], LN_EPS)
 
 
-def _mlp(x, w, prefix, q=None):
-    h = F.relu(_lin(x if q is None else q(x), w, prefix + ".fc1"))
+def _mlp(x, w, prefix, q=None, site="ffn"):
+    h = F.relu(_lin(x if q is None else q(x, site + ".in"), w, prefix + ".fc1"))
     if q is not None:
-        h = q(h)
+        h = q(h, site + ".h")
     return _lin(h, w, prefix + ".fc2")
 
 
@@ -192,11 +193,11 @@ def encoder(w, x, pos, n_layers, heads, key_mask_add=None, taps=None, q=None):
         p = f"model.encoder.layers.{i}"
         qk = x + pos
         if q is not None:
-            a = _mha(w, p + ".self_attn", q(qk), q(qk), q(x), heads, key_mask_add, q)
+            a = _mha(w, p + ".self_attn", q(qk, "enc.attn.in"), q(qk, "enc.attn.in"), q(x, "enc.attn.in"), heads, key_mask_add, q, None, "enc.attn")
         else:
             a = _mha(w, p + ".self_attn", qk, qk, x, heads, key_mask_add)
         x = _ln(x + a, w, p + ".self_attn_layer_norm")
-        x = _ln(x + _mlp(x, w, p + ".mlp", q), w, p + ".final_layer_norm")
+        x = _ln(x + _mlp(x, w, p + ".mlp", q, "enc.ffn"), w, p + ".final_layer_norm")
         if taps is not None:
             taps[f"enc{i}"] = x
     return x
@@ -206,18 +207,19 @@ def decoder(w, memory, pos, n_layers, heads, key_mask_add=None, taps=None, q=Non
     B = memory.shape[0]
     qpos = w["model.query_position_embeddings.weight"].unsqueeze(0).expand(B, -1, -1)
     h = torch.zeros_like(qpos)
-    ident = (lambda t: t) if q is None else q
+    ident = (lambda t, site=None: t) if q is None else q
     for i in range(n_layers):
         p = f"model.decoder.layers.{i}"
-        qk = ident(h + qpos)
-        a = _mha(w, p + ".self_attn", qk, qk, ident(h), heads, None, q)
+        qk = ident(h + qpos, "dec.self.in")
+        a = _mha(w, p + ".self_attn", qk, qk, ident(h, "dec.self.in"), heads, None, q, None, "dec.self")
         h = _ln(h + a, w, p + ".self_attn_layer_norm")
         cross = [] if taps is not None else None
-        a = _mha(w, p + ".encoder_attn", ident(h + qpos), ident(memory + pos), ident(memory), heads, key_mask_add, q, cross)
+        a = _mha(w, p + ".encoder_attn", ident(h + qpos, "dec.cross.in"), ident(memory + pos, "dec.cross.kvin"), ident(memory, "dec.cross.kvin"), heads,
+                 key_mask_add, q, cross, "dec.cross")
         if taps is not None:
             taps[f"dec{i}_cross_probs"] = cross[0]
         h = _ln(h + a, w, p + ".encoder_attn_layer_norm")
-        h = _ln(h + _mlp(h, w, p + ".mlp", q), w, p + ".final_layer_norm")
+        h = _ln(h + _mlp(h, w, p + ".mlp", q, "dec.ffn"), w, p + ".final_layer_norm")
         if taps is not None:
             taps[f"dec{i}"] = h
     return _ln(h, w, "model.decoder.layernorm")
@@ -248,26 +250,69 @@ def to_torch(weights: Dict[str, np.ndarray]) -> Dict[str, torch.Tensor]:
     return {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in weights.items()}
 
 
-def _quantizer(mode: Optional[str]):
-    """Optional emulation of low-precision *storage* of activations (predicts GPU drift on CPU)."""
-    if mode is None:
+class _SiteQuant:
+    """Emulation of low-precision *storage* (predicts GPU drift on CPU): `q(t, site)` rounds `t` through `mode` when `sites` is None
+    (every rounding site) or `site` starts with one of the prefixes in `sites`.  Activation sites of the transformer:
+    enc.attn.{in,q,kv,p,o}, enc.ffn.{in,h}, dec.self.{in,q,kv,p,o}, dec.cross.{in,kvin,q,kv,p,o}, dec.ffn.{in,h}, heads;
+    weight sites (see `forward`): w.proj, w.enc.attn, w.enc.ffn, w.dec.self, w.dec.cross.q, w.dec.cross.kv, w.dec.cross.o, w.dec.ffn, w.heads."""
+
+    def __init__(self, mode: str, sites=None):
+        self.dt = {"f16": torch.float16, "bf16": torch.bfloat16}[mode]
+        self.sites = None if sites is None else tuple(sites)
+
+    def on(self, site: Optional[str]) -> bool:
+        return self.sites is None or (site is not None and any(site.startswith(p) for p in self.sites))
+
+    def __call__(self, t, site: Optional[str] = None):
+        return t.to(self.dt).to(torch.float32) if self.on(site) else t
+
+
+def _quantizer(mode: Optional[str], sites=None):
+    return None if mode is None else _SiteQuant(mode, sites)
+
+
+def _weight_site(k: str) -> Optional[str]:
+    """Rounding site of a transformer GEMM weight (None: not a GEMM weight of the transformer)."""
+    if not k.endswith(".weight"):
         return None
-    dt = {"f16": torch.float16, "bf16": torch.bfloat16}[mode]
-    return lambda t: t.to(dt).to(torch.float32)
+    if k.startswith("model.input_proj"):
+        return "w.proj"
+    if k.startswith(("bbox_predictor", "class_labels")):
+        return "w.heads"
+    if k.startswith("model.encoder"):
+        return "w.enc.ffn" if ".mlp." in k else "w.enc.attn"
+    if k.startswith("model.decoder"):
+        if ".mlp." in k:
+            return "w.dec.ffn"
+        if ".self_attn." in k:
+            return "w.dec.self"
+        if ".encoder_attn.q_proj" in k:
+            return "w.dec.cross.q"
+        if ".encoder_attn.o_proj" in k:
+            return "w.dec.cross.o"
+        if ".encoder_attn." in k:
+            return "w.dec.cross.kv"
+    return None
 
 
 @torch.no_grad()
 def forward(weights: Dict[str, torch.Tensor], pixel_values: torch.Tensor, pixel_mask: Optional[torch.Tensor] = None,
-            taps: Optional[dict] = None, emulate: Optional[str] = None, emulate_transformer: Optional[str] = None):
-    """-> (logits [B,Q,C+1], pred_boxes [B,Q,4] cxcywh in [0,1], encoder_last_hidden_state [B,HW,D])."""
+            taps: Optional[dict] = None, emulate: Optional[str] = None, emulate_transformer: Optional[str] = None,
+            transformer_sites=None, backbone_features: Optional[torch.Tensor] = None, backbone_sites=None):
+    """-> (logits [B,Q,C+1], pred_boxes [B,Q,4] cxcywh in [0,1], encoder_last_hidden_state [B,HW,D]).
+    `emulate` / `emulate_transformer` ("f16" | "bf16"): storage emulation of the backbone / the transformer; `transformer_sites`
+    restricts the latter to the named rounding sites (_SiteQuant), `backbone_sites` the former to "bb.w" (folded kernels) and / or
+    "bb.act" (activations).  `backbone_features`: skip the backbone and start from this
+    stage-4 map (tools/drift_split.py runs many transformer variants on one backbone pass)."""
     w = weights
     arch = infer_arch(w)
     B, _, H, W = pixel_values.shape
     if pixel_mask is None:
         pixel_mask = torch.ones((B, H, W), dtype=torch.int64)
-    qb = _quantizer(emulate)
-    qt = _quantizer(emulate_transformer)
-    x_in = pixel_values if qb is None else qb(pixel_values)
+    qb = _quantizer(emulate, backbone_sites)
+    qb_act = None if qb is None else (lambda t: qb(t, "bb.act"))
+    qt = _quantizer(emulate_transformer, transformer_sites)
+    x_in = pixel_values if qb is None else qb(pixel_values, "bb.act")
     if qb is not None:
         w = dict(w)
         # product folds BN into the conv in fp32 and stores the folded kernel in low precision
@@ -275,7 +320,7 @@ def forward(weights: Dict[str, torch.Tensor], pixel_values: torch.Tensor, pixel_
             if k.endswith(".convolution.weight"):
                 pre = k[: -len(".convolution.weight")] + ".normalization"
                 scale = w[pre + ".weight"] * (w[pre + ".running_var"] + BN_EPS).rsqrt()
-                w[k] = qb(w[k] * scale.view(-1, 1, 1, 1))
+                w[k] = qb(w[k] * scale.view(-1, 1, 1, 1), "bb.w")
                 w[pre + ".bias"] = w[pre + ".bias"] - w[pre + ".running_mean"] * scale
                 w[pre + ".weight"] = torch.ones_like(scale)
                 w[pre + ".running_mean"] = torch.zeros_like(scale)
@@ -283,10 +328,9 @@ def forward(weights: Dict[str, torch.Tensor], pixel_values: torch.Tensor, pixel_
     if qt is not None:
         w = dict(w)
         for k in list(w.keys()):
-            if (k.startswith(("model.encoder", "model.decoder", "bbox_predictor", "class_labels", "model.input_proj"))
-                    and k.endswith(".weight") and w[k].dim() >= 2):
-                w[k] = qt(w[k])
-    feat = backbone(w, x_in, arch["depths"], taps, qb)
+            if w[k].dim() >= 2 and _weight_site(k) is not None:
+                w[k] = qt(w[k], _weight_site(k))
+    feat = backbone(w, x_in, arch["depths"], taps, qb_act) if backbone_features is None else backbone_features
     h, wd = feat.shape[-2:]
     mask = F.interpolate(pixel_mask[None].float(), size=(h, wd)).to(torch.bool)[0]  # nearest
     proj = F.conv2d(feat, w["model.input_projection.weight"], w["model.input_projection.bias"])
@@ -302,11 +346,11 @@ def forward(weights: Dict[str, torch.Tensor], pixel_values: torch.Tensor, pixel_
     hs = decoder(w, mem, pos, arch["decoder_layers"], arch["heads"], key_mask_add, taps, qt)
     if taps is not None:
         taps["hs"] = hs
-    hq = hs if qt is None else qt(hs)
+    hq = hs if qt is None else qt(hs, "heads")
     logits = _lin(hq, w, "class_labels_classifier")
     b = F.relu(_lin(hq, w, "bbox_predictor.layers.0"))
-    b = F.relu(_lin(b if qt is None else qt(b), w, "bbox_predictor.layers.1"))
-    boxes = _lin(b if qt is None else qt(b), w, "bbox_predictor.layers.2").sigmoid()
+    b = F.relu(_lin(b if qt is None else qt(b, "heads"), w, "bbox_predictor.layers.1"))
+    boxes = _lin(b if qt is None else qt(b, "heads"), w, "bbox_predictor.layers.2").sigmoid()
     return logits, boxes, mem
 
 
