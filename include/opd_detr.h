@@ -27,6 +27,13 @@
 #include <stddef.h>
 #include <stdint.h>
 
+/* The product library is built with -fvisibility=hidden: exactly the functions declared here are exported. */
+#if defined(__GNUC__)
+#define OPD_API __attribute__((visibility("default")))
+#else
+#define OPD_API
+#endif
+
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -88,18 +95,18 @@ typedef struct opd_model_info {
  * `YOLOv8Detector.load_model`, yolov8_detector.py:70-88): parse a safetensors checkpoint carrying the HF
  * `DetrForObjectDetection` state dict (5.x or 4.x key names), fold every FrozenBN into its convolution in fp32
  * (HF:models/detr/modeling_detr.py:179-215), convert to the device layouts and upload to GPU `device_ordinal`. */
-int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out);
+OPD_API int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out);
 
 /* Replaces `cleanup_resources` / detector release (`src/utils/memory_utils.py:33-41`). */
-void opd_detr_destroy(opd_detr* m);
+OPD_API void opd_detr_destroy(opd_detr* m);
 
 /* A second handle on the SAME model: own stream, workspace and graph cache, the weights in HBM shared with `src` (read-only after
  * creation; freed when the last handle that uses them is destroyed, in any order).  For several batches in flight on one GPU
  * (`HipDetrDetector(streams=N)`, bench.py): no second parse of the checkpoint, one copy of the 83 MB of weights for L2 and the
  * Infinity Cache to hold instead of N.  No reference counterpart (one detector object per process there). */
-int opd_detr_clone(const opd_detr* src, opd_detr** out);
+OPD_API int opd_detr_clone(const opd_detr* src, opd_detr** out);
 
-int opd_detr_info(const opd_detr* m, opd_model_info* info);
+OPD_API int opd_detr_info(const opd_detr* m, opd_model_info* info);
 
 /* Replaces `with torch.no_grad(): outputs = model(pixel_values, pixel_mask)` in `ViTDetector.detect_batch`
  * (deleted vit_detector.py 508-550; HF:models/detr/modeling_detr.py:1329-1443), including the BGR->RGB / 1/255 /
@@ -107,7 +114,7 @@ int opd_detr_info(const opd_detr* m, opd_model_info* info);
  * All B frames share one size HxW (pixel_mask all ones).  `enc_features` may be NULL.
  * `mem_kind` says whether pixels AND outputs are host or device pointers.  Synchronous: results are complete on
  * return. */
-int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+OPD_API int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                      float* logits, float* boxes, float* enc_features);
 
 /* The same call for a RAGGED batch: `model(pixel_values, pixel_mask)` with a padding mask, i.e. what HF's
@@ -118,7 +125,7 @@ int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_
  * `pixels` is the H x W canvas batch with every frame in its top-left corner; `valid_hw` = host [B][2] int32 (height, width)
  * of each frame inside the canvas (NULL or all (H, W): identical to opd_detr_forward).  Canvas pixels outside a frame are
  * ignored (written as zeros on the device).  `enc_features` covers the whole canvas map, padded positions included. */
-int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+OPD_API int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                             const int32_t* valid_hw, float* logits, float* boxes, float* enc_features);
 
 /* Device-side resize: frames at CAMERA resolution in, the resize half of `_preprocess_batch` on the GPU.
@@ -127,21 +134,21 @@ int opd_detr_forward_ragged(opd_detr* m, const void* pixels, int pixel_format, i
  * that is BIT-EXACT with Pillow's 8-bit bilinear resampler, i.e. with `DetrImageProcessor.resize`
  * (HF:models/detr/image_processing_detr.py:424-436), then run through the same path as opd_detr_forward.
  * Outputs follow `mem_kind`. */
-int opd_detr_forward_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W,
+OPD_API int opd_detr_forward_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W,
                              float* logits, float* boxes, float* enc_features);
 /* The resize alone (host in, host out): [B][h][w][3] -> [B][out_h][out_w][3]; for parity tests against Pillow. */
-int opd_detr_resize_u8(opd_detr* m, const uint8_t* frames, int B, int h, int w, int out_h, int out_w, uint8_t* out);
+OPD_API int opd_detr_resize_u8(opd_detr* m, const uint8_t* frames, int B, int h, int w, int out_h, int out_w, uint8_t* out);
 
 /* Replaces `_postprocess_batch` part 1 = HF `post_process_object_detection` (deleted vit_detector.py 591-647;
  * HF:models/detr/image_processing_detr.py:805-856): softmax over C+1, max over the first C classes, cxcywh->xyxy,
  * scale by the ORIGINAL (height,width) of each frame, keep score > threshold.  Runs on the device on the logits and
  * boxes of the LAST forward of this handle.  `orig_hw` = [B][2] int32 host array (height, width) or NULL (= model
  * input size).  `out` (host) receives `counts[b]` records for frame b at out[b*Q ...]; records keep query order. */
-int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
+OPD_API int opd_detr_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
 
 /* One call = forward + device post-process, pixels in HBM when `mem_kind == OPD_MEM_DEVICE` (the benchmark's
  * timed region).  Equivalent to opd_detr_forward(..., NULL, NULL, NULL) followed by opd_detr_postprocess(...). */
-int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+OPD_API int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                     float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
 /* With `mem_kind == OPD_MEM_DEVICE`, `out` ([B][Q] records) and `counts` ([B]) are DEVICE pointers too, so a sharded
  * caller can hand them straight to an RCCL all-gather; `orig_hw` is always a host array. */
@@ -154,32 +161,32 @@ int opd_detr_detect(opd_detr* m, const void* pixels, int pixel_format, int mem_k
  * handle runs in submission order; SEVERAL handles on one device (own stream, workspace and captured graph each) overlap:
  * the latency-bound tail of one batch fills the CUs the next batch's trunk leaves idle (+25 % frames/s with three handles at
  * batch 8). */
-int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
+OPD_API int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
                           const int32_t* orig_hw, opd_det* out, int32_t* counts, int* ticket);
-int opd_detr_wait(opd_detr* m, int ticket);
+OPD_API int opd_detr_wait(opd_detr* m, int ticket);
 /* Camera-resolution form (see opd_detr_forward_resized): resize on the device, detect, and scale the boxes back to the
  * camera frame size (h, w). */
-int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W,
+OPD_API int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W,
                             float threshold, opd_det* out, int32_t* counts);
 /* Ragged-batch form (see opd_detr_forward_ragged); `valid_hw` and `orig_hw` are host arrays. */
-int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
+OPD_API int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                            const int32_t* valid_hw, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);
 
 /* Replaces `_postprocess_batch` part 2 (deleted vit_detector.py 591-647; `docs/plan.md:30`,
  * `config.yaml.disabled:38`): keep `label == person_label` (pass -1 to keep every class), greedy IoU-NMS in
  * descending score order at `nms_threshold` (pass >= 1 to disable).  Host-side, in place: compacts `dets[0..n)` and
  * returns the new count (>= 0) or a negative error. */
-int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold);
+OPD_API int opd_person_nms(opd_det* dets, int n, int person_label, float nms_threshold);
 /* The same for a whole batch in one call: frame f owns `dets[f * stride .. f * stride + counts[f])` (the fixed-slot layout
  * opd_detr_detect writes, stride = num_queries); every frame is compacted in place and `counts[f]` becomes its new count.
  * A negative `counts[f]` (padding slot of an uneven shard) is left alone.  Returns 0 or a negative error. */
-int opd_person_nms_batch(opd_det* dets, int32_t* counts, int n_frames, int stride, int person_label, float nms_threshold);
+OPD_API int opd_person_nms_batch(opd_det* dets, int32_t* counts, int n_frames, int stride, int person_label, float nms_threshold);
 
 /* Page-locked host memory for frame batches handed over with OPD_MEM_HOST: the upload of such a buffer is one asynchronous DMA
  * instead of the runtime's staged copy of pageable memory.  Optional (any host pointer is accepted everywhere); the Python shim
  * stacks the caller's frames (`detect_batch(frames: list[np.ndarray])`, the reference's calling convention) directly into it. */
-int opd_host_alloc(size_t bytes, void** out);
-void opd_host_free(void* p);
+OPD_API int opd_host_alloc(size_t bytes, void** out);
+OPD_API void opd_host_free(void* p);
 
 /* "Next" row: replaces `SimilarityCalculator.compute_similarity_matrix` / `compute_distance_matrix`
  * (`src/tracking/similarity.py:42-220`), the tracker's cost matrix built right after the detect path:
@@ -187,7 +194,7 @@ void opd_host_free(void* p);
  * features (has == 0, or a NULL feature matrix) drops the appearance term and renormalises.  Boxes are (x, y, w, h).
  * All pointers are host pointers; `out` = [n1][n2] f32; `as_distance` != 0 returns 1 - similarity.  Runs on the device
  * `device_ordinal`; needs no model handle. */
-int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* boxes1, const uint8_t* has1, int n1,
+OPD_API int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* boxes1, const uint8_t* has1, int n1,
                           const float* feats2, const float* boxes2, const uint8_t* has2, int n2, int D,
                           double appearance_weight, double motion_weight, int as_distance, float* out);
 
@@ -195,7 +202,7 @@ int opd_similarity_matrix(int device_ordinal, const float* feats1, const float* 
  * (`src/tracking/feature_extractor.py:39-88`; deleted vit_detector.py 224-273): for each (x,y,w,h) box in original
  * pixels, mean-pool the last forward's encoder map of frame `frame` over the int-truncated, clamped ROI and
  * L2-normalise (x / (||x|| + 1e-8)).  `features` = host [n][D] f32.  Runs on the device. */
-int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n, int orig_h, int orig_w,
+OPD_API int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n, int orig_h, int orig_w,
                           float* features);
 
 /* Replaces `get_attention_map` / `_extract_attention_map` (deleted vit_detector.py 392-446, `coverage.json:1`; the surviving stand-in
@@ -203,25 +210,27 @@ int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n
  * which takes a 1-D or 2-D array in [0, 1]).  The DETR-era source is gone, so the definition is this build's: the decoder's
  * cross-attention weights of layer `layer` (negative: counted from the last) of the LAST forward's frame `frame`, averaged over the
  * heads and over the `n_queries` query indices in `queries` (n_queries == 0: all queries).  `out` = host [fh * fw] f32, row-major over
- * the feature map, summing to 1; runs on the device from the q / k operands the forward left there. */
-int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* queries, int n_queries, float* out);
+ * the feature map of that forward (fh = ceil(H/32), fw = ceil(W/32)), summing to 1; `out_capacity` = floats the caller allocated: a
+ * map larger than that is OPD_EINVAL, nothing is written.  Runs on the device from the q / k operands the forward left there, so the
+ * call belongs to the caller that ran that forward: no other submission to this handle in between (single caller per handle). */
+OPD_API int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* queries, int n_queries, float* out, int out_capacity);
 
 /* Device time (ms) of the last forward/detect per stage, measured with HIP events on the handle's stream:
  * [0] preprocess+stem+pool, [1] stage1, [2] stage2, [3] stage3, [4] stage4, [5] projection+encoder, [6] decoder+heads,
  * [7] post-process.  Only filled when profiling was enabled with opd_detr_set_profiling(m, 1). */
-int opd_detr_set_profiling(opd_detr* m, int enabled);
-int opd_detr_stage_times(const opd_detr* m, float* ms8);
+OPD_API int opd_detr_set_profiling(opd_detr* m, int enabled);
+OPD_API int opd_detr_stage_times(const opd_detr* m, float* ms8);
 /* Per-kernel-class totals of the last profiled forward, from HIP event pairs recorded around EVERY launch on the
  * handle's stream: class 0 = conv_gemm_kernel on backbone convolutions (+ input projection), 1 = conv_gemm_kernel as
  * transformer linear layer, 2 = attention_kernel, 3 = reserved.  ms4[c] = summed device time, launches4[c] = number of
  * launches, flops4[c] = summed ALGORITHMIC FLOPs (2 x MAC) of those launches. */
-int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, double* flops4);
+OPD_API int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, double* flops4);
 
 /* Thread-local description of the last error returned on this thread ("" if none). */
-const char* opd_last_error(void);
+OPD_API const char* opd_last_error(void);
 
 /* Library / kernel build identification, e.g. "opd_hip 0.1 gfx950". */
-const char* opd_version(void);
+OPD_API const char* opd_version(void);
 
 #ifdef __cplusplus
 }

@@ -12,6 +12,7 @@ from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libopd_hip.so")
+TEST_LIB_PATH = os.path.join(_HERE, "libopd_hip_test.so")   # the same objects + csrc/opd_test_api.cpp: tests/ and tools/ only
 
 OPD_PIXELS_U8_BGR_HWC = 0
 OPD_PIXELS_F32_NCHW = 1
@@ -68,7 +69,7 @@ API = {
     "opd_similarity_matrix": (C.c_int, [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                         C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p]),
     "opd_detr_roi_features": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "opd_detr_attention_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
+    "opd_detr_attention_map": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_detr_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "opd_detr_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
@@ -123,27 +124,46 @@ TEST_API = {
     "opd_test_check_redzones": (C.c_int, [C.c_void_p]),
     "opd_test_set_taps": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_test_read_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_char_p, C.c_int]),
+    "opd_test_round_f16_diffused": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "opd_test_dec_qkv": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 + [C.c_int] * 2 + [C.c_void_p] * 4),
+    "opd_test_dec_self": (C.c_int, [C.c_void_p] * 10 + [C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "opd_test_attention_split": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 4 + [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "opd_test_dec_cross_out": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int] + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]),
+    "opd_test_dec_ffn": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
+    "opd_test_bench_dec": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_float)]),
+    "opd_test_heads_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "opd_test_set_fused_dec": (C.c_int, [C.c_void_p, C.c_int]),
 }
 
 _lib: Optional[C.CDLL] = None
+_lib_has_hooks = False
 
 
-def load_library() -> C.CDLL:
-    """dlopen libopd_hip.so (built in-tree by ``csrc/build.py``) and attach prototypes.  Raises if it is missing."""
-    global _lib
+def load_library(test_hooks: bool = False) -> C.CDLL:
+    """dlopen libopd_hip.so (built in-tree by ``csrc/build.py``) and attach prototypes.  Raises if it is missing.
+
+    ``test_hooks=True`` (tests/ and tools/ only; also ``OPD_TEST_HOOKS=1`` in the environment) loads ``libopd_hip_test.so`` instead:
+    the same objects plus the ``opd_test_*`` hooks of ``csrc/opd_test_api.cpp``.  One process uses ONE of the two (the hooks flip
+    process-wide switches of the library they live in), so asking for the hooks after the product library has been loaded raises."""
+    global _lib, _lib_has_hooks
+    test_hooks = test_hooks or os.environ.get("OPD_TEST_HOOKS") == "1"
     if _lib is not None:
+        if test_hooks and not _lib_has_hooks:
+            raise RuntimeError("the product library is already loaded in this process; load the test build first "
+                               "(_capi.load_library(test_hooks=True) or OPD_TEST_HOOKS=1)")
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = TEST_LIB_PATH if test_hooks else LIB_PATH
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"HIP extension not built: {LIB_PATH} is missing (run `python -c 'import __graft_entry__ as g; g.build()'`). "
+            f"HIP extension not built: {path} is missing (run `python -c 'import __graft_entry__ as g; g.build()'`). "
             "This package has no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
-    for table in (API, TEST_API):
+    lib = C.CDLL(path)
+    for table in (API, TEST_API) if test_hooks else (API,):
         for name, (res, args) in table.items():
             fn = getattr(lib, name)  # AttributeError here = the library does not export a declared symbol
             fn.restype = res
             fn.argtypes = args
-    _lib = lib
+    _lib, _lib_has_hooks = lib, test_hooks
     return lib
 
 

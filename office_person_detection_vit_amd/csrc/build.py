@@ -1,4 +1,9 @@
-"""Build libopd_hip.so in-tree with hipcc for gfx950 (cross-compiles without a GPU)."""
+"""Build the native libraries in-tree with hipcc for gfx950 (cross-compiles without a GPU):
+
+  libopd_hip.so       the PRODUCT: exports exactly the functions of include/opd_detr.h (-fvisibility=hidden + OPD_API)
+  libopd_hip_test.so  the same objects + opd_test_api.o (kernel-level hooks, fusion switches, poison allocator): what tests/ and
+                      tools/ load (`_capi.load_library(test_hooks=True)`); never loaded by the package on its own
+"""
 
 from __future__ import annotations
 
@@ -8,9 +13,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_test_api.cpp"]
-HEADERS = ["opd_kernels.h", "opd_loader.h", "opd_host.h", os.path.join("..", "..", "include", "opd_detr.h")]
+SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_dec.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_test_api.cpp"]
+TEST_ONLY = {"opd_test_api.cpp"}
+HEADERS = ["opd_kernels.h", "opd_loader.h", "opd_host.h", "opd_model.h", os.path.join("..", "..", "include", "opd_detr.h")]
 LIB = os.path.join(PKG, "libopd_hip.so")
+TEST_LIB = os.path.join(PKG, "libopd_hip_test.so")
 
 
 def _stale(target: str, deps) -> bool:
@@ -26,7 +33,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []
-    common = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function"]
+    common = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-fvisibility=hidden"]
     # per-file code-generation options: the attention kernel consumes its S = K.Q^T accumulators with VALU right away, so its
     # MFMAs should write VGPRs (the default AGPR form costs 56 v_accvgpr moves per key tile in a VALU-bound loop)
     extra = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
@@ -47,11 +54,13 @@ def build(verbose: bool = False, force: bool = False) -> str:
         from concurrent.futures import ThreadPoolExecutor
         with ThreadPoolExecutor(max_workers=max(1, min(len(jobs), os.cpu_count() or 1))) as pool:
             list(pool.map(compile_one, jobs))
-    if force or _stale(LIB, objs):
-        cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", LIB] + objs
-        if verbose:
-            print(" ".join(cmd), flush=True)
-        subprocess.run(cmd, check=True)
+    test_objs = {os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in TEST_ONLY}
+    for lib, members in ((LIB, [o for o in objs if o not in test_objs]), (TEST_LIB, objs)):
+        if force or _stale(lib, members):
+            cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + members
+            if verbose:
+                print(" ".join(cmd), flush=True)
+            subprocess.run(cmd, check=True)
     return LIB
 
 

@@ -77,7 +77,11 @@ __device__ __forceinline__ float xmax16_32(const float v) {
 // MASKED: per-frame key mask of a ragged batch (compile time: the unmasked loop carries no mask arithmetic).
 // KT: keys per LDS tile.  64 for the encoder (many workgroups per CU: the smaller tile keeps registers low); 128 for the decoder's
 // cross-attention (<= 128 queries: a handful of workgroups, each a latency chain of per-tile barriers).
-template <bool MASKED, int KT, bool TRACE = false>
+// SPLIT (the fused decoder's cross-attention, kernels_dec.hip): the key tiles are cut into p.splits contiguous ranges, one workgroup each;
+// a workgroup writes its unnormalised sum_k p v, its exponent reference and its sum_k p instead of the normalised output, and
+// dec_cross_out_kernel combines the splits.  A 100 x 1050 cross-attention is a latency chain of nine 128-key tiles on 128 workgroups;
+// three splits make it three tiles on 384.
+template <bool MASKED, int KT, bool TRACE = false, bool SPLIT = false>
 __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     constexpr int NKT = KT / 16;              // 16-key score tiles per LDS tile
     constexpr int RPT = KT / 64;              // 1-KiB blocks per wave, operand and tile
@@ -92,10 +96,12 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     // tile) order.  The query tiles of one frame then share one L2: its K/V rows (all heads of a key share 128-byte lines) come
     // from HBM once instead of once per XCD.
     const int nq = (p.Lq + 63) >> 6;
-    const int total = nq * p.heads * p.B;
+    const int nsp = SPLIT ? p.splits : 1;
+    const int total = nq * p.heads * p.B * nsp;
     const int chunk = (total + 7) >> 3;
-    const int n = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
-    if (n >= total) return;   // whole workgroup leaves before the first barrier
+    const int n0 = (int)(blockIdx.x & 7u) * chunk + (int)(blockIdx.x >> 3);
+    if (n0 >= total) return;   // whole workgroup leaves before the first barrier
+    const int split = SPLIT ? n0 % nsp : 0, n = SPLIT ? n0 / nsp : n0;   // (the splits of one query tile are neighbours: same XCD)
     const int b = n / (nq * p.heads), h = (n / nq) % p.heads;
     const int q = (n % nq) * 64 + wave * 16 + li;
     const bool q_ok = q < p.Lq;
@@ -141,16 +147,27 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
     // attention mask of the reference (HF:models/detr/modeling_detr.py:402-427, 933-991); key 0 is always valid
     const int kv_rows = MASKED ? p.key_valid[2 * b] : 0, kv_cols = MASKED ? p.key_valid[2 * b + 1] : 0;
     const int ntiles = (p.Lk + KT - 1) / KT;
+    const int tps = SPLIT ? (ntiles + nsp - 1) / nsp : ntiles;                 // key tiles per split
+    const int t0 = split * tps, t1 = SPLIT ? (t0 + tps < ntiles ? t0 + tps : ntiles) : ntiles;
     const float scale2 = p.scale * 1.44269504088896340736f;  // exponents are taken in base 2: scores are multiplied by scale * log2(e)
-    dma_tile(0, 0);
+    if (SPLIT && t0 >= t1) {   // more splits than tiles: an empty range carries no weight (workgroup-uniform: nobody reaches a barrier)
+        if (q_ok) {
+            const size_t prow = (size_t)split * p.B * p.Lq + (size_t)b * p.Lq + q;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<float4v*>(p.part_o + prow * (p.heads * 32) + h * 32 + dt * 16 + g * 4) = float4v{0.f, 0.f, 0.f, 0.f};
+            if (g == 0) *reinterpret_cast<float2v*>(p.part_ml + (prow * p.heads + h) * 2) = float2v{-INFINITY, 0.f};
+        }
+        return;
+    }
+    dma_tile(t0, 0);
     __syncthreads();   // (an LDS-DMA in flight is a pending LDS write: the barrier's fence waits for it)
 
     // One key tile.  LAST (compile time): the tile may hold keys >= Lk; every other tile of an unmasked launch is full and carries no
     // masking code at all.
     auto tile_step = [&](const int t, auto last_tag) {
         constexpr bool LAST = decltype(last_tag)::value;
-        const int buf = t & 1;
-        if (!LAST) dma_tile(t + 1, buf ^ 1);
+        const int buf = (t - t0) & 1;
+        if (!LAST && (!SPLIT || t + 1 < t1)) dma_tile(t + 1, buf ^ 1);
         ATTN_STAMP(0);
         const unsigned char* Kl = lds + buf * TILE_BYTES;
         const unsigned char* Vl = Kl + K_BYTES;
@@ -205,7 +222,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         }
         ATTN_STAMP(1);
         // ---- p = exp2(s * scale * log2(e) - m_ref): one packed fma per two scores, one v_exp_f32 per score ---------------
-        const float2v sc2 = {scale2, scale2}, mneg = {-m_ref, -m_ref};
+        // (a split of a masked frame may hold no valid key at all: its reference stays -inf and every weight must come out as 0, not NaN)
+        const float mn = (SPLIT && MASKED && m_ref == -INFINITY) ? 0.f : -m_ref;
+        const float2v sc2 = {scale2, scale2}, mneg = {mn, mn};
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt)
 #pragma unroll
@@ -242,8 +261,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         __syncthreads();
         ATTN_STAMP(4);
     };
-    for (int t = 0; t + 1 < ntiles; ++t) tile_step(t, std::false_type{});
-    tile_step(ntiles - 1, std::true_type{});
+    if constexpr (SPLIT) {   // only the last tile of the whole key range can hold keys >= Lk
+        for (int t = t0; t < t1; ++t) {
+            if (t + 1 == ntiles) tile_step(t, std::true_type{});
+            else tile_step(t, std::false_type{});
+        }
+    } else {
+        for (int t = 0; t + 1 < ntiles; ++t) tile_step(t, std::false_type{});
+        tile_step(ntiles - 1, std::true_type{});
+    }
 
     if constexpr (TRACE) {
         if (tid == 0 && p.trace) {
@@ -258,6 +284,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             tr[10] = (unsigned long long)__builtin_amdgcn_s_getreg((20 << 0) | (0 << 6) | (3 << 11));   // HW_REG_XCC_ID bits 0..3
             tr[11] = (unsigned long long)__builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));   // HW_REG_HW_ID
         }
+    }
+    if constexpr (SPLIT) {
+        if (q_ok) {
+            const size_t prow = (size_t)split * p.B * p.Lq + (size_t)b * p.Lq + q;
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) *reinterpret_cast<float4v*>(p.part_o + prow * (p.heads * 32) + h * 32 + dt * 16 + g * 4) = oacc[dt];
+            if (g == 0) *reinterpret_cast<float2v*>(p.part_ml + (prow * p.heads + h) * 2) = float2v{m_ref, lacc[0]};
+        }
+        return;
     }
     if (q_ok) {
         const float inv = 1.0f / lacc[0];
@@ -276,6 +311,15 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 
 hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Lq <= 0 || p.Lk <= 0) return hipErrorInvalidValue;
+    if (p.splits > 0) {   // key-split partials (fused decoder cross-attention): 128-key tiles
+        if (!p.part_o || !p.part_ml || p.trace || (p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.key_valid && p.key_row < 1)) return hipErrorInvalidValue;
+        if ((size_t)p.B * p.Lk * p.ldk * 2 >= (1ull << 32) || (size_t)p.B * p.Lk * p.ldv * 2 >= (1ull << 32)) return hipErrorInvalidValue;
+        const int total = ((p.Lq + 63) / 64) * p.heads * p.B * p.splits;
+        dim3 grid(8 * ((total + 7) / 8));
+        if (p.key_valid) hipLaunchKernelGGL((attention_kernel<true, 128, false, true>), grid, dim3(256), 0, stream, p);
+        else hipLaunchKernelGGL((attention_kernel<false, 128, false, true>), grid, dim3(256), 0, stream, p);
+        return hipGetLastError();
+    }
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;  // 16-byte row chunks
     if (p.key_valid && p.key_row < 1) return hipErrorInvalidValue;
     if ((size_t)p.B * p.Lk * p.ldk * 2 >= (1ull << 32) || (size_t)p.B * p.Lk * p.ldv * 2 >= (1ull << 32)) return hipErrorInvalidValue;   // buffer descriptors

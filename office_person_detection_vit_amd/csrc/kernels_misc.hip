@@ -298,7 +298,7 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadParams p) {
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) v[j] = row0 + r < p.rows ? p.hs[(size_t)(row0 + r) * 256 + c0 + j] : 0.f;
-        if (p.ln_gamma) {
+        auto ln_rows = [&](const float* __restrict__ gamma, const float* __restrict__ beta) {   // two-pass fp32 LayerNorm by the row's 32 threads
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 8; ++j) s += v[j];
@@ -312,8 +312,33 @@ __global__ __launch_bounds__(512) void heads_kernel(HeadParams p) {
             for (int o = 16; o > 0; o >>= 1) q += __shfl_xor(q, o);
             const float rstd = 1.0f / sqrtf(q * (1.0f / 256.0f) + 1e-5f);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * p.ln_gamma[c0 + j] + p.ln_beta[c0 + j];
+            for (int j = 0; j < 8; ++j) v[j] = v[j] * rstd * gamma[c0 + j] + beta[c0 + j];
+        };
+        if (p.partials) {   // fused decoder: the last layer's FFN arrives as partial sums (kernels_dec.hip::dec_ffn_kernel): + b2, summed in order, LN3
+            const size_t rc = (size_t)(row0 + r < p.rows ? row0 + r : p.rows - 1) * 256 + c0;
+            float4m pa[16], pb[16];
+#pragma unroll
+            for (int sp = 0; sp < 16; ++sp) {   // every slab requested before the first one is needed (a dependent load costs ~1 us)
+                const float* ps = p.partials + (size_t)(sp < p.nsplit ? sp : p.nsplit - 1) * p.rows * 256 + rc;
+                pa[sp] = *reinterpret_cast<const float4m*>(ps);
+                pb[sp] = *reinterpret_cast<const float4m*>(ps + 4);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] += p.ffn_b2[c0 + j];
+#pragma unroll
+            for (int sp = 0; sp < 16; ++sp)
+                if (sp < p.nsplit) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += pa[sp][j]; v[4 + j] += pb[sp][j]; }
+                }
+            if (row0 + r >= p.rows) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) v[j] = 0.f;
+            }
+            ln_rows(p.ln3_gamma, p.ln3_beta);
         }
+        if (p.ln_gamma) ln_rows(p.ln_gamma, p.ln_beta);
 #pragma unroll
         for (int j = 0; j < 8; ++j) h[r][c0 + j] = v[j];
     }
@@ -645,6 +670,7 @@ hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bia
 
 hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
     if (p.ncls > 256 || p.rows <= 0) return hipErrorInvalidValue;
+    if (p.partials && (p.nsplit < 1 || p.nsplit > 16 || !p.ffn_b2 || !p.ln3_gamma || !p.ln3_beta)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(512), 0, stream, p);
     return hipGetLastError();
 }

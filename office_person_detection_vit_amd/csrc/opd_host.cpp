@@ -9,6 +9,7 @@
 
 #include "../../include/opd_detr.h"
 #include "opd_host.h"
+#include "opd_loader.h"
 
 namespace opd {
 
@@ -17,6 +18,25 @@ thread_local std::string g_err;
 int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
+}
+
+// (opd_host.h) error-diffusion rounding of a weight matrix to fp16 values; the carry is kept in double so that it is exact
+void round_f16_diffused(float* w, size_t rows, int taps, int cin) {
+    const size_t K = (size_t)taps * cin;
+    for (size_t r = 0; r < rows; ++r) {
+        float* row = w + r * K;
+        double carry = 0.0;
+        for (int c = 0; c < cin; ++c)
+            for (int t = 0; t < taps; ++t) {
+                float& v = row[(size_t)t * cin + c];
+                const double target = (double)v + carry;
+                const float q = f16_to_f32(f32_to_f16((float)target));
+                // (a carry can only push a value over the fp16 range if the value itself was at its edge: keep plain rounding then)
+                if (!(fabsf(q) <= 65504.0f)) { v = f16_to_f32(f32_to_f16(v)); carry = 0.0; continue; }
+                carry = target - (double)q;
+                v = q;
+            }
+    }
 }
 
 // Valid extent of a frame on the feature map: the reference down-samples the pixel mask with nearest-neighbour

@@ -15,8 +15,7 @@ typedef uint16_t f16_t;  // raw IEEE half bits on the host side
         static std::once_flag once_[16];                                                                                     \
         static hipError_t err_[16];                                                                                          \
         int dev_ = 0;                                                                                                        \
-        (void)hipGetDevice(&dev_);                                                                                           \
-        dev_ &= 15;                                                                                                          \
+        if (hipGetDevice(&dev_) != hipSuccess || dev_ < 0 || dev_ >= 16) return hipErrorInvalidDevice;   /* one node: <= 16 GPUs */ \
         std::call_once(once_[dev_], [&] { err_[dev_] = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (bytes)); }); \
         if (err_[dev_] != hipSuccess) return err_[dev_];                                                                     \
     } while (0)
@@ -183,6 +182,10 @@ hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bia
 // passed TRANSPOSED ([in = 256][out]).
 struct HeadParams {
     const float* hs;  // [rows][256]
+    // optional (fused decoder): hs is the state before the last layer's FFN; the rows become LN3(hs + b2 + sum partials) first
+    const float* partials;   // [nsplit][rows][256]
+    int nsplit;
+    const float *ffn_b2, *ln3_gamma, *ln3_beta;   // that FFN-2's bias, LN3
     const float *ln_gamma, *ln_beta;  // optional: hs is the decoder state BEFORE its final LayerNorm, applied here first
     const float *wc, *bc, *w1, *b1, *w2, *b2, *w3, *b3;
     float* logits;    // [rows][ncls]
@@ -216,6 +219,62 @@ hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const 
                                         const uint8_t* has2, int n2, int D, double aw, double mw, int as_distance, float* out,
                                         hipStream_t stream);
 
+// ---- fused decoder (kernels_dec.hip) -----------------------------------------------------------------------------------------------
+// The decoder (M = batch x queries rows, 2 % of the FLOPs) is a latency chain and the part of the path whose fp16 operand rounding
+// moves the boxes most (tools/drift_split.py), so it runs as FIVE launches per layer on SPLIT operands: every GEMM input x and weight
+// W travels as two fp16 numbers, x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048), and a product is three MFMAs,
+// W.x = Whi.xhi + (Whi.xlo + Wlo.xhi) / 2048 (two fp32 accumulators, combined once): ~22 mantissa bits, no fp16 rounding of weights
+// or activations left on the decoder's residual path.  opd_split_f16: host-side split of a weight matrix.
+void opd_split_f16(const float* w, size_t n, f16_t* hi, f16_t* lo);   // host
+struct DecQkvParams {   // [previous layer: h = LN3(h_in + b2 + sum partials)] ; q | k | v = h . Wqkv^T + bias[row % Q]
+    const float* h_in;       // [M][256] residual stream before the previous layer's FFN (null with partials == null: h_out is the input)
+    const float* partials;   // [nsplit][M][256] fp32 partial sums of the previous layer's FFN-2 (null: no reduce / LayerNorm, h = h_out as it is)
+    int nsplit;
+    const float* b2;         // [256] that FFN-2's bias
+    const float *ln_g, *ln_b;
+    float* h_out;            // [M][256] the layer's input state (written by the q workgroups when partials != null; read otherwise)
+    const f16_t *w_hi, *w_lo;   // [768][256] = [Wq; Wk; Wv]
+    const float* bias;       // [Q][768] row-periodic: query-position fold + biases (fp32)
+    f16_t *q16, *k16;        // [M][256]
+    f16_t* vT;               // [B][8][32][128]: v transposed per (frame, head): [dim][key]
+    int M, Q;
+};
+hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream);
+struct DecSelfParams {  // self-attention of one (frame, 16-query slab) + o-proj + residual + LayerNorm + the cross-attention query projection
+    const f16_t *q16, *k16, *vT;
+    float* h;                // [M][256] in: the layer's input state (residual), out: LayerNorm output
+    const f16_t *wo_hi, *wo_lo;   // [256][256]
+    const float *bo, *ln_g, *ln_b;
+    const f16_t *wq_hi, *wq_lo;   // cross-attention q_proj [256][256]
+    const float* rbq;        // [Q][256]: query-position fold + bias of that projection
+    f16_t* qc16;             // [M][256] out
+    int B, Q;
+    float scale;
+};
+hipError_t opd_launch_dec_self(const DecSelfParams& p, hipStream_t stream);
+struct DecCrossOutParams {   // combine the key splits of the cross-attention, o-proj + residual + LayerNorm
+    const float* part_o;     // [splits][M][256] unnormalised sum_k p v per split
+    const float* part_ml;    // [splits][M][8][2]: (exponent reference in the log2 domain, sum_k p) per split and head
+    int splits;
+    const float* res;        // residual rows [M][256], or [res_period][256] repeated per frame (layer 0: the constant state)
+    int res_period;
+    float* h;                // [M][256] out (may alias res when res_period == 0)
+    const f16_t *wo_hi, *wo_lo;
+    const float *bo, *ln_g, *ln_b;
+    int M;
+};
+hipError_t opd_launch_dec_cross_out(const DecCrossOutParams& p, hipStream_t stream);
+#define OPD_DEC_FFN_CHUNK 128   // hidden channels per workgroup of dec_ffn_kernel; partial sums: ffn / 128 slabs
+struct DecFfnParams {   // partial[c] = relu(h . W1[chunk c]^T + b1[chunk c]) . W2[:, chunk c]^T for 64-row slabs (bias b2 added by the consumer)
+    const float* h;          // [M][256]
+    const f16_t *w1_hi, *w1_lo;   // [F][256]
+    const float* b1;         // [F]
+    const f16_t *w2_hi, *w2_lo;   // [256][F]
+    float* partials;         // [F / 128][M][256]
+    int M, F;
+};
+hipError_t opd_launch_dec_ffn(const DecFfnParams& p, hipStream_t stream);
+
 // ---- attention (kernels_attn.hip) -----------------------------------------------------------------------------------
 // O[b][q][h*32 + d] = softmax(Q K^T * scale) V, head_dim 32; Q/K/V are fp16 row-major with independent leading dims:
 // Q at q_ptr[(b*Lq + i)*ldq + h*32 + d] etc.  Output fp16 [B*Lq][ldo].
@@ -228,5 +287,10 @@ struct AttnParams {
     const int32_t* key_valid;  // optional (device) [B][2] = (rows, cols) of the valid top-left rectangle of each frame's key map
     int key_row;               // key map row length (key k sits at (k / key_row, k % key_row)); used with key_valid
     unsigned long long* trace; // tools only (tools/trace_attn.py): per-workgroup phase sums [grid][12]; null in the model
+    // key-split form (the fused decoder's cross-attention): splits > 0 cuts the key tiles into `splits` contiguous ranges, one workgroup
+    // each; a workgroup writes its UNNORMALISED partial result part_o[split][b*Lq + q][h*32 + d] = sum_k p v (fp32) and
+    // part_ml[split][b*Lq + q][h][0..1] = (exponent reference of p in the log2 domain, sum_k p); `o` is unused
+    int splits;
+    float *part_o, *part_ml;
 };
 hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream);

@@ -7,251 +7,17 @@
 // kernels + fp32 bias, transformer residual stream fp32 [tokens][256] with an fp16 shadow feeding the MFMA GEMMs.
 // The sine position embedding is constant per (h, w), so pos.Wq / pos.Wk (+ biases) are folded into row-periodic
 // fp32 bias matrices at plan-build time and q/k/v become ONE GEMM over x per layer.
-#include <math.h>
-#include <stdlib.h>
-#include <string.h>
-
-#include <atomic>
-#include <memory>
 #include <new>
 #include <stdexcept>
-#include <mutex>
-#include <shared_mutex>
-#include <string>
-#include <vector>
 
-#include "../../include/opd_detr.h"
-#include "opd_kernels.h"
-#include "opd_loader.h"
-#include "opd_host.h"
-
-namespace opd {
-
-// (g_err / fail: opd_host.cpp)
-
-#define HIPCHK(expr)                                                                                           \
-    do {                                                                                                       \
-        hipError_t _e = (expr);                                                                                \
-        if (_e != hipSuccess)                                                                                  \
-            return fail(OPD_EHIP, std::string(#expr) + " failed: " + hipGetErrorString(_e) + " (" + __FILE__ + \
-                                      ":" + std::to_string(__LINE__) + ")");                                   \
-    } while (0)
-
-#define RCCHK(expr)            \
-    do {                       \
-        int _rc = (expr);      \
-        if (_rc != 0) return _rc; \
-    } while (0)
-
-struct Conv {
-    f16_t* w = nullptr;
-    f16_t* wp = nullptr;  // 1x1 only: the same weights K-permuted for the fused bottleneck tail (opd_permute_k32's order)
-    float* bias = nullptr;
-    int Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad = 0, K = 0;
-    bool stem = false;
-};
-struct Lin {
-    f16_t* w = nullptr;
-    float* b = nullptr;
-    int N = 0, K = 0;
-};
-struct LNp {
-    float* g = nullptr;
-    float* b = nullptr;
-};
-struct Block {
-    Conv c0, c1, c2, sc;
-    bool has_sc = false;
-    float* bias2sc = nullptr;   // c2.bias + sc.bias (fp32): the fused bottleneck tail adds the shortcut GEMM into the expand's accumulators
-    f16_t* w2sc = nullptr;      // [Cout][c2.K + sc.Cin] = [W2 | Wsc] per output channel: the dual-source expand GEMM of stages 3-4
-};
-struct EncLayer {
-    f16_t* wqkv = nullptr;  // [768][256] = [Wq; Wk; Wv]
-    float* bqkv = nullptr;  // [768] = [bq; bk; bv] (pos_shadow path: plain bias vector)
-    Lin o, fc1, fc2;
-    LNp ln1, ln2;
-};
-struct DecLayer {
-    f16_t* wqkv = nullptr;  // self-attention [768][256]
-    f16_t* wq_c = nullptr;  // cross-attention query projection [256][256]
-    Lin so, co, fc1, fc2;
-    LNp ln1, ln2, ln3;
-    float* rb_self = nullptr;  // [Q][768] = qpos.[Wq;Wk;0]^T + [bq;bk;bv]
-    float* rb_q = nullptr;     // [Q][256] = qpos.Wq_c^T + bq_c
-};
-
-struct Plan {  // everything that depends on the feature-map size (h, w)
-    int fh = 0, fw = 0;
-    int vh = 0, vw = 0;          // valid (unpadded) rows / columns of the feature map this fold was built for (== fh, fw unless ragged)
-    std::vector<float*> rb_enc;  // per encoder layer [hw][768]
-    float* rb_kv = nullptr;      // [hw][dec_layers*512]
-    float* d_pos = nullptr;      // [hw][256] the sine position embedding itself (pos_shadow path)
-};
-
-struct Dims {
-    int B, H, W, H1, W1, H2, W2;
-    int sh[4], sw[4];
-};
-
-static int down2(int n) { return (n - 1) / 2 + 1; }
-
-}  // namespace opd
+#include "opd_model.h"
 
 using namespace opd;
 
-// Device buffers of the folded weights: shared (read-only after opd_detr_create) by a handle and its clones, freed with the last one.
-struct RedZoned { void* base; size_t bytes; int poison; };   // a poison-mode allocation: [red zone | bytes | red zone] at base
-struct WeightSet {
-    std::vector<void*> allocs;
-    std::vector<RedZoned> zoned;
-    int device = 0;
-    // per-resolution bias folds (Plan): functions of the weights and the feature-map size only, so clones share them too
-    std::mutex plan_mu;
-    std::vector<std::unique_ptr<Plan>> plans;
-    ~WeightSet() {
-        (void)hipSetDevice(device);
-        for (void* p : allocs) (void)hipFree(p);
-    }
-};
-
-struct opd_detr {
-    Arch arch;
-    opd_config cfg{};
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;   // second branch of the forward (stage-3 frame split, see enqueue_forward); joins the capture of `stream`
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    std::vector<void*> allocs;              // this handle's own buffers: workspace, per-resolution plans
-    std::vector<RedZoned> zoned;            // poison mode only: the same buffers with their red zones
-    std::shared_ptr<WeightSet> weights;     // the model's weights (shared with clones)
-    bool weights_sealed = false;            // set once the weights are built: later "weight" allocations (plans) are the handle's own
-    int64_t weight_bytes = 0, workspace_bytes = 0;
-
-    Conv stem;
-    std::vector<Block> blocks;
-    std::vector<int> stage_first;  // index of first block of each stage
-    Conv proj;
-    std::vector<EncLayer> enc;
-    std::vector<DecLayer> dec;
-    f16_t* wkv_all = nullptr;  // [dec_layers*512][256] = per layer [Wk_c; Wv_c]
-    float* bkv_all = nullptr;  // [dec_layers*512] = per layer [bk_c; bv_c] (pos_shadow path)
-    float* dec0_h = nullptr;   // [256]: decoder state after the self-attention block of layer 0 (input independent, see build_weights)
-    int fuse_dec0 = 1;         // use it (0: run that block's four launches on the zero state like every other layer)
-    LNp dec_ln;
-    float *wc = nullptr, *bc = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
-    float* zero_bias = nullptr;  // [3072] zeros
-
-    // host copies needed to build plans for new resolutions
-    std::vector<std::vector<float>> h_enc_cat_w, h_enc_cat_b;  // per enc layer: [768*256] ([Wq;Wk;0]), [768]
-    std::vector<float> h_kv_cat_w, h_kv_cat_b;                 // [L*512*256] ([Wk;0] per layer), [L*512]
-
-    // workspace
-    uint8_t* d_u8 = nullptr;
-    float* d_pv = nullptr;
-    f16_t *d_x4 = nullptr, *d_stem = nullptr, *d_pool = nullptr, *d_t0 = nullptr, *d_t1 = nullptr, *d_m0 = nullptr,
-          *d_m1 = nullptr, *d_sc = nullptr;
-    float *d_x32 = nullptr, *d_y32 = nullptr, *d_slab = nullptr;
-    f16_t* d_xp16 = nullptr;   // fp16(x + position embedding): the q / k projections' input (pos_shadow)
-    f16_t *d_x16 = nullptr, *d_qkv16 = nullptr, *d_attn16 = nullptr, *d_ffn16 = nullptr, *d_memkv16 = nullptr;
-    float *d_h32 = nullptr, *d_yd32 = nullptr, *d_hs32 = nullptr;
-    f16_t *d_h16 = nullptr, *d_qkvd16 = nullptr, *d_qd16 = nullptr, *d_attnd16 = nullptr, *d_ffnd16 = nullptr;
-    float *d_logits = nullptr, *d_boxes = nullptr;
-    opd_det* d_records = nullptr;
-    int32_t *d_counts = nullptr, *d_orig_hw = nullptr;
-    // ragged batches (frames smaller than the canvas): per-frame valid sizes and per-frame bias-fold pointers
-    int32_t *d_valid_hw = nullptr, *d_key_valid = nullptr;
-    const float** d_bias_ptrs = nullptr;   // [(enc_layers + 2)][max_batch]: bias folds per encoder layer, K/V fold, position embeddings
-    std::vector<int32_t> h_valid_hw, h_key_valid;
-    std::vector<const float*> h_bias_ptrs;
-    // asynchronous submissions (opd_detr_detect_async): one completion event per in-flight ticket
-    hipEvent_t ev_async[4] = {};
-    unsigned async_next = 0;
-    bool async_pending[4] = {};   // ticket handed out and not yet waited for: its slot (event, output pointers, staging) is in use
-    // host-output submissions: the records travel device -> pinned slot (asynchronous) -> caller buffer (in opd_detr_wait)
-    struct AsyncHost { void* pinned = nullptr; opd_det* out = nullptr; int32_t* counts = nullptr; int B = 0; };
-    AsyncHost async_host[4];
-    // device-side resize (camera resolution -> model resolution): source staging (grown on demand) and coefficient tables
-    uint8_t* d_src = nullptr;
-    size_t src_bytes = 0;
-    struct ResizeTab { int h, w, oh, ow, ksh, ksv; int32_t *bh, *kh, *bv, *kv; };
-    std::vector<ResizeTab> resize_tabs;
-    float *d_amap = nullptr, *d_amap_stat = nullptr;   // opd_detr_attention_map: output [hw], row statistics
-    int32_t* d_amap_sel = nullptr;
-    bool last_ragged = false;
-    int32_t* d_rois = nullptr;
-    float* d_roi_out = nullptr;
-    std::vector<int32_t> h_orig_hw;
-
-    // state of the last forward
-    int last_B = 0, last_H = 0, last_W = 0, last_fh = 0, last_fw = 0;
-    bool profiling = false;
-    hipEvent_t ev[9] = {};
-    float stage_ms[8] = {};
-    int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
-    int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)
-    int deep_fc2 = 1;        // encoder FFN-2 (K = 2048) + residual + LayerNorm as ONE row-owner launch (0: split-K slabs + reduce launch)
-    int fuse_btail = 1;      // stages 1-2: 3x3 -> expand + residual -> next reduce in one kernel (0: three launches)
-    int tail_rev = 1;        // consecutive fused tails walk their tiles in opposite directions (Infinity Cache reuse of the block output)
-    int tail3 = 1;           // stage 3 (256-channel blocks) through the eight-wave fused tail (kernels_btail3.hip) where it pays (see run_blocks);
-                             // 0: never (three launches per block), 2: always
-    int num_cus = 256;
-    int tail3_split = 1;     // stage 3: frames beyond whole rounds of the fused tail run as a second chain on `stream2` (0: one launch per tail)
-    int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
-    int trunk_subbatch = 0;  // > 0: stages 1-2 run this many frames at a time (Infinity-Cache-sized block outputs); 0: whole batch
-    int fuse_shortcut = 1;   // first block of stage 1: the shortcut convolution as a second GEMM inside the fused tail (0: own launch)
-    int fuse_stem_pool = 1;  // stem conv + max-pool in one kernel (0: two kernels, for cross-checking)
-    int pos_shadow = 1;      // q / k projections read a second fp16 shadow "x + position embedding" (written by the producer of x) instead
-                             // of adding a row-periodic fp32 bias table W.pos + b per output tile (0: the table, the round-1 form)
-    int fuse_prep = 1;       // uint8 frames: pre-processing inside that kernel (0: preprocess_u8_kernel writes the padded NHWC4 image first)
-
-    // hipGraph cache: the whole forward (~180 launches, many of them 5-10 us decoder kernels) replayed as one graph
-    struct GraphEntry { int B, H, W, fmt, fh, fw; const void* pixels; int uses; hipGraphExec_t exec; unsigned epoch; };
-    std::vector<GraphEntry> graphs;
-
-    // per-kernel-class timing (profiling mode only): event pairs around every launch of the last forward
-    struct Timed { int cls; hipEvent_t a, b; double flops; };
-    std::vector<Timed> timed;           // pairs used by the current forward
-    std::vector<hipEvent_t> event_pool;  // all events ever created (reused across forwards)
-    size_t pool_next = 0;
-    float class_ms[4] = {};
-    int class_launches[4] = {};
-    double class_flops[4] = {};
-
-    // diagnostic taps (opd_test_set_taps): a checksum launch after every launch of the forward, captured into the graph with it
-    int taps = 0;
-    unsigned long long* d_taps = nullptr;   // [OPD_MAX_TAPS][OPD_TAP_BLOCKS]
-    int tap_next = 0;
-    std::vector<std::string> tap_names;
-};
-enum { OPD_MAX_TAPS = 512 };
 
 namespace opd {
 
-// Diagnostic allocation mode (opd_test_set_alloc_poison; -1 = off): every device buffer of handles created afterwards is filled with
-// this byte and sits between two red zones of OPD_REDZONE bytes filled with it as well.  A forward that reads workspace it has not
-// written, or memory next to its buffers, then gives results that depend on the byte: tests/test_detector_gpu.py runs the same
-// batches through handles poisoned with 0x00 / 0xFF (fp16 and fp32 NaN patterns) and an unpoisoned one and demands identical bits.
-static std::atomic<int> g_alloc_poison{-1};
-enum : size_t { OPD_REDZONE = 256 * 1024 };
-
-template <typename T>
-static int dalloc(opd_detr* m, T** p, size_t count, bool weight) {
-    void* q = nullptr;
-    const size_t bytes = count * sizeof(T);
-    const int poison = g_alloc_poison.load();
-    const size_t pad = poison >= 0 ? OPD_REDZONE : 0, total = (bytes ? bytes : 16) + 2 * pad;
-    hipError_t e = hipMalloc(&q, total);
-    if (e != hipSuccess) return fail(OPD_ENOMEM, "hipMalloc of " + std::to_string(bytes) + " bytes failed: " + hipGetErrorString(e));
-    const bool to_weights = weight && !m->weights_sealed && m->weights;
-    (to_weights ? m->weights->allocs : m->allocs).push_back(q);   // (the base pointer: what hipFree takes)
-    if (poison >= 0) {
-        HIPCHK(hipMemset(q, poison, total));
-        (to_weights ? m->weights->zoned : m->zoned).push_back({q, bytes ? bytes : 16, poison});
-    }
-    (weight ? m->weight_bytes : m->workspace_bytes) += (int64_t)bytes;
-    *p = reinterpret_cast<T*>(static_cast<char*>(q) + pad);
-    return OPD_OK;
-}
+std::atomic<int> g_alloc_poison{-1};   // opd_model.h: diagnostic allocation mode
 
 static int upload_f32(opd_detr* m, float** dst, const std::vector<float>& v) {
     RCCHK(dalloc(m, dst, v.size(), true));
@@ -263,6 +29,17 @@ static int upload_f16(opd_detr* m, f16_t** dst, const std::vector<float>& v) {
     for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_f16(v[i]);
     RCCHK(dalloc(m, dst, h.size(), true));
     HIPCHK(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    return OPD_OK;
+}
+
+// a linear layer's weights as the split pair of the fused decoder (opd_split_f16: hi = fp16(w), lo = fp16((w - hi) * 2048))
+static int upload_split(opd_detr* m, f16_t** hi, f16_t** lo, const std::vector<float>& v) {
+    std::vector<f16_t> h(v.size()), l(v.size());
+    opd_split_f16(v.data(), v.size(), h.data(), l.data());
+    RCCHK(dalloc(m, hi, h.size(), true));
+    RCCHK(dalloc(m, lo, l.size(), true));
+    HIPCHK(hipMemcpy(*hi, h.data(), h.size() * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(*lo, l.data(), l.size() * 2, hipMemcpyHostToDevice));
     return OPD_OK;
 }
 
@@ -287,12 +64,18 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
     if (Cin == 3) {  // stem: [64][8][8][4], zero padded (kh = 7, kw = 7, c = 3)
         c->stem = true;
         c->K = 256;
-        wt.assign((size_t)Cout * 256, 0.f);
+        std::vector<float> cw((size_t)Cout * 147);   // folded, [o][kh][kw][ci] without the padding: what gets rounded
         for (int o = 0; o < Cout; ++o)
             for (int ci = 0; ci < 3; ++ci)
                 for (int kh = 0; kh < 7; ++kh)
                     for (int kw = 0; kw < 7; ++kw)
-                        wt[(size_t)o * 256 + kh * 32 + kw * 4 + ci] = w.data[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * scale[o];
+                        cw[(size_t)o * 147 + (kh * 7 + kw) * 3 + ci] = w.data[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * scale[o];
+        if (m->wround) round_f16_diffused(cw.data(), (size_t)Cout, 49, 3);
+        wt.assign((size_t)Cout * 256, 0.f);
+        for (int o = 0; o < Cout; ++o)
+            for (int kh = 0; kh < 7; ++kh)
+                for (int kw = 0; kw < 7; ++kw)
+                    for (int ci = 0; ci < 3; ++ci) wt[(size_t)o * 256 + kh * 32 + kw * 4 + ci] = cw[(size_t)o * 147 + (kh * 7 + kw) * 3 + ci];
     } else {
         c->K = KH * KW * Cin;
         wt.resize((size_t)Cout * c->K);
@@ -302,6 +85,8 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
                     for (int kw = 0; kw < KW; ++kw)
                         wt[(size_t)o * c->K + (size_t)(kh * KW + kw) * Cin + ci] =
                             w.data[(((size_t)o * Cin + ci) * KH + kh) * KW + kw] * scale[o];
+        // the fp16 image of the folded kernel: error diffusion along the reduction (opd_host.h) instead of round-to-nearest
+        if (m->wround) round_f16_diffused(wt.data(), (size_t)Cout, KH * KW, Cin);
     }
     RCCHK(upload_f16(m, &c->w, wt));
     if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 1024) {  // operands of kernels_btail.hip / kernels_btail3.hip (stages 1-3)
@@ -442,6 +227,13 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln3));
+        // split pairs for the fused decoder
+        RCCHK(upload_split(m, &L.wqkv_hi, &L.wqkv_lo, wfull));
+        RCCHK(upload_split(m, &L.so_hi, &L.so_lo, T(sd, p + ".self_attn.o_proj.weight").data));
+        RCCHK(upload_split(m, &L.wqc_hi, &L.wqc_lo, T(sd, p + ".encoder_attn.q_proj.weight").data));
+        RCCHK(upload_split(m, &L.co_hi, &L.co_lo, T(sd, p + ".encoder_attn.o_proj.weight").data));
+        RCCHK(upload_split(m, &L.fc1_hi, &L.fc1_lo, T(sd, p + ".mlp.fc1.weight").data));
+        RCCHK(upload_split(m, &L.fc2_hi, &L.fc2_lo, T(sd, p + ".mlp.fc2.weight").data));
     }
     RCCHK(upload_f16(m, &m->wkv_all, kv_full));
     RCCHK(upload_f32(m, &m->bkv_all, m->h_kv_cat_b));
@@ -469,6 +261,19 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         const float rstd = 1.0f / sqrtf(var + 1e-5f);
         for (int n = 0; n < D; ++n) c[n] = (x[n] - mean) * rstd * g[n] + be[n];
         RCCHK(upload_f32(m, &m->dec0_h, c));
+        // ... and so are layer 0's cross-attention queries, (h1 + qpos) . Wq_c^T + bq_c: one [Q][D] table (fp32 sums, stored as the fp16 operand
+        // the attention kernel reads)
+        const auto& qpos = T(sd, "model.query_position_embeddings.weight").data;
+        const auto& wq = T(sd, p0 + ".encoder_attn.q_proj.weight").data;
+        const auto& bq = T(sd, p0 + ".encoder_attn.q_proj.bias").data;
+        std::vector<float> q0((size_t)Q * D);
+        for (int q = 0; q < Q; ++q)
+            for (int n = 0; n < D; ++n) {
+                double acc = bq[n];
+                for (int k = 0; k < D; ++k) acc += ((double)c[k] + qpos[(size_t)q * D + k]) * wq[(size_t)n * D + k];
+                q0[(size_t)q * D + n] = (float)acc;
+            }
+        RCCHK(upload_f16(m, &m->qc0, q0));
     }
     RCCHK(make_ln(m, sd, "model.decoder.layernorm", &m->dec_ln));
     auto transposed = [&](const std::string& key) {  // [out][in] -> [in][out] (coalesced reads in heads_kernel)
@@ -498,6 +303,16 @@ static void compute_dims(int B, int H, int W, Dims* d) {
     d->H2 = down2(d->H1); d->W2 = down2(d->W1);
     d->sh[0] = d->H2; d->sw[0] = d->W2;
     for (int s = 1; s < 4; ++s) { d->sh[s] = down2(d->sh[s - 1]); d->sw[s] = down2(d->sw[s - 1]); }
+}
+
+// Layer 0's cross-attention queries do not depend on the frames (build_weights: qc0): the fused decoder reads them from layer 0's region of
+// d_qd16, where opd_detr_attention_map finds them too; written once per handle, every frame slot (and again by the test hooks that
+// switch between the fused and the unfused decoder, whose layer 0 writes its own rounding of the same values there).
+int fill_qc0(opd_detr* m) {
+    if (!m->qc0 || !m->d_qd16) return OPD_OK;
+    const size_t QD = (size_t)m->arch.queries * m->arch.d_model;
+    for (int b = 0; b < m->cfg.max_batch; ++b) HIPCHK(hipMemcpy(m->d_qd16 + b * QD, m->qc0, QD * 2, hipMemcpyDeviceToDevice));
+    return OPD_OK;
 }
 
 static int build_workspace(opd_detr* m) {
@@ -552,6 +367,13 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_amap_sel, (size_t)a.queries, false));
     RCCHK(dalloc(m, &m->d_attnd16, Md * D, false));
     RCCHK(dalloc(m, &m->d_ffnd16, Md * a.ffn, false));
+    RCCHK(dalloc(m, &m->d_dq16, Md * D, false));
+    RCCHK(dalloc(m, &m->d_dk16, Md * D, false));
+    RCCHK(dalloc(m, &m->d_dvT, B * D * 128, false));
+    RCCHK(dalloc(m, &m->d_part_o, (size_t)m->dec_splits * Md * D, false));
+    RCCHK(dalloc(m, &m->d_part_ml, (size_t)m->dec_splits * Md * a.heads * 2, false));
+    RCCHK(dalloc(m, &m->d_ffn_part, (size_t)(a.ffn / OPD_DEC_FFN_CHUNK + 1) * Md * D, false));
+    RCCHK(fill_qc0(m));
     RCCHK(dalloc(m, &m->d_logits, Md * a.ncls, false));
     RCCHK(dalloc(m, &m->d_boxes, Md * 4, false));
     RCCHK(dalloc(m, &m->d_records, Md, false));
@@ -1001,15 +823,18 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             TrunkState ta = st, tb = st;
             HIPCHK(hipEventRecord(m->ev_fork, m->stream));
             HIPCHK(hipStreamWaitEvent(m->stream2, m->ev_fork, 0));
-            RCCHK(run_blocks(2, 3, 0, nbA, ta, 1));
+            // whatever happens in either chain, `stream2` is rejoined before this function returns (an unjoined fork would leak into
+            // the next forward's events, or leave a capture with a dangling branch) and m->stream is the main stream again
             hipStream_t main_stream = m->stream;
+            const int rc_a = run_blocks(2, 3, 0, nbA, ta, 1);
             m->stream = m->stream2;
-            const int rc_b = run_blocks(2, 3, nbA, B - nbA, tb, 1);
-            const hipError_t ej = hipEventRecord(m->ev_join, m->stream);
+            const int rc_b = rc_a == OPD_OK ? run_blocks(2, 3, nbA, B - nbA, tb, 1) : OPD_OK;
             m->stream = main_stream;
+            const hipError_t ej = hipEventRecord(m->ev_join, m->stream2);
+            const hipError_t ew = ej == hipSuccess ? hipStreamWaitEvent(m->stream, m->ev_join, 0) : ej;
+            RCCHK(rc_a);
             RCCHK(rc_b);
-            HIPCHK(ej);
-            HIPCHK(hipStreamWaitEvent(m->stream, m->ev_join, 0));
+            HIPCHK(ew);
             st = ta;
         } else {
             RCCHK(run_blocks(2, 3, 0, B, st, 1));
@@ -1063,8 +888,9 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         }
         {
             RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
-            // (fc2 + residual + LayerNorm as ONE row-owner launch — gemm_ln256_kernel with K = 2048 — was measured: encoder 1.05 ms
-            //  against 1.00 ms; every 32-row workgroup would stream the whole 1 MiB of fc2 weights)
+            // fc2 + residual + LayerNorm (+ the position shadow) as ONE row-owner launch of the three-stage ring kernel: 36.9 us in the
+            // forward against 19.4 + 12.2 us for split-K slabs + reduce, but 514 MB less HBM traffic per forward and half the CUs left to
+            // other batches (+1.3 % with three streams, -5 us per layer for a lone stream; profiles/NOTES.md "Deep-K row owners")
             if (deep_ok && F % 64 == 0 && (size_t)M * F * 2 < 0x7fffff00ull) {
                 RCCHK(run_deep(m->d_ffn16, nullptr, L.fc2.w, L.fc2.b, F, m->d_x32, &L.ln2, CLS_GEMM));
             } else {
@@ -1080,6 +906,71 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     else
         RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs, 2 * D, D));   // (per layer [k | v]: pos enters k only)
     const bool dec0 = m->fuse_dec0 && m->dec0_h && D == 256;
+    // The fused decoder (kernels_dec.hip): five launches per layer on split fp16 operands; layer 0 starts at its cross-attention (its
+    // self-attention block and its queries are constants of the weights).  Taken when the architecture fits the kernels' fixed shapes.
+    const bool fused_dec = m->fused_dec && dec0 && m->qc0 && a.heads == 8 && Q <= 128 && (Q & 3) == 0 && F % OPD_DEC_FFN_CHUNK == 0 && F / OPD_DEC_FFN_CHUNK <= 16 && m->dec_splits <= 6 && m->dec[0].wqkv_hi &&
+                           (size_t)M * NKV * 2 < (1ull << 32);
+    const float* dec_final_h = m->d_h32;   // the state the heads read (fused: before the last FFN, whose partial sums travel with it)
+    if (fused_dec) {
+        const int S = m->dec_splits, nchunk = F / OPD_DEC_FFN_CHUNK;
+        float* hbuf[2] = {m->d_h32, m->d_yd32};
+        int cur = 0;   // hbuf[cur] holds the layer's state from its self-attention block on
+        for (int i = 0; i < a.dec_layers; ++i) {
+            const DecLayer& L = m->dec[i];
+            f16_t* qd = m->d_qd16 + (size_t)i * m->cfg.max_batch * Q * D;   // (per-layer regions of max_batch frames: layer 0's constants stay put)
+            if (i > 0) {
+                const DecLayer& P = m->dec[i - 1];
+                DecQkvParams qp{};
+                qp.h_in = hbuf[cur]; qp.partials = m->d_ffn_part; qp.nsplit = nchunk; qp.b2 = P.fc2.b; qp.ln_g = P.ln3.g; qp.ln_b = P.ln3.b;
+                qp.h_out = hbuf[cur ^ 1]; qp.w_hi = L.wqkv_hi; qp.w_lo = L.wqkv_lo; qp.bias = L.rb_self;
+                qp.q16 = m->d_dq16; qp.k16 = m->d_dk16; qp.vT = m->d_dvT; qp.M = Md; qp.Q = Q;
+                RCCHK(timed_begin(m, CLS_GEMM, 2.0 * Md * 768.0 * D));
+                HIPCHK(opd_launch_dec_qkv(qp, m->stream));
+                RCCHK(timed_end(m));
+                cur ^= 1;
+                RCCHK(tap(m, "dec_qkv_h", hbuf[cur], (size_t)Md * D * 4));
+                DecSelfParams sp{};
+                sp.q16 = m->d_dq16; sp.k16 = m->d_dk16; sp.vT = m->d_dvT; sp.h = hbuf[cur]; sp.wo_hi = L.so_hi; sp.wo_lo = L.so_lo; sp.bo = L.so.b;
+                sp.ln_g = L.ln1.g; sp.ln_b = L.ln1.b; sp.wq_hi = L.wqc_hi; sp.wq_lo = L.wqc_lo; sp.rbq = L.rb_q; sp.qc16 = qd; sp.B = B; sp.Q = Q;
+                sp.scale = 1.0f / sqrtf((float)(D / a.heads));
+                RCCHK(timed_begin(m, CLS_GEMM, 4.0 * Md * (double)D * D + 4.0 * B * (double)a.heads * Q * Q * 32));
+                HIPCHK(opd_launch_dec_self(sp, m->stream));
+                RCCHK(timed_end(m));
+                RCCHK(tap(m, "dec_self_h", hbuf[cur], (size_t)Md * D * 4));
+            }
+            {   // cross-attention over S key ranges: unnormalised partials
+                AttnParams ap{};
+                ap.q = qd; ap.k = m->d_memkv16 + (size_t)i * 2 * D; ap.v = m->d_memkv16 + (size_t)i * 2 * D + D; ap.o = nullptr;
+                ap.B = B; ap.heads = a.heads; ap.Lq = Q; ap.Lk = hw; ap.ldq = D; ap.ldk = NKV; ap.ldv = NKV; ap.ldo = D;
+                ap.scale = 1.0f / sqrtf((float)(D / a.heads)); ap.key_valid = d_keyv; ap.key_row = cw;
+                ap.splits = S; ap.part_o = m->d_part_o; ap.part_ml = m->d_part_ml;
+                RCCHK(timed_begin(m, CLS_ATTN, 4.0 * B * (double)a.heads * Q * hw * 32));
+                HIPCHK(opd_launch_attention(ap, m->stream));
+                RCCHK(timed_end(m));
+                RCCHK(tap(m, "dec_cross_part", m->d_part_o, (size_t)S * Md * D * 4));
+            }
+            {
+                DecCrossOutParams cp{};
+                cp.part_o = m->d_part_o; cp.part_ml = m->d_part_ml; cp.splits = S;
+                cp.res = i == 0 ? m->dec0_h : hbuf[cur]; cp.res_period = i == 0 ? 1 : 0; cp.h = hbuf[cur];
+                cp.wo_hi = L.co_hi; cp.wo_lo = L.co_lo; cp.bo = L.co.b; cp.ln_g = L.ln2.g; cp.ln_b = L.ln2.b; cp.M = Md;
+                RCCHK(timed_begin(m, CLS_GEMM, 2.0 * Md * (double)D * D));
+                HIPCHK(opd_launch_dec_cross_out(cp, m->stream));
+                RCCHK(timed_end(m));
+                RCCHK(tap(m, "dec_cross_h", hbuf[cur], (size_t)Md * D * 4));
+            }
+            {
+                DecFfnParams fp{};
+                fp.h = hbuf[cur]; fp.w1_hi = L.fc1_hi; fp.w1_lo = L.fc1_lo; fp.b1 = L.fc1.b; fp.w2_hi = L.fc2_hi; fp.w2_lo = L.fc2_lo;
+                fp.partials = m->d_ffn_part; fp.M = Md; fp.F = F;
+                RCCHK(timed_begin(m, CLS_GEMM, 4.0 * Md * (double)D * F));
+                HIPCHK(opd_launch_dec_ffn(fp, m->stream));
+                RCCHK(timed_end(m));
+                RCCHK(tap(m, "dec_ffn_part", m->d_ffn_part, (size_t)nchunk * Md * D * 4));
+            }
+        }
+        dec_final_h = hbuf[cur];
+    } else {
     if (dec0) {
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
         HIPCHK(opd_launch_broadcast_rows(m->dec0_h, m->d_h32, m->d_h16, Md, m->stream));
@@ -1101,7 +992,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         else
             RCCHK(run_gemm_splitk_ln(m, m->d_attnd16, L.so.w, L.so.b, Md, D, D, 4, m->d_h32, &L.ln1, m->d_h32, m->d_h16, CLS_GEMM));
         }
-        f16_t* qd = m->d_qd16 + (size_t)i * Md * D;
+        f16_t* qd = m->d_qd16 + (size_t)i * m->cfg.max_batch * Q * D;
         if (small) RCCHK(run_small_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, qd, false));
         else RCCHK(run_gemm(m, m->d_h16, L.wq_c, L.rb_q, Q, Md, D, D, qd, false, false, nullptr));
         RCCHK(run_attn(m, qd, D, m->d_memkv16 + (size_t)i * 2 * D, NKV, m->d_memkv16 + (size_t)i * 2 * D + D, NKV,
@@ -1118,8 +1009,13 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(run_gemm_splitk_ln(m, m->d_ffnd16, L.fc2.w, L.fc2.b, Md, D, F, 8, m->d_h32, &L.ln3, m->d_h32, m->d_h16, CLS_GEMM));
         }
     }
+    }
     HeadParams hp{};
-    if (m->fuse_gemm_ln) {   // the final LayerNorm runs inside the heads kernel
+    if (fused_dec) {   // the last layer's FFN sum + LN3 and the final LayerNorm run inside the heads kernel
+        const DecLayer& P = m->dec[a.dec_layers - 1];
+        hp.hs = dec_final_h; hp.partials = m->d_ffn_part; hp.nsplit = F / OPD_DEC_FFN_CHUNK; hp.ffn_b2 = P.fc2.b; hp.ln3_gamma = P.ln3.g; hp.ln3_beta = P.ln3.b;
+        hp.ln_gamma = m->dec_ln.g; hp.ln_beta = m->dec_ln.b;
+    } else if (m->fuse_gemm_ln) {   // the final LayerNorm runs inside the heads kernel
         hp.hs = m->d_h32; hp.ln_gamma = m->dec_ln.g; hp.ln_beta = m->dec_ln.b;
     } else {
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
@@ -1138,41 +1034,10 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     return OPD_OK;
 }
 
-// Stream capture and other threads: the Python shim drives several handles from worker threads (HipDetrDetector(streams=N)).
-// ROCm invalidates a capture in progress when ANOTHER thread allocates or frees memory, pins host memory or runs its
-// one-time eager setup meanwhile, even in thread-local capture mode ("operation failed due to a previous error during
-// capture").  Every entry point therefore holds this lock shared; a capture takes it exclusively for its few milliseconds.
-static std::shared_mutex g_api_mu;
-// Handle churn and captured graphs.  Round 2 saw replays of a graph captured BEFORE another handle was destroyed and a third one
-// created give wrong (finite or NaN) outputs, while the same launches issued eagerly stayed bit-exact; re-capturing after every
-// handle creation / destruction (this epoch) made the symptom go away.  Round 3 went after the cause (profiles/r03_graph_churn_*.txt,
-// tools/graph_churn_probe.py, tools/fresh_box_probe.sh) and did NOT find one:
-//   * the round-2 binary with the guard patched out reproduced the corruption ONCE (first GPU process of a freshly acquired box) and
-//     then 0 times in 22 further runs, 17 of them as the first GPU process of a fresh container; HEAD with the guard off: 0 of 26;
-//   * per-launch checksum taps captured INTO the graph (opd_test_set_taps) never differed between capture run and replay;
-//   * with every device buffer pre-filled with 0x00 / 0xFF and fenced by 256-KiB red zones (opd_test_set_alloc_poison) outputs are
-//     bit-identical to an unpoisoned handle and every red zone stays intact, at HEAD and at the round-2 revision: no kernel reads
-//     memory it has not written or writes next to its buffers (tests/test_workloads_gpu.py keeps this under test);
-//   * foreign allocations between capture and replay (torch's caching allocator: 1 GiB of NaNs allocated, freed to the driver,
-//     re-allocated; an RCCL communicator created and destroyed), pinned or pageable staging, captured memset nodes: no effect.
-// The guard therefore stays as a cheap belt-and-braces measure against an unreproduced fault, not as a fix of a known cause; the
-// regression test is test_graph_replay_survives_foreign_allocations_and_handle_churn, which runs with the guard OFF.
-static std::atomic<unsigned> g_handle_epoch{0};
-static std::atomic<int> g_graph_guard{1};   // opd_test_set_graph_guard(0): leave stale-epoch graphs alone (diagnosis only)
-static thread_local std::shared_lock<std::shared_mutex>* tl_api_lock = nullptr;
-struct ApiScope {   // first statement of every HIP-calling entry point; entry points calling each other nest harmlessly
-    std::shared_lock<std::shared_mutex> lk;
-    bool outer;
-    ApiScope() : lk(g_api_mu, std::defer_lock), outer(tl_api_lock == nullptr) {
-        if (outer) { lk.lock(); tl_api_lock = &lk; }
-    }
-    ~ApiScope() { if (outer) tl_api_lock = nullptr; }
-};
-struct CaptureExclusive {   // the calling thread's shared hold is handed back for the duration
-    std::shared_lock<std::shared_mutex>* s;
-    CaptureExclusive() : s(tl_api_lock) { if (s) s->unlock(); g_api_mu.lock(); }
-    ~CaptureExclusive() { g_api_mu.unlock(); if (s) s->lock(); }
-};
+std::shared_mutex g_api_mu;
+std::atomic<unsigned> g_handle_epoch{0};
+std::atomic<int> g_graph_guard{1};   // opd_test_set_graph_guard(0): leave stale-epoch graphs alone (diagnosis only)
+thread_local std::shared_lock<std::shared_mutex>* tl_api_lock = nullptr;
 
 // Forward through the graph cache.  First call of a (shape, pixel pointer) key runs eagerly (one-time function-attribute
 // setup and plan building are not capturable); the second call captures the stream into a hipGraph; later calls replay it.
@@ -1212,15 +1077,21 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
         ec = hipStreamEndCapture(m->stream, &graph);
     }
     if (rc != OPD_OK) { if (graph) (void)hipGraphDestroy(graph); return rc; }
-    if (ec != hipSuccess || !graph) {  // capture refused: stay eager for this key
-        e->uses = -1000000;
+    // A refused capture or instantiation is an ERROR of the call, not a reason to go on eagerly without saying so (round 3 did): the
+    // caller asked for the graph path, and a runtime that rejects the recorded launch sequence has a reason a caller should see.
+    if (ec != hipSuccess || !graph) {
+        e->uses = 1;   // (the next call tries again)
         (void)hipGetLastError();
-        return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
+        return fail(OPD_EHIP, std::string("hipStreamEndCapture refused the forward: ") + hipGetErrorString(ec) + " (OPD_FLAG_NO_GRAPH runs eagerly)");
     }
     hipGraphExec_t exec = nullptr;
     const hipError_t ei = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
-    if (ei != hipSuccess) { e->uses = -1000000; (void)hipGetLastError(); return enqueue_forward(m, d_pixels, pixel_format, B, H, W); }
+    if (ei != hipSuccess) {
+        e->uses = 1;
+        (void)hipGetLastError();
+        return fail(OPD_EHIP, std::string("hipGraphInstantiate failed: ") + hipGetErrorString(ei) + " (OPD_FLAG_NO_GRAPH runs eagerly)");
+    }
     e->exec = exec; e->fh = m->last_fh; e->fw = m->last_fw; e->epoch = g_handle_epoch.load();
     HIPCHK(hipGraphLaunch(exec, m->stream));
     return OPD_OK;
@@ -1413,6 +1284,8 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
     if (const char* v = getenv("OPD_POS_SHADOW")) m->pos_shadow = atoi(v);
     if (const char* v = getenv("OPD_DEEP_FC2")) m->deep_fc2 = atoi(v);
+    if (const char* v = getenv("OPD_WROUND")) m->wround = atoi(v);
+    if (const char* v = getenv("OPD_FUSED_DEC")) m->fused_dec = atoi(v);
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1457,7 +1330,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
-    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0;
+    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->dec_splits = src->dec_splits; m->wround = src->wround;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());
@@ -1727,7 +1600,7 @@ int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xywh, int n
     return OPD_OK;
 }
 
-int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* queries, int n_queries, float* out) {
+int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* queries, int n_queries, float* out, int out_capacity) {
     ApiScope api_scope;
     if (!m || !out) return fail(OPD_EINVAL, "opd_detr_attention_map: null argument");
     if (m->last_B == 0) return fail(OPD_ESTATE, "opd_detr_attention_map called before any forward");
@@ -1743,8 +1616,11 @@ int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* que
     }
     HIPCHK(hipSetDevice(m->device));
     const int hw = m->last_fh * m->last_fw, NKV = L * 2 * D, Md = m->last_B * Q;
+    if (out_capacity < hw)
+        return fail(OPD_EINVAL, "opd_detr_attention_map: the last forward's map has " + std::to_string(m->last_fh) + " x " + std::to_string(m->last_fw) +
+                                    " positions, the output buffer holds " + std::to_string(out_capacity));
     HIPCHK(hipMemcpyAsync(m->d_amap_sel, sel.data(), sel.size() * 4, hipMemcpyHostToDevice, m->stream));
-    const f16_t* q = m->d_qd16 + (size_t)layer * Md * D + (size_t)frame * Q * D;
+    const f16_t* q = m->d_qd16 + (size_t)layer * m->cfg.max_batch * Q * D + (size_t)frame * Q * D;
     const f16_t* k = m->d_memkv16 + (size_t)frame * hw * NKV + (size_t)layer * 2 * D;
     const float scale = 1.0f / sqrtf((float)(D / m->arch.heads));
     HIPCHK(opd_launch_attention_map(q, D, k, NKV, m->d_amap_sel, (int)sel.size(), m->arch.heads, hw, scale,
@@ -1773,136 +1649,5 @@ int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, dou
     for (int i = 0; i < 4; ++i) { ms4[i] = m->class_ms[i]; launches4[i] = m->class_launches[i]; flops4[i] = m->class_flops[i]; }
     return OPD_OK;
 }
-
-// ---- test / diagnostic hooks (not part of include/opd_detr.h; used by tests/test_kernels_gpu.py) ----------------------
-// Pillow coefficient tables of the device resize (host only): bounds [out][2], coeffs [out][ksize]; returns ksize
-int opd_test_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int coeffs_capacity) {
-    std::vector<int32_t> b, k;
-    int ksize = 0;
-    opd_resize_coeffs(in_size, out_size, &b, &k, &ksize);
-    if ((int)k.size() > coeffs_capacity) return fail(OPD_EINVAL, "coefficient buffer too small");
-    memcpy(bounds, b.data(), b.size() * 4);
-    memcpy(coeffs, k.data(), k.size() * 4);
-    return ksize;
-}
-// host-only pieces of the ragged-batch path, exported for the CPU tests
-int opd_test_valid_prefix(int valid, int in, int out) { return valid_prefix(valid, in, out); }
-int opd_test_sine_pos_embed(int h, int w, int vh, int vw, int D, float* out) {
-    if (!out || h < 1 || w < 1 || vh < 1 || vw < 1 || vh > h || vw > w || D < 2 || (D & 1)) return fail(OPD_EINVAL, "bad sine_pos_embed arguments");
-    std::vector<float> pos;
-    sine_pos_embed(h, w, vh, vw, D, &pos);
-    memcpy(out, pos.data(), pos.size() * sizeof(float));
-    return OPD_OK;
-}
-int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->fuse_gemm_ln = on ? 1 : 0;
-    m->small_m_gemm = on ? 1 : 0;   // the switch covers the transformer-side specialisations
-    m->deep_fc2 = on ? 1 : 0;
-    m->fuse_dec0 = on ? 1 : 0;
-    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    m->graphs.clear();
-    return OPD_OK;
-}
-int opd_test_set_fuse_btail(opd_detr* m, int on) {   // bit 0: fused bottleneck tails, bit 1: the shortcut of stage 1 inside its first tail
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->fuse_btail = (on & 1) ? 1 : 0;
-    m->fuse_shortcut = (on & 2) ? 1 : 0;
-    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    m->graphs.clear();
-    return OPD_OK;
-}
-int opd_test_set_pos_shadow(opd_detr* m, int on) {   // 0: row-periodic bias tables W.pos + b (round-1 form) instead of the fp16(x + pos) shadow
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->pos_shadow = on ? 1 : 0;
-    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    m->graphs.clear();
-    return OPD_OK;
-}
-int opd_test_set_fuse_stem_pool(opd_detr* m, int on) {
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->fuse_stem_pool = (on & 1) ? 1 : 0;   // bit 0: stem + pool in one kernel; bit 1: pre-processing inside it as well
-    m->fuse_prep = (on & 2) ? 1 : 0;
-    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    m->graphs.clear();
-    return OPD_OK;
-}
-
-int opd_test_set_alloc_poison(int byte) {   // -1: off; 0 .. 255: fill byte for the buffers and red zones of handles created from now on
-    g_alloc_poison = byte < 0 ? -1 : (byte & 255);
-    return OPD_OK;
-}
-// Scans the red zones of a poison-mode handle (its own buffers and its weight set's): returns the number of buffers with a damaged
-// zone (0 = intact) and describes the first one in opd_last_error().
-int opd_test_check_redzones(opd_detr* m) {
-    ApiScope api_scope;
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipDeviceSynchronize());
-    std::vector<unsigned char> h(OPD_REDZONE);
-    int bad = 0;
-    std::string first;
-    auto scan = [&](const std::vector<RedZoned>& v, const char* what) -> int {
-        for (size_t i = 0; i < v.size(); ++i)
-            for (int side = 0; side < 2; ++side) {
-                const char* z = static_cast<const char*>(v[i].base) + (side ? OPD_REDZONE + v[i].bytes : 0);
-                HIPCHK(hipMemcpy(h.data(), z, OPD_REDZONE, hipMemcpyDeviceToHost));
-                size_t lo = OPD_REDZONE, hi = 0;
-                for (size_t k = 0; k < OPD_REDZONE; ++k)
-                    if (h[k] != (unsigned char)v[i].poison) { lo = std::min(lo, k); hi = k; }
-                if (lo <= hi) {
-                    if (!bad++) first = std::string(what) + " buffer #" + std::to_string(i) + " (" + std::to_string(v[i].bytes) + " bytes): " +
-                                        (side ? "zone BEHIND it" : "zone IN FRONT of it") + " overwritten at zone offsets " + std::to_string(lo) + " .. " + std::to_string(hi);
-                }
-            }
-        return OPD_OK;
-    };
-    RCCHK(scan(m->zoned, "handle"));
-    if (m->weights) RCCHK(scan(m->weights->zoned, "weight-set"));
-    if (bad) g_err = first;
-    return bad;
-}
-int opd_test_set_graph_guard(int on) {
-    g_graph_guard = on ? 1 : 0;
-    return OPD_OK;
-}
-// Diagnostic taps: after every launch of the forward a checksum launch of that launch's output (captured into the graph with it).
-int opd_test_set_taps(opd_detr* m, int on) {
-    ApiScope api_scope;
-    if (!m) return fail(OPD_EINVAL, "null model handle");
-    HIPCHK(hipSetDevice(m->device));
-    if (on && !m->d_taps) RCCHK(dalloc(m, &m->d_taps, (size_t)OPD_MAX_TAPS * OPD_TAP_BLOCKS, false));
-    m->taps = on ? 1 : 0;
-    for (auto& g : m->graphs)
-        if (g.exec) (void)hipGraphExecDestroy(g.exec);
-    m->graphs.clear();
-    return OPD_OK;
-}
-// sums[i] = checksum of tap i of the last forward, names = '\n'-joined tap names; returns the number of taps
-int opd_test_read_taps(opd_detr* m, unsigned long long* sums, int cap, char* names, int names_cap) {
-    ApiScope api_scope;
-    if (!m || !sums || !m->d_taps) return fail(OPD_EINVAL, "opd_test_read_taps: taps are not enabled");
-    HIPCHK(hipSetDevice(m->device));
-    HIPCHK(hipStreamSynchronize(m->stream));
-    const int n = std::min(cap, (int)m->tap_names.size());
-    std::vector<unsigned long long> h((size_t)n * OPD_TAP_BLOCKS);
-    if (n) HIPCHK(hipMemcpy(h.data(), m->d_taps, h.size() * 8, hipMemcpyDeviceToHost));
-    std::string all;
-    for (int i = 0; i < n; ++i) {
-        unsigned long long s = 0;
-        for (int j = 0; j < OPD_TAP_BLOCKS; ++j) s += h[(size_t)i * OPD_TAP_BLOCKS + j];
-        sums[i] = s;
-        all += m->tap_names[i];
-        all += '\n';
-    }
-    if (names && names_cap > 0) { strncpy(names, all.c_str(), (size_t)names_cap - 1); names[names_cap - 1] = 0; }
-    return n;
-}
-
-
 
 }  // extern "C"

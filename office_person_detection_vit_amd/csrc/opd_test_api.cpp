@@ -1,19 +1,14 @@
 // opd_test_api.cpp — kernel-level test hooks (host buffers in, host buffers out).  NOT part of the drop-in boundary
-// (include/opd_detr.h); exported so tests/test_kernels_gpu.py can check each hand-written kernel against the oracle
-// on identical inputs.  Every hook allocates its own device buffers, runs ONE kernel on the null stream and frees.
+// (include/opd_detr.h) and NOT part of the product library: this file is linked only into libopd_hip_test.so (csrc/build.py), which
+// tests/ and tools/ load instead of libopd_hip.so, so that tests/test_kernels_gpu.py can check each hand-written kernel against the
+// oracle on identical inputs.  Every kernel hook allocates its own device buffers, runs ONE kernel on the null stream and frees.
 #include <string.h>
 
 #include <string>
 #include <cstring>
 #include <vector>
 
-#include "../../include/opd_detr.h"
-#include "opd_kernels.h"
-#include "opd_loader.h"
-
-namespace opd {
-extern thread_local std::string g_err;
-}
+#include "opd_model.h"
 
 namespace {
 int tfail(int code, const std::string& msg) {
@@ -41,6 +36,7 @@ struct DevMem {
     } while (0)
 }  // namespace
 
+#pragma GCC visibility push(default)   // (the library is built with -fvisibility=hidden; these are the test build's extra exports)
 extern "C" {
 
 // Launch options of the hooks below (test infrastructure only; the kernel tests are single-threaded): bits 8-10 = forced tile height
@@ -803,4 +799,336 @@ int opd_test_inspect_checkpoint(const char* path, int32_t* info8) {
     return OPD_OK;
 }
 
+
+// ---- hooks that reach into a model handle (opd_model.h): fusion switches, poison allocation, graph guard, diagnostic taps ----------
+// Pillow coefficient tables of the device resize (host only): bounds [out][2], coeffs [out][ksize]; returns ksize
+int opd_test_resize_coeffs(int in_size, int out_size, int32_t* bounds, int32_t* coeffs, int coeffs_capacity) {
+    std::vector<int32_t> b, k;
+    int ksize = 0;
+    opd_resize_coeffs(in_size, out_size, &b, &k, &ksize);
+    if ((int)k.size() > coeffs_capacity) return fail(OPD_EINVAL, "coefficient buffer too small");
+    memcpy(bounds, b.data(), b.size() * 4);
+    memcpy(coeffs, k.data(), k.size() * 4);
+    return ksize;
+}
+// host-only pieces of the ragged-batch path, exported for the CPU tests
+int opd_test_valid_prefix(int valid, int in, int out) { return valid_prefix(valid, in, out); }
+int opd_test_sine_pos_embed(int h, int w, int vh, int vw, int D, float* out) {
+    if (!out || h < 1 || w < 1 || vh < 1 || vw < 1 || vh > h || vw > w || D < 2 || (D & 1)) return fail(OPD_EINVAL, "bad sine_pos_embed arguments");
+    std::vector<float> pos;
+    sine_pos_embed(h, w, vh, vw, D, &pos);
+    memcpy(out, pos.data(), pos.size() * sizeof(float));
+    return OPD_OK;
+}
+int opd_test_set_fuse_gemm_ln(opd_detr* m, int on) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->fuse_gemm_ln = on ? 1 : 0;
+    m->small_m_gemm = on ? 1 : 0;   // the switch covers the transformer-side specialisations
+    m->deep_fc2 = on ? 1 : 0;
+    m->fuse_dec0 = on ? 1 : 0;
+    m->fused_dec = on ? 1 : 0;   // (the unfused chain is the cross-check of the fused decoder as well)
+    if (fill_qc0(m) != OPD_OK) return OPD_EHIP;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+int opd_test_set_fuse_btail(opd_detr* m, int on) {   // bit 0: fused bottleneck tails, bit 1: the shortcut of stage 1 inside its first tail
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->fuse_btail = (on & 1) ? 1 : 0;
+    m->fuse_shortcut = (on & 2) ? 1 : 0;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+int opd_test_set_pos_shadow(opd_detr* m, int on) {   // 0: row-periodic bias tables W.pos + b (round-1 form) instead of the fp16(x + pos) shadow
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->pos_shadow = on ? 1 : 0;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+int opd_test_set_fuse_stem_pool(opd_detr* m, int on) {
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    m->fuse_stem_pool = (on & 1) ? 1 : 0;   // bit 0: stem + pool in one kernel; bit 1: pre-processing inside it as well
+    m->fuse_prep = (on & 2) ? 1 : 0;
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+
+int opd_test_set_alloc_poison(int byte) {   // -1: off; 0 .. 255: fill byte for the buffers and red zones of handles created from now on
+    g_alloc_poison = byte < 0 ? -1 : (byte & 255);
+    return OPD_OK;
+}
+// Scans the red zones of a poison-mode handle (its own buffers and its weight set's): returns the number of buffers with a damaged
+// zone (0 = intact) and describes the first one in opd_last_error().
+int opd_test_check_redzones(opd_detr* m) {
+    ApiScope api_scope;
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipDeviceSynchronize());
+    std::vector<unsigned char> h(OPD_REDZONE);
+    int bad = 0;
+    std::string first;
+    auto scan = [&](const std::vector<RedZoned>& v, const char* what) -> int {
+        for (size_t i = 0; i < v.size(); ++i)
+            for (int side = 0; side < 2; ++side) {
+                const char* z = static_cast<const char*>(v[i].base) + (side ? OPD_REDZONE + v[i].bytes : 0);
+                HIPCHK(hipMemcpy(h.data(), z, OPD_REDZONE, hipMemcpyDeviceToHost));
+                size_t lo = OPD_REDZONE, hi = 0;
+                for (size_t k = 0; k < OPD_REDZONE; ++k)
+                    if (h[k] != (unsigned char)v[i].poison) { lo = std::min(lo, k); hi = k; }
+                if (lo <= hi) {
+                    if (!bad++) first = std::string(what) + " buffer #" + std::to_string(i) + " (" + std::to_string(v[i].bytes) + " bytes): " +
+                                        (side ? "zone BEHIND it" : "zone IN FRONT of it") + " overwritten at zone offsets " + std::to_string(lo) + " .. " + std::to_string(hi);
+                }
+            }
+        return OPD_OK;
+    };
+    RCCHK(scan(m->zoned, "handle"));
+    if (m->weights) RCCHK(scan(m->weights->zoned, "weight-set"));
+    if (bad) g_err = first;
+    return bad;
+}
+int opd_test_set_graph_guard(int on) {
+    g_graph_guard = on ? 1 : 0;
+    return OPD_OK;
+}
+// Diagnostic taps: after every launch of the forward a checksum launch of that launch's output (captured into the graph with it).
+int opd_test_set_taps(opd_detr* m, int on) {
+    ApiScope api_scope;
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    HIPCHK(hipSetDevice(m->device));
+    if (on && !m->d_taps) RCCHK(dalloc(m, &m->d_taps, (size_t)OPD_MAX_TAPS * OPD_TAP_BLOCKS, false));
+    m->taps = on ? 1 : 0;
+    for (auto& g : m->graphs)
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+// sums[i] = checksum of tap i of the last forward, names = '\n'-joined tap names; returns the number of taps
+int opd_test_read_taps(opd_detr* m, unsigned long long* sums, int cap, char* names, int names_cap) {
+    ApiScope api_scope;
+    if (!m || !sums || !m->d_taps) return fail(OPD_EINVAL, "opd_test_read_taps: taps are not enabled");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    const int n = std::min(cap, (int)m->tap_names.size());
+    std::vector<unsigned long long> h((size_t)n * OPD_TAP_BLOCKS);
+    if (n) HIPCHK(hipMemcpy(h.data(), m->d_taps, h.size() * 8, hipMemcpyDeviceToHost));
+    std::string all;
+    for (int i = 0; i < n; ++i) {
+        unsigned long long s = 0;
+        for (int j = 0; j < OPD_TAP_BLOCKS; ++j) s += h[(size_t)i * OPD_TAP_BLOCKS + j];
+        sums[i] = s;
+        all += m->tap_names[i];
+        all += '\n';
+    }
+    if (names && names_cap > 0) { strncpy(names, all.c_str(), (size_t)names_cap - 1); names[names_cap - 1] = 0; }
+    return n;
+}
+
+
+
+
+// ---- fused decoder kernels (kernels_dec.hip), one launch each; weights arrive as fp32 and are split here like the loader does ----------
+static bool up_split(DevMem& dm, const float* w, size_t n, const f16_t** hi, const f16_t** lo) {
+    std::vector<f16_t> h(n), l(n);
+    opd_split_f16(w, n, h.data(), l.data());
+    *hi = dm.up(h.data(), n);
+    *lo = dm.up(l.data(), n);
+    return *hi && *lo;
+}
+// h_out / q16 / k16 [M][256], vT [M / Q][8][32][128] (host; vT is returned as the device wrote it: padding keys untouched = zero-filled here)
+int opd_test_dec_qkv(const float* h_in, const float* partials, int nsplit, const float* b2, const float* ln_g, const float* ln_b, const float* w,
+                     const float* bias, int M, int Q, float* h_out, uint16_t* q16, uint16_t* k16, uint16_t* vT) {
+    DevMem dm;
+    DecQkvParams p{};
+    const size_t n = (size_t)M * 256, nv = (size_t)(M / Q) * 8 * 32 * 128;
+    if (partials) {
+        p.h_in = dm.up(h_in, n); p.partials = dm.up(partials, n * nsplit); p.nsplit = nsplit; p.b2 = dm.up(b2, 256); p.ln_g = dm.up(ln_g, 256); p.ln_b = dm.up(ln_b, 256);
+        p.h_out = dm.up<float>(nullptr, n);
+        if (!p.h_in || !p.partials || !p.b2 || !p.ln_g || !p.ln_b) return tfail(OPD_ENOMEM, "test alloc failed");
+    } else {
+        p.h_out = dm.up(const_cast<const float*>(h_in), n);
+    }
+    if (!up_split(dm, w, (size_t)768 * 256, &p.w_hi, &p.w_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.bias = dm.up(bias, (size_t)Q * 768);
+    p.q16 = dm.up<uint16_t>(nullptr, n); p.k16 = dm.up<uint16_t>(nullptr, n); p.vT = dm.up<uint16_t>(nullptr, nv);
+    if (!p.h_out || !p.bias || !p.q16 || !p.k16 || !p.vT) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(hipMemset(p.vT, 0, nv * 2));
+    p.M = M; p.Q = Q;
+    TCHK(opd_launch_dec_qkv(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(h_out, p.h_out, n * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(q16, p.q16, n * 2, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(k16, p.k16, n * 2, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(vT, p.vT, nv * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+// h [B * Q][256] in / out, qc16 [B * Q][256] out
+int opd_test_dec_self(const uint16_t* q16, const uint16_t* k16, const uint16_t* vT, float* h, const float* wo, const float* bo, const float* ln_g,
+                      const float* ln_b, const float* wq, const float* rbq, int B, int Q, float scale, uint16_t* qc16) {
+    DevMem dm;
+    DecSelfParams p{};
+    const size_t n = (size_t)B * Q * 256, nv = (size_t)B * 8 * 32 * 128;
+    p.q16 = dm.up(q16, n); p.k16 = dm.up(k16, n); p.vT = dm.up(vT, nv); p.h = dm.up(const_cast<const float*>(h), n);
+    p.bo = dm.up(bo, 256); p.ln_g = dm.up(ln_g, 256); p.ln_b = dm.up(ln_b, 256); p.rbq = dm.up(rbq, (size_t)Q * 256);
+    p.qc16 = dm.up<uint16_t>(nullptr, n);
+    if (!up_split(dm, wo, 65536, &p.wo_hi, &p.wo_lo) || !up_split(dm, wq, 65536, &p.wq_hi, &p.wq_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    if (!p.q16 || !p.k16 || !p.vT || !p.h || !p.bo || !p.ln_g || !p.ln_b || !p.rbq || !p.qc16) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.Q = Q; p.scale = scale;
+    TCHK(opd_launch_dec_self(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(h, p.h, n * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(qc16, p.qc16, n * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+// key-split attention partials: part_o [splits][B * Lq][heads * 32], part_ml [splits][B * Lq][heads][2]
+int opd_test_attention_split(const uint16_t* q, const uint16_t* k, const uint16_t* v, int B, int heads, int Lq, int Lk, float scale, int splits,
+                             const int32_t* key_valid, int key_row, float* part_o, float* part_ml) {
+    DevMem dm;
+    const int D = heads * 32;
+    AttnParams p{};
+    p.q = dm.up(q, (size_t)B * Lq * D); p.k = dm.up(k, (size_t)B * Lk * D); p.v = dm.up(v, (size_t)B * Lk * D);
+    p.key_valid = key_valid ? dm.up(key_valid, (size_t)B * 2) : nullptr;
+    const size_t no = (size_t)splits * B * Lq * D, nm = (size_t)splits * B * Lq * heads * 2;
+    p.part_o = dm.up<float>(nullptr, no); p.part_ml = dm.up<float>(nullptr, nm);
+    if (!p.q || !p.k || !p.v || !p.part_o || !p.part_ml || (key_valid && !p.key_valid)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.B = B; p.heads = heads; p.Lq = Lq; p.Lk = Lk; p.ldq = p.ldk = p.ldv = p.ldo = D; p.scale = scale; p.key_row = key_row; p.splits = splits;
+    TCHK(opd_launch_attention(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(part_o, p.part_o, no * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(part_ml, p.part_ml, nm * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+int opd_test_dec_cross_out(const float* part_o, const float* part_ml, int splits, const float* res, int res_period, const float* wo, const float* bo,
+                           const float* ln_g, const float* ln_b, int M, float* h) {
+    DevMem dm;
+    DecCrossOutParams p{};
+    const size_t n = (size_t)M * 256;
+    p.part_o = dm.up(part_o, n * splits); p.part_ml = dm.up(part_ml, (size_t)splits * M * 16); p.splits = splits;
+    p.res = dm.up(res, res_period > 0 ? (size_t)res_period * 256 : n); p.res_period = res_period;
+    p.h = dm.up<float>(nullptr, n); p.bo = dm.up(bo, 256); p.ln_g = dm.up(ln_g, 256); p.ln_b = dm.up(ln_b, 256); p.M = M;
+    if (!up_split(dm, wo, 65536, &p.wo_hi, &p.wo_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    if (!p.part_o || !p.part_ml || !p.res || !p.h || !p.bo || !p.ln_g || !p.ln_b) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_dec_cross_out(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(h, p.h, n * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+// partials [F / 128][M][256]
+int opd_test_dec_ffn(const float* h, const float* w1, const float* b1, const float* w2, int M, int F, float* partials) {
+    DevMem dm;
+    DecFfnParams p{};
+    const size_t n = (size_t)M * 256, np = n * (F / OPD_DEC_FFN_CHUNK);
+    p.h = dm.up(h, n); p.b1 = dm.up(b1, (size_t)F); p.partials = dm.up<float>(nullptr, np); p.M = M; p.F = F;
+    if (!up_split(dm, w1, (size_t)F * 256, &p.w1_hi, &p.w1_lo) || !up_split(dm, w2, (size_t)F * 256, &p.w2_hi, &p.w2_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    if (!p.h || !p.b1 || !p.partials) return tfail(OPD_ENOMEM, "test alloc failed");
+    TCHK(opd_launch_dec_ffn(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(partials, p.partials, np * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+// isolated timing of the fused decoder's kernels on zero-filled operands at M = B x Q rows, Lk keys: us per launch of
+// [qkv, self, cross-split, cross-out, ffn] (tools/bench_dec.py)
+int opd_test_bench_dec(int B, int Q, int Lk, int F, int splits, int iters, float* us5) {
+    DevMem dm;
+    const int M = B * Q;
+    const size_t n = (size_t)M * 256;
+    auto z16 = [&](size_t c) { uint16_t* p = dm.up<uint16_t>(nullptr, c); if (p) (void)hipMemset(p, 0, c * 2); return p; };
+    auto z32 = [&](size_t c) { float* p = dm.up<float>(nullptr, c); if (p) (void)hipMemset(p, 0, c * 4); return p; };
+    DecQkvParams a{}; DecSelfParams b{}; AttnParams c{}; DecCrossOutParams d{}; DecFfnParams e{};
+    const int nchunk = F / OPD_DEC_FFN_CHUNK;
+    float *h0 = z32(n), *h1 = z32(n), *part = z32(n * nchunk), *vec = z32(4096), *tabs = z32((size_t)Q * 768), *po = z32(n * splits), *pml = z32((size_t)splits * M * 16);
+    uint16_t *q16 = z16(n), *k16 = z16(n), *vT = z16((size_t)B * 8 * 32 * 128), *qc = z16(n), *w768 = z16(768 * 256), *w256 = z16(65536), *wf = z16((size_t)F * 256),
+             *mem = z16((size_t)B * Lk * 512);
+    if (!h0 || !h1 || !part || !vec || !tabs || !po || !pml || !q16 || !k16 || !vT || !qc || !w768 || !w256 || !wf || !mem) return tfail(OPD_ENOMEM, "test alloc failed");
+    a.h_in = h0; a.partials = part; a.nsplit = nchunk; a.b2 = vec; a.ln_g = vec; a.ln_b = vec; a.h_out = h1; a.w_hi = w768; a.w_lo = w768; a.bias = tabs;
+    a.q16 = q16; a.k16 = k16; a.vT = vT; a.M = M; a.Q = Q;
+    b.q16 = q16; b.k16 = k16; b.vT = vT; b.h = h1; b.wo_hi = w256; b.wo_lo = w256; b.bo = vec; b.ln_g = vec; b.ln_b = vec; b.wq_hi = w256; b.wq_lo = w256;
+    b.rbq = tabs; b.qc16 = qc; b.B = B; b.Q = Q; b.scale = 0.17677669f;
+    c.q = qc; c.k = mem; c.v = mem + 256; c.B = B; c.heads = 8; c.Lq = Q; c.Lk = Lk; c.ldq = 256; c.ldk = c.ldv = 512; c.ldo = 256; c.scale = 0.17677669f;
+    c.splits = splits; c.part_o = po; c.part_ml = pml;
+    d.part_o = po; d.part_ml = pml; d.splits = splits; d.res = h1; d.h = h1; d.wo_hi = w256; d.wo_lo = w256; d.bo = vec; d.ln_g = vec; d.ln_b = vec; d.M = M;
+    e.h = h1; e.w1_hi = wf; e.w1_lo = wf; e.b1 = vec; e.w2_hi = wf; e.w2_lo = wf; e.partials = part; e.M = M; e.F = F;
+    hipEvent_t e0, e1;
+    TCHK(hipEventCreate(&e0)); TCHK(hipEventCreate(&e1));
+    for (int k = 0; k < 5; ++k) {
+        auto run = [&]() -> hipError_t {
+            switch (k) {
+                case 0: return opd_launch_dec_qkv(a, nullptr);
+                case 1: return opd_launch_dec_self(b, nullptr);
+                case 2: return opd_launch_attention(c, nullptr);
+                case 3: return opd_launch_dec_cross_out(d, nullptr);
+                default: return opd_launch_dec_ffn(e, nullptr);
+            }
+        };
+        for (int i = 0; i < 3; ++i) TCHK(run());
+        TCHK(hipEventRecord(e0, nullptr));
+        for (int i = 0; i < iters; ++i) TCHK(run());
+        TCHK(hipEventRecord(e1, nullptr));
+        TCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        TCHK(hipEventElapsedTime(&ms, e0, e1));
+        us5[k] = ms * 1000.f / iters;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return OPD_OK;
+}
+// heads_kernel with the fused decoder's prologue: rows = LN3(hs + b2f + sum partials), then the final LayerNorm, then the heads
+int opd_test_heads_fused(const float* hs, const float* partials, int nsplit, const float* b2f, const float* ln3_g, const float* ln3_b, const float* ln_g,
+                         const float* ln_b, const float* wc, const float* bc, const float* w1, const float* b1, const float* w2, const float* b2,
+                         const float* w3, const float* b3, int rows, int ncls, float* logits, float* boxes) {
+    DevMem dm;
+    auto tr = [&](const float* w, int O, int I) -> const float* {
+        std::vector<float> t((size_t)O * I);
+        for (int o = 0; o < O; ++o)
+            for (int i = 0; i < I; ++i) t[(size_t)i * O + o] = w[(size_t)o * I + i];
+        return dm.up(t.data(), t.size());
+    };
+    HeadParams p{};
+    p.hs = dm.up(hs, (size_t)rows * 256);
+    p.partials = dm.up(partials, (size_t)nsplit * rows * 256); p.nsplit = nsplit; p.ffn_b2 = dm.up(b2f, 256);
+    p.ln3_gamma = dm.up(ln3_g, 256); p.ln3_beta = dm.up(ln3_b, 256);
+    p.ln_gamma = dm.up(ln_g, 256); p.ln_beta = dm.up(ln_b, 256);
+    p.wc = tr(wc, ncls, 256); p.bc = dm.up(bc, ncls);
+    p.w1 = tr(w1, 256, 256); p.b1 = dm.up(b1, 256);
+    p.w2 = tr(w2, 256, 256); p.b2 = dm.up(b2, 256);
+    p.w3 = tr(w3, 4, 256); p.b3 = dm.up(b3, 4);
+    p.logits = dm.up<float>(nullptr, (size_t)rows * ncls);
+    p.boxes = dm.up<float>(nullptr, (size_t)rows * 4);
+    if (!p.hs || !p.partials || !p.ffn_b2 || !p.ln3_gamma || !p.ln3_beta || !p.ln_gamma || !p.ln_beta || !p.wc || !p.bc || !p.w1 || !p.b1 || !p.w2 || !p.b2 ||
+        !p.w3 || !p.b3 || !p.logits || !p.boxes)
+        return tfail(OPD_ENOMEM, "test alloc failed");
+    p.rows = rows; p.ncls = ncls;
+    TCHK(opd_launch_heads(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(logits, p.logits, (size_t)rows * ncls * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(boxes, p.boxes, (size_t)rows * 4 * 4, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+int opd_test_set_fused_dec(opd_detr* m, int on) {   // 0: the unfused decoder chain (single fp16 operands, nine launches per layer)
+    ApiScope api_scope;
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    HIPCHK(hipSetDevice(m->device));
+    HIPCHK(hipStreamSynchronize(m->stream));
+    m->fused_dec = on ? 1 : 0;
+    RCCHK(fill_qc0(m));
+    for (auto& g : m->graphs)  // captured graphs hold the old launch sequence
+        if (g.exec) (void)hipGraphExecDestroy(g.exec);
+    m->graphs.clear();
+    return OPD_OK;
+}
+// host-only: the error-diffusion rounding of the weight loader (opd_host.h), in place on [rows][taps][cin]
+int opd_test_round_f16_diffused(float* w, int rows, int taps, int cin) {
+    if (!w || rows < 0 || taps < 1 || cin < 1) return tfail(OPD_EINVAL, "opd_test_round_f16_diffused: bad arguments");
+    opd::round_f16_diffused(w, (size_t)rows, taps, cin);
+    return OPD_OK;
+}
+
 }  // extern "C"
+#pragma GCC visibility pop

@@ -439,14 +439,16 @@ class HipDetrDetector:
         ``src/visualization/visualizer.py:148-200``, takes a 1-D or 2-D array in [0, 1]).  The DETR-era source is gone, so the
         definition is this build's: detect on ``frame``, then the decoder's cross-attention weights of layer ``layer_index``,
         averaged over the heads and over the queries of the kept person detections (all queries when there is none), as a
-        ``(feature_h, feature_w)`` float32 array scaled so that its maximum is 1."""
+        ``(feature_h, feature_w)`` float32 array scaled so that its maximum is 1.  Like the reference's detector this call is
+        single-threaded: the map is read from the state the ``detect`` inside it leaves on handle 0, so no other call on this
+        detector may run between the two (the library refuses a map that does not fit the buffer sized here)."""
         self._require_model()
         dets = self.detect(frame)
         fh, fw = (_feature_hw(s) for s in self._model_hw(frame))
         q = np.asarray(sorted({d.query_index for d in dets if d.query_index is not None}), dtype=np.int32)
         out = np.empty((fh * fw,), np.float32)
         rc = self._lib.opd_detr_attention_map(C.c_void_p(self.model), 0, int(layer_index), q.ctypes.data_as(C.c_void_p) if len(q) else None,
-                                              len(q), out.ctypes.data_as(C.c_void_p))
+                                              len(q), out.ctypes.data_as(C.c_void_p), int(out.size))
         _capi.check(rc, "opd_detr_attention_map")
         mx = float(out.max())
         return (out / mx if mx > 0 else out).reshape(fh, fw)

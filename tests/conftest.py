@@ -5,6 +5,10 @@ import sys
 
 import pytest
 
+# the test suite drives the TEST build of the library (libopd_hip_test.so = the product's objects + the opd_test_* hooks of
+# csrc/opd_test_api.cpp); the product library itself is checked by tests/test_host_cpu.py and run by smoke() / bench.py
+os.environ.setdefault("OPD_TEST_HOOKS", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -383,16 +383,17 @@ def test_attention_map_matches_oracle(detectors):
     for frame, layer, queries in ((0, -1, None), (1, -1, [3, 17, 64]), (1, 2, None), (0, 0, [99])):
         q = None if queries is None else np.asarray(queries, np.int32)
         rc = lib.opd_detr_attention_map(C.c_void_p(det.model), frame, layer, None if q is None else q.ctypes.data_as(C.c_void_p),
-                                        0 if q is None else len(q), out.ctypes.data_as(C.c_void_p))
+                                        0 if q is None else len(q), out.ctypes.data_as(C.c_void_p), out.size)
         _capi.check(rc, "opd_detr_attention_map")
         ref = O.cross_attention_map(taps, frame, layer, queries)
         assert abs(float(out.sum()) - 1.0) < 1e-4
         assert float(np.abs(out - ref).max()) <= 2e-4, (frame, layer, queries, float(np.abs(out - ref).max()))
     # argument errors are reported, not executed
-    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 2, -1, None, 0, out.ctypes.data_as(C.c_void_p)) != 0
-    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 0, 6, None, 0, out.ctypes.data_as(C.c_void_p)) != 0
+    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 2, -1, None, 0, out.ctypes.data_as(C.c_void_p), out.size) != 0
+    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 0, -1, None, 0, out.ctypes.data_as(C.c_void_p), out.size - 1) != 0   # buffer too small
+    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 0, 6, None, 0, out.ctypes.data_as(C.c_void_p), out.size) != 0
     bad = np.asarray([100], np.int32)
-    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 0, -1, bad.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p)) != 0
+    assert lib.opd_detr_attention_map(C.c_void_p(det.model), 0, -1, bad.ctypes.data_as(C.c_void_p), 1, out.ctypes.data_as(C.c_void_p), out.size) != 0
 
 
 def test_attention_map_ragged_batch_ignores_padding(detectors):
@@ -409,7 +410,7 @@ def test_attention_map_ragged_batch_ignores_padding(detectors):
     taps = {}
     O.forward(w, pv, pm, taps=taps)
     out = np.empty(80, np.float32)
-    _capi.check(_capi.load_library().opd_detr_attention_map(C.c_void_p(det.model), 1, -1, None, 0, out.ctypes.data_as(C.c_void_p)), "attention_map")
+    _capi.check(_capi.load_library().opd_detr_attention_map(C.c_void_p(det.model), 1, -1, None, 0, out.ctypes.data_as(C.c_void_p), out.size), "attention_map")
     ref = O.cross_attention_map(taps, 1, -1, None)
     assert float(np.abs(out - ref).max()) <= 2e-4
     m = out.reshape(8, 10)

@@ -32,6 +32,57 @@ def test_library_exports_every_declared_symbol():
     assert b"gfx950" in lib.opd_version()
 
 
+def test_product_library_exports_exactly_the_header():
+    """libopd_hip.so (the product) exports the functions of include/opd_detr.h and nothing else of ours: no opd_test_* hook, no
+    launcher, no C++ helper (the test API used to ship inside the product library).  The hooks live in
+    libopd_hip_test.so, which tests/ and tools/ load instead (conftest.py sets OPD_TEST_HOOKS=1)."""
+    import subprocess
+    header = open(os.path.join(ROOT, "include", "opd_detr.h")).read()
+    declared = set(re.findall(r"\b(opd_[a-z0-9_]+)\s*\(", header)) - {"opd_config", "opd_det", "opd_model_info"}
+
+    def exported(path):
+        out = subprocess.run(["nm", "-D", "--defined-only", path], check=True, capture_output=True, text=True).stdout
+        return {l.split()[2] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] == "T"}
+
+    prod = exported(_capi.LIB_PATH)
+    assert {n for n in prod if "opd" in n.lower()} == declared, sorted(prod ^ declared)[:10]
+    test = exported(_capi.TEST_LIB_PATH)
+    assert declared <= test and set(_capi.TEST_API) <= test
+    raw = C.CDLL(_capi.LIB_PATH)   # (a second, prototype-less handle: does not disturb the process's _capi library)
+    assert not hasattr(raw, "opd_test_set_graph_guard") and not hasattr(raw, "opd_launch_conv_gemm")
+
+
+def test_weight_rounding_by_error_diffusion():
+    """csrc/opd_host.cpp::round_f16_diffused: every value lands on an fp16 value next to it, the errors of a row sum to at most
+    half an ulp of its largest weight (round-to-nearest: a random walk), fp16-exact input is untouched, and the result is the
+    sequential carry algorithm visiting (channel outer, tap inner)."""
+    lib = _capi.load_library()
+    rng = np.random.default_rng(5)
+    rows, taps, cin = 7, 9, 64
+    w = (rng.standard_normal((rows, taps, cin)) * 0.02).astype(np.float32)
+    got = w.copy()
+    assert lib.opd_test_round_f16_diffused(got.ctypes.data_as(C.c_void_p), rows, taps, cin) == 0
+    want = np.empty_like(w)
+    for r in range(rows):
+        carry = 0.0
+        for c in range(cin):
+            for t in range(taps):
+                target = float(w[r, t, c]) + carry
+                q = float(np.float32(target).astype(np.float16))
+                want[r, t, c] = q
+                carry = target - q
+    np.testing.assert_array_equal(got, want)
+    np.testing.assert_array_equal(got, got.astype(np.float16).astype(np.float32))                    # fp16 values
+    ulp_max = np.spacing(np.abs(w).max(axis=(1, 2)).astype(np.float16)).astype(np.float64)
+    assert np.all(np.abs(got.astype(np.float64) - w) <= ulp_max[:, None, None])   # own half-ulp + the carried half-ulp of a larger neighbour
+    assert np.all(np.abs((got.astype(np.float64) - w).sum(axis=(1, 2))) <= 0.5 * ulp_max + 1e-12)
+    rtn = w.astype(np.float16).astype(np.float32)
+    assert np.abs((rtn.astype(np.float64) - w).sum(axis=(1, 2))).mean() > 4 * np.abs((got.astype(np.float64) - w).sum(axis=(1, 2))).mean()
+    exact = rtn.copy()
+    assert lib.opd_test_round_f16_diffused(exact.ctypes.data_as(C.c_void_p), rows, taps, cin) == 0
+    np.testing.assert_array_equal(exact, rtn)
+
+
 def test_struct_layouts_match_header():
     assert C.sizeof(_capi.OpdDet) == 32
     assert C.sizeof(_capi.OpdConfig) == 32

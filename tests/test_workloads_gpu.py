@@ -250,3 +250,28 @@ def test_parity_on_weights_that_are_not_device_exact(weight_cache, parity_log, s
     parity_log(f"r50 mild {H}x{W}, weights NOT device-exact (raw fp32 checkpoint) vs live oracle", dbox, dprob, denc, bound,
                "weight rounding included")
     assert dbox <= bound and dprob <= 2 * bound
+
+
+def test_stage3_frame_split_is_bit_identical(mild_path):
+    """Single-stream handles run the frames of stage 3 beyond whole rounds of its fused tail as a second chain on a forked stream,
+    captured into the graph as a fork / join (csrc/opd_model.cpp::enqueue_forward).  Per-row arithmetic does not depend on the
+    tiling, so the split must be invisible: batch 8 at 800x1333, eager launch, capture and replay, each against a handle created with
+    OPD_TAIL3_SPLIT=0 (one launch per tail) -- equal bits."""
+    frames = structured_frames(8, 800, 1333, seed=808)
+    outs = {}
+    for split in ("1", "0"):
+        os.environ["OPD_TAIL3_SPLIT"] = split
+        try:
+            det = HipDetrDetector(model_path=mild_path, max_batch=8, max_size=(800, 1333), resize=False)
+            det.load_model()
+        finally:
+            del os.environ["OPD_TAIL3_SPLIT"]
+        try:
+            outs[split] = [det.forward_raw(frames) for _ in range(3)]   # eager, capture + first launch, replay
+        finally:
+            det.close()
+    for call in range(3):
+        for x, y in zip(outs["1"][call], outs["0"][call]):
+            np.testing.assert_array_equal(x, y)
+        for x, y in zip(outs["1"][call], outs["1"][0]):
+            np.testing.assert_array_equal(x, y)

@@ -3,7 +3,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from office_person_detection_vit_amd import _capi
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 for s in [(8, 50, 84, 256, 256, 1), (8, 67, 120, 256, 256, 1), (7, 50, 84, 256, 256, 1)]:
     B, H, W, C1, C3, st = s
     t = []

@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from office_person_detection_vit_amd import _capi  # noqa: E402
 
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 50
 rng = np.random.default_rng(0)
 _p = lambda a: a.ctypes.data_as(C.c_void_p)

@@ -7,7 +7,7 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from office_person_detection_vit_amd import _capi  # noqa: E402
 
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 SHAPES = [  # B, H, W, C1, C3, stride
     (8, 200, 334, 64, 64, 1),     # s0b0 / s0b1 tails (-> next block's reduce)
     (8, 200, 334, 64, 128, 1),    # s0b2 tail (-> s1b0.c0)

@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from office_person_detection_vit_amd import _capi  # noqa: E402
 
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 for M, K in ((8400, 2048), (16320, 2048), (8400, 256), (800, 2048), (800, 256)):
     line = f"M {M:6d} K {K:5d}:"
     for deep in (0, 1):

@@ -27,7 +27,7 @@ SHAPES = [  # name, B, H, W, Cin, N, k, stride, residual
 
 
 def main():
-    lib = _capi.load_library()
+    lib = _capi.load_library(test_hooks=True)
     variants = [int(v, 0) for v in (sys.argv[1] if len(sys.argv) > 1 else "0").split(",")]   # flag words (opd_test_set_conv_flags)
     us = C.c_float()
     print(f"{'layer':28s} {'var':>3s} {'full us':>9s} {'TFLOP/s':>8s} {'loads-only':>10s} {'compute-only':>12s} {'no-stage full':>12s} {'loads B only':>12s} {'no-store':>9s} {'ns+comp':>9s}")

@@ -20,7 +20,7 @@ from office_person_detection_vit_amd.frames import structured_frames  # noqa: E4
 from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file  # noqa: E402
 
 scen = sys.argv[1]
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 lib.opd_test_set_graph_guard(1 if scen == "guard_on" else 0)
 mild = ensure_weight_file("/tmp/opd_weights", DetrArch.resnet50(), 0, 1.0, "r50")
 sharp = ensure_weight_file("/tmp/opd_weights", DetrArch.resnet50(), 0, 2.0, "r50")

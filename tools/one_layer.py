@@ -6,7 +6,7 @@ from office_person_detection_vit_amd import _capi
 a = [int(v) for v in sys.argv[1:9]]
 variant = int(sys.argv[9], 0) if len(sys.argv) > 9 else 0   # flag word of opd_test_set_conv_flags
 dbg = int(sys.argv[10]) if len(sys.argv) > 10 else 0
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 us = C.c_float()
 _capi.check(lib.opd_test_bench_conv(*a, variant, dbg, 6, C.byref(us)), "bench_conv")
 print("avg us", us.value)

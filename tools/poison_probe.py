@@ -17,7 +17,7 @@ from office_person_detection_vit_amd import HipDetrDetector, _capi  # noqa: E402
 from office_person_detection_vit_amd.frames import structured_frames  # noqa: E402
 from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file  # noqa: E402
 
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 big = len(sys.argv) > 1 and sys.argv[1] == "big"
 mild = ensure_weight_file(os.environ.get("OPD_WEIGHT_CACHE", "/tmp/opd_weights"), DetrArch.resnet50(), 0, 1.0, "r50")
 

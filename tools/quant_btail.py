@@ -3,7 +3,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from office_person_detection_vit_amd import _capi
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 for (C1, C3, shapes) in [(128, 128, [(8, 100, 167), (8, 99, 167), (8, 98, 167), (8, 97, 167), (8, 128, 128), (8, 96, 128), (8, 128, 192), (8, 160, 128)]),
                          (64, 64, [(8, 200, 334), (8, 256, 256), (8, 256, 224), (8, 256, 288)])]:
     for (B, H, W) in shapes:

@@ -1,7 +1,7 @@
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from office_person_detection_vit_amd import _capi
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 SHAPES = [("r101 s2.c0 1024->256", 8, 67, 120, 1024, 256, 1, 1, 0), ("r101 s2.c1 3x3 256", 8, 67, 120, 256, 256, 3, 1, 0), ("r101 s2.c2 256->1024 +res", 8, 67, 120, 256, 1024, 1, 1, 1)]
 us = C.c_float()
 print(f"{'layer':28s} {'auto':>8s} {'128':>8s} {'160':>8s} {'192':>8s}  TFLOP/s(best)")

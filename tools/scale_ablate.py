@@ -4,7 +4,7 @@ Separates per-workgroup throughput from fill / quantisation effects."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from office_person_detection_vit_amd import _capi
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 us = C.c_float()
 print(f"{'batch':>5s} {'wgs':>6s} {'full us':>8s} {'TF':>7s} {'no-DMA us':>9s} {'TF':>7s} {'no-MFMA us':>10s}")
 for B in (4, 8, 10, 16, 32, 64):

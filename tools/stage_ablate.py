@@ -11,7 +11,7 @@ SHAPES = [("s0b0.sc 64->256", 8, 200, 334, 64, 256, 1, 1, 0), ("s0b0.c0 64->64",
           ("s1b0.sc 256->512 s2", 8, 200, 334, 256, 512, 1, 2, 0), ("s1b0.c0 256->128", 8, 200, 334, 256, 128, 1, 1, 0),
           ("enc.qkv 256->768", 8400, 1, 1, 256, 768, 1, 1, 0), ("enc.fc1 256->2048", 8400, 1, 1, 256, 2048, 1, 1, 0),
           ("memkv 256->3072", 8400, 1, 1, 256, 3072, 1, 1, 0)]
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 us = C.c_float()
 print(f"{'layer':26s} {'staged':>8s} {'paired':>8s}  (auto tile height)")
 for name, B, H, W, Cin, N, k, st, res in SHAPES:

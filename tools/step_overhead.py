@@ -8,7 +8,7 @@ from office_person_detection_vit_amd.frames import structured_frame
 from office_person_detection_vit_amd.weights import DetrArch, ensure_weight_file
 B, H, W = 8, 800, 1333
 path = ensure_weight_file(os.environ.get("OPD_WEIGHT_CACHE", "/tmp/opd_weights"), DetrArch.resnet50(), 0, 1.0, "r50")
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
 h = C.c_void_p()
 _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), 0, C.byref(h)), "create")

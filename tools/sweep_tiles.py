@@ -28,7 +28,7 @@ SHAPES = [  # name, B, H, W, Cin, N, k, stride, residual
     ("enc.fc1 256->2048", 8400, 1, 1, 256, 2048, 1, 1, 0),
     ("memkv 256->3072", 8400, 1, 1, 256, 3072, 1, 1, 0),
 ]
-lib = _capi.load_library()
+lib = _capi.load_library(test_hooks=True)
 us = C.c_float()
 print(f"{'layer':26s} {'auto':>8s} {'128':>8s} {'160':>8s} {'192':>8s}   TFLOP/s(best)")
 for name, B, H, W, Cin, N, k, st, res in SHAPES:

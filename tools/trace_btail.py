@@ -17,7 +17,7 @@ SHAPES = [("stage-1 tail 64 -> 256 (+ reduce 64), residual through LDS-DMA (80 K
 
 
 def main():
-    lib = _capi.load_library()
+    lib = _capi.load_library(test_hooks=True)
     MAXW = 8192
     buf = (C.c_ulonglong * (MAXW * 16))()
     n = C.c_int()
@@ -40,7 +40,7 @@ def main():
 
 def main_stage3():
     """kernels_btail3.hip (eight waves, one workgroup per CU): stamps = entry, prologue, 3x3 loop, a1 exchange, every second chunk, z stores."""
-    lib = _capi.load_library()
+    lib = _capi.load_library(test_hooks=True)
     MAXW = 8192
     buf = (C.c_ulonglong * (MAXW * 16))()
     n = C.c_int()

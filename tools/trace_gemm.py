@@ -27,7 +27,7 @@ PH = ["prologue", "first tile", "k-loop", "epilogue issue", "stores retire"]
 
 
 def main():
-    lib = _capi.load_library()
+    lib = _capi.load_library(test_hooks=True)
     only = sys.argv[1] if len(sys.argv) > 1 else ""
     MAXW = 8192
     buf = (C.c_ulonglong * (3 * MAXW * 8))()
