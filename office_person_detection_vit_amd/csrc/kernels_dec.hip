@@ -8,15 +8,20 @@
 // of the box drift (4.9e-4 of 8.6e-4).  Both are addressed by one design:
 //
 //  * Split operands.  Every GEMM input x and weight W of the decoder's linear layers is carried as TWO fp16 numbers,
-//        hi = fp16(x),  lo = fp16((x - hi) * 2048)          (x - hi is exact in fp32; the scale keeps lo out of the subnormals)
+//        hi = fp16(x),  lo = fp16((x - hi) * 2048)          (x - hi is exact in fp32; the scale keeps lo out of the subnormals, and
+//                                                             |x| < 2^-14 travels in lo alone: the matrix pipe flushes subnormal inputs)
 //    and a product is three MFMAs into two fp32 accumulators,  W.x = [Whi.xhi] + [Whi.xlo + Wlo.xhi] / 2048  (the lo.lo term is
 //    2^-22 relative): fp32-grade linear layers at 3/16 of the fp16 matrix rate instead of the 1/16 of v_mfma_f32_16x16x4_f32.
 //    Attention scores and P.V stay single fp16 (their rounding sites measure 1e-5 .. 5e-5 of box drift).
-//  * Row-slab workgroups with weights as MFMA A operands straight from L2.  M = 800 rows are 50 slabs of 16: a workgroup of eight
-//    waves owns a slab, keeps it (hi / lo) in LDS as the B operand and reads its weight fragments (16 rows x 64 bytes per
-//    wave-instruction) directly from global memory into registers, all requested up front: one L2 round trip per GEMM instead of the
-//    LDS-DMA staging chain of a tile GEMM.  What needs the whole frame (self-attention K / V) or all heads (output projections) fixes
-//    the five launches per layer:
+//  * Row-slab workgroups, weights in MFMA-FRAGMENT ORDER through wave-private LDS-DMA rings.  M = 800 rows are 50 slabs of 16: a
+//    workgroup of eight waves owns a slab and keeps it (hi / lo) in LDS as the B operand; wave w owns output columns 32w .. 32w + 31.  The
+//    loader stores every weight matrix so that the 1 KiB a wave's MFMA needs as its A operand for one (16-column tile, 32-wide k-step) is
+//    contiguous, lane L's 16 bytes at offset 16 L, hi block then lo block (opd_split_f16_frag): a wave streams ITS tiles with
+//    global_load_lds (1 KiB per instruction, fully coalesced) into its own ring of LDS slots and reads them back lane-linear
+//    (conflict free), with counted vmcnt waits and no barrier.  Measured (tools/microbench/oneshot.hip): 256 KiB per workgroup arrive
+//    0.7 us after the launch floor by LDS-DMA, against 5.8 us through coalesced VGPR loads and 12.8 us through 16 x 64-byte fragment
+//    loads (the first form of this file: 23 us for the self-attention block).  What needs the whole frame (self-attention K / V) or
+//    all heads (output projections) fixes the five launches per layer:
 //      dec_qkv_kernel        [previous FFN: reduce partial sums + b2 + residual + LN3] -> q | k | v^T                        (slab)
 //      dec_self_kernel       self-attention (wave = head) + o-proj + residual + LN1 + cross-attention q projection   (frame x slab)
 //      attention_kernel<SPLIT>  cross-attention over a third of the keys, unnormalised partials (kernels_attn.hip)
@@ -43,8 +48,10 @@ constexpr int XP = 528;                 // bytes per LDS row of a [rows][256] fp
 constexpr int HP = 272;                 // the same for a [rows][128] operand
 constexpr float LO_SCALE = 2048.0f, LO_INV = 1.0f / 2048.0f;
 
+// (the matrix pipe reads fp16 SUBNORMAL inputs as zero — measured: elements |x| < 2^-14 lost their hi part, 6e-5 absolute — while the
+//  conversion produces them: such a value travels in lo alone, x * 2048 < 0.125 is a normal fp16 number)
 __device__ __forceinline__ void split1(const float v, _Float16& hi, _Float16& lo) {
-    hi = (_Float16)v;
+    hi = fabsf(v) < 6.103515625e-5f ? (_Float16)0.f : (_Float16)v;
     lo = (_Float16)((v - (float)hi) * LO_SCALE);
 }
 // three MFMAs of one split product: ah += Whi.xhi ; al += Whi.xlo ; am += Wlo.xhi  (three accumulators: no MFMA waits for its predecessor)
@@ -55,17 +62,6 @@ __device__ __forceinline__ void mma3(const half8& wh, const half8& wl, const hal
 }
 __device__ __forceinline__ half8 lds_frag(const unsigned char* X, const int pitch, const int row, const int ks, const int g) {
     return *reinterpret_cast<const half8*>(X + row * pitch + (ks * 32 + g * 8) * 2);
-}
-// weight fragments of the 16 rows n0 .. n0 + 15 of a [N][ldw] matrix, k = k0 + 32 ks + 8g .. + 7, for NKS k-steps: requested together
-template <int NKS>
-__device__ __forceinline__ void load_w(const f16_t* __restrict__ whi, const f16_t* __restrict__ wlo, const int ldw, const int n, const int k0,
-                                       const int g, half8 (&fh)[NKS], half8 (&fl)[NKS]) {
-    const size_t off = (size_t)n * ldw + k0 + g * 8;
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        fh[ks] = *reinterpret_cast<const half8*>(whi + off + ks * 32);
-        fl[ks] = *reinterpret_cast<const half8*>(wlo + off + ks * 32);
-    }
 }
 // 8 consecutive fp32 values -> hi / lo halves at X*[row][c0 .. c0 + 7]
 __device__ __forceinline__ void store_split8(unsigned char* Xhi, unsigned char* Xlo, const int pitch, const int row, const int c0, const float (&v)[8]) {
@@ -87,6 +83,7 @@ __device__ __forceinline__ void store_split4(unsigned char* Xhi, unsigned char* 
 // and are zeroed by a select afterwards: a predicated load becomes a branch with its own wait), and the scheduler is fenced so that it
 // neither sinks them to their uses nor hoists the consumers' waits.
 #define DEC_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define DEC_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 struct Acc3 { float4v h[2], l[2], m[2]; };
 __device__ __forceinline__ void acc3_zero(Acc3& a) {
@@ -94,16 +91,79 @@ __device__ __forceinline__ void acc3_zero(Acc3& a) {
     for (int j = 0; j < 2; ++j) { a.h[j] = float4v{0.f, 0.f, 0.f, 0.f}; a.l[j] = a.h[j]; a.m[j] = a.h[j]; }
 }
 __device__ __forceinline__ float acc3_get(const Acc3& a, const int j, const int r) { return a.h[j][r] + (a.l[j][r] + a.m[j][r]) * LO_INV; }
-// [16 rows][32 NKS of K] (hi / lo in LDS, k-steps ks0 ..) x this wave's two 16-channel weight tiles (fragments in registers)
-template <int NKS>
-__device__ __forceinline__ void gemm16(const unsigned char* Xhi, const unsigned char* Xlo, const int ks0, const half8 (&wh)[2][NKS], const half8 (&wl)[2][NKS],
-                                       const int g, const int li, Acc3& a) {
-#pragma unroll
-    for (int ks = 0; ks < NKS; ++ks) {
-        const half8 xh = lds_frag(Xhi, XP, li, ks0 + ks, g), xl = lds_frag(Xlo, XP, li, ks0 + ks, g);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) mma3(wh[j][ks], wl[j][ks], xh, xl, a.h[j], a.l[j], a.m[j]);
+
+// ---- wave-private LDS-DMA ring ------------------------------------------------------------------------------------------------------
+// A wave consumes a fixed SEQUENCE of 1-KiB pieces (weight fragment blocks, rows of fp32 partial sums) in order; piece n lives in slot
+// n mod R of the wave's ring.  R pieces are requested up front; when pieces [first, first + count) have been consumed (their LDS reads
+// have returned: lgkmcnt(0)) pieces [first + R, ...) are requested into the freed slots.  vmcnt retires in issue order, so piece `last`
+// has landed once at most (pieces issued so far) - 1 - last requests are outstanding; other, younger vector-memory operations of the
+// wave only make that wait longer than necessary, never shorter.  Every index is a compile-time constant after unrolling.
+__device__ __forceinline__ void dma1k(const unsigned char* src_lane, unsigned char* slot) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
+}
+__device__ __forceinline__ void wait_vm(const int n) {
+    switch (n) {
+        case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+        case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+        case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+        case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+        case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+        case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+        case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+        case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+        case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+        case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+        case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+        case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+        case 12: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;   // (never taken with R <= 16 and groups >= 4; safe if it were)
     }
+}
+template <int R, int TOTAL>
+struct PieceRing {
+    unsigned char* ring;   // this wave's R KiB of LDS
+    int lane16;
+    template <typename Src>
+    __device__ __forceinline__ void prime(Src&& src) {
+#pragma unroll
+        for (int n = 0; n < (R < TOTAL ? R : TOTAL); ++n) dma1k(src(n) + lane16, ring + n * 1024);
+    }
+    __device__ __forceinline__ void wait(const int first, const int last) const { wait_vm((TOTAL < R + first ? TOTAL : R + first) - 1 - last); }
+    template <typename Src>
+    __device__ __forceinline__ void advance(Src&& src, const int first, const int count) {
+        DEC_LGKM0();
+#pragma unroll
+        for (int n = first; n < first + count; ++n)
+            if (n + R < TOTAL) dma1k(src(n + R) + lane16, ring + ((n + R) % R) * 1024);
+    }
+    __device__ __forceinline__ const unsigned char* slot(const int n) const { return ring + (n % R) * 1024; }
+};
+// one group of 8 pieces = four k-steps (hi block, lo block each) of one 16-column weight tile, against rows li of X (k-steps ks0 ..)
+template <typename RingT>
+__device__ __forceinline__ void gemm_group(const RingT& rg, const int first, const unsigned char* Xhi, const unsigned char* Xlo, const int xrow, const int ks0,
+                                           const int lane16, const int g, float4v& ah, float4v& al, float4v& am) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const half8 wh = *reinterpret_cast<const half8*>(rg.slot(first + 2 * i) + lane16);
+        const half8 wl = *reinterpret_cast<const half8*>(rg.slot(first + 2 * i + 1) + lane16);
+        const half8 xh = lds_frag(Xhi, XP, xrow, ks0 + i, g), xl = lds_frag(Xlo, XP, xrow, ks0 + i, g);
+        mma3(wh, wl, xh, xl, ah, al, am);
+    }
+}
+// [16 rows][256] x this wave's two 16-column tiles of a [256 k] weight matrix = sequence pieces [seq0, seq0 + 32): tile j, half hf at
+// seq0 + 16 j + 8 hf
+template <typename RingT, typename Src>
+__device__ __forceinline__ void gemm256(RingT& rg, Src&& src, const int seq0, const unsigned char* Xhi, const unsigned char* Xlo, const int lane16, const int g,
+                                        const int li, Acc3& a) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            const int first = seq0 + 16 * j + 8 * hf;
+            rg.wait(first, first + 7);
+            gemm_group(rg, first, Xhi, Xlo, li, 4 * hf, lane16, g, a.h[j], a.l[j], a.m[j]);
+            rg.advance(src, first, 8);
+        }
 }
 
 // LayerNorm over the 256 channels of the slab's 16 rows in accumulator layout: lane (g, li) of wave w holds, for row li, the channels
@@ -117,7 +177,8 @@ __device__ __forceinline__ void layernorm_acc(float4v (&v)[2], float (*red)[8][1
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     if (g == 0) red[0][wave][li] = sum;
-    __syncthreads();
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();   // (raw barriers: __syncthreads would also drain the weight pieces in flight)
     float mean = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) mean += red[0][w][li];
@@ -131,7 +192,8 @@ __device__ __forceinline__ void layernorm_acc(float4v (&v)[2], float (*red)[8][1
     sq += __shfl_xor(sq, 16);
     sq += __shfl_xor(sq, 32);
     if (g == 0) red[1][wave][li] = sq;
-    __syncthreads();
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
     float var = 0.f;
 #pragma unroll
     for (int w = 0; w < 8; ++w) var += red[1][w][li];
@@ -159,47 +221,64 @@ __device__ __forceinline__ void layernorm_row32(float (&v)[8], const float4v g0,
     for (int j = 0; j < 4; ++j) { v[j] = v[j] * rstd * g0[j] + b0[j]; v[4 + j] = v[4 + j] * rstd * g1[j] + b1[j]; }
 }
 
+// LDS map of the 16-row slab kernels: X hi / lo, LayerNorm scratch, then the eight waves' rings of 16 KiB
+constexpr int SLAB_X = 2 * 16 * XP;              // 16 896
+constexpr int SLAB_RED = SLAB_X;                 // float [2][8][16] = 1 KiB
+constexpr int SLAB_RING = 18432;                 // 1 KiB aligned
+constexpr int SLAB_R = 16;
+constexpr int SLAB_LDS = SLAB_RING + 8 * SLAB_R * 1024;   // 149 504
+
 // ---------------------------------------------------------------------------------------------------------------------------------
-// dec_qkv_kernel: grid (slabs of 16 rows), 512 threads.  One workgroup reduces the previous FFN's partial sums for its rows ONCE (16
-// slabs x 16 KiB) and then runs the three projections q, k, v as six half-rounds (2 column tiles per wave x 4 k-steps each) whose weight
-// fragments are double-buffered in registers: while one half multiplies, the next is in flight.
+// dec_qkv_kernel: grid (slabs of 16 rows), 512 threads.  One workgroup reduces the previous FFN's partial sums for its rows ONCE and
+// then runs the three projections q, k, v.  A wave's piece sequence: 32 rows of partial sums (rows 2w, 2w + 1 of the slab: exactly the
+// rows its own lanes normalise, so no barrier), then the 96 weight pieces of its two column tiles of q, of k, of v.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int QKV_MAXS = 16;
+template <bool PRO>
 __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Xhi[16 * XP];
-    __shared__ __attribute__((aligned(16))) unsigned char Xlo[16 * XP];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* const Xhi = smem;
+    unsigned char* const Xlo = smem + 16 * XP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, li = lane & 15;
+    const int g = lane >> 4, li = lane & 15, lane16 = lane * 16;
     const int row0 = blockIdx.x * 16;
-    half8 wh[2][2][4], wl[2][2][4];   // [buffer][column tile][k-step of the half]
-    auto load_half = [&](const int part, const int half, const int buf) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) load_w<4>(p.w_hi, p.w_lo, 256, part * 256 + (2 * wave + j) * 16 + li, half * 128, g, wh[buf][j], wl[buf][j]);
+    constexpr int NP = PRO ? 32 : 0, TOTAL = NP + 96;
+    PieceRing<SLAB_R, TOTAL> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.w) + (size_t)(2 * wave) * 16384;
+    const int ra = row0 + 2 * wave < p.M ? row0 + 2 * wave : p.M - 1, rb = row0 + 2 * wave + 1 < p.M ? row0 + 2 * wave + 1 : p.M - 1;
+    auto src = [&](const int n) -> const unsigned char* {
+        if (PRO && n < NP) {   // partial slab s = n / 2, row 2w + (n & 1)
+            const int s = n >> 1 < p.nsplit ? n >> 1 : p.nsplit - 1;
+            return reinterpret_cast<const unsigned char*>(p.partials + ((size_t)s * p.M + ((n & 1) ? rb : ra)) * 256);
+        }
+        const int m = n - NP;   // part m / 32: tiles 16 part + 2w, + 1 are consecutive 16-KiB blocks
+        return wsrc + (size_t)(m >> 5) * (16 * 16384) + (size_t)(m & 31) * 1024;
     };
     {   // the slab's rows: 32 threads per row, 8 consecutive channels each; [previous FFN's sum + LN3]
         const int r = tid >> 5, c0 = (tid & 31) * 8, row = row0 + r;
         const size_t rc = (size_t)(row < p.M ? row : p.M - 1) * 256 + c0;   // (rows beyond M: a valid address, results unused)
-        const float* src = p.partials ? p.h_in : p.h_out;
-        float4v xa = *reinterpret_cast<const float4v*>(src + rc), xb = *reinterpret_cast<const float4v*>(src + rc + 4);
+        const float* hsrc = PRO ? p.h_in : p.h_out;
+        float4v xa = *reinterpret_cast<const float4v*>(hsrc + rc), xb = *reinterpret_cast<const float4v*>(hsrc + rc + 4);
         float v[8];
-        if (p.partials) {   // (uniform over the launch)
-            float4v pa[QKV_MAXS], pb[QKV_MAXS];
-#pragma unroll
-            for (int s = 0; s < QKV_MAXS; ++s) {   // every slab requested before the first one is needed
-                const float* ps = p.partials + (size_t)(s < p.nsplit ? s : p.nsplit - 1) * p.M * 256 + rc;
-                pa[s] = *reinterpret_cast<const float4v*>(ps);
-                pb[s] = *reinterpret_cast<const float4v*>(ps + 4);
-            }
+        if constexpr (PRO) {
             const float4v ba = *reinterpret_cast<const float4v*>(p.b2 + c0), bb = *reinterpret_cast<const float4v*>(p.b2 + c0 + 4);
             const float4v g0 = *reinterpret_cast<const float4v*>(p.ln_g + c0), g1 = *reinterpret_cast<const float4v*>(p.ln_g + c0 + 4);
             const float4v e0 = *reinterpret_cast<const float4v*>(p.ln_b + c0), e1 = *reinterpret_cast<const float4v*>(p.ln_b + c0 + 4);
-            load_half(0, 0, 0);   // q's first half: in flight behind the slabs
+            rg.prime(src);
             DEC_FENCE();
             xa += ba; xb += bb;
 #pragma unroll
-            for (int s = 0; s < QKV_MAXS; ++s)   // fixed order: deterministic
-                if (s < p.nsplit) { xa += pa[s]; xb += pb[s]; }
+            for (int bt = 0; bt < 4; ++bt) {   // four batches of 4 slabs x 2 rows; fixed order: deterministic
+                rg.wait(8 * bt, 8 * bt + 7);
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    const unsigned char* sl = rg.slot(8 * bt + 2 * s + (lane >> 5)) + (lane & 31) * 32;
+                    const float4v pa = *reinterpret_cast<const float4v*>(sl), pb = *reinterpret_cast<const float4v*>(sl + 16);
+                    if (4 * bt + s < p.nsplit) { xa += pa; xb += pb; }
+                }
+                rg.advance(src, 8 * bt, 8);
+            }
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] = xa[j]; v[4 + j] = xb[j]; }
             layernorm_row32(v, g0, g1, e0, e1);
@@ -208,16 +287,15 @@ __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
                 *reinterpret_cast<float4v*>(p.h_out + (size_t)row * 256 + c0 + 4) = float4v{v[4], v[5], v[6], v[7]};
             }
         } else {
-            load_half(0, 0, 0);
+            rg.prime(src);
             DEC_FENCE();
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] = xa[j]; v[4 + j] = xb[j]; }
         }
         store_split8(Xhi, Xlo, XP, r, c0, v);
     }
-    load_half(0, 1, 1);
-    DEC_FENCE();
-    __syncthreads();
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
     const int row = row0 + li;
     const bool ok = row < p.M;
     const int rcl = ok ? row : p.M - 1;
@@ -229,14 +307,7 @@ __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
         for (int j = 0; j < 2; ++j) bs[j] = *reinterpret_cast<const float4v*>(p.bias + (size_t)qi * 768 + part * 256 + (2 * wave + j) * 16 + 4 * g);
         Acc3 a;
         acc3_zero(a);
-        gemm16<4>(Xhi, Xlo, 0, wh[0], wl[0], g, li, a);
-        DEC_FENCE();
-        if (part < 2) load_half(part + 1, 0, 0);
-        DEC_FENCE();
-        gemm16<4>(Xhi, Xlo, 4, wh[1], wl[1], g, li, a);
-        DEC_FENCE();
-        if (part < 2) load_half(part + 1, 1, 1);
-        DEC_FENCE();
+        gemm256(rg, src, NP + 32 * part, Xhi, Xlo, lane16, g, li, a);
         if (ok) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -256,36 +327,27 @@ __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
     }
 }
 
-// o-proj + bias + residual + LayerNorm of a 16-row slab whose attention output sits (hi / lo) in LDS; returns the normalised rows in
-// accumulator layout.  rs = bias (+ residual) of this lane's channels, gm / bt = gamma / beta: loaded by the caller, early.
-__device__ __forceinline__ void oproj_ln(const unsigned char* Xhi, const unsigned char* Xlo, const half8 (&wh)[2][8], const half8 (&wl)[2][8],
-                                         const float4v (&rs)[2], const float4v (&gm)[2], const float4v (&bt)[2], float (*red)[8][16], const int wave,
-                                         const int g, const int li, float4v (&out)[2]) {
-    Acc3 a;
-    acc3_zero(a);
-    gemm16<8>(Xhi, Xlo, 0, wh, wl, g, li, a);
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) out[j][r] = acc3_get(a, j, r) + rs[j][r];
-    layernorm_acc(out, red, wave, g, li, gm, bt);
-}
-
 // ---------------------------------------------------------------------------------------------------------------------------------
 // dec_self_kernel: grid (ceil(Q / 16) query slabs, B frames), 512 threads: wave = head during the attention, then column tiles.
+// Piece sequence of a wave: its two tiles of Wo (32), then of Wq_c (32).
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Xhi[16 * XP];
-    __shared__ __attribute__((aligned(16))) unsigned char Xlo[16 * XP];
-    __shared__ float red[2][8][16];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* const Xhi = smem;
+    unsigned char* const Xlo = smem + 16 * XP;
+    float (*red)[8][16] = reinterpret_cast<float (*)[8][16]>(smem + SLAB_RED);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, li = lane & 15;
+    const int g = lane >> 4, li = lane & 15, lane16 = lane * 16;
     const int q0 = blockIdx.x * 16, b = blockIdx.y;
     const int Q = p.Q;
     const bool q_ok = q0 + li < Q;
     const size_t row = (size_t)b * Q + (q_ok ? q0 + li : Q - 1);   // this lane's data row (clamped: padding lanes compute on a valid row, store nothing)
     const int h = wave;
+    PieceRing<SLAB_R, 64> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
+    const unsigned char* const wo = reinterpret_cast<const unsigned char*>(p.wo) + (size_t)(2 * wave) * 16384;
+    const unsigned char* const wq = reinterpret_cast<const unsigned char*>(p.wq) + (size_t)(2 * wave) * 16384;
+    auto src = [&](const int n) -> const unsigned char* { return (n < 32 ? wo : wq) + (size_t)(n & 31) * 1024; };
     // ---- every load of the attention and of the o-proj, requested at once --------------------------------------------------------
     const half8 qf = *reinterpret_cast<const half8*>(p.q16 + row * 256 + h * 32 + g * 8);
     half8 kf[8];
@@ -306,17 +368,16 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
                 const int key0 = kb * 32 + hh * 16 + g * 4;   // (Q % 4 == 0: a group of 4 keys is all valid or all padding)
                 v4[kb][dt][hh] = *reinterpret_cast<const half4*>(vt + (size_t)(dt * 16 + li) * 128 + (key0 < Q ? key0 : 0));
             }
-    float4v rs[2], gm[2], bt[2];
+    float4v rs[2], gm[2], bt[2], bs[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = (2 * wave + j) * 16 + 4 * g;
         rs[j] = *reinterpret_cast<const float4v*>(p.bo + c) + *reinterpret_cast<const float4v*>(p.h + row * 256 + c);
         gm[j] = *reinterpret_cast<const float4v*>(p.ln_g + c);
         bt[j] = *reinterpret_cast<const float4v*>(p.ln_b + c);
+        bs[j] = *reinterpret_cast<const float4v*>(p.rbq + (size_t)(q_ok ? q0 + li : 0) * 256 + c);
     }
-    half8 wh[2][8], wl[2][8];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) load_w<8>(p.wo_hi, p.wo_lo, 256, (2 * wave + j) * 16 + li, 0, g, wh[j], wl[j]);
+    rg.prime(src);   // Wo's first half-tiles travel during the attention
     DEC_FENCE();
     // ---- attention of head `wave`: S^T = K Q^T over the frame's Q keys, softmax per query, O^T = V^T P^T -------------------------------
     float4v s[8];
@@ -363,18 +424,18 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
     const float inv = 1.0f / lsum;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) store_split4(Xhi, Xlo, XP, li, h * 32 + dt * 16 + g * 4, oacc[dt] * inv);
-    __syncthreads();
-    // ---- o-proj + residual + LN1 --------------------------------------------------------------------------------------
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    // ---- o-proj + residual + LN1 (Wq_c's first half-tiles are requested as Wo's slots drain: they travel during the LayerNorm) -------------
+    Acc3 a;
+    acc3_zero(a);
+    gemm256(rg, src, 0, Xhi, Xlo, lane16, g, li, a);
     float4v hn[2];
-    oproj_ln(Xhi, Xlo, wh, wl, rs, gm, bt, red, wave, g, li, hn);
-    // cross-attention query projection: weights and bias table requested now, they travel during the exchange below
-    DEC_FENCE();
 #pragma unroll
-    for (int j = 0; j < 2; ++j) load_w<8>(p.wq_hi, p.wq_lo, 256, (2 * wave + j) * 16 + li, 0, g, wh[j], wl[j]);
-    float4v bs[2];
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) bs[j] = *reinterpret_cast<const float4v*>(p.rbq + (size_t)(q_ok ? q0 + li : 0) * 256 + (2 * wave + j) * 16 + 4 * g);
-    DEC_FENCE();
+        for (int r = 0; r < 4; ++r) hn[j][r] = acc3_get(a, j, r) + rs[j][r];
+    layernorm_acc(hn, red, wave, g, li, gm, bt);
     // (layernorm_acc's barriers lie between the o-proj's last fragment read and these writes)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -382,11 +443,11 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
         if (q_ok) *reinterpret_cast<float4v*>(p.h + row * 256 + c) = hn[j];
         store_split4(Xhi, Xlo, XP, li, c, hn[j]);
     }
-    __syncthreads();
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
     // ---- q_c = h . Wq_c^T + (qpos . Wq_c^T + bq_c) ----------------------------------------------------------------------
-    Acc3 a;
     acc3_zero(a);
-    gemm16<8>(Xhi, Xlo, 0, wh, wl, g, li, a);
+    gemm256(rg, src, 32, Xhi, Xlo, lane16, g, li, a);
     if (q_ok) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -403,16 +464,22 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int CROSS_MAXS = 6;
 __global__ __launch_bounds__(512) void dec_cross_out_kernel(DecCrossOutParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned char Xhi[16 * XP];
-    __shared__ __attribute__((aligned(16))) unsigned char Xlo[16 * XP];
-    __shared__ float red[2][8][16];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* const Xhi = smem;
+    unsigned char* const Xlo = smem + 16 * XP;
+    float (*red)[8][16] = reinterpret_cast<float (*)[8][16]>(smem + SLAB_RED);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, li = lane & 15;
+    const int g = lane >> 4, li = lane & 15, lane16 = lane * 16;
     const int row0 = blockIdx.x * 16;
     const int row = row0 + li;
     const bool ok = row < p.M;
     const int rcl = ok ? row : p.M - 1;
+    PieceRing<SLAB_R, 32> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
+    const unsigned char* const wo = reinterpret_cast<const unsigned char*>(p.wo) + (size_t)(2 * wave) * 16384;
+    auto src = [&](const int n) -> const unsigned char* { return wo + (size_t)n * 1024; };
+    float4v rs[2], gm[2], bt[2];
+    const float* res = p.res + (size_t)(p.res_period > 0 ? rcl % p.res_period : rcl) * 256;
     {   // combine the key splits: o = sum_s 2^(m_s - m) O_s / sum_s 2^(m_s - m) l_s ; 32 threads per row, 8 channels (a quarter head) each
         const int r = tid >> 5, c0 = (tid & 31) * 8, prow = row0 + r < p.M ? row0 + r : p.M - 1, head = c0 >> 5;
         float2v ml[CROSS_MAXS];
@@ -424,6 +491,14 @@ __global__ __launch_bounds__(512) void dec_cross_out_kernel(DecCrossOutParams p)
             oa[s] = *reinterpret_cast<const float4v*>(p.part_o + sr * 256 + c0);
             ob[s] = *reinterpret_cast<const float4v*>(p.part_o + sr * 256 + c0 + 4);
         }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int c = (2 * wave + j) * 16 + 4 * g;
+            rs[j] = *reinterpret_cast<const float4v*>(p.bo + c) + *reinterpret_cast<const float4v*>(res + c);
+            gm[j] = *reinterpret_cast<const float4v*>(p.ln_g + c);
+            bt[j] = *reinterpret_cast<const float4v*>(p.ln_b + c);
+        }
+        rg.prime(src);
         DEC_FENCE();
         float mmax = -INFINITY;
 #pragma unroll
@@ -445,22 +520,17 @@ __global__ __launch_bounds__(512) void dec_cross_out_kernel(DecCrossOutParams p)
         for (int j = 0; j < 4; ++j) { v[j] = va[j] * inv; v[4 + j] = vb[j] * inv; }
         store_split8(Xhi, Xlo, XP, r, c0, v);
     }
-    float4v rs[2], gm[2], bt[2];
-    const float* res = p.res + (size_t)(p.res_period > 0 ? rcl % p.res_period : rcl) * 256;
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int c = (2 * wave + j) * 16 + 4 * g;
-        rs[j] = *reinterpret_cast<const float4v*>(p.bo + c) + *reinterpret_cast<const float4v*>(res + c);
-        gm[j] = *reinterpret_cast<const float4v*>(p.ln_g + c);
-        bt[j] = *reinterpret_cast<const float4v*>(p.ln_b + c);
-    }
-    half8 wh[2][8], wl[2][8];
-#pragma unroll
-    for (int j = 0; j < 2; ++j) load_w<8>(p.wo_hi, p.wo_lo, 256, (2 * wave + j) * 16 + li, 0, g, wh[j], wl[j]);
-    DEC_FENCE();
-    __syncthreads();
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    Acc3 a;
+    acc3_zero(a);
+    gemm256(rg, src, 0, Xhi, Xlo, lane16, g, li, a);
     float4v hn[2];
-    oproj_ln(Xhi, Xlo, wh, wl, rs, gm, bt, red, wave, g, li, hn);
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hn[j][r] = acc3_get(a, j, r) + rs[j][r];
+    layernorm_acc(hn, red, wave, g, li, gm, bt);
     if (ok) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) *reinterpret_cast<float4v*>(p.h + (size_t)row * 256 + (2 * wave + j) * 16 + 4 * g) = hn[j];
@@ -468,58 +538,68 @@ __global__ __launch_bounds__(512) void dec_cross_out_kernel(DecCrossOutParams p)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// dec_ffn_kernel: grid (slabs of 64 rows, F / 128 hidden chunks), 512 threads, 100 KiB of LDS.
+// dec_ffn_kernel: grid (slabs of 64 rows, F / 128 hidden chunks), 512 threads.
 //   fc1: wave w owns hidden tile w of the chunk (16 channels) for the slab's four 16-row tiles; fc2: wave w owns output tiles 2w, 2w + 1.
+// Piece sequence of a wave (ring of 11 slots): 8 rows of the slab (fp32: the wave converts rows 8w .. 8w + 7 to hi / lo), the 16 pieces
+// of its W1 tile, then the 16 pieces of its two W2 tiles for this chunk's four k-steps, k-step major.  The hidden chunk (hi / lo)
+// takes the place of the input rows in LDS.
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int FFN_ROWS = 64;
-constexpr int FFN_LDS = 2 * FFN_ROWS * XP + 2 * FFN_ROWS * HP;
+constexpr int FFN_R = 11;
+constexpr int FFN_RING = 2 * FFN_ROWS * XP;                 // 67 584 (1 KiB aligned)
+constexpr int FFN_LDS = FFN_RING + 8 * FFN_R * 1024;        // 157 696
 
 __global__ __launch_bounds__(512) void dec_ffn_kernel(DecFfnParams p) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     unsigned char* const Xhi = smem;
     unsigned char* const Xlo = smem + FFN_ROWS * XP;
-    unsigned char* const Hhi = smem + 2 * FFN_ROWS * XP;
-    unsigned char* const Hlo = Hhi + FFN_ROWS * HP;
+    unsigned char* const Hhi = smem;                        // (after the barrier that ends fc1)
+    unsigned char* const Hlo = smem + FFN_ROWS * HP;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int g = lane >> 4, li = lane & 15;
+    const int g = lane >> 4, li = lane & 15, lane16 = lane * 16;
     const int row0 = blockIdx.x * FFN_ROWS, chunk = blockIdx.y;
-    // every load of the kernel, requested at once: the slab's rows, W1's fragments, W2's fragments, b1
-    const int r = tid >> 3, t8 = tid & 7;   // rows -> hi / lo in LDS: 8 threads per row, four 8-channel pieces each
-    const size_t xrow = (size_t)(row0 + r < p.M ? row0 + r : p.M - 1) * 256;
-    float4v xa[4], xb[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        xa[i] = *reinterpret_cast<const float4v*>(p.h + xrow + (i * 8 + t8) * 8);
-        xb[i] = *reinterpret_cast<const float4v*>(p.h + xrow + (i * 8 + t8) * 8 + 4);
-    }
-    half8 w1h[8], w1l[8];
-    load_w<8>(p.w1_hi, p.w1_lo, 256, chunk * OPD_DEC_FFN_CHUNK + wave * 16 + li, 0, g, w1h, w1l);
+    PieceRing<FFN_R, 40> rg{smem + FFN_RING + wave * FFN_R * 1024, lane16};
+    const unsigned char* const w1 = reinterpret_cast<const unsigned char*>(p.w1) + (size_t)(chunk * 8 + wave) * 16384;
+    const size_t w2tile = (size_t)(p.F / 32) * 2048;   // bytes of one 16-row tile of W2 (F / 32 k-steps x (hi, lo))
+    const unsigned char* const w2 = reinterpret_cast<const unsigned char*>(p.w2) + (size_t)(2 * wave) * w2tile + (size_t)chunk * 4 * 2048;
+    auto src = [&](const int n) -> const unsigned char* {
+        if (n < 8) { const int r = row0 + 8 * wave + n; return reinterpret_cast<const unsigned char*>(p.h + (size_t)(r < p.M ? r : p.M - 1) * 256); }
+        if (n < 24) return w1 + (size_t)(n - 8) * 1024;
+        const int i = n - 24;   // k-step i / 4, tile (i / 2) & 1, hi / lo i & 1
+        return w2 + (size_t)((i >> 1) & 1) * w2tile + (size_t)(i >> 2) * 2048 + (size_t)(i & 1) * 1024;
+    };
     const float4v b1 = *reinterpret_cast<const float4v*>(p.b1 + chunk * OPD_DEC_FFN_CHUNK + wave * 16 + 4 * g);
-    half8 w2h[2][4], w2l[2][4];   // rows = output channels, k = this chunk's 128 hidden channels
-#pragma unroll
-    for (int j = 0; j < 2; ++j) load_w<4>(p.w2_hi, p.w2_lo, p.F, (2 * wave + j) * 16 + li, chunk * OPD_DEC_FFN_CHUNK, g, w2h[j], w2l[j]);
+    rg.prime(src);
     DEC_FENCE();
-    const bool rok = row0 + r < p.M;
+    // ---- rows 8w .. 8w + 7 -> hi / lo -----------------------------------------------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { v[j] = rok ? xa[i][j] : 0.f; v[4 + j] = rok ? xb[i][j] : 0.f; }
-        store_split8(Xhi, Xlo, XP, r, (i * 8 + t8) * 8, v);
+    for (int n = 0; n < 8; ++n) {
+        rg.wait(n, n);
+        float4v x = *reinterpret_cast<const float4v*>(rg.slot(n) + lane16);
+        if (row0 + 8 * wave + n >= p.M) x = float4v{0.f, 0.f, 0.f, 0.f};
+        store_split4(Xhi, Xlo, XP, 8 * wave + n, lane * 4, x);
+        rg.advance(src, n, 1);
     }
-    __syncthreads();
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
     // ---- hidden chunk = relu(x . W1^T + b1) ---------------------------------------------------------------------------------
     float4v ah[4], al[4], am[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) { ah[mt] = float4v{0.f, 0.f, 0.f, 0.f}; al[mt] = ah[mt]; am[mt] = ah[mt]; }
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks)
+    for (int ks = 0; ks < 8; ++ks) {
+        rg.wait(8 + 2 * ks, 9 + 2 * ks);
+        const half8 wh = *reinterpret_cast<const half8*>(rg.slot(8 + 2 * ks) + lane16), wl = *reinterpret_cast<const half8*>(rg.slot(9 + 2 * ks) + lane16);
 #pragma unroll
         for (int mt = 0; mt < 4; ++mt) {
             const half8 xh = lds_frag(Xhi, XP, mt * 16 + li, ks, g), xl = lds_frag(Xlo, XP, mt * 16 + li, ks, g);
-            mma3(w1h[ks], w1l[ks], xh, xl, ah[mt], al[mt], am[mt]);
+            mma3(wh, wl, xh, xl, ah[mt], al[mt], am[mt]);
         }
+        rg.advance(src, 8 + 2 * ks, 2);
+    }
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();   // every wave has read the input rows: the hidden chunk may overwrite them
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
         float4v hid;
@@ -527,25 +607,35 @@ __global__ __launch_bounds__(512) void dec_ffn_kernel(DecFfnParams p) {
         for (int rr = 0; rr < 4; ++rr) { const float tv = ah[mt][rr] + (al[mt][rr] + am[mt][rr]) * LO_INV + b1[rr]; hid[rr] = tv > 0.f ? tv : 0.f; }
         store_split4(Hhi, Hlo, HP, mt * 16 + li, wave * 16 + 4 * g, hid);
     }
-    __syncthreads();
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
     // ---- partial = hidden chunk . W2[:, chunk]^T ----------------------------------------------------------------------------
+    Acc3 a[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) acc3_zero(a[mt]);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        rg.wait(24 + 4 * ks, 27 + 4 * ks);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const half8 wh = *reinterpret_cast<const half8*>(rg.slot(24 + 4 * ks + 2 * j) + lane16), wl = *reinterpret_cast<const half8*>(rg.slot(25 + 4 * ks + 2 * j) + lane16);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) {
+                const half8 xh = lds_frag(Hhi, HP, mt * 16 + li, ks, g), xl = lds_frag(Hlo, HP, mt * 16 + li, ks, g);
+                mma3(wh, wl, xh, xl, a[mt].h[j], a[mt].l[j], a[mt].m[j]);
+            }
+        }
+        rg.advance(src, 24 + 4 * ks, 4);
+    }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        Acc3 a;
-        acc3_zero(a);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            const half8 xh = lds_frag(Hhi, HP, mt * 16 + li, ks, g), xl = lds_frag(Hlo, HP, mt * 16 + li, ks, g);
-#pragma unroll
-            for (int j = 0; j < 2; ++j) mma3(w2h[j][ks], w2l[j][ks], xh, xl, a.h[j], a.l[j], a.m[j]);
-        }
         const int row = row0 + mt * 16 + li;
         if (row < p.M) {
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float4v o;
 #pragma unroll
-                for (int rr = 0; rr < 4; ++rr) o[rr] = acc3_get(a, j, rr);
+                for (int rr = 0; rr < 4; ++rr) o[rr] = acc3_get(a[mt], j, rr);
                 *reinterpret_cast<float4v*>(p.partials + ((size_t)chunk * p.M + row) * 256 + (2 * wave + j) * 16 + 4 * g) = o;
             }
         }
@@ -554,39 +644,50 @@ __global__ __launch_bounds__(512) void dec_ffn_kernel(DecFfnParams p) {
 
 }  // namespace
 
-// host: x -> (fp16(x), fp16((x - fp16(x)) * 2048)) as raw half bits
-void opd_split_f16(const float* w, size_t n, f16_t* hi, f16_t* lo) {
-    for (size_t i = 0; i < n; ++i) {
-        const _Float16 h = (_Float16)w[i];
-        const _Float16 l = (_Float16)((w[i] - (float)h) * 2048.0f);
-        __builtin_memcpy(&hi[i], &h, 2);
-        __builtin_memcpy(&lo[i], &l, 2);
-    }
+// host: [N][K] fp32 -> the split pair in MFMA-fragment order: for every (16-row tile nt, 32-wide k-step ks) 1 KiB of hi = fp16(w) followed by
+// 1 KiB of lo = fp16((w - hi) * 2048); inside a KiB lane L = 16 g + li holds w[16 nt + li][32 ks + 8 g .. + 7].  out: 2 * N * K halves.
+void opd_split_f16_frag(const float* w, int N, int K, f16_t* out) {
+    const int nks = K / 32;
+    for (int nt = 0; nt < N / 16; ++nt)
+        for (int ks = 0; ks < nks; ++ks) {
+            f16_t* blk = out + ((size_t)nt * nks + ks) * 1024;
+            for (int L = 0; L < 64; ++L)
+                for (int e = 0; e < 8; ++e) {
+                    const float v = w[(size_t)(nt * 16 + (L & 15)) * K + ks * 32 + (L >> 4) * 8 + e];
+                    const _Float16 h = fabsf(v) < 6.103515625e-5f ? (_Float16)0.f : (_Float16)v;   // (no subnormal hi: see split1)
+                    const _Float16 l = (_Float16)((v - (float)h) * 2048.0f);
+                    __builtin_memcpy(&blk[L * 8 + e], &h, 2);
+                    __builtin_memcpy(&blk[512 + L * 8 + e], &l, 2);
+                }
+        }
 }
 
 hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.Q <= 0 || !p.h_out || !p.w_hi || !p.w_lo || !p.bias || !p.q16 || !p.k16 || !p.vT) return hipErrorInvalidValue;
-    if (p.partials && (!p.h_in || !p.b2 || !p.ln_g || !p.ln_b || p.nsplit < 1)) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.Q <= 0 || !p.h_out || !p.w || !p.bias || !p.q16 || !p.k16 || !p.vT) return hipErrorInvalidValue;
+    if (p.partials && (!p.h_in || !p.b2 || !p.ln_g || !p.ln_b || p.nsplit < 1 || p.nsplit > QKV_MAXS)) return hipErrorInvalidValue;
     if (p.Q > 128 || p.M % p.Q != 0) return hipErrorInvalidValue;   // v^T rows hold 128 keys; rows are (frame, query)
-    if (p.partials && p.nsplit > QKV_MAXS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_qkv_kernel, dim3((p.M + 15) / 16), dim3(512), 0, stream, p);
+    OPD_SET_MAX_LDS_ONCE(dec_qkv_kernel<true>, SLAB_LDS);
+    OPD_SET_MAX_LDS_ONCE(dec_qkv_kernel<false>, SLAB_LDS);
+    if (p.partials) hipLaunchKernelGGL(dec_qkv_kernel<true>, dim3((p.M + 15) / 16), dim3(512), SLAB_LDS, stream, p);
+    else hipLaunchKernelGGL(dec_qkv_kernel<false>, dim3((p.M + 15) / 16), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_self(const DecSelfParams& p, hipStream_t stream) {
-    if (p.B <= 0 || p.Q <= 0 || p.Q > 128 || (p.Q & 3) || !p.q16 || !p.k16 || !p.vT || !p.h || !p.wo_hi || !p.wo_lo || !p.bo || !p.ln_g || !p.ln_b ||
-        !p.wq_hi || !p.wq_lo || !p.rbq || !p.qc16)
+    if (p.B <= 0 || p.Q <= 0 || p.Q > 128 || (p.Q & 3) || !p.q16 || !p.k16 || !p.vT || !p.h || !p.wo || !p.bo || !p.ln_g || !p.ln_b || !p.wq || !p.rbq || !p.qc16)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_self_kernel, dim3((p.Q + 15) / 16, p.B), dim3(512), 0, stream, p);
+    OPD_SET_MAX_LDS_ONCE(dec_self_kernel, SLAB_LDS);
+    hipLaunchKernelGGL(dec_self_kernel, dim3((p.Q + 15) / 16, p.B), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_cross_out(const DecCrossOutParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.splits < 1 || p.splits > CROSS_MAXS || !p.part_o || !p.part_ml || !p.res || !p.h || !p.wo_hi || !p.wo_lo || !p.bo || !p.ln_g || !p.ln_b || p.res_period < 0)
+    if (p.M <= 0 || p.splits < 1 || p.splits > CROSS_MAXS || !p.part_o || !p.part_ml || !p.res || !p.h || !p.wo || !p.bo || !p.ln_g || !p.ln_b || p.res_period < 0)
         return hipErrorInvalidValue;
-    hipLaunchKernelGGL(dec_cross_out_kernel, dim3((p.M + 15) / 16), dim3(512), 0, stream, p);
+    OPD_SET_MAX_LDS_ONCE(dec_cross_out_kernel, SLAB_LDS);
+    hipLaunchKernelGGL(dec_cross_out_kernel, dim3((p.M + 15) / 16), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_ffn(const DecFfnParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.F <= 0 || p.F % OPD_DEC_FFN_CHUNK != 0 || !p.h || !p.w1_hi || !p.w1_lo || !p.b1 || !p.w2_hi || !p.w2_lo || !p.partials) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.F <= 0 || p.F % OPD_DEC_FFN_CHUNK != 0 || !p.h || !p.w1 || !p.b1 || !p.w2 || !p.partials) return hipErrorInvalidValue;
     OPD_SET_MAX_LDS_ONCE(dec_ffn_kernel, FFN_LDS);
     hipLaunchKernelGGL(dec_ffn_kernel, dim3((p.M + FFN_ROWS - 1) / FFN_ROWS, p.F / OPD_DEC_FFN_CHUNK), dim3(512), FFN_LDS, stream, p);
     return hipGetLastError();

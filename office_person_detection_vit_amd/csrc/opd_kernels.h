@@ -224,8 +224,10 @@ hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const 
 // moves the boxes most (tools/drift_split.py), so it runs as FIVE launches per layer on SPLIT operands: every GEMM input x and weight
 // W travels as two fp16 numbers, x = hi + lo / 2048 with hi = fp16(x), lo = fp16((x - hi) * 2048), and a product is three MFMAs,
 // W.x = Whi.xhi + (Whi.xlo + Wlo.xhi) / 2048 (two fp32 accumulators, combined once): ~22 mantissa bits, no fp16 rounding of weights
-// or activations left on the decoder's residual path.  opd_split_f16: host-side split of a weight matrix.
-void opd_split_f16(const float* w, size_t n, f16_t* hi, f16_t* lo);   // host
+// or activations left on the decoder's residual path.  Weights are stored in MFMA-FRAGMENT ORDER (opd_split_f16_frag, host): per (16-row
+// tile, 32-wide k-step) 1 KiB of hi then 1 KiB of lo, lane L's 16 bytes at offset 16 L -- what a wave streams by LDS-DMA and reads back
+// lane-linear (kernels_dec.hip).  All `w*` pointers of the structs below are such [N][K] matrices (2 * N * K halves).
+void opd_split_f16_frag(const float* w, int N, int K, f16_t* out);   // host
 struct DecQkvParams {   // [previous layer: h = LN3(h_in + b2 + sum partials)] ; q | k | v = h . Wqkv^T + bias[row % Q]
     const float* h_in;       // [M][256] residual stream before the previous layer's FFN (null with partials == null: h_out is the input)
     const float* partials;   // [nsplit][M][256] fp32 partial sums of the previous layer's FFN-2 (null: no reduce / LayerNorm, h = h_out as it is)
@@ -233,7 +235,7 @@ struct DecQkvParams {   // [previous layer: h = LN3(h_in + b2 + sum partials)] ;
     const float* b2;         // [256] that FFN-2's bias
     const float *ln_g, *ln_b;
     float* h_out;            // [M][256] the layer's input state (written by the q workgroups when partials != null; read otherwise)
-    const f16_t *w_hi, *w_lo;   // [768][256] = [Wq; Wk; Wv]
+    const f16_t* w;          // [768][256] = [Wq; Wk; Wv], fragment order
     const float* bias;       // [Q][768] row-periodic: query-position fold + biases (fp32)
     f16_t *q16, *k16;        // [M][256]
     f16_t* vT;               // [B][8][32][128]: v transposed per (frame, head): [dim][key]
@@ -243,9 +245,9 @@ hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream);
 struct DecSelfParams {  // self-attention of one (frame, 16-query slab) + o-proj + residual + LayerNorm + the cross-attention query projection
     const f16_t *q16, *k16, *vT;
     float* h;                // [M][256] in: the layer's input state (residual), out: LayerNorm output
-    const f16_t *wo_hi, *wo_lo;   // [256][256]
+    const f16_t* wo;         // [256][256], fragment order
     const float *bo, *ln_g, *ln_b;
-    const f16_t *wq_hi, *wq_lo;   // cross-attention q_proj [256][256]
+    const f16_t* wq;         // cross-attention q_proj [256][256], fragment order
     const float* rbq;        // [Q][256]: query-position fold + bias of that projection
     f16_t* qc16;             // [M][256] out
     int B, Q;
@@ -259,7 +261,7 @@ struct DecCrossOutParams {   // combine the key splits of the cross-attention, o
     const float* res;        // residual rows [M][256], or [res_period][256] repeated per frame (layer 0: the constant state)
     int res_period;
     float* h;                // [M][256] out (may alias res when res_period == 0)
-    const f16_t *wo_hi, *wo_lo;
+    const f16_t* wo;         // [256][256], fragment order
     const float *bo, *ln_g, *ln_b;
     int M;
 };
@@ -267,9 +269,9 @@ hipError_t opd_launch_dec_cross_out(const DecCrossOutParams& p, hipStream_t stre
 #define OPD_DEC_FFN_CHUNK 128   // hidden channels per workgroup of dec_ffn_kernel; partial sums: ffn / 128 slabs
 struct DecFfnParams {   // partial[c] = relu(h . W1[chunk c]^T + b1[chunk c]) . W2[:, chunk c]^T for 64-row slabs (bias b2 added by the consumer)
     const float* h;          // [M][256]
-    const f16_t *w1_hi, *w1_lo;   // [F][256]
+    const f16_t* w1;         // [F][256], fragment order
     const float* b1;         // [F]
-    const f16_t *w2_hi, *w2_lo;   // [256][F]
+    const f16_t* w2;         // [256][F], fragment order
     float* partials;         // [F / 128][M][256]
     int M, F;
 };

@@ -32,14 +32,13 @@ static int upload_f16(opd_detr* m, f16_t** dst, const std::vector<float>& v) {
     return OPD_OK;
 }
 
-// a linear layer's weights as the split pair of the fused decoder (opd_split_f16: hi = fp16(w), lo = fp16((w - hi) * 2048))
-static int upload_split(opd_detr* m, f16_t** hi, f16_t** lo, const std::vector<float>& v) {
-    std::vector<f16_t> h(v.size()), l(v.size());
-    opd_split_f16(v.data(), v.size(), h.data(), l.data());
-    RCCHK(dalloc(m, hi, h.size(), true));
-    RCCHK(dalloc(m, lo, l.size(), true));
-    HIPCHK(hipMemcpy(*hi, h.data(), h.size() * 2, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(*lo, l.data(), l.size() * 2, hipMemcpyHostToDevice));
+// a linear layer's weights [N][K] as the fused decoder's split pair in MFMA-fragment order (opd_split_f16_frag)
+static int upload_frag(opd_detr* m, f16_t** dst, const std::vector<float>& v, int N, int K) {
+    if ((size_t)N * K != v.size() || N % 16 || K % 32) return fail(OPD_ESCHEMA, "decoder weight matrix does not tile into 16 x 32 fragments");
+    std::vector<f16_t> f(v.size() * 2);
+    opd_split_f16_frag(v.data(), N, K, f.data());
+    RCCHK(dalloc(m, dst, f.size(), true));
+    HIPCHK(hipMemcpy(*dst, f.data(), f.size() * 2, hipMemcpyHostToDevice));
     return OPD_OK;
 }
 
@@ -228,12 +227,14 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln3));
         // split pairs for the fused decoder
-        RCCHK(upload_split(m, &L.wqkv_hi, &L.wqkv_lo, wfull));
-        RCCHK(upload_split(m, &L.so_hi, &L.so_lo, T(sd, p + ".self_attn.o_proj.weight").data));
-        RCCHK(upload_split(m, &L.wqc_hi, &L.wqc_lo, T(sd, p + ".encoder_attn.q_proj.weight").data));
-        RCCHK(upload_split(m, &L.co_hi, &L.co_lo, T(sd, p + ".encoder_attn.o_proj.weight").data));
-        RCCHK(upload_split(m, &L.fc1_hi, &L.fc1_lo, T(sd, p + ".mlp.fc1.weight").data));
-        RCCHK(upload_split(m, &L.fc2_hi, &L.fc2_lo, T(sd, p + ".mlp.fc2.weight").data));
+        if (D % 32 == 0 && a.ffn % 32 == 0) {
+            RCCHK(upload_frag(m, &L.wqkv_f, wfull, 3 * D, D));
+            RCCHK(upload_frag(m, &L.so_f, T(sd, p + ".self_attn.o_proj.weight").data, D, D));
+            RCCHK(upload_frag(m, &L.wqc_f, T(sd, p + ".encoder_attn.q_proj.weight").data, D, D));
+            RCCHK(upload_frag(m, &L.co_f, T(sd, p + ".encoder_attn.o_proj.weight").data, D, D));
+            RCCHK(upload_frag(m, &L.fc1_f, T(sd, p + ".mlp.fc1.weight").data, a.ffn, D));
+            RCCHK(upload_frag(m, &L.fc2_f, T(sd, p + ".mlp.fc2.weight").data, D, a.ffn));
+        }
     }
     RCCHK(upload_f16(m, &m->wkv_all, kv_full));
     RCCHK(upload_f32(m, &m->bkv_all, m->h_kv_cat_b));
@@ -908,7 +909,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     const bool dec0 = m->fuse_dec0 && m->dec0_h && D == 256;
     // The fused decoder (kernels_dec.hip): five launches per layer on split fp16 operands; layer 0 starts at its cross-attention (its
     // self-attention block and its queries are constants of the weights).  Taken when the architecture fits the kernels' fixed shapes.
-    const bool fused_dec = m->fused_dec && dec0 && m->qc0 && a.heads == 8 && Q <= 128 && (Q & 3) == 0 && F % OPD_DEC_FFN_CHUNK == 0 && F / OPD_DEC_FFN_CHUNK <= 16 && m->dec_splits <= 6 && m->dec[0].wqkv_hi &&
+    const bool fused_dec = m->fused_dec && dec0 && m->qc0 && a.heads == 8 && Q <= 128 && (Q & 3) == 0 && F % OPD_DEC_FFN_CHUNK == 0 && F / OPD_DEC_FFN_CHUNK <= 16 && m->dec_splits <= 6 && D == 256 && m->dec[0].wqkv_f &&
                            (size_t)M * NKV * 2 < (1ull << 32);
     const float* dec_final_h = m->d_h32;   // the state the heads read (fused: before the last FFN, whose partial sums travel with it)
     if (fused_dec) {
@@ -922,7 +923,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 const DecLayer& P = m->dec[i - 1];
                 DecQkvParams qp{};
                 qp.h_in = hbuf[cur]; qp.partials = m->d_ffn_part; qp.nsplit = nchunk; qp.b2 = P.fc2.b; qp.ln_g = P.ln3.g; qp.ln_b = P.ln3.b;
-                qp.h_out = hbuf[cur ^ 1]; qp.w_hi = L.wqkv_hi; qp.w_lo = L.wqkv_lo; qp.bias = L.rb_self;
+                qp.h_out = hbuf[cur ^ 1]; qp.w = L.wqkv_f; qp.bias = L.rb_self;
                 qp.q16 = m->d_dq16; qp.k16 = m->d_dk16; qp.vT = m->d_dvT; qp.M = Md; qp.Q = Q;
                 RCCHK(timed_begin(m, CLS_GEMM, 2.0 * Md * 768.0 * D));
                 HIPCHK(opd_launch_dec_qkv(qp, m->stream));
@@ -930,8 +931,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 cur ^= 1;
                 RCCHK(tap(m, "dec_qkv_h", hbuf[cur], (size_t)Md * D * 4));
                 DecSelfParams sp{};
-                sp.q16 = m->d_dq16; sp.k16 = m->d_dk16; sp.vT = m->d_dvT; sp.h = hbuf[cur]; sp.wo_hi = L.so_hi; sp.wo_lo = L.so_lo; sp.bo = L.so.b;
-                sp.ln_g = L.ln1.g; sp.ln_b = L.ln1.b; sp.wq_hi = L.wqc_hi; sp.wq_lo = L.wqc_lo; sp.rbq = L.rb_q; sp.qc16 = qd; sp.B = B; sp.Q = Q;
+                sp.q16 = m->d_dq16; sp.k16 = m->d_dk16; sp.vT = m->d_dvT; sp.h = hbuf[cur]; sp.wo = L.so_f; sp.bo = L.so.b;
+                sp.ln_g = L.ln1.g; sp.ln_b = L.ln1.b; sp.wq = L.wqc_f; sp.rbq = L.rb_q; sp.qc16 = qd; sp.B = B; sp.Q = Q;
                 sp.scale = 1.0f / sqrtf((float)(D / a.heads));
                 RCCHK(timed_begin(m, CLS_GEMM, 4.0 * Md * (double)D * D + 4.0 * B * (double)a.heads * Q * Q * 32));
                 HIPCHK(opd_launch_dec_self(sp, m->stream));
@@ -953,7 +954,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 DecCrossOutParams cp{};
                 cp.part_o = m->d_part_o; cp.part_ml = m->d_part_ml; cp.splits = S;
                 cp.res = i == 0 ? m->dec0_h : hbuf[cur]; cp.res_period = i == 0 ? 1 : 0; cp.h = hbuf[cur];
-                cp.wo_hi = L.co_hi; cp.wo_lo = L.co_lo; cp.bo = L.co.b; cp.ln_g = L.ln2.g; cp.ln_b = L.ln2.b; cp.M = Md;
+                cp.wo = L.co_f; cp.bo = L.co.b; cp.ln_g = L.ln2.g; cp.ln_b = L.ln2.b; cp.M = Md;
                 RCCHK(timed_begin(m, CLS_GEMM, 2.0 * Md * (double)D * D));
                 HIPCHK(opd_launch_dec_cross_out(cp, m->stream));
                 RCCHK(timed_end(m));
@@ -961,7 +962,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             }
             {
                 DecFfnParams fp{};
-                fp.h = hbuf[cur]; fp.w1_hi = L.fc1_hi; fp.w1_lo = L.fc1_lo; fp.b1 = L.fc1.b; fp.w2_hi = L.fc2_hi; fp.w2_lo = L.fc2_lo;
+                fp.h = hbuf[cur]; fp.w1 = L.fc1_f; fp.b1 = L.fc1.b; fp.w2 = L.fc2_f;
                 fp.partials = m->d_ffn_part; fp.M = Md; fp.F = F;
                 RCCHK(timed_begin(m, CLS_GEMM, 4.0 * Md * (double)D * F));
                 HIPCHK(opd_launch_dec_ffn(fp, m->stream));

@@ -72,9 +72,8 @@ struct DecLayer {
     LNp ln1, ln2, ln3;
     float* rb_self = nullptr;  // [Q][768] = qpos.[Wq;Wk;0]^T + [bq;bk;bv]
     float* rb_q = nullptr;     // [Q][256] = qpos.Wq_c^T + bq_c
-    // fused decoder (kernels_dec.hip): every linear layer's weights as split fp16 pairs, w = hi + lo / 2048
-    f16_t *wqkv_hi = nullptr, *wqkv_lo = nullptr, *so_hi = nullptr, *so_lo = nullptr, *wqc_hi = nullptr, *wqc_lo = nullptr, *co_hi = nullptr,
-          *co_lo = nullptr, *fc1_hi = nullptr, *fc1_lo = nullptr, *fc2_hi = nullptr, *fc2_lo = nullptr;
+    // fused decoder (kernels_dec.hip): every linear layer's weights as split fp16 pairs, w = hi + lo / 2048, in MFMA-fragment order
+    f16_t *wqkv_f = nullptr, *so_f = nullptr, *wqc_f = nullptr, *co_f = nullptr, *fc1_f = nullptr, *fc2_f = nullptr;
 };
 
 struct Plan {  // everything that depends on the feature-map size (h, w)

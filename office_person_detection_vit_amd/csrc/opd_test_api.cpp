@@ -935,12 +935,10 @@ int opd_test_read_taps(opd_detr* m, unsigned long long* sums, int cap, char* nam
 
 
 // ---- fused decoder kernels (kernels_dec.hip), one launch each; weights arrive as fp32 and are split here like the loader does ----------
-static bool up_split(DevMem& dm, const float* w, size_t n, const f16_t** hi, const f16_t** lo) {
-    std::vector<f16_t> h(n), l(n);
-    opd_split_f16(w, n, h.data(), l.data());
-    *hi = dm.up(h.data(), n);
-    *lo = dm.up(l.data(), n);
-    return *hi && *lo;
+static const f16_t* up_frag(DevMem& dm, const float* w, int N, int K) {
+    std::vector<f16_t> f((size_t)N * K * 2);
+    opd_split_f16_frag(w, N, K, f.data());
+    return dm.up(f.data(), f.size());
 }
 // h_out / q16 / k16 [M][256], vT [M / Q][8][32][128] (host; vT is returned as the device wrote it: padding keys untouched = zero-filled here)
 int opd_test_dec_qkv(const float* h_in, const float* partials, int nsplit, const float* b2, const float* ln_g, const float* ln_b, const float* w,
@@ -955,7 +953,8 @@ int opd_test_dec_qkv(const float* h_in, const float* partials, int nsplit, const
     } else {
         p.h_out = dm.up(const_cast<const float*>(h_in), n);
     }
-    if (!up_split(dm, w, (size_t)768 * 256, &p.w_hi, &p.w_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.w = up_frag(dm, w, 768, 256);
+    if (!p.w) return tfail(OPD_ENOMEM, "test alloc failed");
     p.bias = dm.up(bias, (size_t)Q * 768);
     p.q16 = dm.up<uint16_t>(nullptr, n); p.k16 = dm.up<uint16_t>(nullptr, n); p.vT = dm.up<uint16_t>(nullptr, nv);
     if (!p.h_out || !p.bias || !p.q16 || !p.k16 || !p.vT) return tfail(OPD_ENOMEM, "test alloc failed");
@@ -978,7 +977,8 @@ int opd_test_dec_self(const uint16_t* q16, const uint16_t* k16, const uint16_t* 
     p.q16 = dm.up(q16, n); p.k16 = dm.up(k16, n); p.vT = dm.up(vT, nv); p.h = dm.up(const_cast<const float*>(h), n);
     p.bo = dm.up(bo, 256); p.ln_g = dm.up(ln_g, 256); p.ln_b = dm.up(ln_b, 256); p.rbq = dm.up(rbq, (size_t)Q * 256);
     p.qc16 = dm.up<uint16_t>(nullptr, n);
-    if (!up_split(dm, wo, 65536, &p.wo_hi, &p.wo_lo) || !up_split(dm, wq, 65536, &p.wq_hi, &p.wq_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.wo = up_frag(dm, wo, 256, 256); p.wq = up_frag(dm, wq, 256, 256);
+    if (!p.wo || !p.wq) return tfail(OPD_ENOMEM, "test alloc failed");
     if (!p.q16 || !p.k16 || !p.vT || !p.h || !p.bo || !p.ln_g || !p.ln_b || !p.rbq || !p.qc16) return tfail(OPD_ENOMEM, "test alloc failed");
     p.B = B; p.Q = Q; p.scale = scale;
     TCHK(opd_launch_dec_self(p, nullptr));
@@ -1013,7 +1013,8 @@ int opd_test_dec_cross_out(const float* part_o, const float* part_ml, int splits
     p.part_o = dm.up(part_o, n * splits); p.part_ml = dm.up(part_ml, (size_t)splits * M * 16); p.splits = splits;
     p.res = dm.up(res, res_period > 0 ? (size_t)res_period * 256 : n); p.res_period = res_period;
     p.h = dm.up<float>(nullptr, n); p.bo = dm.up(bo, 256); p.ln_g = dm.up(ln_g, 256); p.ln_b = dm.up(ln_b, 256); p.M = M;
-    if (!up_split(dm, wo, 65536, &p.wo_hi, &p.wo_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.wo = up_frag(dm, wo, 256, 256);
+    if (!p.wo) return tfail(OPD_ENOMEM, "test alloc failed");
     if (!p.part_o || !p.part_ml || !p.res || !p.h || !p.bo || !p.ln_g || !p.ln_b) return tfail(OPD_ENOMEM, "test alloc failed");
     TCHK(opd_launch_dec_cross_out(p, nullptr));
     TCHK(hipDeviceSynchronize());
@@ -1026,7 +1027,8 @@ int opd_test_dec_ffn(const float* h, const float* w1, const float* b1, const flo
     DecFfnParams p{};
     const size_t n = (size_t)M * 256, np = n * (F / OPD_DEC_FFN_CHUNK);
     p.h = dm.up(h, n); p.b1 = dm.up(b1, (size_t)F); p.partials = dm.up<float>(nullptr, np); p.M = M; p.F = F;
-    if (!up_split(dm, w1, (size_t)F * 256, &p.w1_hi, &p.w1_lo) || !up_split(dm, w2, (size_t)F * 256, &p.w2_hi, &p.w2_lo)) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.w1 = up_frag(dm, w1, F, 256); p.w2 = up_frag(dm, w2, 256, F);
+    if (!p.w1 || !p.w2) return tfail(OPD_ENOMEM, "test alloc failed");
     if (!p.h || !p.b1 || !p.partials) return tfail(OPD_ENOMEM, "test alloc failed");
     TCHK(opd_launch_dec_ffn(p, nullptr));
     TCHK(hipDeviceSynchronize());
@@ -1044,17 +1046,17 @@ int opd_test_bench_dec(int B, int Q, int Lk, int F, int splits, int iters, float
     DecQkvParams a{}; DecSelfParams b{}; AttnParams c{}; DecCrossOutParams d{}; DecFfnParams e{};
     const int nchunk = F / OPD_DEC_FFN_CHUNK;
     float *h0 = z32(n), *h1 = z32(n), *part = z32(n * nchunk), *vec = z32(4096), *tabs = z32((size_t)Q * 768), *po = z32(n * splits), *pml = z32((size_t)splits * M * 16);
-    uint16_t *q16 = z16(n), *k16 = z16(n), *vT = z16((size_t)B * 8 * 32 * 128), *qc = z16(n), *w768 = z16(768 * 256), *w256 = z16(65536), *wf = z16((size_t)F * 256),
+    uint16_t *q16 = z16(n), *k16 = z16(n), *vT = z16((size_t)B * 8 * 32 * 128), *qc = z16(n), *w768 = z16(2 * 768 * 256), *w256 = z16(2 * 65536), *wf = z16((size_t)2 * F * 256),
              *mem = z16((size_t)B * Lk * 512);
     if (!h0 || !h1 || !part || !vec || !tabs || !po || !pml || !q16 || !k16 || !vT || !qc || !w768 || !w256 || !wf || !mem) return tfail(OPD_ENOMEM, "test alloc failed");
-    a.h_in = h0; a.partials = part; a.nsplit = nchunk; a.b2 = vec; a.ln_g = vec; a.ln_b = vec; a.h_out = h1; a.w_hi = w768; a.w_lo = w768; a.bias = tabs;
+    a.h_in = h0; a.partials = part; a.nsplit = nchunk; a.b2 = vec; a.ln_g = vec; a.ln_b = vec; a.h_out = h1; a.w = w768; a.bias = tabs;
     a.q16 = q16; a.k16 = k16; a.vT = vT; a.M = M; a.Q = Q;
-    b.q16 = q16; b.k16 = k16; b.vT = vT; b.h = h1; b.wo_hi = w256; b.wo_lo = w256; b.bo = vec; b.ln_g = vec; b.ln_b = vec; b.wq_hi = w256; b.wq_lo = w256;
+    b.q16 = q16; b.k16 = k16; b.vT = vT; b.h = h1; b.wo = w256; b.bo = vec; b.ln_g = vec; b.ln_b = vec; b.wq = w256;
     b.rbq = tabs; b.qc16 = qc; b.B = B; b.Q = Q; b.scale = 0.17677669f;
     c.q = qc; c.k = mem; c.v = mem + 256; c.B = B; c.heads = 8; c.Lq = Q; c.Lk = Lk; c.ldq = 256; c.ldk = c.ldv = 512; c.ldo = 256; c.scale = 0.17677669f;
     c.splits = splits; c.part_o = po; c.part_ml = pml;
-    d.part_o = po; d.part_ml = pml; d.splits = splits; d.res = h1; d.h = h1; d.wo_hi = w256; d.wo_lo = w256; d.bo = vec; d.ln_g = vec; d.ln_b = vec; d.M = M;
-    e.h = h1; e.w1_hi = wf; e.w1_lo = wf; e.b1 = vec; e.w2_hi = wf; e.w2_lo = wf; e.partials = part; e.M = M; e.F = F;
+    d.part_o = po; d.part_ml = pml; d.splits = splits; d.res = h1; d.h = h1; d.wo = w256; d.bo = vec; d.ln_g = vec; d.ln_b = vec; d.M = M;
+    e.h = h1; e.w1 = wf; e.b1 = vec; e.w2 = wf; e.partials = part; e.M = M; e.F = F;
     hipEvent_t e0, e1;
     TCHK(hipEventCreate(&e0)); TCHK(hipEventCreate(&e1));
     for (int k = 0; k < 5; ++k) {
