@@ -215,6 +215,34 @@ OPD_API int opd_detr_roi_features(opd_detr* m, int frame, const float* boxes_xyw
  * call belongs to the caller that ran that forward: no other submission to this handle in between (single caller per handle). */
 OPD_API int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* queries, int n_queries, float* out, int out_capacity);
 
+/* ---- multi-GPU: the path's one exchange step ------------------------------------------------------------------------------
+ * The reference has no distributed mode; the port it reserves for batched detectors is `DetectorPort.detect(frames: Sequence[FrameDTO])`
+ * (`src/core/interfaces.py:30-34`, home `src/adapters/__init__.py:1`).  Frames are independent, so the path shards by frame: one process
+ * per GPU, each with its own detector handle, and ONE RCCL all-gather of fixed-size records per exchange (opd_det x num_queries per frame
+ * slot + one int32 count per slot; count -1 = the slot holds no frame).  A communicator is bound to one handle and works on that
+ * handle's stream: forward -> post-process (writes the send buffer) -> ncclAllGather -> copy to page-locked host memory, one host wait
+ * (opd_comm_wait).  RCCL is resolved at run time (librccl.so.1); single-GPU callers never load it.  The 128-byte unique id travels from
+ * rank 0 to the other ranks by whatever launched them (file, socket, MPI, a torch.distributed store): the library does no rendezvous. */
+typedef struct opd_comm opd_comm;
+#define OPD_COMM_ID_BYTES 128
+OPD_API int opd_comm_unique_id(void* id128);   /* rank 0 only: ncclGetUniqueId */
+/* collective over the `world` ranks (ncclCommInitRank): every rank passes the same id, its rank, and its OWN handle (device and stream) */
+OPD_API int opd_comm_create(const void* id128, int rank, int world, opd_detr* m, opd_comm** out);
+OPD_API void opd_comm_destroy(opd_comm* c);
+OPD_API int opd_comm_info(const opd_comm* c, int* rank, int* world);
+/* One exchange = begin(slots) ; detect(slot0, frames ...) once or several times (a shard larger than max_batch goes in chunks) ; exchange ;
+ * wait.  `slots` = frame slots per rank, the same number on every rank (an uneven shard leaves trailing slots at count -1).
+ * opd_comm_detect = opd_detr_detect_async into the send buffer at slot0 (arguments as there); nothing synchronises before opd_comm_wait,
+ * which delivers every rank's records: out_all [world][slots][num_queries], counts_all [world][slots] (host). */
+OPD_API int opd_comm_begin(opd_comm* c, int slots);
+OPD_API int opd_comm_detect(opd_comm* c, int slot0, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float threshold,
+                            const int32_t* orig_hw);
+/* Device pointers of slot `slot0` of the send buffer (records [.][num_queries], counts [.]): for callers that fill the slots through another
+ * entry point with device outputs (opd_detr_detect_resized / _ragged with OPD_MEM_HOST_PIXELS_DEVICE_OUT) on the SAME handle. */
+OPD_API int opd_comm_buffers(opd_comm* c, int slot0, void** records, void** counts);
+OPD_API int opd_comm_exchange(opd_comm* c);
+OPD_API int opd_comm_wait(opd_comm* c, opd_det* out_all, int32_t* counts_all);
+
 /* Device time (ms) of the last forward/detect per stage, measured with HIP events on the handle's stream:
  * [0] preprocess+stem+pool, [1] stage1, [2] stage2, [3] stage3, [4] stage4, [5] projection+encoder, [6] decoder+heads,
  * [7] post-process.  Only filled when profiling was enabled with opd_detr_set_profiling(m, 1). */

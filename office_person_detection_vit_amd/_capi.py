@@ -21,6 +21,7 @@ OPD_MEM_DEVICE = 1
 OPD_MEM_HOST_PIXELS_DEVICE_OUT = 2
 OPD_FLAG_NO_GRAPH = 1
 OPD_FLAG_MULTI_STREAM = 2
+OPD_COMM_ID_BYTES = 128
 
 
 class OpdConfig(C.Structure):
@@ -73,6 +74,15 @@ API = {
     "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_detr_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "opd_detr_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "opd_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "opd_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "opd_comm_destroy": (None, [C.c_void_p]),
+    "opd_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "opd_comm_begin": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_comm_detect": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "opd_comm_buffers": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "opd_comm_exchange": (C.c_int, [C.c_void_p]),
+    "opd_comm_wait": (C.c_int, [C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_last_error": (C.c_char_p, []),
     "opd_version": (C.c_char_p, []),
 }
@@ -133,6 +143,7 @@ TEST_API = {
     "opd_test_bench_dec": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_float)]),
     "opd_test_heads_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "opd_test_set_fused_dec": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_test_trace_dec_self": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_dec.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_test_api.cpp"]
+SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_dec.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_comm.cpp", "opd_test_api.cpp"]
 TEST_ONLY = {"opd_test_api.cpp"}
 HEADERS = ["opd_kernels.h", "opd_loader.h", "opd_host.h", "opd_model.h", os.path.join("..", "..", "include", "opd_detr.h")]
 LIB = os.path.join(PKG, "libopd_hip.so")
@@ -57,7 +57,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
     test_objs = {os.path.join(objdir, os.path.splitext(s)[0] + ".o") for s in TEST_ONLY}
     for lib, members in ((LIB, [o for o in objs if o not in test_objs]), (TEST_LIB, objs)):
         if force or _stale(lib, members):
-            cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + members
+            cmd = [hipcc, "-shared", "-fPIC", "--offload-arch=gfx950", "-o", lib] + members + ["-ldl"]
             if verbose:
                 print(" ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)

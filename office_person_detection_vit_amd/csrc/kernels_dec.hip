@@ -84,6 +84,15 @@ __device__ __forceinline__ void store_split4(unsigned char* Xhi, unsigned char* 
 // neither sinks them to their uses nor hoists the consumers' waits.
 #define DEC_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DEC_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+// tools only: wave 0 stamps the shader clock (s_memtime) into trace[block][i]
+#define DEC_STAMP(tr, i)                                                                                   \
+    do {                                                                                                   \
+        if (tr) {                                                                                          \
+            unsigned long long now_;                                                                       \
+            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                    \
+            if (threadIdx.x == 0) (tr)[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = now_;     \
+        }                                                                                                  \
+    } while (0)
 
 struct Acc3 { float4v h[2], l[2], m[2]; };
 __device__ __forceinline__ void acc3_zero(Acc3& a) {
@@ -229,9 +238,14 @@ constexpr int SLAB_R = 16;
 constexpr int SLAB_LDS = SLAB_RING + 8 * SLAB_R * 1024;   // 149 504
 
 // ---------------------------------------------------------------------------------------------------------------------------------
-// dec_qkv_kernel: grid (slabs of 16 rows), 512 threads.  One workgroup reduces the previous FFN's partial sums for its rows ONCE and
-// then runs the three projections q, k, v.  A wave's piece sequence: 32 rows of partial sums (rows 2w, 2w + 1 of the slab: exactly the
-// rows its own lanes normalise, so no barrier), then the 96 weight pieces of its two column tiles of q, of k, of v.
+// dec_qkv_kernel: grid (slabs of 16 rows, 3 = q | k | v), 512 threads.  A workgroup reduces the previous FFN's partial sums for its rows
+// and runs ONE of the three projections.  A wave's piece sequence: 32 rows of partial sums (rows 2w, 2w + 1 of the slab: exactly the rows
+// its own lanes normalise, so no barrier), then the 32 weight pieces of its two column tiles.  (One workgroup per slab running q, k and v
+// in turn was measured: 14.2 us — eight ring rounds in a row; three workgroups re-read the partial sums, 39 MB of L2 / Infinity Cache
+// traffic per launch, and finish in four.)
+// k and v are written in the ORDER dec_self_kernel's waves stream them, one KiB per MFMA operand:
+//   kf [frame][head][key tile kt][lane 16 g + li][8]   = k[key 16 kt + li][32 head + 8 g ..]                (A operand of S^T = K Q^T)
+//   vf [frame][head][kb][dt][lane 16 g + li][8]        = v[key kb*32 + {4g .. 4g+3, 16+4g .. 16+4g+3}][32 head + 16 dt + li]   (A operand of O^T = V^T P^T)
 // ---------------------------------------------------------------------------------------------------------------------------------
 constexpr int QKV_MAXS = 16;
 template <bool PRO>
@@ -242,24 +256,30 @@ __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = lane >> 4, li = lane & 15, lane16 = lane * 16;
-    const int row0 = blockIdx.x * 16;
-    constexpr int NP = PRO ? 32 : 0, TOTAL = NP + 96;
+    const int row0 = blockIdx.x * 16, part = blockIdx.y;
+    constexpr int NP = PRO ? 32 : 0, TOTAL = NP + 32;
     PieceRing<SLAB_R, TOTAL> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
-    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.w) + (size_t)(2 * wave) * 16384;
+    const unsigned char* const wsrc = reinterpret_cast<const unsigned char*>(p.w) + (size_t)(part * 16 + 2 * wave) * 16384;
     const int ra = row0 + 2 * wave < p.M ? row0 + 2 * wave : p.M - 1, rb = row0 + 2 * wave + 1 < p.M ? row0 + 2 * wave + 1 : p.M - 1;
     auto src = [&](const int n) -> const unsigned char* {
         if (PRO && n < NP) {   // partial slab s = n / 2, row 2w + (n & 1)
             const int s = n >> 1 < p.nsplit ? n >> 1 : p.nsplit - 1;
             return reinterpret_cast<const unsigned char*>(p.partials + ((size_t)s * p.M + ((n & 1) ? rb : ra)) * 256);
         }
-        const int m = n - NP;   // part m / 32: tiles 16 part + 2w, + 1 are consecutive 16-KiB blocks
-        return wsrc + (size_t)(m >> 5) * (16 * 16384) + (size_t)(m & 31) * 1024;
+        return wsrc + (size_t)(n - NP) * 1024;   // tiles 16 part + 2w, + 1 are consecutive 16-KiB blocks
     };
+    const int row = row0 + li;
+    const bool ok = row < p.M;
+    const int rcl = ok ? row : p.M - 1;
+    const int fr = rcl / p.Q, qi = rcl - fr * p.Q;
+    float4v bs[2];
     {   // the slab's rows: 32 threads per row, 8 consecutive channels each; [previous FFN's sum + LN3]
-        const int r = tid >> 5, c0 = (tid & 31) * 8, row = row0 + r;
-        const size_t rc = (size_t)(row < p.M ? row : p.M - 1) * 256 + c0;   // (rows beyond M: a valid address, results unused)
+        const int r = tid >> 5, c0 = (tid & 31) * 8, prow = row0 + r;
+        const size_t rc = (size_t)(prow < p.M ? prow : p.M - 1) * 256 + c0;   // (rows beyond M: a valid address, results unused)
         const float* hsrc = PRO ? p.h_in : p.h_out;
         float4v xa = *reinterpret_cast<const float4v*>(hsrc + rc), xb = *reinterpret_cast<const float4v*>(hsrc + rc + 4);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) bs[j] = *reinterpret_cast<const float4v*>(p.bias + (size_t)qi * 768 + part * 256 + (2 * wave + j) * 16 + 4 * g);
         float v[8];
         if constexpr (PRO) {
             const float4v ba = *reinterpret_cast<const float4v*>(p.b2 + c0), bb = *reinterpret_cast<const float4v*>(p.b2 + c0 + 4);
@@ -267,10 +287,10 @@ __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
             const float4v e0 = *reinterpret_cast<const float4v*>(p.ln_b + c0), e1 = *reinterpret_cast<const float4v*>(p.ln_b + c0 + 4);
             rg.prime(src);
             DEC_FENCE();
-            xa += ba; xb += bb;
 #pragma unroll
             for (int bt = 0; bt < 4; ++bt) {   // four batches of 4 slabs x 2 rows; fixed order: deterministic
                 rg.wait(8 * bt, 8 * bt + 7);
+                if (bt == 0) { xa += ba; xb += bb; }
 #pragma unroll
                 for (int s = 0; s < 4; ++s) {
                     const unsigned char* sl = rg.slot(8 * bt + 2 * s + (lane >> 5)) + (lane & 31) * 32;
@@ -282,9 +302,9 @@ __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { v[j] = xa[j]; v[4 + j] = xb[j]; }
             layernorm_row32(v, g0, g1, e0, e1);
-            if (row < p.M) {
-                *reinterpret_cast<float4v*>(p.h_out + (size_t)row * 256 + c0) = float4v{v[0], v[1], v[2], v[3]};
-                *reinterpret_cast<float4v*>(p.h_out + (size_t)row * 256 + c0 + 4) = float4v{v[4], v[5], v[6], v[7]};
+            if (part == 0 && prow < p.M) {
+                *reinterpret_cast<float4v*>(p.h_out + (size_t)prow * 256 + c0) = float4v{v[0], v[1], v[2], v[3]};
+                *reinterpret_cast<float4v*>(p.h_out + (size_t)prow * 256 + c0 + 4) = float4v{v[4], v[5], v[6], v[7]};
             }
         } else {
             rg.prime(src);
@@ -296,40 +316,35 @@ __global__ __launch_bounds__(512) void dec_qkv_kernel(DecQkvParams p) {
     }
     DEC_LGKM0();
     __builtin_amdgcn_s_barrier();
-    const int row = row0 + li;
-    const bool ok = row < p.M;
-    const int rcl = ok ? row : p.M - 1;
-    const int fr = rcl / p.Q, qi = rcl - fr * p.Q;
+    Acc3 a;
+    acc3_zero(a);
+    gemm256(rg, src, NP, Xhi, Xlo, lane16, g, li, a);
+    if (!ok) return;
 #pragma unroll
-    for (int part = 0; part < 3; ++part) {
-        float4v bs[2];
+    for (int j = 0; j < 2; ++j) {
+        const int c = (2 * wave + j) * 16 + 4 * g;   // channel inside this part: head c >> 5, dim c & 31 .. + 3
+        half4 o;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) bs[j] = *reinterpret_cast<const float4v*>(p.bias + (size_t)qi * 768 + part * 256 + (2 * wave + j) * 16 + 4 * g);
-        Acc3 a;
-        acc3_zero(a);
-        gemm256(rg, src, NP + 32 * part, Xhi, Xlo, lane16, g, li, a);
-        if (ok) {
+        for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc3_get(a, j, r) + bs[j][r]);
+        const int hd = c >> 5, d = c & 31;
+        if (part == 0) {
+            *reinterpret_cast<half4*>(p.q16 + (size_t)row * 256 + c) = o;
+        } else if (part == 1) {   // kf: tile qi >> 4, lane 16 (d >> 3) + (qi & 15), elements d & 7 .. + 3
+            _Float16* kf = reinterpret_cast<_Float16*>(p.k16) + ((size_t)((fr * 8 + hd) * 8 + (qi >> 4)) * 64 + (d >> 3) * 16 + (qi & 15)) * 8 + (d & 7);
+            *reinterpret_cast<half4*>(kf) = o;
+        } else {                  // vf: block (qi >> 5, d >> 4), lane 16 gk + (d & 15), element j = 4 * upper half + (key & 3)
+            const int kk = qi & 31, hi16 = kk >> 4, gk = (kk & 15) >> 2, jj = hi16 * 4 + (kk & 3);
+            _Float16* vf = reinterpret_cast<_Float16*>(p.vT) + ((size_t)(((fr * 8 + hd) * 4 + (qi >> 5)) * 2 + (d >> 4)) * 64 + gk * 16 + (d & 15)) * 8 + jj;
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int c = (2 * wave + j) * 16 + 4 * g;   // channel inside this part
-                half4 o;
-#pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc3_get(a, j, r) + bs[j][r]);
-                if (part == 0) *reinterpret_cast<half4*>(p.q16 + (size_t)row * 256 + c) = o;
-                else if (part == 1) *reinterpret_cast<half4*>(p.k16 + (size_t)row * 256 + c) = o;
-                else {   // v^T [frame][head][dim][key]
-                    _Float16* vt = reinterpret_cast<_Float16*>(p.vT) + ((size_t)(fr * 8 + (c >> 5)) * 32 + (c & 31)) * 128 + qi;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) vt[(size_t)r * 128] = o[r];
-                }
-            }
+            for (int r = 0; r < 4; ++r) vf[(size_t)r * 8] = o[r];   // dims d .. d + 3 are consecutive lanes
         }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
 // dec_self_kernel: grid (ceil(Q / 16) query slabs, B frames), 512 threads: wave = head during the attention, then column tiles.
-// Piece sequence of a wave: its two tiles of Wo (32), then of Wq_c (32).
+// Everything but the 16 query rows arrives through the wave's ring: K and V^T of its head (fragment order, written by dec_qkv_kernel),
+// then its two tiles of Wo, then of Wq_c.  (K / V through fragment-shaped VGPR loads: 170 KiB per workgroup on the slow path, 3.5 us.)
 // ---------------------------------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -344,53 +359,49 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
     const bool q_ok = q0 + li < Q;
     const size_t row = (size_t)b * Q + (q_ok ? q0 + li : Q - 1);   // this lane's data row (clamped: padding lanes compute on a valid row, store nothing)
     const int h = wave;
-    PieceRing<SLAB_R, 64> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
+    unsigned long long* const tr = p.trace;
+    DEC_STAMP(tr, 0);
+    PieceRing<SLAB_R, 80> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
     const unsigned char* const wo = reinterpret_cast<const unsigned char*>(p.wo) + (size_t)(2 * wave) * 16384;
     const unsigned char* const wq = reinterpret_cast<const unsigned char*>(p.wq) + (size_t)(2 * wave) * 16384;
-    auto src = [&](const int n) -> const unsigned char* { return (n < 32 ? wo : wq) + (size_t)(n & 31) * 1024; };
-    // ---- every load of the attention and of the o-proj, requested at once --------------------------------------------------------
+    const unsigned char* const kfs = reinterpret_cast<const unsigned char*>(p.k16) + (size_t)(b * 8 + h) * 8192;
+    const unsigned char* const vfs = reinterpret_cast<const unsigned char*>(p.vT) + (size_t)(b * 8 + h) * 8192;
+    // piece sequence: this head's 8 key tiles of K, its 8 blocks of V^T, this wave's two tiles of Wo (32), of Wq_c (32)
+    auto src = [&](const int n) -> const unsigned char* {
+        if (n < 8) return kfs + (size_t)n * 1024;
+        if (n < 16) return vfs + (size_t)(n - 8) * 1024;
+        return (n < 48 ? wo : wq) + (size_t)((n - 16) & 31) * 1024;
+    };
+    // ---- every load of the kernel that does not wait for computed data, requested at once ----------------------------------------------
     const half8 qf = *reinterpret_cast<const half8*>(p.q16 + row * 256 + h * 32 + g * 8);
-    half8 kf[8];
-#pragma unroll
-    for (int kt = 0; kt < 8; ++kt) {
-        const int key = kt * 16 + li;
-        kf[kt] = *reinterpret_cast<const half8*>(p.k16 + ((size_t)b * Q + (key < Q ? key : Q - 1)) * 256 + h * 32 + g * 8);   // (keys >= Q are masked below)
-    }
-    // V^T operand: A[dim li][k-slot 8g + j]: j < 4 -> key kb*32 + 4g + j, j >= 4 -> key kb*32 + 16 + 4g + (j - 4) (the P operand's k order)
-    const _Float16* vt = reinterpret_cast<const _Float16*>(p.vT) + (size_t)(b * 8 + h) * 32 * 128;
-    half4 v4[4][2][2];
-#pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-#pragma unroll
-            for (int hh = 0; hh < 2; ++hh) {
-                const int key0 = kb * 32 + hh * 16 + g * 4;   // (Q % 4 == 0: a group of 4 keys is all valid or all padding)
-                v4[kb][dt][hh] = *reinterpret_cast<const half4*>(vt + (size_t)(dt * 16 + li) * 128 + (key0 < Q ? key0 : 0));
-            }
-    float4v rs[2], gm[2], bt[2], bs[2];
+    float4v bo[2], hres[2], gm[2], bt[2], bs[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int c = (2 * wave + j) * 16 + 4 * g;
-        rs[j] = *reinterpret_cast<const float4v*>(p.bo + c) + *reinterpret_cast<const float4v*>(p.h + row * 256 + c);
+        bo[j] = *reinterpret_cast<const float4v*>(p.bo + c);
+        hres[j] = *reinterpret_cast<const float4v*>(p.h + row * 256 + c);
         gm[j] = *reinterpret_cast<const float4v*>(p.ln_g + c);
         bt[j] = *reinterpret_cast<const float4v*>(p.ln_b + c);
         bs[j] = *reinterpret_cast<const float4v*>(p.rbq + (size_t)(q_ok ? q0 + li : 0) * 256 + c);
     }
-    rg.prime(src);   // Wo's first half-tiles travel during the attention
+    rg.prime(src);
     DEC_FENCE();
+    DEC_STAMP(tr, 1);
     // ---- attention of head `wave`: S^T = K Q^T over the frame's Q keys, softmax per query, O^T = V^T P^T -------------------------------
     float4v s[8];
     float mx = -INFINITY;
+    rg.wait(0, 7);
 #pragma unroll
     for (int kt = 0; kt < 8; ++kt) {
-        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf[kt], qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+        const half8 kf = *reinterpret_cast<const half8*>(rg.slot(kt) + lane16);   // (tiles / rows beyond Q: whatever the buffer holds, masked below)
+        s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             s[kt][r] = kt * 16 + g * 4 + r < Q ? s[kt][r] : -INFINITY;
             mx = fmaxf(mx, s[kt][r]);
         }
     }
+    rg.advance(src, 0, 8);
     mx = fmaxf(mx, __shfl_xor(mx, 16));
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float scale2 = p.scale * 1.44269504088896340736f;
@@ -405,8 +416,9 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
         }
     lsum += __shfl_xor(lsum, 16);
     lsum += __shfl_xor(lsum, 32);
+    DEC_STAMP(tr, 2);
     float4v oacc[2] = {float4v{0.f, 0.f, 0.f, 0.f}, float4v{0.f, 0.f, 0.f, 0.f}};
-    const half4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+    rg.wait(8, 15);
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
         half8 pf;
@@ -414,28 +426,36 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
         for (int r = 0; r < 4; ++r) { pf[r] = (_Float16)s[2 * kb][r]; pf[4 + r] = (_Float16)s[2 * kb + 1][r]; }
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt) {
-            const half4 lo4 = kb * 32 + g * 4 < Q ? v4[kb][dt][0] : z4, hi4 = kb * 32 + 16 + g * 4 < Q ? v4[kb][dt][1] : z4;   // (padding keys: whatever the buffer holds x 0 must stay 0)
-            half8 vf;
+            half8 vf = *reinterpret_cast<const half8*>(rg.slot(8 + 2 * kb + dt) + lane16);
+            // k-slots 0..3 = keys kb*32 + 4g .., 4..7 = keys kb*32 + 16 + 4g ..  (Q % 4 == 0: a group of 4 keys is all valid or all padding);
+            // padding keys: whatever the buffer holds x 0 must stay 0
 #pragma unroll
-            for (int r = 0; r < 4; ++r) { vf[r] = lo4[r]; vf[4 + r] = hi4[r]; }
+            for (int r = 0; r < 4; ++r) {
+                vf[r] = kb * 32 + g * 4 < Q ? vf[r] : (_Float16)0.f;
+                vf[4 + r] = kb * 32 + 16 + g * 4 < Q ? vf[4 + r] : (_Float16)0.f;
+            }
             oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
         }
     }
+    rg.advance(src, 8, 8);
     const float inv = 1.0f / lsum;
 #pragma unroll
     for (int dt = 0; dt < 2; ++dt) store_split4(Xhi, Xlo, XP, li, h * 32 + dt * 16 + g * 4, oacc[dt] * inv);
     DEC_LGKM0();
     __builtin_amdgcn_s_barrier();
+    DEC_STAMP(tr, 3);
     // ---- o-proj + residual + LN1 (Wq_c's first half-tiles are requested as Wo's slots drain: they travel during the LayerNorm) -------------
     Acc3 a;
     acc3_zero(a);
-    gemm256(rg, src, 0, Xhi, Xlo, lane16, g, li, a);
+    gemm256(rg, src, 16, Xhi, Xlo, lane16, g, li, a);
     float4v hn[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) hn[j][r] = acc3_get(a, j, r) + rs[j][r];
+        for (int r = 0; r < 4; ++r) hn[j][r] = acc3_get(a, j, r) + (bo[j][r] + hres[j][r]);
+    DEC_STAMP(tr, 4);
     layernorm_acc(hn, red, wave, g, li, gm, bt);
+    DEC_STAMP(tr, 5);
     // (layernorm_acc's barriers lie between the o-proj's last fragment read and these writes)
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -447,7 +467,9 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
     __builtin_amdgcn_s_barrier();
     // ---- q_c = h . Wq_c^T + (qpos . Wq_c^T + bq_c) ----------------------------------------------------------------------
     acc3_zero(a);
-    gemm256(rg, src, 32, Xhi, Xlo, lane16, g, li, a);
+    DEC_STAMP(tr, 6);
+    gemm256(rg, src, 48, Xhi, Xlo, lane16, g, li, a);
+    DEC_STAMP(tr, 7);
     if (q_ok) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -668,8 +690,8 @@ hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream) {
     if (p.Q > 128 || p.M % p.Q != 0) return hipErrorInvalidValue;   // v^T rows hold 128 keys; rows are (frame, query)
     OPD_SET_MAX_LDS_ONCE(dec_qkv_kernel<true>, SLAB_LDS);
     OPD_SET_MAX_LDS_ONCE(dec_qkv_kernel<false>, SLAB_LDS);
-    if (p.partials) hipLaunchKernelGGL(dec_qkv_kernel<true>, dim3((p.M + 15) / 16), dim3(512), SLAB_LDS, stream, p);
-    else hipLaunchKernelGGL(dec_qkv_kernel<false>, dim3((p.M + 15) / 16), dim3(512), SLAB_LDS, stream, p);
+    if (p.partials) hipLaunchKernelGGL(dec_qkv_kernel<true>, dim3((p.M + 15) / 16, 3), dim3(512), SLAB_LDS, stream, p);
+    else hipLaunchKernelGGL(dec_qkv_kernel<false>, dim3((p.M + 15) / 16, 3), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_self(const DecSelfParams& p, hipStream_t stream) {

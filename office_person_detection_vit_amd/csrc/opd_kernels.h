@@ -237,8 +237,9 @@ struct DecQkvParams {   // [previous layer: h = LN3(h_in + b2 + sum partials)] ;
     float* h_out;            // [M][256] the layer's input state (written by the q workgroups when partials != null; read otherwise)
     const f16_t* w;          // [768][256] = [Wq; Wk; Wv], fragment order
     const float* bias;       // [Q][768] row-periodic: query-position fold + biases (fp32)
-    f16_t *q16, *k16;        // [M][256]
-    f16_t* vT;               // [B][8][32][128]: v transposed per (frame, head): [dim][key]
+    f16_t* q16;              // [M][256]
+    f16_t* k16;              // [B][8 heads][8 key tiles][512]: k in MFMA-fragment order (kernels_dec.hip::dec_qkv_kernel)
+    f16_t* vT;               // [B][8 heads][4][2][512]: v^T in MFMA-fragment order
     int M, Q;
 };
 hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream);
@@ -252,6 +253,7 @@ struct DecSelfParams {  // self-attention of one (frame, 16-query slab) + o-proj
     f16_t* qc16;             // [M][256] out
     int B, Q;
     float scale;
+    unsigned long long* trace;   // tools only (tools/trace_dec.py): per-workgroup shader-clock stamps [grid][8] of wave 0; null in the model
 };
 hipError_t opd_launch_dec_self(const DecSelfParams& p, hipStream_t stream);
 struct DecCrossOutParams {   // combine the key splits of the cross-attention, o-proj + residual + LayerNorm

@@ -369,8 +369,8 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_attnd16, Md * D, false));
     RCCHK(dalloc(m, &m->d_ffnd16, Md * a.ffn, false));
     RCCHK(dalloc(m, &m->d_dq16, Md * D, false));
-    RCCHK(dalloc(m, &m->d_dk16, Md * D, false));
-    RCCHK(dalloc(m, &m->d_dvT, B * D * 128, false));
+    RCCHK(dalloc(m, &m->d_dk16, B * 8 * 8 * 512, false));   // (fragment order: 8 heads x 8 key tiles x 1 KiB per frame)
+    RCCHK(dalloc(m, &m->d_dvT, B * 8 * 8 * 512, false));
     RCCHK(dalloc(m, &m->d_part_o, (size_t)m->dec_splits * Md * D, false));
     RCCHK(dalloc(m, &m->d_part_ml, (size_t)m->dec_splits * Md * a.heads * 2, false));
     RCCHK(dalloc(m, &m->d_ffn_part, (size_t)(a.ffn / OPD_DEC_FFN_CHUNK + 1) * Md * D, false));
@@ -916,7 +916,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         const int S = m->dec_splits, nchunk = F / OPD_DEC_FFN_CHUNK;
         float* hbuf[2] = {m->d_h32, m->d_yd32};
         int cur = 0;   // hbuf[cur] holds the layer's state from its self-attention block on
-        for (int i = 0; i < a.dec_layers; ++i) {
+        for (int i = 0; i < a.dec_layers && i < m->dbg_dec_layers; ++i) {
             const DecLayer& L = m->dec[i];
             f16_t* qd = m->d_qd16 + (size_t)i * m->cfg.max_batch * Q * D;   // (per-layer regions of max_batch frames: layer 0's constants stay put)
             if (i > 0) {
@@ -981,7 +981,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         HIPCHK(hipMemsetAsync(m->d_h32, 0, (size_t)Md * D * 4, m->stream));
         HIPCHK(hipMemsetAsync(m->d_h16, 0, (size_t)Md * D * 2, m->stream));
     }
-    for (int i = 0; i < a.dec_layers; ++i) {
+    for (int i = 0; i < a.dec_layers && i < m->dbg_dec_layers; ++i) {
         const DecLayer& L = m->dec[i];
         const bool small = m->small_m_gemm && D == 256 && F % 256 == 0 && F / 256 <= 8;
         if (!(dec0 && i == 0)) {   // (layer 0's self-attention block is the broadcast above)
@@ -1042,7 +1042,7 @@ thread_local std::shared_lock<std::shared_mutex>* tl_api_lock = nullptr;
 
 // Forward through the graph cache.  First call of a (shape, pixel pointer) key runs eagerly (one-time function-attribute
 // setup and plan building are not capturable); the second call captures the stream into a hipGraph; later calls replay it.
-static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw = nullptr) {
+int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw) {
     // ragged batches run eagerly: their launch sequence depends on per-call host data (fold pointers, valid sizes)
     if (is_ragged(valid_hw, B, H, W)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W, valid_hw);
     if (m->profiling || (m->cfg.flags & OPD_FLAG_NO_GRAPH)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
@@ -1102,7 +1102,7 @@ static int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int 
 static inline bool pixels_on_device(int mem_kind) { return mem_kind == OPD_MEM_DEVICE; }
 static inline bool outputs_on_device(int mem_kind) { return mem_kind != OPD_MEM_HOST; }
 
-static int check_shape(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W) {
+int check_shape(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     if (!pixels) return fail(OPD_EINVAL, "null pixel buffer");
     if (pixel_format != OPD_PIXELS_U8_BGR_HWC && pixel_format != OPD_PIXELS_F32_NCHW) return fail(OPD_EINVAL, "unknown pixel_format");
@@ -1117,7 +1117,7 @@ static int check_shape(opd_detr* m, const void* pixels, int pixel_format, int me
     return OPD_OK;
 }
 
-static int stage_pixels(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, const void** d_pixels) {
+int stage_pixels(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, const void** d_pixels) {
     if (pixels_on_device(mem_kind)) { *d_pixels = pixels; return OPD_OK; }
     const size_t n = (size_t)B * H * W * 3;
     if (pixel_format == OPD_PIXELS_U8_BGR_HWC) {
@@ -1171,8 +1171,7 @@ static int enqueue_resize(opd_detr* m, const uint8_t* frames, int mem_kind, int 
 
 // `dev_out` / `dev_counts` (nullable): device buffers of the caller; the kernel then writes there directly instead of the
 // library's own record buffers (no device-to-device copies afterwards).
-static int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* dev_out = nullptr,
-                               int32_t* dev_counts = nullptr) {
+int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* dev_out, int32_t* dev_counts) {
     const int B = m->last_B;
     std::vector<int32_t> hw((size_t)B * 2);
     for (int b = 0; b < B; ++b) {
@@ -1287,6 +1286,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_DEEP_FC2")) m->deep_fc2 = atoi(v);
     if (const char* v = getenv("OPD_WROUND")) m->wround = atoi(v);
     if (const char* v = getenv("OPD_FUSED_DEC")) m->fused_dec = atoi(v);
+    if (const char* v = getenv("OPD_DBG_DEC_LAYERS")) m->dbg_dec_layers = atoi(v);   // timing ablation (tools/dec_cost.sh): results are wrong
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1331,7 +1331,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
-    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->dec_splits = src->dec_splits; m->wround = src->wround;
+    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());

@@ -137,6 +137,7 @@ struct opd_detr {
     int fused_dec = 1;         // the decoder as five launches per layer on split fp16 operands (kernels_dec.hip; 0: the round-3 chain of nine launches
                                // per layer on single fp16 operands, also taken when the architecture does not fit: d_model != 256, heads != 8, queries % 4)
     int dec_splits = 3;        // key ranges of the fused decoder's cross-attention
+    int dbg_dec_layers = 1 << 20;   // timing ablation only (OPD_DBG_DEC_LAYERS): run this many decoder layers
     LNp dec_ln;
     float *wc = nullptr, *bc = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     float* zero_bias = nullptr;  // [3072] zeros
@@ -259,6 +260,11 @@ inline int dalloc(opd_detr* m, T** p, size_t count, bool weight) {
 }
 
 int fill_qc0(opd_detr* m);   // opd_model.cpp
+// forward / post-process building blocks shared with opd_comm.cpp (all enqueue on m->stream; none synchronises unless it must)
+int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw = nullptr);
+int check_shape(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W);
+int stage_pixels(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, const void** d_pixels);
+int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, opd_det* dev_out = nullptr, int32_t* dev_counts = nullptr);
 
 // Stream capture and other threads: the Python shim drives several handles from worker threads (HipDetrDetector(streams=N)).
 // ROCm invalidates a capture in progress when ANOTHER thread allocates or frees memory, pins host memory or runs its

@@ -940,12 +940,12 @@ static const f16_t* up_frag(DevMem& dm, const float* w, int N, int K) {
     opd_split_f16_frag(w, N, K, f.data());
     return dm.up(f.data(), f.size());
 }
-// h_out / q16 / k16 [M][256], vT [M / Q][8][32][128] (host; vT is returned as the device wrote it: padding keys untouched = zero-filled here)
+// h_out / q16 [M][256]; k16 / vT [M / Q][8][8][512] in fragment order (host; returned as the device wrote them: padding keys untouched = zero-filled here)
 int opd_test_dec_qkv(const float* h_in, const float* partials, int nsplit, const float* b2, const float* ln_g, const float* ln_b, const float* w,
                      const float* bias, int M, int Q, float* h_out, uint16_t* q16, uint16_t* k16, uint16_t* vT) {
     DevMem dm;
     DecQkvParams p{};
-    const size_t n = (size_t)M * 256, nv = (size_t)(M / Q) * 8 * 32 * 128;
+    const size_t n = (size_t)M * 256, nv = (size_t)(M / Q) * 8 * 8 * 512;
     if (partials) {
         p.h_in = dm.up(h_in, n); p.partials = dm.up(partials, n * nsplit); p.nsplit = nsplit; p.b2 = dm.up(b2, 256); p.ln_g = dm.up(ln_g, 256); p.ln_b = dm.up(ln_b, 256);
         p.h_out = dm.up<float>(nullptr, n);
@@ -956,15 +956,16 @@ int opd_test_dec_qkv(const float* h_in, const float* partials, int nsplit, const
     p.w = up_frag(dm, w, 768, 256);
     if (!p.w) return tfail(OPD_ENOMEM, "test alloc failed");
     p.bias = dm.up(bias, (size_t)Q * 768);
-    p.q16 = dm.up<uint16_t>(nullptr, n); p.k16 = dm.up<uint16_t>(nullptr, n); p.vT = dm.up<uint16_t>(nullptr, nv);
+    p.q16 = dm.up<uint16_t>(nullptr, n); p.k16 = dm.up<uint16_t>(nullptr, nv); p.vT = dm.up<uint16_t>(nullptr, nv);
     if (!p.h_out || !p.bias || !p.q16 || !p.k16 || !p.vT) return tfail(OPD_ENOMEM, "test alloc failed");
     TCHK(hipMemset(p.vT, 0, nv * 2));
+    TCHK(hipMemset(p.k16, 0, nv * 2));
     p.M = M; p.Q = Q;
     TCHK(opd_launch_dec_qkv(p, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(h_out, p.h_out, n * 4, hipMemcpyDeviceToHost));
     TCHK(hipMemcpy(q16, p.q16, n * 2, hipMemcpyDeviceToHost));
-    TCHK(hipMemcpy(k16, p.k16, n * 2, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(k16, p.k16, nv * 2, hipMemcpyDeviceToHost));
     TCHK(hipMemcpy(vT, p.vT, nv * 2, hipMemcpyDeviceToHost));
     return OPD_OK;
 }
@@ -973,8 +974,8 @@ int opd_test_dec_self(const uint16_t* q16, const uint16_t* k16, const uint16_t* 
                       const float* ln_b, const float* wq, const float* rbq, int B, int Q, float scale, uint16_t* qc16) {
     DevMem dm;
     DecSelfParams p{};
-    const size_t n = (size_t)B * Q * 256, nv = (size_t)B * 8 * 32 * 128;
-    p.q16 = dm.up(q16, n); p.k16 = dm.up(k16, n); p.vT = dm.up(vT, nv); p.h = dm.up(const_cast<const float*>(h), n);
+    const size_t n = (size_t)B * Q * 256, nv = (size_t)B * 8 * 8 * 512;
+    p.q16 = dm.up(q16, n); p.k16 = dm.up(k16, nv); p.vT = dm.up(vT, nv); p.h = dm.up(const_cast<const float*>(h), n);
     p.bo = dm.up(bo, 256); p.ln_g = dm.up(ln_g, 256); p.ln_b = dm.up(ln_b, 256); p.rbq = dm.up(rbq, (size_t)Q * 256);
     p.qc16 = dm.up<uint16_t>(nullptr, n);
     p.wo = up_frag(dm, wo, 256, 256); p.wq = up_frag(dm, wq, 256, 256);
@@ -1046,7 +1047,7 @@ int opd_test_bench_dec(int B, int Q, int Lk, int F, int splits, int iters, float
     DecQkvParams a{}; DecSelfParams b{}; AttnParams c{}; DecCrossOutParams d{}; DecFfnParams e{};
     const int nchunk = F / OPD_DEC_FFN_CHUNK;
     float *h0 = z32(n), *h1 = z32(n), *part = z32(n * nchunk), *vec = z32(4096), *tabs = z32((size_t)Q * 768), *po = z32(n * splits), *pml = z32((size_t)splits * M * 16);
-    uint16_t *q16 = z16(n), *k16 = z16(n), *vT = z16((size_t)B * 8 * 32 * 128), *qc = z16(n), *w768 = z16(2 * 768 * 256), *w256 = z16(2 * 65536), *wf = z16((size_t)2 * F * 256),
+    uint16_t *q16 = z16(n), *k16 = z16((size_t)B * 8 * 8 * 512), *vT = z16((size_t)B * 8 * 8 * 512), *qc = z16(n), *w768 = z16(2 * 768 * 256), *w256 = z16(2 * 65536), *wf = z16((size_t)2 * F * 256),
              *mem = z16((size_t)B * Lk * 512);
     if (!h0 || !h1 || !part || !vec || !tabs || !po || !pml || !q16 || !k16 || !vT || !qc || !w768 || !w256 || !wf || !mem) return tfail(OPD_ENOMEM, "test alloc failed");
     a.h_in = h0; a.partials = part; a.nsplit = nchunk; a.b2 = vec; a.ln_g = vec; a.ln_b = vec; a.h_out = h1; a.w = w768; a.bias = tabs;
@@ -1079,6 +1080,26 @@ int opd_test_bench_dec(int B, int Q, int Lk, int F, int splits, int iters, float
         us5[k] = ms * 1000.f / iters;
     }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    return OPD_OK;
+}
+// phase stamps of dec_self_kernel (wave 0 of every workgroup, shader clocks): trace_out [ceil(Q / 16) * B][8]
+int opd_test_trace_dec_self(int B, int Q, unsigned long long* trace_out) {
+    DevMem dm;
+    const size_t n = (size_t)B * Q * 256;
+    auto z16 = [&](size_t c) { uint16_t* p = dm.up<uint16_t>(nullptr, c); if (p) (void)hipMemset(p, 0, c * 2); return p; };
+    auto z32 = [&](size_t c) { float* p = dm.up<float>(nullptr, c); if (p) (void)hipMemset(p, 0, c * 4); return p; };
+    DecSelfParams b{};
+    const int wgs = ((Q + 15) / 16) * B;
+    b.q16 = z16(n); b.k16 = z16((size_t)B * 8 * 8 * 512); b.vT = z16((size_t)B * 8 * 8 * 512); b.h = z32(n); b.wo = z16(2 * 65536); b.wq = z16(2 * 65536);
+    float* vec = z32(4096);
+    b.bo = vec; b.ln_g = vec; b.ln_b = vec; b.rbq = z32((size_t)Q * 256); b.qc16 = z16(n); b.B = B; b.Q = Q; b.scale = 0.17677669f;
+    unsigned long long* tr = dm.up<unsigned long long>(nullptr, (size_t)wgs * 8);
+    if (!b.q16 || !b.k16 || !b.vT || !b.h || !b.wo || !b.wq || !vec || !b.rbq || !b.qc16 || !tr) return tfail(OPD_ENOMEM, "test alloc failed");
+    for (int i = 0; i < 3; ++i) TCHK(opd_launch_dec_self(b, nullptr));   // warm: code and weights in the caches
+    b.trace = tr;
+    TCHK(opd_launch_dec_self(b, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(trace_out, tr, (size_t)wgs * 8 * 8, hipMemcpyDeviceToHost));
     return OPD_OK;
 }
 // heads_kernel with the fused decoder's prologue: rows = LN3(hs + b2f + sum partials), then the final LayerNorm, then the heads

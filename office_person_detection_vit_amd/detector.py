@@ -337,6 +337,15 @@ class HipDetrDetector:
             raise ValueError("records / counts must be contiguous")
         self._detect_into(frames, self.model, int(records.data_ptr()), int(counts.data_ptr()), on_device=bool(records.is_cuda))
 
+    def detect_records_at(self, frames: Sequence[np.ndarray], rec_ptr: int, cnt_ptr: int) -> None:
+        """The same with raw DEVICE pointers on this detector's GPU (``sharding.NativeExchange``: slots of the send buffer of an
+        ``opd_comm`` bound to handle 0, ``opd_comm_buffers``)."""
+        self._require_model()
+        if len(frames) > self.max_batch:
+            raise ValueError(f"{len(frames)} frames exceed max_batch = {self.max_batch}")
+        if len(frames):
+            self._detect_into(frames, self.model, int(rec_ptr), int(cnt_ptr), on_device=True)
+
     def _postprocess_batch(self, recs, counts, Q: int) -> List[List[Detection]]:
         """``_postprocess_batch`` (deleted vit_detector.py 591-647): person filter + NMS (C-ABI), xyxy -> xywh, foot point."""
         rc = self._lib.opd_person_nms_batch(recs, counts, len(counts), Q, PERSON_LABEL, float(self.nms_threshold))   # in place

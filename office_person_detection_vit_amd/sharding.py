@@ -7,8 +7,13 @@ all-gather of fixed-size detection records (32 bytes x ``num_queries`` per frame
 returns everything to every rank (rank 0 is the orchestrator that feeds tracking/transform).  The payload is tiny, so the
 collective is latency-bound; xGMI link bandwidth is irrelevant at this size.
 
-``torch.distributed`` is plumbing only: backend ``nccl`` (= RCCL) with device tensors on the GPU box, ``gloo`` with CPU
-tensors in the CPU tests of the exchange/assembly logic.
+Two exchanges behind one interface (``ShardedDetector(exchange=...)``):
+
+* ``"native"`` — the C-ABI's own step (``opd_comm_*``, ``csrc/opd_comm.cpp``): ``ncclAllGather`` from librccl enqueued on the detector
+  handle's stream right behind the post-process kernel, one host wait per exchange.  ``torch.distributed`` only carries the 128-byte
+  unique id from rank 0 to the others at set-up (any launcher could: the library does no rendezvous).
+* ``"torch"`` — ``dist.all_gather_into_tensor`` on a torch tensor: backend ``nccl`` (= RCCL) with device tensors, or ``gloo`` with CPU
+  tensors in the CPU tests of the exchange / assembly logic (no GPU there, hence no native path).
 """
 
 from __future__ import annotations
@@ -61,6 +66,45 @@ def assemble(g_rec: np.ndarray, g_cnt: np.ndarray, n_frames: int, person_label: 
     return out
 
 
+class NativeExchange:
+    """One ``opd_comm`` (``include/opd_detr.h``) bound to handle 0 of a loaded ``HipDetrDetector``: the records of this rank's frames
+    go from the post-process kernel into the communicator's send buffer, ``ncclAllGather`` runs on the handle's stream, and ``wait``
+    returns every rank's records from page-locked host memory."""
+
+    def __init__(self, detector, rank: int, world: int, unique_id: bytes):
+        self._lib = _capi.load_library()
+        self.detector, self.rank, self.world = detector, rank, world
+        self._comm = C.c_void_p()
+        _capi.check(self._lib.opd_comm_create(unique_id, rank, world, C.c_void_p(detector.model), C.byref(self._comm)), "opd_comm_create")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = C.create_string_buffer(_capi.OPD_COMM_ID_BYTES)
+        _capi.check(_capi.load_library().opd_comm_unique_id(buf), "opd_comm_unique_id")
+        return buf.raw
+
+    def gather(self, local_frames: Sequence[np.ndarray], per: int) -> Tuple[np.ndarray, np.ndarray]:
+        """-> (records int32 [world][per][Q][8], counts int32 [world][per]) of all ranks; ``per`` frame slots per rank."""
+        det, lib = self.detector, self._lib
+        Q = det.num_queries
+        _capi.check(lib.opd_comm_begin(self._comm, per), "opd_comm_begin")
+        for s0 in range(0, len(local_frames), det.max_batch):   # the handle's workspace holds max_batch frames
+            rec, cnt = C.c_void_p(), C.c_void_p()
+            _capi.check(lib.opd_comm_buffers(self._comm, s0, C.byref(rec), C.byref(cnt)), "opd_comm_buffers")
+            det.detect_records_at(list(local_frames[s0:s0 + det.max_batch]), rec.value, cnt.value)
+        _capi.check(lib.opd_comm_exchange(self._comm), "opd_comm_exchange")
+        recs = np.empty((self.world, per, Q, 8), np.int32)
+        counts = np.empty((self.world, per), np.int32)
+        _capi.check(lib.opd_comm_wait(self._comm, recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), counts.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "opd_comm_wait")
+        return recs, counts
+
+    def close(self) -> None:
+        if self._comm:
+            self._lib.opd_comm_destroy(self._comm)
+            self._comm = C.c_void_p()
+
+
 class ShardedDetector:
     """``detect_batch`` over all ranks of an initialised ``torch.distributed`` process group (one rank per GPU).
 
@@ -69,9 +113,30 @@ class ShardedDetector:
     inject a stand-in for the compute).  ``device``: torch device of the exchange buffer: this rank's GPU under RCCL — the
     post-process kernel then writes the records straight into the tensor the all-gather reads — or None (host memory, gloo)."""
 
-    def __init__(self, detector, device: Optional[str] = None):
+    def __init__(self, detector, device: Optional[str] = None, exchange: str = "torch"):
+        """``exchange``: "torch" (``dist.all_gather_into_tensor``: RCCL with device tensors, gloo with host tensors) or "native" (the
+        C-ABI's ``opd_comm_*``: RCCL on the detector handle's own stream; the unique id travels through the process group once)."""
+        if exchange not in ("torch", "native"):
+            raise ValueError("exchange must be 'torch' or 'native'")
         self.detector = detector
         self.device = device
+        self.exchange = exchange
+        self._native: Optional[NativeExchange] = None
+
+    def _native_exchange(self) -> NativeExchange:
+        if self._native is None:
+            import torch.distributed as dist
+            rank, world = dist.get_rank(), dist.get_world_size()
+            box = [NativeExchange.unique_id() if rank == 0 else None]
+            if world > 1:
+                dist.broadcast_object_list(box, src=0)   # (set-up only: 128 bytes)
+            self._native = NativeExchange(self.detector, rank, world, box[0])
+        return self._native
+
+    def close(self) -> None:
+        if self._native is not None:
+            self._native.close()
+            self._native = None
 
     def detect_batch(self, frames: Sequence[np.ndarray]) -> List[List[Detection]]:
         """Every rank passes the SAME global frame list; every rank returns the full result."""
@@ -92,6 +157,9 @@ class ShardedDetector:
             raise ValueError(f"rank {rank} of {world} owns frames [{start}, {stop}) of {n_frames} but was given {len(local_frames)} frames")
         det = self.detector
         Q = det.num_queries
+        if self.exchange == "native":
+            g_rec, g_cnt = self._native_exchange().gather(local_frames, per)
+            return assemble(g_rec, g_cnt, n_frames, nms_threshold=det.nms_threshold, foot=det._get_foot_position)
         nrec = per * Q * 8
         # ONE flat int32 buffer per rank: per x Q records (8 words each), then per counts; -1 marks the padding slots of an
         # uneven shard.  The collective is latency bound: one launch, not two.

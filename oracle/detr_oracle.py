@@ -254,7 +254,7 @@ class _SiteQuant:
     """Emulation of low-precision *storage* (predicts GPU drift on CPU): `q(t, site)` rounds `t` through `mode` when `sites` is None
     (every rounding site) or `site` starts with one of the prefixes in `sites`.  Activation sites of the transformer:
     enc.attn.{in,q,kv,p,o}, enc.ffn.{in,h}, dec.self.{in,q,kv,p,o}, dec.cross.{in,kvin,q,kv,p,o}, dec.ffn.{in,h}, heads;
-    weight sites (see `forward`): w.proj, w.enc.attn, w.enc.ffn, w.dec.self, w.dec.cross.q, w.dec.cross.kv, w.dec.cross.o, w.dec.ffn, w.heads."""
+    weight sites (see `forward`): w.proj, w.enc.attn, w.enc.ffn, w.dec.self.{qk,v,o}, w.dec.cross.q, w.dec.cross.kv, w.dec.cross.o, w.dec.ffn, w.heads."""
 
     def __init__(self, mode: str, sites=None):
         self.dt = {"f16": torch.float16, "bf16": torch.bfloat16}[mode]
@@ -285,7 +285,7 @@ def _weight_site(k: str) -> Optional[str]:
         if ".mlp." in k:
             return "w.dec.ffn"
         if ".self_attn." in k:
-            return "w.dec.self"
+            return "w.dec.self.o" if ".o_proj" in k else ("w.dec.self.v" if ".v_proj" in k else "w.dec.self.qk")
         if ".encoder_attn.q_proj" in k:
             return "w.dec.cross.q"
         if ".encoder_attn.o_proj" in k:

@@ -48,6 +48,25 @@ def _ulp16(x):
         return np.spacing(np.abs(x).astype(np.float16)).astype(np.float64)
 
 
+def k_frag(k, pad=0.0):
+    """k [B][Q][256] -> kf [B][8 heads][8 key tiles][64 lanes][8]: lane 16 g + li of tile kt holds k[16 kt + li][32 h + 8 g ..]
+    (the order dec_qkv_kernel writes and dec_self_kernel streams: one KiB per MFMA A operand).  Keys >= Q: `pad`."""
+    B, Q, _ = k.shape
+    kp = np.full((B, 128, 256), pad, np.float64)
+    kp[:, :Q] = k
+    return kp.reshape(B, 8, 16, 8, 4, 8).transpose(0, 3, 1, 4, 2, 5).reshape(B, 8, 8, 64, 8)   # [b][kt][li][h][g][e] -> [b][h][kt][g][li][e]
+
+
+def v_frag(v, pad=0.0):
+    """v [B][Q][256] -> vf [B][8 heads][4 kb][2 dt][64 lanes][8]: lane 16 g + li holds v[key][32 h + 16 dt + li] for the keys
+    kb*32 + 4g + (0..3) and kb*32 + 16 + 4g + (0..3)."""
+    B, Q, _ = v.shape
+    vp = np.full((B, 128, 256), pad, np.float64)
+    vp[:, :Q] = v
+    x = vp.reshape(B, 4, 2, 4, 4, 8, 2, 16)            # [b][kb][half][g][j4][h][dt][li]
+    return x.transpose(0, 5, 1, 6, 3, 7, 2, 4).reshape(B, 8, 4, 2, 64, 8)   # -> [b][h][kb][dt][g][li][half][j4]
+
+
 def _ln_params(rng):
     return (1.0 + 0.1 * rng.standard_normal(D)).astype(np.float32), (0.1 * rng.standard_normal(D)).astype(np.float32)
 
@@ -64,7 +83,7 @@ def test_dec_qkv_kernel(lib, B, Q, with_partials):
     w = (rng.standard_normal((768, D)) / 16).astype(np.float32)
     bias = (rng.standard_normal((Q, 768)) * 0.5).astype(np.float32)
     h_out = np.zeros((M, D), np.float32)
-    q16 = np.zeros((M, D), np.uint16); k16 = np.zeros((M, D), np.uint16); vT = np.zeros((B, 8, 32, 128), np.uint16)
+    q16 = np.zeros((M, D), np.uint16); k16 = np.zeros((B, 8, 8, 64, 8), np.uint16); vT = np.zeros((B, 8, 4, 2, 64, 8), np.uint16)
     rc = lib.opd_test_dec_qkv(_p(h_in), _p(parts) if with_partials else None, ns, _p(b2), _p(g), _p(be), _p(w), _p(bias), M, Q, _p(h_out), _p(q16), _p(k16), _p(vT))
     _capi.check(rc, "opd_test_dec_qkv")
     if with_partials:
@@ -77,13 +96,13 @@ def test_dec_qkv_kernel(lib, B, Q, with_partials):
         h = t(h_in)
     qkv = (h @ t(w).T).reshape(B, Q, 768) + t(bias)[None]
     ulp = _ulp16   # one fp16 output rounding
-    want_q, want_k = qkv[..., :256].reshape(M, D).numpy(), qkv[..., 256:512].reshape(M, D).numpy()
+    want_q = qkv[..., :256].reshape(M, D).numpy()
     assert np.all(np.abs(_from16(q16) - want_q) <= 0.51 * ulp(want_q) + 2e-6)
-    assert np.all(np.abs(_from16(k16) - want_k) <= 0.51 * ulp(want_k) + 2e-6)
-    want_v = qkv[..., 512:].reshape(B, Q, 8, 32).permute(0, 2, 3, 1).numpy()     # [B][head][dim][key]
-    got_v = _from16(vT)
-    assert np.all(np.abs(got_v[..., :Q] - want_v) <= 0.51 * ulp(want_v) + 2e-6)
-    assert not got_v[..., Q:].any()                                               # padding keys are never written
+    # k and v arrive in MFMA-fragment order; padding keys are never written (the hook zero-fills the buffers)
+    for got, want in ((_from16(k16), k_frag(qkv[..., 256:512].numpy())), (_from16(vT), v_frag(qkv[..., 512:].numpy()))):
+        assert np.all(np.abs(got - want) <= 0.51 * ulp(want) + 2e-6)
+    valid = k_frag(np.ones((B, Q, 256)))
+    assert not _from16(k16)[valid == 0].any() and not _from16(vT)[v_frag(np.ones((B, Q, 256))) == 0].any()
 
 
 @pytest.mark.parametrize("B,Q", [(8, 100), (1, 100), (2, 36)])
@@ -95,10 +114,10 @@ def test_dec_self_kernel(lib, B, Q):
     q = (rng.standard_normal((B, Q, D)) * 1.5).astype(np.float32)
     k = (rng.standard_normal((B, Q, D)) * 1.5).astype(np.float32)
     v = rng.standard_normal((B, Q, D)).astype(np.float32)
-    q16, k16 = _f16(q.reshape(M, D)), _f16(k.reshape(M, D))
-    vt = np.full((B, 8, 32, 128), np.float16(np.nan))            # NaN in the padding keys
-    vt[..., :Q] = v.reshape(B, Q, 8, 32).transpose(0, 2, 3, 1).astype(np.float16)
-    vT = np.ascontiguousarray(vt.view(np.uint16))
+    q16 = _f16(q.reshape(M, D))
+    k_r, v_r = k.astype(np.float16).astype(np.float64), v.astype(np.float16).astype(np.float64)   # the fp16 operands, row-major
+    k16 = np.ascontiguousarray(k_frag(k_r, np.nan).astype(np.float16).view(np.uint16))            # NaN in the padding keys
+    vT = np.ascontiguousarray(v_frag(v_r, np.nan).astype(np.float16).view(np.uint16))
     h = rng.standard_normal((M, D)).astype(np.float32)
     wo = (rng.standard_normal((D, D)) / 16).astype(np.float32); bo = (rng.standard_normal(D) * 0.1).astype(np.float32)
     g, be = _ln_params(rng)
@@ -108,8 +127,8 @@ def test_dec_self_kernel(lib, B, Q):
     _capi.check(lib.opd_test_dec_self(_p(q16), _p(k16), _p(vT), _p(h_io), _p(wo), _p(bo), _p(g), _p(be), _p(wq), _p(rbq), B, Q, SCALE, _p(qc16)),
                 "opd_test_dec_self")
     qh = t(_from16(q16)).reshape(B, Q, 8, 32).transpose(1, 2)
-    kh = t(_from16(k16)).reshape(B, Q, 8, 32).transpose(1, 2)
-    vh = t(vt[..., :Q].astype(np.float64)).transpose(2, 3)       # [B][8][Q][32]
+    kh = t(k_r).reshape(B, Q, 8, 32).transpose(1, 2)
+    vh = t(v_r).reshape(B, Q, 8, 32).transpose(1, 2)
     p = torch.softmax(qh @ kh.transpose(2, 3) * SCALE, -1)
     o = (p @ vh).transpose(1, 2).reshape(M, D)
     h1 = F.layer_norm(t(h) + o @ t(wo).T + t(bo), (D,), t(g), t(be), 1e-5)

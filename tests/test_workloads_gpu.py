@@ -275,3 +275,62 @@ def test_stage3_frame_split_is_bit_identical(mild_path):
             np.testing.assert_array_equal(x, y)
         for x, y in zip(outs["1"][call], outs["1"][0]):
             np.testing.assert_array_equal(x, y)
+
+
+def test_native_exchange_world_size_1(mild_path):
+    """The C-ABI's own exchange step (csrc/opd_comm.cpp: ncclAllGather from librccl on the detector handle's stream, one host wait) over a
+    communicator of ONE rank — all a one-GPU box can run: (a) opd_comm_begin / detect / exchange / wait deliver exactly the records and
+    counts of opd_detr_detect on the same frames, trailing slots at count -1; (b) ShardedDetector(exchange="native") — no
+    torch.distributed process group needed beyond the unique id, which rank 0 generates itself here — equals detect_batch, also for a
+    shard larger than max_batch (chunks into consecutive slots) and through the device-resize path."""
+    import torch.distributed as dist
+    from office_person_detection_vit_amd.sharding import NativeExchange, ShardedDetector
+    lib = _capi.load_library()
+    det = HipDetrDetector(model_path=mild_path, max_batch=4, max_size=(256, 320), resize=False)
+    det.load_model()
+    try:
+        frames = np.stack(structured_frames(3, 256, 320, seed=91))
+        Q = det.num_queries
+        hw = np.asarray([[256, 320]] * 3, np.int32)
+        want = np.zeros((3, Q, 8), np.int32); want_c = np.zeros(3, np.int32)
+        _capi.check(lib.opd_detr_detect(C.c_void_p(det.model), frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 3, 256, 320,
+                                        0.5, hw.ctypes.data_as(C.c_void_p), want.ctypes.data_as(C.POINTER(_capi.OpdDet)), want_c.ctypes.data_as(C.POINTER(C.c_int32))),
+                    "opd_detr_detect")
+        uid = NativeExchange.unique_id()
+        assert len(uid) == _capi.OPD_COMM_ID_BYTES
+        comm = C.c_void_p()
+        _capi.check(lib.opd_comm_create(uid, 0, 1, C.c_void_p(det.model), C.byref(comm)), "opd_comm_create")
+        try:
+            r, w = C.c_int(-1), C.c_int(-1)
+            _capi.check(lib.opd_comm_info(comm, C.byref(r), C.byref(w)), "opd_comm_info")
+            assert (r.value, w.value) == (0, 1)
+            for _ in range(2):   # (twice: buffers are reused, the second exchange starts from a clean slate)
+                _capi.check(lib.opd_comm_begin(comm, 4), "opd_comm_begin")
+                _capi.check(lib.opd_comm_detect(comm, 0, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 3, 256, 320, 0.5,
+                                                hw.ctypes.data_as(C.c_void_p)), "opd_comm_detect")
+                _capi.check(lib.opd_comm_exchange(comm), "opd_comm_exchange")
+                assert lib.opd_comm_begin(comm, 4) != 0            # an exchange is outstanding
+                got = np.zeros((1, 4, Q, 8), np.int32); got_c = np.zeros((1, 4), np.int32)
+                _capi.check(lib.opd_comm_wait(comm, got.ctypes.data_as(C.POINTER(_capi.OpdDet)), got_c.ctypes.data_as(C.POINTER(C.c_int32))), "opd_comm_wait")
+                assert got_c[0].tolist() == want_c.tolist() + [-1]
+                for f in range(3):
+                    np.testing.assert_array_equal(got[0, f, :want_c[f]], want[f, :want_c[f]])
+            assert lib.opd_comm_wait(comm, got.ctypes.data_as(C.POINTER(_capi.OpdDet)), got_c.ctypes.data_as(C.POINTER(C.c_int32))) != 0   # nothing outstanding
+            assert lib.opd_comm_detect(comm, 2, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 3, 256, 320, 0.5,
+                                       hw.ctypes.data_as(C.c_void_p)) != 0                                                                  # slots 2..4 of 4
+        finally:
+            lib.opd_comm_destroy(comm)
+        # (b) the Python layer: world size 1 needs no process group beyond what dist.get_rank() answers
+        s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+        os.environ.update({"MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port)})
+        dist.init_process_group("gloo", rank=0, world_size=1)   # (gloo: torch.distributed carries the unique id only, never the records)
+        try:
+            sharded = ShardedDetector(det, exchange="native")
+            many = structured_frames(9, 256, 320, seed=92)   # 9 frames through a max_batch = 4 handle: three chunks
+            assert _sig(sharded.detect_batch(many)) == _sig(det.detect_batch(many))
+            assert sum(len(f) for f in sharded.detect_batch(many)) > 0
+            sharded.close()
+        finally:
+            dist.destroy_process_group()
+    finally:
+        det.close()
