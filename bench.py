@@ -17,8 +17,11 @@ records, so a step ends with what `DetectionPhase` consumes.  Rank 0 prints ONE 
 Steps are submitted asynchronously to `--streams` detector handles per GPU (default 3: own stream / workspace / graph, one
 shared copy of the weights), so up to three batches of 8 are in flight per GPU; every step's records reach host memory inside
 the timed region, which is bracketed by barrier + device synchronisation.  The line also carries a `serial` record — a short
-leg with ONE handle and one blocking call per step — so that the per-kernel times of `roofline` (HIP events around every
-launch of a serial forward) can be checked against a timed number of the same mode: kernel_ms_per_step <= serial.ms_per_step.
+leg with ONE handle (a single-stream caller's kernel plan) and one blocking call per step — and both profiling legs run on
+that handle: `stage_ms` / `roofline.graph_ms_per_step` from stage marks recorded INSIDE the replayed graph
+(`roofline_serial.closes`: graph_ms_per_step <= serial.ms_per_step), `roofline` from HIP event pairs around every launch of
+an eagerly launched forward (true kernel durations; their sum, `kernel_ms_per_step`, carries ~10 us of eager dispatch and
+event overhead per launch and therefore exceeds the step it dissects).
 """
 
 from __future__ import annotations
@@ -121,11 +124,18 @@ def cpu_baseline(path: str, H: int, W: int, batch: int = 4, iters: int = 3) -> d
                       f"(all: {', '.join(f'{t:.2f}' for t in times[1:])})"}
 
 
+def _capi_unique_id(lib):
+    buf = C.create_string_buffer(128)
+    if lib.opd_comm_unique_id(buf) != 0:
+        raise RuntimeError(lib.opd_last_error().decode())
+    return buf.raw
+
+
 def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1000)  # 2.8 s timed.  A 200-step window (0.1-0.6 s after the load starts) sits in the
-                                                        # power-management transient and reads ~4 % low: profiles/r03_clock_vs_window.txt
+    ap.add_argument("--steps", type=int, default=1000)  # 2.8 s timed (windows of 20 / 1000 / 3000 steps read within 2 % of each other; a
+                                                        # 200-step window read ~4 % low on the boxes of round 3, cause not established)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=8, help="frames per GPU per step")
     ap.add_argument("--height", type=int, default=800)
@@ -213,6 +223,35 @@ def main() -> int:
         Q = info.num_queries
     NS = max(1, len(handles))
     dev = "cpu" if rehearsal else "cuda"
+    # N > 1: the path's exchange step runs inside the C-ABI (opd_comm_*: ncclAllGather on each handle's own stream, one host wait per
+    # step); torch.distributed carries the 128-byte unique ids at set-up, the barriers and the max-over-ranks of the timing.  The
+    # torch.distributed all-gather of rounds 1-3 remains for the gloo rehearsal (ranks sharing one device cannot form an RCCL
+    # communicator) and as the fallback should communicator creation fail on a node.
+    comms, exchange = [], "none"
+    if world > 1:
+        exchange = "torch.distributed"
+        if backend == "nccl" and os.environ.get("OPD_BENCH_EXCHANGE", "native") == "native":
+            try:
+                ids = [[bytes(_capi_unique_id(lib)) for _ in handles] if rank == 0 else None]
+                dist.broadcast_object_list(ids, src=0)
+                for hx, uid in zip(handles, ids[0]):
+                    cx = C.c_void_p()
+                    _capi.check(lib.opd_comm_create(uid, rank, world, hx, C.byref(cx)), "opd_comm_create")
+                    comms.append(cx)
+                exchange = "native (opd_comm_*: ncclAllGather on the handle's stream)"
+            except Exception as e:   # noqa: BLE001 — any failure: say so and use the torch path
+                print(f"bench.py: native exchange unavailable on rank {rank} ({e}); using torch.distributed", file=sys.stderr, flush=True)
+                for cx in comms:
+                    lib.opd_comm_destroy(cx)
+                comms = []
+            ok = torch.tensor([1 if comms else 0], device="cuda")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank or none
+            if int(ok.item()) == 0 and comms:
+                for cx in comms:
+                    lib.opd_comm_destroy(cx)
+                comms, exchange = [], "torch.distributed"
+            elif int(ok.item()) == 0:
+                exchange = "torch.distributed"
 
     # synthetic office-camera frames, resident in HBM before the timed region (torch = device memory plumbing only)
     d_frames = None
@@ -230,10 +269,18 @@ def main() -> int:
     if not rehearsal:
         torch.cuda.synchronize()   # the buffers above were filled on torch's stream; the library writes them from its own streams
 
-    def collect(buf):
+    g_recs = np.zeros((world * B * Q, 8), np.int32)
+    g_counts = np.zeros((world * B,), np.int32)
+
+    def collect(buf, j=0):
         """records (+ counts) of one finished step -> the orchestrator's host memory (the path's one exchange step for N > 1),
         then the host tail of the path on rank 0: person filter + greedy NMS on every gathered frame, in place"""
-        if world > 1:
+        if comms:   # native exchange: the all-gather was enqueued with the step; this is the step's one host wait
+            _capi.check(lib.opd_comm_wait(comms[j % NS], g_recs.ctypes.data_as(DetP), g_counts.ctypes.data_as(I32P)), "opd_comm_wait")
+            if rank != 0:
+                return None
+            recs, counts = g_recs, g_counts
+        elif world > 1:
             dist.all_gather_into_tensor(g_flat, buf if backend == "nccl" else buf.cpu())
             if rank != 0:
                 # `buf` is a rotating buffer that a later step's post-process kernel rewrites from the LIBRARY's stream, which knows
@@ -261,6 +308,13 @@ def main() -> int:
         """enqueue step i on a handle's stream (forward + post-process into a rotating buffer) and return its ticket"""
         if rehearsal:
             return 0
+        if comms:   # forward -> post-process into the communicator's send buffer -> ncclAllGather -> copy to pinned memory: all enqueued
+            cx = comms[i % NS]
+            _capi.check(lib.opd_comm_begin(cx, B), "opd_comm_begin")
+            _capi.check(lib.opd_comm_detect(cx, 0, C.c_void_p(d_frames.data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_DEVICE, B, H, W, 0.5,
+                                            hw.ctypes.data_as(C.c_void_p)), "opd_comm_detect")
+            _capi.check(lib.opd_comm_exchange(cx), "opd_comm_exchange")
+            return -1
         buf = d_flats[i % (2 * NS)]
         ticket = C.c_int()
         rc = lib.opd_detr_detect_async(handles[i % NS], C.c_void_p(d_frames.data_ptr()), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_DEVICE,
@@ -274,8 +328,11 @@ def main() -> int:
         out = None
         if blocking and not rehearsal:
             for _ in range(n):
-                detect_blocking(handles[0], d_flats[0])
-                out = collect(d_flats[0])
+                if comms:
+                    submit(0)
+                else:
+                    detect_blocking(handles[0], d_flats[0])
+                out = collect(d_flats[0], 0)
             return out
         # NS steps stay submitted ahead (one per handle); step i - NS is collected right after step i has been submitted
         tickets = {}
@@ -285,9 +342,9 @@ def main() -> int:
             j = i - NS
             if j >= 0:
                 t = tickets.pop(j)
-                if not rehearsal:
+                if not rehearsal and not comms:
                     _capi.check(lib.opd_detr_wait(handles[j % NS], t), "opd_detr_wait")
-                out = collect(d_flats[j % (2 * NS)])
+                out = collect(d_flats[j % (2 * NS)], j)
         return out
 
     def sync():
@@ -334,7 +391,24 @@ def main() -> int:
             torch.cuda.synchronize()
             s_ms = 1e3 * (time.perf_counter() - ts) / args.serial_steps
             serial = {"streams": 1, "steps": args.serial_steps, "ms_per_step": round(s_ms, 3), "frames_per_s": round(B / s_ms * 1e3, 1)}
+        # Both profiling legs run on the handle of the serial leg (a single-stream caller's kernel plan), so that they describe the
+        # mode that leg timed:  (a) stage marks INSIDE the replayed graph (opd_detr_set_profiling 2): the device time of a step as a
+        # caller gets it — their sum must not exceed serial.ms_per_step;  (b) HIP event pairs around every launch (mode 1: eager
+        # launches; the events and the eager dispatch add ~10 us per launch, so this sum exceeds the step it dissects).
+        phandle = handles[-1] if args.serial_steps > 0 else handle
+        stage_graph = None
+        _capi.check(lib.opd_detr_set_profiling(phandle, 2), "opd_detr_set_profiling")
+        sg = np.zeros(8)
+        for it in range(2 + 5):   # eager, capture, then five replays
+            detect_blocking(phandle, d_flats[0])
+            if it >= 2:
+                s8 = (C.c_float * 8)()
+                _capi.check(lib.opd_detr_stage_times(phandle, s8), "opd_detr_stage_times")
+                sg += np.asarray(list(s8))
+        if sg.sum() > 0:
+            stage_graph = [round(float(v), 4) for v in sg / 5]
         # roofline of the dominant kernel: HIP event pairs around every launch on the library's stream (eager, serial)
+        handle = phandle
         _capi.check(lib.opd_detr_set_profiling(handle, 1), "opd_detr_set_profiling")
         ms_acc, st_acc = np.zeros(4), np.zeros(8)
         fl, ln = np.zeros(4), np.zeros(4, dtype=np.int64)
@@ -346,7 +420,8 @@ def main() -> int:
             _capi.check(lib.opd_detr_stage_times(handle, s8), "opd_detr_stage_times")
             ms_acc += np.asarray(list(ms4)); fl = np.asarray(list(f4)); ln = np.asarray(list(l4)); st_acc += np.asarray(list(s8))
         ms_avg = ms_acc / reps
-        stage_ms = [round(float(v), 4) for v in st_acc / reps]
+        stage_eager = [round(float(v), 4) for v in st_acc / reps]
+        stage_ms = stage_graph if stage_graph is not None else stage_eager
         _capi.check(lib.opd_detr_set_profiling(handle, 0), "opd_detr_set_profiling")
         # dominant kernel = the implicit-GEMM family (backbone convolutions incl. the fused tails + transformer linears): classes 0 and 1
         k_ms = float(ms_avg[0] + ms_avg[1])
@@ -356,7 +431,7 @@ def main() -> int:
         # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
         # in separate runs, gfx950 x2 fetch correction: tools/pmc_traffic.py) — valid for the default 8 x 800x1333 workload
         traffic = None
-        for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333) and args.arch == "r50":
                 traffic = round(json.load(open(tpath))["conv_gemm_family"]["bytes_per_launch"])
@@ -367,7 +442,9 @@ def main() -> int:
                 "launches_per_step": k_n, "avg_launch_us": round(1e3 * k_ms / max(k_n, 1), 2),
                 "flops_per_launch": round(k_fl / max(k_n, 1)),
                 "family_ms_per_step": round(k_ms, 4),
-                "kernel_ms_per_step": round(float(ms_avg.sum()), 4),   # every launch of a serial forward + post-process
+                "kernel_ms_per_step": round(float(ms_avg.sum()), 4),   # every launch of a serial forward + post-process, EAGER mode (event pair per launch)
+                "graph_ms_per_step": round(float(sum(stage_graph)), 4) if stage_graph else None,   # the same forward inside the replayed graph (stage marks in the graph)
+                "stage_ms_eager": stage_eager,
                 "by_class_ms": {"conv": round(float(ms_avg[0]), 4), "linear": round(float(ms_avg[1]), 4),
                                 "attention": round(float(ms_avg[2]), 4), "other": round(float(ms_avg[3]), 4)}}
         if (B, H, W) == (8, 800, 1333) and args.arch == "r50":
@@ -382,11 +459,11 @@ def main() -> int:
                  "frac_of_peak": round(mb * B / 1e3 / (stage_ms[i] * 1e-3) / PEAK_HBM_GBS, 3) if stage_ms[i] > 0 else None}
                 for i, (name, mb) in enumerate(stage_mb.items())]
             # MFMA-pipe utilisation of the attention / linear kernels from the committed SQ counter pass of the same build
-            sq_path = os.path.join(ROOT, "profiles", "r03_pmc_sq.json")
-            if os.path.exists(sq_path):
+            sq_path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_sq.json", "r03_pmc_sq.json")) if os.path.exists(q)), "")
+            if sq_path:
                 sq = json.load(open(sq_path))
                 pick = lambda sub: {k: v["mfma_busy_pct"] for k, v in sq["kernels"].items() if sub in k}
-                roof["mfma_busy_pct"] = {"source": "profiles/r03_pmc_sq.json (rocprofv3 --pmc SQ pass, one serial forward)",
+                roof["mfma_busy_pct"] = {"source": f"profiles/{os.path.basename(sq_path)} (rocprofv3 --pmc SQ pass, one serial forward)",
                                          "whole_forward": sq["whole_forward_mfma_busy_pct"], "attention": pick("attention_kernel"),
                                          "row_owner_linears": pick("gemm_ln256"), "implicit_gemm": pick("conv_gemm_dma_kernel"),
                                          "fused_tails": {**pick("btail_kernel"), **pick("btail256_kernel")}}
@@ -412,11 +489,21 @@ def main() -> int:
                        "batches_in_flight_per_gpu": 1 if args.sync_steps else NS},
             "roofline": roof,
             "serial": serial,
-            "stage_ms": stage_ms,
+            "stage_ms": stage_ms,   # inside the replayed graph of a single-stream handle (eager per-launch form: roofline.stage_ms_eager)
+            "exchange": exchange,
             "detections_last_step": int(np.asarray(counts).clip(min=0).sum()) if counts is not None else None,
         }
         if rehearsal:
             out["rehearsal"] = "cpu: no device compute, not a measurement"
+        if roof is not None and serial is not None and roof.get("graph_ms_per_step"):
+            # the serial leg dissected: device time of its forward inside the graph (<= the step, which adds the records' way to the host
+            # and the NMS), and the whole path's algorithmic FLOPs against it
+            g_ms = roof["graph_ms_per_step"]
+            rs = {"ms_per_step": serial["ms_per_step"], "graph_device_ms": g_ms, "closes": bool(g_ms <= serial["ms_per_step"])}
+            if (H, W) == (800, 1333) and args.arch == "r50":
+                tf = 203.2e9 * B / (g_ms * 1e-3) / 1e12
+                rs.update({"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / PEAK_MFMA_TFLOPS, 4)})
+            out["roofline_serial"] = rs
         if (H, W) == (800, 1333) and args.arch == "r50" and roof is not None:
             # SURVEY.md section 8(d) headline: the whole path's algorithmic FLOPs (203.2 GFLOP per r50 frame at 800x1333) x frames/s
             # per GPU against the dense MFMA peak; this one includes every gap, the attention, pre- and post-processing
@@ -426,6 +513,8 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(path, H, W)
             out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), file=json_out, flush=True)
+    for cx in comms:
+        lib.opd_comm_destroy(cx)
     for hx in handles:
         lib.opd_detr_destroy(hx)
     if world > 1:

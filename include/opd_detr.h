@@ -245,7 +245,9 @@ OPD_API int opd_comm_wait(opd_comm* c, opd_det* out_all, int32_t* counts_all);
 
 /* Device time (ms) of the last forward/detect per stage, measured with HIP events on the handle's stream:
  * [0] preprocess+stem+pool, [1] stage1, [2] stage2, [3] stage3, [4] stage4, [5] projection+encoder, [6] decoder+heads,
- * [7] post-process.  Only filled when profiling was enabled with opd_detr_set_profiling(m, 1). */
+ * [7] post-process.  Only filled when profiling is on: opd_detr_set_profiling(m, 1) = the forward is launched EAGERLY with an event pair
+ * around every launch (opd_detr_kernel_times; the eager launches and their events add ~10 us per launch to the stage times), (m, 2) =
+ * the stage marks are recorded INSIDE the replayed hipGraph: the stage times of the path as a caller gets it (no per-kernel times). */
 OPD_API int opd_detr_set_profiling(opd_detr* m, int enabled);
 OPD_API int opd_detr_stage_times(const opd_detr* m, float* ms8);
 /* Per-kernel-class totals of the last profiled forward, from HIP event pairs recorded around EVERY launch on the

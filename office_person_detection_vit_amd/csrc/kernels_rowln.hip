@@ -361,7 +361,11 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
         __builtin_amdgcn_s_barrier();       // everybody's pieces of ks are in LDS; everybody has finished multiplying stage (ks - 1) % 3
         if (ks + 2 < nk) issue(ks + 2);     // ... which is the stage this goes to
         // (a second barrier per k-step, so that k-step ks + 2 is issued BEFORE the wait for ks and two whole stages stay in flight, measured
-        //  slower: 30.0 against 26.7 us -- the CU's LDS-DMA path, ~20 bytes per clock here, is the limit, not the bytes in flight)
+        //  slower: 30.0 against 26.7 us.  Round 4 tried more bytes in flight outright: FOUR 64-wide stages (all 160 KiB of LDS, LayerNorm
+        //  scratch over stage 0): 27.2 us, no change; SEVEN 32-wide stages (120 KiB in flight): 40.0 us.  A one-shot LDS-DMA of 256 KiB per
+        //  workgroup lands 0.7 us after the launch floor (tools/microbench/oneshot.hip), so neither the path's rate nor the bytes in flight
+        //  bound this loop: a k-step costs ~0.8 us of wait + barrier + fragment-read latency + 96 KiB of LDS fragment reads per workgroup
+        //  (every wave reads the whole 64 x 64 activation tile) whatever its width, and 64 narrow steps cost more than 32 wide ones.)
         if (ks + 1 == nk) {                 // last k-step: the residual rows travel during its MFMAs
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt) {

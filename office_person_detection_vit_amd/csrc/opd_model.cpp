@@ -435,7 +435,7 @@ static int get_plan(opd_detr* m, int fh, int fw, int vh, int vw, Plan** out) {
 enum { CLS_CONV = 0, CLS_GEMM = 1, CLS_ATTN = 2, CLS_OTHER = 3 };
 
 static int timed_begin(opd_detr* m, int cls, double flops) {
-    if (!m->profiling) return OPD_OK;
+    if (m->profiling != 1) return OPD_OK;
     hipEvent_t e[2];
     for (int i = 0; i < 2; ++i) {
         if (m->pool_next == m->event_pool.size()) {
@@ -450,7 +450,7 @@ static int timed_begin(opd_detr* m, int cls, double flops) {
     return OPD_OK;
 }
 static int timed_end(opd_detr* m) {
-    if (!m->profiling) return OPD_OK;
+    if (m->profiling != 1) return OPD_OK;
     HIPCHK(hipEventRecord(m->timed.back().b, m->stream));
     return OPD_OK;
 }
@@ -803,7 +803,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         {
             const Block& b1 = m->blocks[m->stage_first[2] + (a.depths[2] > 1 ? 1 : 0)];
             const int oh3 = down2(st.ch), ow3 = down2(st.cw);
-            const bool fused3 = m->fuse_btail && a.depths[2] > 2 && b1.c1.Cin == 256 && opd_btail_supported(256, 0) && b1.c2.wp && !m->profiling && !m->taps &&
+            const bool fused3 = m->fuse_btail && a.depths[2] > 2 && b1.c1.Cin == 256 && opd_btail_supported(256, 0) && b1.c2.wp && m->profiling != 1 && !m->taps &&
                                 m->stream2 && m->tail3_split && !(m->cfg.flags & OPD_FLAG_MULTI_STREAM) && B >= 2 && [&] {   // the policy of run_blocks, evaluated for this stage
                                     const long long tiles = ((long long)m->cfg.max_batch * oh3 * ow3 + 127) / 128;
                                     return m->tail3 == 2 || (m->tail3 == 1 && (tiles * 10 >= (long long)m->num_cus * 6 || (m->cfg.flags & OPD_FLAG_MULTI_STREAM)));
@@ -836,6 +836,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             RCCHK(rc_a);
             RCCHK(rc_b);
             HIPCHK(ew);
+            MARK(4);   // (stage 3 ends at the join, not where the second chain's own mark fell)
             st = ta;
         } else {
             RCCHK(run_blocks(2, 3, 0, B, st, 1));
@@ -1043,9 +1044,10 @@ thread_local std::shared_lock<std::shared_mutex>* tl_api_lock = nullptr;
 // Forward through the graph cache.  First call of a (shape, pixel pointer) key runs eagerly (one-time function-attribute
 // setup and plan building are not capturable); the second call captures the stream into a hipGraph; later calls replay it.
 int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw) {
+    m->graph_marks = false;
     // ragged batches run eagerly: their launch sequence depends on per-call host data (fold pointers, valid sizes)
     if (is_ragged(valid_hw, B, H, W)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W, valid_hw);
-    if (m->profiling || (m->cfg.flags & OPD_FLAG_NO_GRAPH)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
+    if (m->profiling == 1 || (m->cfg.flags & OPD_FLAG_NO_GRAPH)) return enqueue_forward(m, d_pixels, pixel_format, B, H, W);
     opd_detr::GraphEntry* e = nullptr;
     for (auto& g : m->graphs)
         if (g.B == B && g.H == H && g.W == W && g.fmt == pixel_format && g.pixels == d_pixels) e = &g;
@@ -1064,6 +1066,7 @@ int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int 
     }
     if (e->exec) {
         HIPCHK(hipGraphLaunch(e->exec, m->stream));
+        if (m->profiling == 2) { HIPCHK(hipEventRecord(m->ev[9], m->stream)); m->graph_marks = true; }   // eager mark behind the graph: the post-process stage is timed between eager events
         m->last_B = B; m->last_H = H; m->last_W = W; m->last_fh = e->fh; m->last_fw = e->fw; m->last_ragged = false;
         return OPD_OK;
     }
@@ -1095,6 +1098,7 @@ int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int 
     }
     e->exec = exec; e->fh = m->last_fh; e->fw = m->last_fw; e->epoch = g_handle_epoch.load();
     HIPCHK(hipGraphLaunch(exec, m->stream));
+    if (m->profiling == 2) { HIPCHK(hipEventRecord(m->ev[9], m->stream)); m->graph_marks = true; }
     return OPD_OK;
 }
 
@@ -1205,9 +1209,13 @@ static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kin
     if (m->profiling) {
         for (int i = 0; i < 8; ++i) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, m->ev[i], m->ev[i + 1]) == hipSuccess) m->stage_ms[i] = ms;
+            // (mode 2: marks 0 .. 7 are nodes of the replayed graph, mark 8 is recorded eagerly behind the post-process launch: events of the
+            //  two kinds do not subtract meaningfully, so the last stage runs from the eager mark 9 behind the graph launch)
+            hipEvent_t from = (i == 7 && m->profiling == 2 && m->graph_marks) ? m->ev[9] : m->ev[i];
+            if (hipEventElapsedTime(&ms, from, m->ev[i + 1]) == hipSuccess) m->stage_ms[i] = ms;
+            else (void)hipGetLastError();   // (a mark that was never recorded: not this call's error)
         }
-        timed_collect(m);
+        if (m->profiling == 1) timed_collect(m);
     }
     return OPD_OK;
 }
@@ -1396,7 +1404,7 @@ static int forward_device(opd_detr* m, const void* d_pixels, int pixel_format, i
     if (enc_features)
         HIPCHK(hipMemcpyAsync(enc_features, m->d_x32, (size_t)B * m->last_fh * m->last_fw * m->arch.d_model * 4, kind, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
-    if (m->profiling) timed_collect(m);
+    if (m->profiling == 1) timed_collect(m);
     return OPD_OK;
 }
 int opd_detr_forward(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W, float* logits,
@@ -1633,7 +1641,16 @@ int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* que
 
 int opd_detr_set_profiling(opd_detr* m, int enabled) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
-    m->profiling = enabled != 0;
+    ApiScope api_scope;
+    const int mode = enabled == 2 ? 2 : (enabled ? 1 : 0);
+    if (mode != m->profiling) {   // the stage marks of mode 2 are nodes of the captured graph: graphs of another mode do not carry them
+        HIPCHK(hipSetDevice(m->device));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        for (auto& g : m->graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        m->graphs.clear();
+    }
+    m->profiling = mode;
     return OPD_OK;
 }
 

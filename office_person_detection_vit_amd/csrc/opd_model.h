@@ -188,8 +188,9 @@ struct opd_detr {
 
     // state of the last forward
     int last_B = 0, last_H = 0, last_W = 0, last_fh = 0, last_fw = 0;
-    bool profiling = false;
-    hipEvent_t ev[9] = {};
+    int profiling = 0;       // 0 off; 1 eager launches with an event pair around each (opd_detr_kernel_times) + stage marks; 2 stage marks INSIDE the replayed graph
+    hipEvent_t ev[10] = {};
+    bool graph_marks = false;   // profiling mode 2: the last forward was a graph replay (marks 0 .. 7 recorded by graph nodes, mark 9 eagerly behind it)
     float stage_ms[8] = {};
     int small_m_gemm = 1;    // decoder linears (M = B x queries): one-shot K = 256 kernel (0: the general k-loop kernel)
     int fuse_gemm_ln = 1;    // attention output projections: Linear + residual + LayerNorm in one kernel (0: GEMM, then LN)

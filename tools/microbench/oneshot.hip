@@ -2,6 +2,7 @@
 // front, one wait) and exit.  How long does such a launch take, by load path and access shape?
 //   mode 0: LDS-DMA, 1-KiB contiguous pieces          mode 1: VGPR dwordx4 loads, 1-KiB contiguous per wave-instruction
 //   mode 2: VGPR loads in MFMA A-fragment shape (16 rows x 64 B, row pitch 512 B)     mode 3: empty kernel (launch floor)
+//   mode 4: LDS-DMA pieces of 8 rows x 128 B at a 4-KiB row pitch (the tile-GEMM staging shape)
 // region: 0 = all workgroups read the SAME KB KiB (weights), 1 = each its own.   Build: hipcc --offload-arch=gfx950 -O3 oneshot.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -18,6 +19,15 @@ __global__ __launch_bounds__(512) void pull(const unsigned char* __restrict__ sr
 #pragma unroll
         for (int j = 0; j < PIECES; ++j)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + j * 1024 + lane * 16),
+                                             (__attribute__((address_space(3))) void*)(smem + ((wave * PIECES + j) % 128) * 1024), 16, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        acc = smem[threadIdx.x * 4];
+    } else if (MODE == 4) {   // LDS-DMA, one piece = 8 rows x 128 B gathered at a 4-KiB row pitch (a [N][2048] fp16 matrix, 64-wide k-step)
+        const int lrow = lane >> 3, lchunk = lane & 7;
+#pragma unroll
+        for (int j = 0; j < PIECES; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (size_t)blockIdx.x * block_stride + (size_t)((wave * 4 + (j & 3)) * 8 + lrow) * 4096 + (j >> 2) * 128 + lchunk * 16),
                                              (__attribute__((address_space(3))) void*)(smem + ((wave * PIECES + j) % 128) * 1024), 16, 0, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
@@ -43,7 +53,7 @@ template <int MODE, int PIECES>
 int run(const char* name, const unsigned char* d, size_t stride, int blocks, unsigned* sink) {
     hipEvent_t a, b;
     CHK(hipEventCreate(&a)); CHK(hipEventCreate(&b));
-    const int lds = MODE == 0 ? (8 * PIECES > 128 ? 128 : 8 * PIECES) * 1024 : 0;
+    const int lds = (MODE == 0 || MODE == 4) ? (8 * PIECES > 128 ? 128 : 8 * PIECES) * 1024 : 0;
     if (lds > 65536) CHK(hipFuncSetAttribute(reinterpret_cast<const void*>(pull<MODE, PIECES>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     const int reps = 200;
     for (int w = 0; w < 5; ++w) hipLaunchKernelGGL((pull<MODE, PIECES>), dim3(blocks), dim3(512), lds, 0, d, stride, sink);
@@ -68,6 +78,8 @@ int main() {
             run<0, 8>("LDS-DMA contiguous", d, stride, blocks, sink);
             run<0, 16>("LDS-DMA contiguous", d, stride, blocks, sink);
             run<0, 32>("LDS-DMA contiguous (128 KiB LDS ring)", d, stride, blocks, sink);
+            run<4, 16>("LDS-DMA 8 rows x 128 B gather", d, stride, blocks, sink);
+            run<4, 32>("LDS-DMA 8 rows x 128 B gather", d, stride, blocks, sink);
             run<1, 8>("VGPR contiguous", d, stride, blocks, sink);
             run<1, 16>("VGPR contiguous", d, stride, blocks, sink);
             run<1, 32>("VGPR contiguous", d, stride, blocks, sink);
