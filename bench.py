@@ -141,6 +141,9 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=800)
     ap.add_argument("--width", type=int, default=1333)
     ap.add_argument("--arch", choices=["r50", "r101"], default="r50", help="backbone depth (r101 = BASELINE configs[3]; not the headline workload)")
+    ap.add_argument("--dtype", choices=["f16", "bf16"], default="f16",
+                    help="16-bit operand type of the device path: f16 (default: fp16 operands, fp32 accumulate; meets the 1e-3 box tolerance) or "
+                         "bf16 (OPD_FLAG_BF16: the type BASELINE configs[1] names; same MFMA rate, looser parity: DESIGN.md section 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--streams", type=int, default=int(os.environ.get("OPD_BENCH_STREAMS", "3")),
                     help="detector handles (own stream, workspace and graph each) that take the steps in turn: the low-"
@@ -210,7 +213,7 @@ def main() -> int:
         path = ensure_weight_file(cache, arch, 0, 1.0, args.arch)
         # several handles keep batches in flight: the library may choose kernels for throughput (include/opd_detr.h, OPD_FLAG_MULTI_STREAM)
         cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W,
-                              flags=_capi.OPD_FLAG_MULTI_STREAM if args.streams > 1 else 0)
+                              flags=(_capi.OPD_FLAG_MULTI_STREAM if args.streams > 1 else 0) | (_capi.OPD_FLAG_BF16 if args.dtype == "bf16" else 0))
         handle = C.c_void_p()
         _capi.check(lib.opd_detr_create(C.byref(cfg), path.encode(), device_index, C.byref(handle)), "opd_detr_create")
         info = _capi.OpdModelInfo()
@@ -376,7 +379,8 @@ def main() -> int:
         if args.serial_steps > 0:
             shandle = handle
             if args.streams > 1:
-                scfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
+                scfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W,
+                                       flags=_capi.OPD_FLAG_BF16 if args.dtype == "bf16" else 0)
                 shandle = C.c_void_p()
                 _capi.check(lib.opd_detr_create(C.byref(scfg), path.encode(), device_index, C.byref(shandle)), "opd_detr_create")
                 handles.append(shandle)   # (destroyed with the others)
@@ -476,11 +480,14 @@ def main() -> int:
             "metric": f"frames/sec (Phase-2 DETR detect) at {H}x{W} batch {B}",
             "value": round(fps, 2), "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"facebook/detr-resnet-{net} architecture (seeded synthetic weights), batch {B} per GPU, "
                                    f"{H}x{W} uint8 BGR frames resident in HBM, forward + device post-process + records to host + person filter/NMS "
-                                   "on the orchestrator; fp16 operands / fp32 accumulate (BASELINE configs[1] names bf16: same MFMA rate, "
-                                   "fp16 keeps the 1e-3 box tolerance); "
+                                   "on the orchestrator; "
+                                   + ("fp16 operands / fp32 accumulate (BASELINE configs[1] names bf16: same MFMA rate, fp16 keeps the 1e-3 box "
+                                      "tolerance; --dtype bf16 runs that mode); " if args.dtype == "f16" else
+                                      "bf16 operands / fp32 accumulate (OPD_FLAG_BF16, the type BASELINE configs[1] names; the decoder's linear layers on "
+                                      "split fp16 operands as in the default mode); ")
                                    + ("blocking steps" if args.sync_steps else
                                       f"steps submitted asynchronously over {NS} detector handle(s), every step's records fetched to host")
                                    + ((", RCCL all-gather of detection records" if backend == "nccl" else f", {backend} REHEARSAL (ranks share device 0)")

@@ -68,6 +68,9 @@ typedef struct opd_config {
 } opd_config;
 
 #define OPD_FLAG_NO_GRAPH 1 /* launch kernels eagerly instead of replaying a captured hipGraph */
+#define OPD_FLAG_BF16 4 /* bf16 instead of fp16 as the 16-bit operand type of every activation buffer and GEMM weight (the type BASELINE.json
+                         * configs[1] names; same MFMA rate on gfx950, 8 mantissa bits instead of 11: the boxes drift more, see DESIGN.md
+                         * section 3).  The decoder's linear layers keep their split fp16 operands (fp32-grade) in both modes. */
 #define OPD_FLAG_MULTI_STREAM 2 /* this handle is one of several that keep batches in flight on one GPU: kernel choices are made for
                                  * throughput (a launch's last, partly filled round overlaps other handles' work) rather than for latency */
 

@@ -21,6 +21,7 @@ OPD_MEM_DEVICE = 1
 OPD_MEM_HOST_PIXELS_DEVICE_OUT = 2
 OPD_FLAG_NO_GRAPH = 1
 OPD_FLAG_MULTI_STREAM = 2
+OPD_FLAG_BF16 = 4
 OPD_COMM_ID_BYTES = 128
 
 
@@ -143,6 +144,7 @@ TEST_API = {
     "opd_test_bench_dec": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_float)]),
     "opd_test_heads_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 13 + [C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "opd_test_set_fused_dec": (C.c_int, [C.c_void_p, C.c_int]),
+    "opd_test_set_elem_bf16": (C.c_int, [C.c_int]),
     "opd_test_trace_dec_self": (C.c_int, [C.c_int, C.c_int, C.c_void_p]),
 }
 

@@ -13,9 +13,11 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_dec.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_comm.cpp", "opd_test_api.cpp"]
+SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_dec.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_comm.cpp", "opd_dispatch.cpp", "opd_test_api.cpp"]
 TEST_ONLY = {"opd_test_api.cpp"}
-HEADERS = ["opd_kernels.h", "opd_loader.h", "opd_host.h", "opd_model.h", os.path.join("..", "..", "include", "opd_detr.h")]
+# kernel files with 16-bit operands: ONE source, compiled for fp16 and (-DOPD_ELEM_BF16) for bf16 (opd_elem.h)
+ELEM_SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip"]
+HEADERS = ["opd_kernels.h", "opd_elem.h", "opd_loader.h", "opd_host.h", "opd_model.h", os.path.join("..", "..", "include", "opd_detr.h")]
 LIB = os.path.join(PKG, "libopd_hip.so")
 TEST_LIB = os.path.join(PKG, "libopd_hip_test.so")
 
@@ -44,6 +46,11 @@ def build(verbose: bool = False, force: bool = False) -> str:
         objs.append(obj)
         if force or _stale(obj, [sp] + hdrs):
             jobs.append([hipcc] + common + extra.get(src, []) + (["-x", "hip"] if src.endswith(".cpp") else []) + ["-c", sp, "-o", obj])
+        if src in ELEM_SOURCES:   # the bf16 instantiation of the same kernels
+            obj16 = os.path.join(objdir, os.path.splitext(src)[0] + "_bf16.o")
+            objs.append(obj16)
+            if force or _stale(obj16, [sp] + hdrs):
+                jobs.append([hipcc] + common + extra.get(src, []) + ["-DOPD_ELEM_BF16=1", "-c", sp, "-o", obj16])
 
     def compile_one(cmd):
         if verbose:

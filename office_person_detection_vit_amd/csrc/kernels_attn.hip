@@ -32,9 +32,10 @@
 #include <type_traits>
 #include <math.h>
 #include "opd_kernels.h"
+#include "opd_elem.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef elem_t half8 __attribute__((ext_vector_type(8)));
+typedef elem_t half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef float float2v __attribute__((ext_vector_type(2)));
 typedef short short4v __attribute__((__vector_size__(4 * sizeof(short))));
@@ -108,11 +109,11 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 
     half8 qf;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) qf[j] = (_Float16)0.f;
+    for (int j = 0; j < 8; ++j) qf[j] = (elem_t)0.f;
     if (q_ok) qf = *reinterpret_cast<const half8*>(p.q + ((size_t)b * p.Lq + q) * p.ldq + h * 32 + g * 8);
     half8 ones;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) ones[j] = (_Float16)1.f;
+    for (int j = 0; j < 8; ++j) ones[j] = (elem_t)1.f;
 
     // LDS-DMA staging: wave w moves key rows 16 w .. 16 w + 15 (+ 64 i) of the tile.  Rows past Lk of the LAST frame fall outside
     // the descriptor (zeros); of earlier frames they are the next frame's rows: finite, and masked like every key >= Lk.
@@ -177,7 +178,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 #pragma unroll
         for (int kt = 0; kt < NKT; ++kt) {
             const half8 kf = *reinterpret_cast<const half8*>(Kl + kt * 1024 + lane * 16);
-            s[kt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(kf, qf, float4v{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+            s[kt] = OPD_MFMA_16x16x32(kf, qf, float4v{0.f, 0.f, 0.f, 0.f});
         }
         float mx = -INFINITY;
         if (MASKED) {
@@ -239,8 +240,8 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
             half8 pf;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                pf[r] = (_Float16)s[2 * kb][r];
-                pf[4 + r] = (_Float16)s[2 * kb + 1][r];
+                pf[r] = (elem_t)s[2 * kb][r];
+                pf[4 + r] = (elem_t)s[2 * kb + 1][r];
             }
 #pragma unroll
             for (int dt = 0; dt < 2; ++dt) {
@@ -251,9 +252,9 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
                 half8 vf;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { vf[r] = lo[r]; vf[4 + r] = hi[r]; }
-                oacc[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vf, pf, oacc[dt], 0, 0, 0);
+                oacc[dt] = OPD_MFMA_16x16x32(vf, pf, oacc[dt]);
             }
-            lacc = __builtin_amdgcn_mfma_f32_16x16x32_f16(ones, pf, lacc, 0, 0, 0);
+            lacc = OPD_MFMA_16x16x32(ones, pf, lacc);
         }
         ATTN_STAMP(2);
         if (TRACE && !LAST) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -301,7 +302,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
         for (int dt = 0; dt < 2; ++dt) {
             half4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)(oacc[dt][r] * inv);
+            for (int r = 0; r < 4; ++r) o[r] = (elem_t)(oacc[dt][r] * inv);
             *reinterpret_cast<half4*>(orow + dt * 16) = o;
         }
     }
@@ -309,7 +310,7 @@ __global__ __launch_bounds__(256) void attention_kernel(AttnParams p) {
 
 }  // namespace
 
-hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_attention)(const AttnParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.heads <= 0 || p.Lq <= 0 || p.Lk <= 0) return hipErrorInvalidValue;
     if (p.splits > 0) {   // key-split partials (fused decoder cross-attention): 128-key tiles
         if (!p.part_o || !p.part_ml || p.trace || (p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.key_valid && p.key_row < 1)) return hipErrorInvalidValue;

@@ -36,8 +36,9 @@
 // 189 us).  PMC: no HBM credit stalls, the vector-memory address FIFO is full 45 % of the busy cycles.
 #include <hip/hip_runtime.h>
 #include "opd_kernels.h"
+#include "opd_elem.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef elem_t half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
@@ -65,16 +66,16 @@ __device__ __forceinline__ int xcd_logical_block_rev(int bid, int nblocks) {
 }
 
 __device__ __forceinline__ unsigned pack2h(float a, float b) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef elem_t half2v __attribute__((ext_vector_type(2)));
     half2v h;
-    h[0] = (_Float16)a;
-    h[1] = (_Float16)b;
+    h[0] = (elem_t)a;
+    h[1] = (elem_t)b;
     unsigned u;
     __builtin_memcpy(&u, &h, 4);
     return u;
 }
 __device__ __forceinline__ void unpack2h(unsigned u, float& a, float& b) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef elem_t half2v __attribute__((ext_vector_type(2)));
     half2v h;
     __builtin_memcpy(&h, &u, 4);
     a = (float)h[0];
@@ -305,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #pragma unroll
             for (int nt = 0; nt < NT1; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc1[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc1[nt][mt]);
         }
     };
 #pragma unroll 1
@@ -390,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], a1[mt][kk], acc2[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = OPD_MFMA_16x16x32(wf[nt], a1[mt][kk], acc2[nt][mt]);
         }
         if constexpr (SC) {   // + Wsc[chunk] . xs: the block's shortcut convolution
             const unsigned char* Wscs = W2s + W2C_BYTES + C3 * ROW_BYTES;
@@ -402,7 +403,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xs[mt][kk], acc2[nt][mt], 0, 0, 0);
+                    for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xs[mt][kk], acc2[nt][mt]);
             }
         }
         // residual (paired layout -> accumulator layout), ReLU, fp16; store y; keep the fp16 values as the next B operand
@@ -445,7 +446,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                 for (int nt = 0; nt < NT3; ++nt) {
                     const half8 wf = *reinterpret_cast<const half8*>(W3s + swz(nt * 16 + li, kk * 4 + g));
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) accz[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, yf[mt], accz[nt][mt], 0, 0, 0);
+                    for (int mt = 0; mt < 2; ++mt) accz[nt][mt] = OPD_MFMA_16x16x32(wf, yf[mt], accz[nt][mt]);
                 }
             }
         }
@@ -500,11 +501,13 @@ hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
 
 }  // namespace
 
+#ifndef OPD_ELEM_BF16   // (shape predicates and the host-side weight permutation do not depend on the element type: defined once)
 bool opd_btail_supported(int C1, int C3) {
     return (C1 == 64 && (C3 == 0 || C3 == 64 || C3 == 128)) || (C1 == 128 && (C3 == 0 || C3 == 128)) || opd_btail256_supported(C1, C3);
 }
+#endif
 
-hipError_t opd_launch_btail(const BtailParams& p_in, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_btail)(const BtailParams& p_in, hipStream_t stream) {
     if (!opd_btail_supported(p_in.C1, p_in.C3) || p_in.OH <= 0 || p_in.OW <= 0) return hipErrorInvalidValue;
     BtailParams p = p_in;
     p.fd_ohw = opd_make_fastdiv((unsigned)p.OH * (unsigned)p.OW);
@@ -512,7 +515,7 @@ hipError_t opd_launch_btail(const BtailParams& p_in, hipStream_t stream) {
     // 31-bit byte offsets in the buffer descriptors
     if ((size_t)p.B * p.H * p.W * p.C1 * 2 + (size_t)(p.W + 1) * p.C1 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
     if ((size_t)p.M * p.C1 * 8 >= 0x7fffff00ull) return hipErrorInvalidValue;
-    if (p.C1 == 256) return opd_launch_btail256(p, stream);   // stage 3: kernels_btail3.hip
+    if (p.C1 == 256) return OPD_SYM(opd_launch_btail256)(p, stream);   // stage 3: kernels_btail3.hip
     if (p.xs) {   // fused shortcut convolution: stride 1, 64 -> 256 channels next to a 64-channel 3x3 (first block of stage 1)
         if (p.C1 != 64 || p.C3 != 64 || p.stride != 1 || !p.wsc || p.res || (size_t)p.M * 64 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
         return launch_btail_t<64, 64, false, true>(p, stream);
@@ -533,6 +536,7 @@ hipError_t opd_launch_btail(const BtailParams& p_in, hipStream_t stream) {
     return launch_btail_t<128, 128, false>(p, stream);
 }
 
+#ifndef OPD_ELEM_BF16
 // K-permutation of a [rows][K] fp16 weight matrix (K % 32 == 0) that makes two fp16-rounded 16x16 accumulator tiles a
 // valid B operand: within each 32-block, slot 8g+e <- channel 4g+e, slot 8g+4+e <- channel 16+4g+e.
 void opd_permute_k32(const f16_t* w, f16_t* out, int rows, int K) {
@@ -544,3 +548,4 @@ void opd_permute_k32(const f16_t* w, f16_t* out, int rows, int K) {
                     out[(size_t)n * K + b + 8 * g + 4 + e] = w[(size_t)n * K + b + 16 + 4 * g + e];
                 }
 }
+#endif

@@ -18,8 +18,9 @@
 // the re-read of y disappear, and so do two launches' fill / drain phases.
 #include <hip/hip_runtime.h>
 #include "opd_kernels.h"
+#include "opd_elem.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef elem_t half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 typedef unsigned int uint2v __attribute__((ext_vector_type(2)));
 typedef unsigned int uint4v __attribute__((ext_vector_type(4)));
@@ -43,16 +44,16 @@ __device__ __forceinline__ int xcd_logical_block_rev(int bid, int nblocks) {
 __device__ __forceinline__ int fdiv(const int m, const FastDiv& f) { return f.one ? m : (int)(__umulhi((unsigned)m, f.mul) >> f.shift); }
 
 __device__ __forceinline__ unsigned pack2h(float a, float b) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef elem_t half2v __attribute__((ext_vector_type(2)));
     half2v h;
-    h[0] = (_Float16)a;
-    h[1] = (_Float16)b;
+    h[0] = (elem_t)a;
+    h[1] = (elem_t)b;
     unsigned u;
     __builtin_memcpy(&u, &h, 4);
     return u;
 }
 __device__ __forceinline__ void unpack2h(unsigned u, float& a, float& b) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef elem_t half2v __attribute__((ext_vector_type(2)));
     half2v h;
     __builtin_memcpy(&h, &u, 4);
     a = (float)h[0];
@@ -243,7 +244,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
 #pragma unroll
             for (int nt = 0; nt < 8; ++nt) {
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[kk][nt], xf[kk][mt], acc1[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = OPD_MFMA_16x16x32(wf[kk][nt], xf[kk][mt], acc1[nt][mt]);
                 if ((nt & 3) == 3) {
                     __builtin_amdgcn_sched_barrier(0);
                     between(kk * 2 + (nt >> 2));
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ring[t % 3][nt], a1[mt][t], acc2[nt][mt], 0, 0, 0);
+                    for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = OPD_MFMA_16x16x32(ring[t % 3][nt], a1[mt][t], acc2[nt][mt]);
                 __builtin_amdgcn_sched_barrier(0);
             }
             __builtin_amdgcn_s_setprio(0);
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
             for (int idx = 0; idx < 16; ++idx) {
                 const half8 wf = ring[idx & 3];
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) accz[idx & 7][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf, yf[idx >> 3][mt], accz[idx & 7][mt], 0, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) accz[idx & 7][mt] = OPD_MFMA_16x16x32(wf, yf[idx >> 3][mt], accz[idx & 7][mt]);
                 if (idx + 4 < 16) ring[idx & 3] = w3frag(idx + 4);
                 __builtin_amdgcn_sched_barrier(0);
                 if (p.dbg & 16) {}   // timing ablation: no weight requests in the chunk loop (tools only)
@@ -521,10 +522,12 @@ hipError_t launch_btail256_t(const BtailParams& p, hipStream_t stream) {
 
 }  // namespace
 
+#ifndef OPD_ELEM_BF16
 bool opd_btail256_supported(int C1, int C3) { return C1 == 256 && (C3 == 0 || C3 == 256); }
+#endif
 
 // called by opd_launch_btail (kernels_btail.hip) for C1 == 256, with the FastDiv fields filled and the offset ranges checked
-hipError_t opd_launch_btail256(const BtailParams& p, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_btail256)(const BtailParams& p, hipStream_t stream) {
     if (!opd_btail256_supported(p.C1, p.C3) || p.xs) return hipErrorInvalidValue;
     if (p.trace) return p.C3 ? launch_btail256_t<256, true>(p, stream) : hipErrorInvalidValue;
     return p.C3 ? launch_btail256_t<256>(p, stream) : launch_btail256_t<0>(p, stream);

@@ -473,10 +473,18 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
     if (q_ok) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            half4 o;
+            if (p.qc_bf16) {   // (launch-uniform: the handle's operand type is bf16, and so are the K / V this query meets)
+                typedef __bf16 bf4 __attribute__((ext_vector_type(4)));
+                bf4 o;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc3_get(a, j, r) + bs[j][r]);
-            *reinterpret_cast<half4*>(p.qc16 + row * 256 + (2 * wave + j) * 16 + 4 * g) = o;
+                for (int r = 0; r < 4; ++r) o[r] = (__bf16)(acc3_get(a, j, r) + bs[j][r]);
+                *reinterpret_cast<bf4*>(p.qc16 + row * 256 + (2 * wave + j) * 16 + 4 * g) = o;
+            } else {
+                half4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = (_Float16)(acc3_get(a, j, r) + bs[j][r]);
+                *reinterpret_cast<half4*>(p.qc16 + row * 256 + (2 * wave + j) * 16 + 4 * g) = o;
+            }
         }
     }
 }

@@ -18,8 +18,9 @@
 // accumulator holds D[row = n][col = m]: lane l owns 4 consecutive n for one m (col = l & 15, row = 4*(l >> 4) + reg).
 #include <hip/hip_runtime.h>
 #include "opd_kernels.h"
+#include "opd_elem.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef elem_t half8 __attribute__((ext_vector_type(8)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -66,16 +67,16 @@ __device__ __forceinline__ void dma16(const void* gsrc, unsigned char* lds_wave_
 }
 
 __device__ __forceinline__ unsigned pack2h(float a, float b) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef elem_t half2v __attribute__((ext_vector_type(2)));
     half2v h;
-    h[0] = (_Float16)a;
-    h[1] = (_Float16)b;
+    h[0] = (elem_t)a;
+    h[1] = (elem_t)b;
     unsigned u;
     __builtin_memcpy(&u, &h, 4);
     return u;
 }
 __device__ __forceinline__ void unpack2h(unsigned u, float& a, float& b) {
-    typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+    typedef elem_t half2v __attribute__((ext_vector_type(2)));
     half2v h;
     __builtin_memcpy(&h, &u, 4);
     a = (float)h[0];
@@ -521,7 +522,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                    acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
         }
     };
     for (int ks = 0; ks + 1 < nk; ++ks) {
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
         }
         // ---- ReLU -> fp16 patch [160 pixels][64 ch] (pixels outside the image: -65504 so that the max ignores them) -------
 #pragma unroll
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
             if (py < p.PH && px < p.PW) {
                 half8 m;
 #pragma unroll
-                for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.f);
+                for (int j = 0; j < 8; ++j) m[j] = (elem_t)(-65504.f);
 #pragma unroll
                 for (int dy = 0; dy < 3; ++dy)
 #pragma unroll
@@ -916,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 
 }  // namespace
 
-hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_conv_gemm)(const ConvGemmParams& p_in, hipStream_t stream) {
     if (p_in.OH <= 0 || p_in.OW <= 0 || p_in.bias_period < 0) return hipErrorInvalidValue;
     ConvGemmParams p = p_in;   // (+ the launch constants' reciprocals; M < 2^31 is the FastDiv range)
     p.fd_ohw = opd_make_fastdiv((unsigned)p.OH * (unsigned)p.OW);
@@ -970,7 +971,7 @@ hipError_t opd_launch_conv_gemm(const ConvGemmParams& p_in, hipStream_t stream) 
 
 // Pre-processing + stem + max-pool in one launch: frames [B][H][W][3] uint8 BGR (valid_hw nullable [B][2]), geometry as below with
 // Hp = 2 OH + 6, Wp = 2 OW + 6 the size the materialised padded image would have.
-hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H,
+hipError_t OPD_SYM(opd_launch_stem_pool_u8)(const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H,
                                    int W, int OH, int OW, int PH, int PW, hipStream_t stream) {
     if (B <= 0 || H <= 0 || W <= 0 || OH != (H - 1) / 2 + 1 || OW != (W - 1) / 2 + 1 || PH != (OH - 1) / 2 + 1 || PW != (OW - 1) / 2 + 1 ||
         (size_t)B * H * W * 3 >= 0x7fffff00ull)
@@ -987,7 +988,7 @@ hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_h
     return hipGetLastError();
 }
 
-hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
+hipError_t OPD_SYM(opd_launch_stem_pool)(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
                                 int OW, int PH, int PW, hipStream_t stream) {
     if (Hp < 2 * OH + 6 || Wp < 2 * OW + 6 || (Wp & 1) || PH != (OH - 1) / 2 + 1 || PW != (OW - 1) / 2 + 1 ||
         (size_t)B * Hp * Wp * 8 >= 0x7fffff00ull)

@@ -10,9 +10,10 @@
 #include <math.h>
 #include <vector>
 #include "opd_kernels.h"
+#include "opd_elem.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef elem_t half8 __attribute__((ext_vector_type(8)));
+typedef elem_t half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -48,17 +49,17 @@ __global__ void preprocess_u8_kernel(const uint8_t* __restrict__ in, f16_t* __re
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int xp = xg * 4 + j, x = xp - 3;
-        o[j][0] = o[j][1] = o[j][2] = o[j][3] = (_Float16)0.f;
+        o[j][0] = o[j][1] = o[j][2] = o[j][3] = (elem_t)0.f;
         if (row_ok && (unsigned)x < (unsigned)vw) {
             const uint8_t* s = srow + (size_t)x * 3;
             const float bl = (float)s[0], g = (float)s[1], r = (float)s[2];
-            o[j][0] = (_Float16)((r * k - c_mean[0]) / c_std[0]);
-            o[j][1] = (_Float16)((g * k - c_mean[1]) / c_std[1]);
-            o[j][2] = (_Float16)((bl * k - c_mean[2]) / c_std[2]);
+            o[j][0] = (elem_t)((r * k - c_mean[0]) / c_std[0]);
+            o[j][1] = (elem_t)((g * k - c_mean[1]) / c_std[1]);
+            o[j][2] = (elem_t)((bl * k - c_mean[2]) / c_std[2]);
         }
     }
     if (xg * 4 + 3 < Wp && (Wp & 1) == 0) {   // rows are 8 Wp bytes long: the 32-byte groups are 16-byte aligned when Wp is even ...
-        typedef _Float16 half8v __attribute__((ext_vector_type(8)));
+        typedef elem_t half8v __attribute__((ext_vector_type(8)));
         half8v a, c;
 #pragma unroll
         for (int q = 0; q < 4; ++q) { a[q] = o[0][q]; a[4 + q] = o[1][q]; c[q] = o[2][q]; c[4 + q] = o[3][q]; }
@@ -81,14 +82,14 @@ __global__ void preprocess_f32_kernel(const float* __restrict__ pv, f16_t* __res
     const int b = (int)(t / Hp);
     const int y = yp - 3, x = xp - 3;
     half4 o;
-    o[0] = o[1] = o[2] = o[3] = (_Float16)0.f;
+    o[0] = o[1] = o[2] = o[3] = (elem_t)0.f;
     const int vh = valid_hw ? valid_hw[2 * b] : H, vw = valid_hw ? valid_hw[2 * b + 1] : W;
     if ((unsigned)y < (unsigned)vh && (unsigned)x < (unsigned)vw) {
         const size_t HW = (size_t)H * W;
         const float* s = pv + (size_t)b * 3 * HW + (size_t)y * W + x;
-        o[0] = (_Float16)s[0];
-        o[1] = (_Float16)s[HW];
-        o[2] = (_Float16)s[2 * HW];
+        o[0] = (elem_t)s[0];
+        o[1] = (elem_t)s[HW];
+        o[2] = (elem_t)s[2 * HW];
     }
     *reinterpret_cast<half4*>(out + i * 4) = o;
 }
@@ -152,7 +153,7 @@ __global__ void maxpool_kernel(const f16_t* __restrict__ x, f16_t* __restrict__ 
     const int b = (int)(r / OH);
     half8 m;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) m[j] = (_Float16)(-65504.f);
+    for (int j = 0; j < 8; ++j) m[j] = (elem_t)(-65504.f);
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh) {
         const int ih = oh * 2 - 1 + kh;
@@ -197,7 +198,7 @@ __global__ __launch_bounds__(256) void layernorm256_kernel(const float* __restri
     if (y) *reinterpret_cast<float4v*>(y + (size_t)row * 256 + lane * 4) = o;
     if (y16) {
         half4 h;
-        h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+        h[0] = (elem_t)o[0]; h[1] = (elem_t)o[1]; h[2] = (elem_t)o[2]; h[3] = (elem_t)o[3];
         *reinterpret_cast<half4*>(y16 + (size_t)row * 256 + lane * 4) = h;
     }
 }
@@ -211,7 +212,7 @@ __global__ __launch_bounds__(256) void broadcast_rows256_kernel(const float* __r
     const float4v v = *reinterpret_cast<const float4v*>(c + lane * 4);
     *reinterpret_cast<float4v*>(y + (size_t)row * 256 + lane * 4) = v;
     half4 h;
-    h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+    h[0] = (elem_t)v[0]; h[1] = (elem_t)v[1]; h[2] = (elem_t)v[2]; h[3] = (elem_t)v[3];
     *reinterpret_cast<half4*>(y16 + (size_t)row * 256 + lane * 4) = h;
 }
 
@@ -244,7 +245,7 @@ __global__ __launch_bounds__(256) void reduce_ln256_kernel(const float* __restri
     if (y) *reinterpret_cast<float4v*>(y + o) = out;
     if (y16) {
         half4 h;
-        h[0] = (_Float16)out[0]; h[1] = (_Float16)out[1]; h[2] = (_Float16)out[2]; h[3] = (_Float16)out[3];
+        h[0] = (elem_t)out[0]; h[1] = (elem_t)out[1]; h[2] = (elem_t)out[2]; h[3] = (elem_t)out[3];
         *reinterpret_cast<half4*>(y16 + o) = h;
     }
     if (yp16) {   // second fp16 shadow: the row PLUS its position embedding (what the q / k projections read); pos [period][256] per frame
@@ -252,14 +253,14 @@ __global__ __launch_bounds__(256) void reduce_ln256_kernel(const float* __restri
         const float* prow = (pos_ptrs ? pos_ptrs[fr] : pos) + (size_t)pr * 256 + lane * 4;
         const float4v pe = *reinterpret_cast<const float4v*>(prow);
         half4 h;
-        h[0] = (_Float16)(out[0] + pe[0]); h[1] = (_Float16)(out[1] + pe[1]); h[2] = (_Float16)(out[2] + pe[2]); h[3] = (_Float16)(out[3] + pe[3]);
+        h[0] = (elem_t)(out[0] + pe[0]); h[1] = (elem_t)(out[1] + pe[1]); h[2] = (elem_t)(out[2] + pe[2]); h[3] = (elem_t)(out[3] + pe[3]);
         *reinterpret_cast<half4*>(yp16 + o) = h;
     }
 }
 
 __global__ void cast_f16_kernel(const float* __restrict__ x, f16_t* __restrict__ y, size_t n) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) reinterpret_cast<_Float16*>(y)[i] = (_Float16)x[i];
+    if (i < n) reinterpret_cast<elem_t*>(y)[i] = (elem_t)x[i];
 }
 
 // Plan-build-time fp32 GEMM (pos-embedding folds): one thread per output, K-loop in order; not on the hot path.
@@ -512,7 +513,7 @@ __global__ __launch_bounds__(256) void attn_map_rowstat_kernel(const f16_t* __re
     const int lane = threadIdx.x & 63, h = row % heads, qi = sel[row / heads];
     float qv[32];
 #pragma unroll
-    for (int d = 0; d < 32; ++d) qv[d] = (float)reinterpret_cast<const _Float16*>(q)[(size_t)qi * ldq + h * 32 + d];
+    for (int d = 0; d < 32; ++d) qv[d] = (float)reinterpret_cast<const elem_t*>(q)[(size_t)qi * ldq + h * 32 + d];
     const int vr = key_valid2 ? key_valid2[0] : 0x7fffffff, vc = key_valid2 ? key_valid2[1] : 0x7fffffff;
     float mx = -INFINITY;
     for (int key = lane; key < Lk; key += 64) {
@@ -520,7 +521,7 @@ __global__ __launch_bounds__(256) void attn_map_rowstat_kernel(const f16_t* __re
         if (kr >= vr || kc >= vc) continue;
         float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) s = fmaf(qv[d], (float)reinterpret_cast<const _Float16*>(k)[(size_t)key * ldk + h * 32 + d], s);
+        for (int d = 0; d < 32; ++d) s = fmaf(qv[d], (float)reinterpret_cast<const elem_t*>(k)[(size_t)key * ldk + h * 32 + d], s);
         mx = fmaxf(mx, s * scale);
     }
 #pragma unroll
@@ -531,7 +532,7 @@ __global__ __launch_bounds__(256) void attn_map_rowstat_kernel(const f16_t* __re
         if (kr >= vr || kc >= vc) continue;
         float s = 0.f;
 #pragma unroll
-        for (int d = 0; d < 32; ++d) s = fmaf(qv[d], (float)reinterpret_cast<const _Float16*>(k)[(size_t)key * ldk + h * 32 + d], s);
+        for (int d = 0; d < 32; ++d) s = fmaf(qv[d], (float)reinterpret_cast<const elem_t*>(k)[(size_t)key * ldk + h * 32 + d], s);
         sum += expf(s * scale - mx);
     }
     sum = wave_sum(sum);
@@ -552,8 +553,8 @@ __global__ __launch_bounds__(256) void attn_map_mean_kernel(const f16_t* __restr
             float s = 0.f;
 #pragma unroll
             for (int d = 0; d < 32; ++d)
-                s = fmaf((float)reinterpret_cast<const _Float16*>(q)[(size_t)qi * ldq + h * 32 + d],
-                         (float)reinterpret_cast<const _Float16*>(k)[(size_t)key * ldk + h * 32 + d], s);
+                s = fmaf((float)reinterpret_cast<const elem_t*>(q)[(size_t)qi * ldq + h * 32 + d],
+                         (float)reinterpret_cast<const elem_t*>(k)[(size_t)key * ldk + h * 32 + d], s);
             const float2 st = stat[row];
             acc += expf(s * scale - st.x) / st.y;
         }
@@ -565,7 +566,7 @@ inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + 
 
 }  // namespace
 
-hipError_t opd_launch_attention_map(const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,
+hipError_t OPD_SYM(opd_launch_attention_map)(const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,
                                     const int32_t* key_valid2, int key_row, void* stat, float* out, hipStream_t stream) {
     if (nsel <= 0 || heads <= 0 || Lk <= 0 || key_row <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(attn_map_rowstat_kernel, dim3((nsel * heads + 3) / 4), dim3(256), 0, stream, q, ldq, k, ldk, sel, nsel, heads, Lk, scale,
@@ -575,7 +576,7 @@ hipError_t opd_launch_attention_map(const f16_t* q, int ldq, const f16_t* k, int
     return hipGetLastError();
 }
 
-hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
+hipError_t OPD_SYM(opd_launch_preprocess_u8)(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
                                     hipStream_t stream) {
     if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
     const size_t ngroups = (size_t)B * Hp * ((Wp + 3) / 4);
@@ -583,7 +584,7 @@ hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, in
     return hipGetLastError();
 }
 
-hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
+hipError_t OPD_SYM(opd_launch_preprocess_f32)(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
                                      hipStream_t stream) {
     if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
     const size_t npix = (size_t)B * Hp * Wp;
@@ -591,6 +592,7 @@ hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, 
     return hipGetLastError();
 }
 
+#ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_resize_u8(const uint8_t* in, uint8_t* out, int B, int h, int w, int oh, int ow, const int32_t* bounds_h,
                                 const int32_t* coeff_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeff_v, int ksize_v,
                                 hipStream_t stream) {
@@ -600,8 +602,9 @@ hipError_t opd_launch_resize_u8(const uint8_t* in, uint8_t* out, int B, int h, i
                        coeff_h, ksize_h, bounds_v, coeff_v, ksize_v);
     return hipGetLastError();
 }
+#endif
 
-hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW,
+hipError_t OPD_SYM(opd_launch_maxpool)(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW,
                               hipStream_t stream) {
     if (C % 8 != 0) return hipErrorInvalidValue;
     const size_t total = (size_t)B * OH * OW * (C / 8);
@@ -609,26 +612,26 @@ hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, i
     return hipGetLastError();
 }
 
-hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, f16_t* y16, int rows,
+hipError_t OPD_SYM(opd_launch_layernorm)(const float* x, const float* gamma, const float* beta, float* y, f16_t* y16, int rows,
                                 hipStream_t stream) {
     if (rows <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, y16, rows);
     return hipGetLastError();
 }
 
-hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_broadcast_rows)(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream) {
     if (rows <= 0 || !c || !y || !y16) return hipErrorInvalidValue;
     hipLaunchKernelGGL(broadcast_rows256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, c, y, y16, rows);
     return hipGetLastError();
 }
 
-hipError_t opd_launch_reduce_ln(const float* partials, int nsplit, size_t slab_stride, const float* residual,
+hipError_t OPD_SYM(opd_launch_reduce_ln)(const float* partials, int nsplit, size_t slab_stride, const float* residual,
                                 const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream) {
-    return opd_launch_reduce_ln_pos(partials, nsplit, slab_stride, residual, gamma, beta, y, y16, rows, nullptr, nullptr, 0, nullptr, stream);
+    return OPD_SYM(opd_launch_reduce_ln_pos)(partials, nsplit, slab_stride, residual, gamma, beta, y, y16, rows, nullptr, nullptr, 0, nullptr, stream);
 }
 
 // ... plus a second fp16 output yp16 = fp16(y + pos[frame][row % period]) (pos: one table, or pos_ptrs: one table per frame)
-hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma,
+hipError_t OPD_SYM(opd_launch_reduce_ln_pos)(const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma,
                                     const float* beta, float* y, f16_t* y16, int rows, const float* pos, const float* const* pos_ptrs,
                                     int period, f16_t* yp16, hipStream_t stream) {
     if (rows <= 0 || nsplit < 1 || (yp16 && (period <= 0 || (!pos && !pos_ptrs)))) return hipErrorInvalidValue;
@@ -652,40 +655,49 @@ static __global__ void checksum_kernel(const uint32_t* __restrict__ buf, size_t 
     if (threadIdx.x == 0) slots[blockIdx.x] = part[0];
 }
 
+#ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_checksum(const void* buf, size_t bytes, unsigned long long* slots, hipStream_t stream) {
     hipLaunchKernelGGL(checksum_kernel, dim3(OPD_TAP_BLOCKS), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(buf), bytes / 4, slots);
     return hipGetLastError();
 }
+#endif
 
-hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_cast_f16)(const float* x, f16_t* y, size_t n, hipStream_t stream) {
     hipLaunchKernelGGL(cast_f16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, y, n);
     return hipGetLastError();
 }
 
+#ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K, int ldc,
                                hipStream_t stream) {
     hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, M), dim3(64), 0, stream, A, Wt, bias, C, M, N, K, ldc);
     return hipGetLastError();
 }
+#endif
 
+#ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
     if (p.ncls > 256 || p.rows <= 0) return hipErrorInvalidValue;
     if (p.partials && (p.nsplit < 1 || p.nsplit > 16 || !p.ffn_b2 || !p.ln3_gamma || !p.ln3_beta)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
+#endif
 
+#ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream) {
     if (p.Q > 128 || p.ncls > 128 || p.B <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(postprocess_kernel, dim3(p.B), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
+#endif
 
 // Tracker cost matrix (src/tracking/similarity.py:42-220): one thread per (track i, detection j).
 //   cos = clip(dot_fp32(f1[i], f2[j]), -1, 1)  if both carry features        (appearance term, weight aw)
 //   iou of the xywh boxes, 0 when the intersection is empty or the union is not positive, clipped to [0, 1]   (weight mw)
 //   similarity = clip((aw*cos + mw*iou) / (weights used), 0, 1) in double like the reference's Python floats, stored as fp32;
 //   as_distance: 1 - similarity (computed on the fp32 value, like `1.0 - similarity_matrix`).
+#ifndef OPD_ELEM_BF16
 __global__ void similarity_matrix_kernel(const float* __restrict__ f1, const float* __restrict__ b1, const uint8_t* __restrict__ has1,
                                          int n1, const float* __restrict__ f2, const float* __restrict__ b2,
                                          const uint8_t* __restrict__ has2, int n2, int D, double aw, double mw, int as_distance,
@@ -732,6 +744,8 @@ __global__ void similarity_matrix_kernel(const float* __restrict__ f1, const flo
     out[idx] = as_distance ? 1.0f - simf : simf;
 }
 
+#endif
+#ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const uint8_t* has1, int n1, const float* f2, const float* b2,
                                         const uint8_t* has2, int n2, int D, double aw, double mw, int as_distance, float* out,
                                         hipStream_t stream) {
@@ -740,10 +754,13 @@ hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const 
                        mw, as_distance, out);
     return hipGetLastError();
 }
+#endif
 
+#ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois, float* out, int n, int h, int w,
                                    hipStream_t stream) {
     if (n <= 0) return hipErrorInvalidValue;
     hipLaunchKernelGGL(roi_features_kernel, dim3(n), dim3(256), 0, stream, enc, rois, out, h, w);
     return hipGetLastError();
 }
+#endif

@@ -14,9 +14,10 @@
 // 4 waves (LDS).
 #include <hip/hip_runtime.h>
 #include "opd_kernels.h"
+#include "opd_elem.h"
 
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+typedef elem_t half8 __attribute__((ext_vector_type(8)));
+typedef elem_t half4 __attribute__((ext_vector_type(4)));
 typedef float float4v __attribute__((ext_vector_type(4)));
 
 namespace {
@@ -80,7 +81,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln256_kernel(GemmLnParams p) {
 #pragma unroll
             for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
         }
         __syncthreads();
     }
@@ -135,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln256_kernel(GemmLnParams p) {
                 if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
                 if (p.y16) {
                     half4 h;
-                    h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+                    h[0] = (elem_t)o[0]; h[1] = (elem_t)o[1]; h[2] = (elem_t)o[2]; h[3] = (elem_t)o[3];
                     *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
                 }
             }
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(64 * OS_NW, 1) void gemm_ln256_os_kernel(GemmLnPara
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 3; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
         }
     // ---- + residual, LayerNorm over the 256 columns of each row (as in gemm_ln256_kernel) -----------------------------------
     float sum[3] = {0.f, 0.f, 0.f};
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(64 * OS_NW, 1) void gemm_ln256_os_kernel(GemmLnPara
                 if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
                 if (p.y16) {
                     half4 h;
-                    h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+                    h[0] = (elem_t)o[0]; h[1] = (elem_t)o[1]; h[2] = (elem_t)o[2]; h[3] = (elem_t)o[3];
                     *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
                 }
             }
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
         }
     }
     // ---- + residual, LayerNorm over the 256 columns of each row (as in gemm_ln256_kernel) -----------------------------------
@@ -457,14 +458,14 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
                 if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
                 if (p.y16) {
                     half4 h;
-                    h[0] = (_Float16)o[0]; h[1] = (_Float16)o[1]; h[2] = (_Float16)o[2]; h[3] = (_Float16)o[3];
+                    h[0] = (elem_t)o[0]; h[1] = (elem_t)o[1]; h[2] = (elem_t)o[2]; h[3] = (elem_t)o[3];
                     *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
                 }
                 if (pos) {
                     const float4v pe = *reinterpret_cast<const float4v*>(pos + c);
                     half4 h;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) h[q] = (_Float16)(o[q] + pe[q]);
+                    for (int q = 0; q < 4; ++q) h[q] = (elem_t)(o[q] + pe[q]);
                     *reinterpret_cast<half4*>(p.yp16 + (size_t)m * 256 + c) = h;
                 }
             }
@@ -475,7 +476,7 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
 
 }  // namespace
 
-hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_gemm_ln)(const GemmLnParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || !p.bias || (!p.deep_k && (!p.gamma || !p.beta)) || (p.gamma && !p.beta)) return hipErrorInvalidValue;
     if ((size_t)p.M * p.K * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;  // 31-bit buffer offsets
     if (p.deep_k) {   // row-owner ring (the encoder's FFN-2): no split-K slabs, no reduce launch
@@ -566,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(GemmK256Params p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
         }
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt)
@@ -584,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(GemmK256Params p) {
                 *reinterpret_cast<float4v*>(p.out32 + ((size_t)z * p.M + m) * p.N + n) = v;
             } else {
                 half4 h;
-                h[0] = (_Float16)v[0]; h[1] = (_Float16)v[1]; h[2] = (_Float16)v[2]; h[3] = (_Float16)v[3];
+                h[0] = (elem_t)v[0]; h[1] = (elem_t)v[1]; h[2] = (elem_t)v[2]; h[3] = (elem_t)v[3];
                 *reinterpret_cast<half4*>(p.out16 + (size_t)m * p.N + n) = h;
             }
         }
@@ -593,7 +594,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(GemmK256Params p) {
 
 }  // namespace
 
-hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream) {
+hipError_t OPD_SYM(opd_launch_gemm_k256)(const GemmK256Params& p, hipStream_t stream) {
     if (p.M <= 0 || p.N <= 0 || p.N % 64 != 0 || p.slices < 1 || !p.bias || (!p.out16 && !p.out32)) return hipErrorInvalidValue;
     if (p.slices > 1 && (!p.out32 || p.relu)) return hipErrorInvalidValue;   // partial sums: fp32 slabs, no activation
     if (p.ldx < 256 * p.slices || p.ldw < 256 * p.slices) return hipErrorInvalidValue;

@@ -21,7 +21,8 @@ int fail(int code, const std::string& msg) {
 }
 
 // (opd_host.h) error-diffusion rounding of a weight matrix to fp16 values; the carry is kept in double so that it is exact
-void round_f16_diffused(float* w, size_t rows, int taps, int cin) {
+void round_f16_diffused(float* w, size_t rows, int taps, int cin, bool bf16) {
+    auto rnd = [bf16](float x) { return bf16 ? bf16_to_f32(f32_to_bf16(x)) : f16_to_f32(f32_to_f16(x)); };
     const size_t K = (size_t)taps * cin;
     for (size_t r = 0; r < rows; ++r) {
         float* row = w + r * K;
@@ -30,9 +31,9 @@ void round_f16_diffused(float* w, size_t rows, int taps, int cin) {
             for (int t = 0; t < taps; ++t) {
                 float& v = row[(size_t)t * cin + c];
                 const double target = (double)v + carry;
-                const float q = f16_to_f32(f32_to_f16((float)target));
+                const float q = rnd((float)target);
                 // (a carry can only push a value over the fp16 range if the value itself was at its edge: keep plain rounding then)
-                if (!(fabsf(q) <= 65504.0f)) { v = f16_to_f32(f32_to_f16(v)); carry = 0.0; continue; }
+                if (!(fabsf(q) <= (bf16 ? 3.3e38f : 65504.0f))) { v = rnd(v); carry = 0.0; continue; }
                 carry = target - (double)q;
                 v = q;
             }

@@ -25,7 +25,7 @@ void sine_pos_embed(int h, int w, int vh, int vw, int D, std::vector<float>* pos
 // under round-to-nearest, at most one half-ulp under diffusion (measured on RAW checkpoint values, tools/wround_probe.py: box drift from
 // the fp16 image of the backbone kernels 7.3e-4 -> 4.6e-4, encoder map 2.5e-2 -> 1.0e-2).  Values that are fp16-exact stay untouched
 // (device-exact test weights, golden vectors).  Deterministic; `taps` * `cin` entries per row.
-void round_f16_diffused(float* w, size_t rows, int taps, int cin);
+void round_f16_diffused(float* w, size_t rows, int taps, int cin, bool bf16 = false);   // bf16: onto bfloat16 values instead
 
 }  // namespace opd
 

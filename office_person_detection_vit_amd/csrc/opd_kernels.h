@@ -5,7 +5,8 @@
 #include <stdint.h>
 #include <vector>
 
-typedef uint16_t f16_t;  // raw IEEE half bits on the host side
+typedef uint16_t f16_t;  // raw 16-bit operand bits on the host side: IEEE half (default) or bfloat16 (OPD_FLAG_BF16)
+enum { OPD_DT_F16 = 0, OPD_DT_BF16 = 1 };   // operand type of a launch: every kernel file with 16-bit operands is compiled for both (opd_elem.h)
 
 // hipFuncSetAttribute(MaxDynamicSharedMemorySize) once per kernel instantiation and device, from whichever thread launches it first
 // (HipDetrDetector(streams = N) drives several handles from worker threads); used by the launchers in kernels_*.hip.
@@ -70,13 +71,14 @@ struct ConvGemmParams {
     unsigned long long* trace;  // tools only: per-workgroup phase stamps [grid][8] (conv_gemm_dma_kernel<..., TRACE>); null in the model
     int force_mt;        // tools only (tools/sweep_tiles.py): 4 / 5 / 6 = tile height 128 / 160 / 192 rows instead of the quantisation-aware choice
     int flat_staging;    // tools / tests: 1 = stage tiles through flat global addresses (the path tensors beyond 2 GiB take) instead of buffer descriptors
+    int dtype;           // OPD_DT_F16 / OPD_DT_BF16: the 16-bit operand type of x / w / res16 / out (opd_elem.h)
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
 // fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16
 hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H,
-                                   int W, int OH, int OW, int PH, int PW, hipStream_t stream);   // pre-processing inside the stem
+                                   int W, int OH, int OW, int PH, int PW, hipStream_t stream, int dtype = 0);   // pre-processing inside the stem
 hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH,
-                                int OW, int PH, int PW, hipStream_t stream);
+                                int OW, int PH, int PW, hipStream_t stream, int dtype = 0);
 // fused bottleneck tail (kernels_btail.hip):  a1 = relu(conv3x3(x1, w1) + b1) ; y = relu(a1*w2 + b2 + res) ; z = relu(y*w3 + b3)
 // x1 [B][H][W][C1] fp16, y/res [M][4*C1], z [M][C3]  (M = B*OH*OW, 3x3 pad 1, stride 1 or 2).  w2p / w3p are the 1x1
 // weights with opd_permute_k32 applied along K.  C3 == 0: no z.  (C1, C3) must satisfy opd_btail_supported.
@@ -98,6 +100,7 @@ struct BtailParams {
     FastDiv fd_ohw, fd_ow;   // filled by opd_launch_btail
     unsigned long long* trace;   // tools only: per-workgroup phase stamps [grid][16] (btail_kernel<..., TRACE>); null in the model
     int rev;           // 1: each XCD walks its tiles in descending order (results identical; see kernels_btail.hip)
+    int dtype;         // OPD_DT_F16 / OPD_DT_BF16
 };
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);
@@ -127,6 +130,7 @@ struct GemmLnParams {
     const float* const* pos_ptrs;
     int pos_period;
     f16_t* yp16;
+    int dtype;           // OPD_DT_F16 / OPD_DT_BF16: x, w, y16, yp16
 };
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream);
 // Small-M linear layer, reduction cut into 256-wide slices: slice z computes x[:, 256z : 256z+256] . w[:, 256z : 256z+256]^T.
@@ -139,6 +143,7 @@ struct GemmK256Params {
     f16_t* out16;       // [M][N] or null
     float* out32;       // [slices][M][N] or null
     int M, N, ldx, ldw, slices, bias_period, relu;
+    int dtype;          // OPD_DT_F16 / OPD_DT_BF16
 };
 hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream);
 
@@ -147,31 +152,31 @@ hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t stream);
 // zero-bordered image [B][Hp][Wp][4] with the frame at offset (3, 3) (Hp >= H + 6, Wp >= W + 6): the stem's padding.
 // valid_hw (device, nullable): [B][2] = (h, w) of each frame inside the H x W canvas (ragged batch); the rest is zero.
 hipError_t opd_launch_preprocess_u8(const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
-                                    hipStream_t stream);
+                                    hipStream_t stream, int dtype = 0);
 // float32 NCHW pixel_values -> the same padded fp16 NHWC4 image.
 hipError_t opd_launch_preprocess_f32(const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw,
-                                     hipStream_t stream);
+                                     hipStream_t stream, int dtype = 0);
 // Pillow-exact bilinear resize of uint8 HxWx3 frames (two 8-bit passes, 22-bit fixed-point taps); tables from opd_resize_coeffs.
 void opd_resize_coeffs(int in_size, int out_size, std::vector<int32_t>* bounds, std::vector<int32_t>* coeffs, int* ksize_out);  // host
 hipError_t opd_launch_resize_u8(const uint8_t* in, uint8_t* out, int B, int h, int w, int oh, int ow, const int32_t* bounds_h,
                                 const int32_t* coeff_h, int ksize_h, const int32_t* bounds_v, const int32_t* coeff_v, int ksize_v,
                                 hipStream_t stream);
 // 3x3 stride-2 pad-1 max-pool, NHWC fp16, C % 8 == 0.
-hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW, hipStream_t stream);
+hipError_t opd_launch_maxpool(const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW, hipStream_t stream, int dtype = 0);
 // y = LayerNorm(x) * gamma + beta over the last dim (D == 256); writes fp32 y and optional fp16 copy.
 hipError_t opd_launch_layernorm(const float* x, const float* gamma, const float* beta, float* y, f16_t* y16,
-                                int rows, hipStream_t stream);
+                                int rows, hipStream_t stream, int dtype = 0);
 // y = LayerNorm( sum_z partial[z] + residual ) (gamma == nullptr: no normalisation, plain sum): the deterministic
 // reduction of split-K GEMM slabs fused with the residual add and the post-LN of the transformer layers.  D == 256.
 hipError_t opd_launch_reduce_ln(const float* partials, int nsplit, size_t slab_stride, const float* residual,
-                                const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream);
+                                const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream, int dtype = 0);
 hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma,
                                     const float* beta, float* y, f16_t* y16, int rows, const float* pos, const float* const* pos_ptrs,
-                                    int period, f16_t* yp16, hipStream_t stream);   // + yp16 = fp16(y + position embedding)
+                                    int period, f16_t* yp16, hipStream_t stream, int dtype = 0);   // + yp16 = fp16(y + position embedding)
 // y[row][0..255] = c[0..255] for every row: fp32 y and its fp16 copy.
-hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream);
+hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream, int dtype = 0);
 // fp32 -> fp16 cast of n elements (n % 8 == 0 not required).
-hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream);
+hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream, int dtype = 0);
 // diagnostic tap: position-weighted 64-bit sums of `bytes / 4` words, OPD_TAP_BLOCKS partials written to slots[0 .. OPD_TAP_BLOCKS)
 #define OPD_TAP_BLOCKS 64
 hipError_t opd_launch_checksum(const void* buf, size_t bytes, unsigned long long* slots, hipStream_t stream);
@@ -212,7 +217,7 @@ hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois /*[n][4
 // q rows [query][ldq] (this frame's), k rows [key][ldk] (this frame's, this layer's), stat: >= nsel * heads * 8 bytes of scratch,
 // key_valid2 (device, nullable): (rows, cols) of the frame's valid key rectangle; out [Lk]
 hipError_t opd_launch_attention_map(const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,
-                                    const int32_t* key_valid2, int key_row, void* stat, float* out, hipStream_t stream);
+                                    const int32_t* key_valid2, int key_row, void* stat, float* out, hipStream_t stream, int dtype = 0);
 
 // tracker cost matrix: similarity (or 1 - similarity) of n1 x n2 (features [n][D] nullable, xywh boxes [n][4], per-row feature flags)
 hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const uint8_t* has1, int n1, const float* f2, const float* b2,
@@ -250,7 +255,8 @@ struct DecSelfParams {  // self-attention of one (frame, 16-query slab) + o-proj
     const float *bo, *ln_g, *ln_b;
     const f16_t* wq;         // cross-attention q_proj [256][256], fragment order
     const float* rbq;        // [Q][256]: query-position fold + bias of that projection
-    f16_t* qc16;             // [M][256] out
+    f16_t* qc16;             // [M][256] out: fp16, or bf16 when qc_bf16 (the cross-attention kernel multiplies it with K / V of the handle's operand type)
+    int qc_bf16;
     int B, Q;
     float scale;
     unsigned long long* trace;   // tools only (tools/trace_dec.py): per-workgroup shader-clock stamps [grid][8] of wave 0; null in the model
@@ -296,5 +302,34 @@ struct AttnParams {
     // part_ml[split][b*Lq + q][h][0..1] = (exponent reference of p in the log2 domain, sum_k p); `o` is unused
     int splits;
     float *part_o, *part_ml;
+    int dtype;                 // OPD_DT_F16 / OPD_DT_BF16: q, k, v, o
 };
 hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream);
+
+// ---- per-element-type entry points (kernels_*.hip compiled for fp16 and for bf16, opd_elem.h); the launchers above are dispatchers on
+// the launch's dtype (opd_dispatch.cpp) -----------------------------------------------------------------------------------------------
+#define OPD_DECL_ELEM(name, ...)          \
+    hipError_t name##_f16(__VA_ARGS__);   \
+    hipError_t name##_bf16(__VA_ARGS__);
+OPD_DECL_ELEM(opd_launch_conv_gemm, const ConvGemmParams& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_stem_pool_u8, const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H, int W, int OH,
+              int OW, int PH, int PW, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_stem_pool, const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH, int OW, int PH, int PW,
+              hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_btail, const BtailParams& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_btail256, const BtailParams& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_gemm_ln, const GemmLnParams& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_gemm_k256, const GemmK256Params& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_attention, const AttnParams& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_attention_map, const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,
+              const int32_t* key_valid2, int key_row, void* stat, float* out, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_preprocess_u8, const uint8_t* frames, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_preprocess_f32, const float* pv, f16_t* out, int B, int H, int W, int Hp, int Wp, const int32_t* valid_hw, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_maxpool, const f16_t* x, f16_t* out, int B, int H, int W, int C, int OH, int OW, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_layernorm, const float* x, const float* gamma, const float* beta, float* y, f16_t* y16, int rows, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_broadcast_rows, const float* c, float* y, f16_t* y16, int rows, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_reduce_ln, const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma, const float* beta, float* y,
+              f16_t* y16, int rows, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_reduce_ln_pos, const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma, const float* beta,
+              float* y, f16_t* y16, int rows, const float* pos, const float* const* pos_ptrs, int period, f16_t* yp16, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_cast_f16, const float* x, f16_t* y, size_t n, hipStream_t stream)

@@ -32,6 +32,9 @@ std::string normalise_key(const std::string& key);
 // IEEE fp32 -> fp16 bits, round-to-nearest-even, overflow -> inf, subnormals handled.
 uint16_t f32_to_f16(float f);
 float f16_to_f32(uint16_t h);
+// IEEE fp32 -> bfloat16 bits, round-to-nearest-even (NaN stays NaN), and back.
+uint16_t f32_to_bf16(float f);
+float bf16_to_f32(uint16_t h);
 
 struct Arch {
     int depths[4] = {0, 0, 0, 0};

@@ -25,8 +25,9 @@ static int upload_f32(opd_detr* m, float** dst, const std::vector<float>& v) {
     return OPD_OK;
 }
 static int upload_f16(opd_detr* m, f16_t** dst, const std::vector<float>& v) {
-    std::vector<f16_t> h(v.size());
-    for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_f16(v[i]);
+    std::vector<f16_t> h(v.size());   // the 16-bit operand type of this handle: fp16, or bf16 under OPD_FLAG_BF16
+    if (m->dtype == OPD_DT_BF16) for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_bf16(v[i]);
+    else for (size_t i = 0; i < v.size(); ++i) h[i] = f32_to_f16(v[i]);
     RCCHK(dalloc(m, dst, h.size(), true));
     HIPCHK(hipMemcpy(*dst, h.data(), h.size() * 2, hipMemcpyHostToDevice));
     return OPD_OK;
@@ -69,7 +70,7 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
                 for (int kh = 0; kh < 7; ++kh)
                     for (int kw = 0; kw < 7; ++kw)
                         cw[(size_t)o * 147 + (kh * 7 + kw) * 3 + ci] = w.data[(((size_t)o * 3 + ci) * 7 + kh) * 7 + kw] * scale[o];
-        if (m->wround) round_f16_diffused(cw.data(), (size_t)Cout, 49, 3);
+        if (m->wround) round_f16_diffused(cw.data(), (size_t)Cout, 49, 3, m->dtype == OPD_DT_BF16);
         wt.assign((size_t)Cout * 256, 0.f);
         for (int o = 0; o < Cout; ++o)
             for (int kh = 0; kh < 7; ++kh)
@@ -85,7 +86,7 @@ static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix
                         wt[(size_t)o * c->K + (size_t)(kh * KW + kw) * Cin + ci] =
                             w.data[(((size_t)o * Cin + ci) * KH + kh) * KW + kw] * scale[o];
         // the fp16 image of the folded kernel: error diffusion along the reduction (opd_host.h) instead of round-to-nearest
-        if (m->wround) round_f16_diffused(wt.data(), (size_t)Cout, KH * KW, Cin);
+        if (m->wround) round_f16_diffused(wt.data(), (size_t)Cout, KH * KW, Cin, m->dtype == OPD_DT_BF16);
     }
     RCCHK(upload_f16(m, &c->w, wt));
     if (KH == 1 && KW == 1 && Cin % 32 == 0 && Cin <= 1024) {  // operands of kernels_btail.hip / kernels_btail3.hip (stages 1-3)
@@ -480,7 +481,7 @@ static int tap(opd_detr* m, const char* name, const void* p, size_t bytes) {
 
 static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, int W, int OH, int OW, void* out, bool relu,
                     const f16_t* res16) {
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = m->dtype;
     p.x = x; p.w = c.w; p.bias = c.bias; p.res16 = res16; p.res32 = nullptr; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = B; p.H = H; p.W = W; p.Cin = c.Cin; p.OH = OH; p.OW = OW; p.N = c.Cout; p.KH = c.KH; p.KW = c.KW;
     p.stride = c.stride; p.pad = c.pad; p.M = B * OH * OW; p.K = c.K; p.relu = relu ? 1 : 0; p.bias_period = 0;
@@ -497,7 +498,7 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
 static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
                     void* out, bool out_f32, bool relu, const float* res32, const float* const* bias_ptrs = nullptr, int bias_pmod = 0,
                     int bias_pcols = 0, const f16_t* x_alt = nullptr, int alt_mod = 0, int alt_cols = 0) {
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = m->dtype;
     p.bias_ptrs = bias_ptrs; p.bias_pmod = bias_pmod; p.bias_pcols = bias_pcols;
     p.x_alt = x_alt; p.alt_mod = alt_mod; p.alt_cols = alt_cols;
     p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
@@ -515,7 +516,7 @@ static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bi
 struct PosShadow { const float* pos; const float* const* pos_ptrs; int period; f16_t* yp16; };   // second fp16 output of a reduce + LN
 static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int N, int K, int splits,
                               const float* res32, const LNp* ln, float* y32, f16_t* y16, int cls, const PosShadow* ps = nullptr) {
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = m->dtype;
     p.x = x; p.w = w; p.bias = bias; p.out = m->d_slab; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
     p.M = M; p.K = K; p.out_f32 = 1; p.split_k = splits;
@@ -525,7 +526,7 @@ static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const
     RCCHK(tap(m, "splitk_slabs", m->d_slab, (size_t)splits * M * N * 4));
     RCCHK(timed_begin(m, CLS_OTHER, 0.0));
     HIPCHK(opd_launch_reduce_ln_pos(m->d_slab, splits, (size_t)M * N, res32, ln ? ln->g : nullptr, ln ? ln->b : nullptr, y32, y16, M,
-                                    ps ? ps->pos : nullptr, ps ? ps->pos_ptrs : nullptr, ps ? ps->period : 0, ps ? ps->yp16 : nullptr, m->stream));
+                                    ps ? ps->pos : nullptr, ps ? ps->pos_ptrs : nullptr, ps ? ps->period : 0, ps ? ps->yp16 : nullptr, m->stream, m->dtype));
     RCCHK(timed_end(m));
     RCCHK(tap(m, "reduce_ln", y32, (size_t)M * N * 4));
     return OPD_OK;
@@ -534,7 +535,7 @@ static int run_gemm_splitk_ln(opd_detr* m, const f16_t* x, const f16_t* w, const
 // y = LayerNorm(x16 . w^T + bias + res32): one launch (kernels_rowln.hip); y32 may alias res32
 static int run_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int K, const float* res32,
                        const LNp& ln, float* y32, f16_t* y16) {
-    GemmLnParams p{};
+    GemmLnParams p{}; p.dtype = m->dtype;
     p.x = x; p.w = w; p.bias = bias; p.res32 = res32; p.gamma = ln.g; p.beta = ln.b; p.y32 = y32; p.y16 = y16; p.M = M; p.K = K;
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * 256.0 * K));
     HIPCHK(opd_launch_gemm_ln(p, m->stream));
@@ -547,7 +548,7 @@ static int run_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float*
 // cut into 256-wide slices whose fp32 slabs are summed by the fused reduce + residual + LayerNorm kernel.
 static int run_small_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int bias_period, int M, int N, int K,
                           f16_t* out16, bool relu) {
-    GemmK256Params p{};
+    GemmK256Params p{}; p.dtype = m->dtype;
     p.x = x; p.w = w; p.bias = bias; p.out16 = out16; p.M = M; p.N = N; p.ldx = K; p.ldw = K; p.slices = 1;
     p.bias_period = bias_period; p.relu = relu ? 1 : 0;
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
@@ -558,13 +559,13 @@ static int run_small_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const flo
 }
 static int run_small_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const float* bias, int M, int K, const float* res32,
                              const LNp& ln, float* y32, f16_t* y16) {
-    GemmK256Params p{};
+    GemmK256Params p{}; p.dtype = m->dtype;
     p.x = x; p.w = w; p.bias = bias; p.out32 = m->d_slab; p.M = M; p.N = 256; p.ldx = K; p.ldw = K; p.slices = K / 256;
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * 256.0 * K));
     HIPCHK(opd_launch_gemm_k256(p, m->stream));
     RCCHK(timed_end(m));
     RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-    HIPCHK(opd_launch_reduce_ln(m->d_slab, p.slices, (size_t)M * 256, res32, ln.g, ln.b, y32, y16, M, m->stream));
+    HIPCHK(opd_launch_reduce_ln(m->d_slab, p.slices, (size_t)M * 256, res32, ln.g, ln.b, y32, y16, M, m->stream, m->dtype));
     RCCHK(timed_end(m));
     RCCHK(tap(m, "small_gemm_ln", y32, (size_t)M * 256 * 4));
     return OPD_OK;
@@ -572,7 +573,7 @@ static int run_small_gemm_ln(opd_detr* m, const f16_t* x, const f16_t* w, const 
 
 static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ldk, const f16_t* v, int ldv, f16_t* o, int ldo,
                     int B, int Lq, int Lk, const int32_t* key_valid = nullptr, int key_row = 0) {
-    AttnParams p{};
+    AttnParams p{}; p.dtype = m->dtype;
     p.key_valid = key_valid; p.key_row = key_row;
     p.q = q; p.k = k; p.v = v; p.o = o; p.B = B; p.heads = m->arch.heads; p.Lq = Lq; p.Lk = Lk;
     p.ldq = ldq; p.ldk = ldk; p.ldv = ldv; p.ldo = ldo;
@@ -649,23 +650,23 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     if (!prep_in_stem) {
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
         if (pixel_format == OPD_PIXELS_U8_BGR_HWC)
-            HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
+            HIPCHK(opd_launch_preprocess_u8(reinterpret_cast<const uint8_t*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream, m->dtype));
         else
-            HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream));
+            HIPCHK(opd_launch_preprocess_f32(reinterpret_cast<const float*>(d_pixels), m->d_x4, B, H, W, Hp, Wp, d_valid, m->stream, m->dtype));
         RCCHK(timed_end(m));
     }
     if (prep_in_stem) {
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
         HIPCHK(opd_launch_stem_pool_u8(reinterpret_cast<const uint8_t*>(d_pixels), d_valid, m->stem.w, m->stem.bias, m->d_pool, B, H, W, d.H1, d.W1,
-                                       d.H2, d.W2, m->stream));
+                                       d.H2, d.W2, m->stream, m->dtype));
         RCCHK(timed_end(m));
         RCCHK(tap(m, "stem_pool_u8", m->d_pool, (size_t)B * d.H2 * d.W2 * 64 * 2));
     } else if (m->fuse_stem_pool) {
         RCCHK(timed_begin(m, CLS_CONV, 2.0 * B * d.H1 * d.W1 * 64.0 * 147.0));
-        HIPCHK(opd_launch_stem_pool(m->d_x4, m->stem.w, m->stem.bias, m->d_pool, B, Hp, Wp, d.H1, d.W1, d.H2, d.W2, m->stream));
+        HIPCHK(opd_launch_stem_pool(m->d_x4, m->stem.w, m->stem.bias, m->d_pool, B, Hp, Wp, d.H1, d.W1, d.H2, d.W2, m->stream, m->dtype));
         RCCHK(timed_end(m));
     } else {
-        ConvGemmParams p{};
+        ConvGemmParams p{}; p.dtype = m->dtype;
         p.x = m->d_x4; p.w = m->stem.w; p.bias = m->stem.bias; p.out = m->d_stem; p.zero16 = m->zero_bias;
         p.B = B; p.H = Hp; p.W = Wp; p.Cin = 256; p.OH = d.H1; p.OW = d.W1; p.N = 64; p.KH = 1; p.KW = 1; p.stride = 2; p.pad = 0;
         p.M = B * d.H1 * d.W1; p.K = 256; p.relu = 1; p.stem = 2;
@@ -673,7 +674,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         HIPCHK(opd_launch_conv_gemm(p, m->stream));
         RCCHK(timed_end(m));
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-        HIPCHK(opd_launch_maxpool(m->d_stem, m->d_pool, B, d.H1, d.W1, 64, d.H2, d.W2, m->stream));
+        HIPCHK(opd_launch_maxpool(m->d_stem, m->d_pool, B, d.H1, d.W1, 64, d.H2, d.W2, m->stream, m->dtype));
         RCCHK(timed_end(m));
     }
     MARK(1);
@@ -744,7 +745,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     int C3 = 0;
                     if (nbk && nbk->c0.wp && nbk->c0.Cin == 4 * C1 && opd_btail_supported(C1, nbk->c0.Cout)) C3 = nbk->c0.Cout;
                     // (a sub-batch pipeline ends with stage 2: its last tail cannot hand z to stage 3 anyway — 256 channels)
-                    BtailParams p{};
+                    BtailParams p{}; p.dtype = m->dtype;
                     p.x1 = x1; p.w1 = b.c1.w; p.b1 = b.c1.bias; p.w2p = b.c2.wp; p.b2 = b.c2.bias; p.res = res; p.y = out;
                     if (sc_in_tail) { p.res = nullptr; p.xs = cur; p.wsc = b.sc.w; p.b2 = b.bias2sc; }
                     f16_t* z = mid(1 - x1_id, (size_t)oh * ow * C3);
@@ -761,7 +762,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
                     RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr));
                     if (sc_in_expand) {
-                        ConvGemmParams p{};
+                        ConvGemmParams p{}; p.dtype = m->dtype;
                         p.x = a1; p.w = b.w2sc; p.bias = b.bias2sc; p.out = out; p.zero16 = m->zero_bias;
                         p.B = nb; p.H = oh; p.W = ow; p.Cin = C1; p.OH = oh; p.OW = ow; p.N = C2; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
                         p.M = nb * oh * ow; p.K1 = C1; p.K = C1 + b.sc.Cin; p.relu = 1;
@@ -857,7 +858,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     // Deep-K row-owner launches (kernels_rowln.hip::gemm_ln256_ring_kernel) for the two K = 2048 -> 256 linears of the encoder side:
     // the input projection (no LayerNorm) and every layer's FFN-2 (+ residual + LayerNorm); both also write the position shadow
     auto run_deep = [&](const f16_t* x, const Lin* lin, const f16_t* w, const float* bias, int K, const float* res32, const LNp* ln, int cls) -> int {
-        GemmLnParams gp{};
+        GemmLnParams gp{}; gp.dtype = m->dtype;
         gp.x = x; gp.w = w; gp.bias = bias; gp.res32 = res32; gp.gamma = ln ? ln->g : nullptr; gp.beta = ln ? ln->b : nullptr;
         gp.y32 = m->d_x32; gp.y16 = m->d_x16; gp.M = M; gp.K = K; gp.deep_k = 1;
         if (ps) { gp.pos = ps->pos; gp.pos_ptrs = ps->pos_ptrs; gp.pos_period = ps->period; gp.yp16 = ps->yp16; }
@@ -885,7 +886,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         } else {
             RCCHK(run_gemm(m, m->d_attn16, L.o.w, L.o.b, 0, M, D, D, m->d_y32, true, false, m->d_x32));
             RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-            HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream));
+            HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream, m->dtype));
             RCCHK(timed_end(m));
         }
         {
@@ -933,7 +934,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 RCCHK(tap(m, "dec_qkv_h", hbuf[cur], (size_t)Md * D * 4));
                 DecSelfParams sp{};
                 sp.q16 = m->d_dq16; sp.k16 = m->d_dk16; sp.vT = m->d_dvT; sp.h = hbuf[cur]; sp.wo = L.so_f; sp.bo = L.so.b;
-                sp.ln_g = L.ln1.g; sp.ln_b = L.ln1.b; sp.wq = L.wqc_f; sp.rbq = L.rb_q; sp.qc16 = qd; sp.B = B; sp.Q = Q;
+                sp.ln_g = L.ln1.g; sp.ln_b = L.ln1.b; sp.wq = L.wqc_f; sp.rbq = L.rb_q; sp.qc16 = qd; sp.qc_bf16 = m->dtype == OPD_DT_BF16; sp.B = B; sp.Q = Q;
                 sp.scale = 1.0f / sqrtf((float)(D / a.heads));
                 RCCHK(timed_begin(m, CLS_GEMM, 4.0 * Md * (double)D * D + 4.0 * B * (double)a.heads * Q * Q * 32));
                 HIPCHK(opd_launch_dec_self(sp, m->stream));
@@ -941,7 +942,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 RCCHK(tap(m, "dec_self_h", hbuf[cur], (size_t)Md * D * 4));
             }
             {   // cross-attention over S key ranges: unnormalised partials
-                AttnParams ap{};
+                AttnParams ap{}; ap.dtype = m->dtype;
                 ap.q = qd; ap.k = m->d_memkv16 + (size_t)i * 2 * D; ap.v = m->d_memkv16 + (size_t)i * 2 * D + D; ap.o = nullptr;
                 ap.B = B; ap.heads = a.heads; ap.Lq = Q; ap.Lk = hw; ap.ldq = D; ap.ldk = NKV; ap.ldv = NKV; ap.ldo = D;
                 ap.scale = 1.0f / sqrtf((float)(D / a.heads)); ap.key_valid = d_keyv; ap.key_row = cw;
@@ -975,7 +976,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     } else {
     if (dec0) {
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-        HIPCHK(opd_launch_broadcast_rows(m->dec0_h, m->d_h32, m->d_h16, Md, m->stream));
+        HIPCHK(opd_launch_broadcast_rows(m->dec0_h, m->d_h32, m->d_h16, Md, m->stream, m->dtype));
         RCCHK(timed_end(m));
         RCCHK(tap(m, "dec0_broadcast", m->d_h32, (size_t)Md * D * 4));
     } else {
@@ -1021,7 +1022,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         hp.hs = m->d_h32; hp.ln_gamma = m->dec_ln.g; hp.ln_beta = m->dec_ln.b;
     } else {
         RCCHK(timed_begin(m, CLS_OTHER, 0.0));
-        HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream));
+        HIPCHK(opd_launch_layernorm(m->d_h32, m->dec_ln.g, m->dec_ln.b, m->d_hs32, nullptr, Md, m->stream, m->dtype));
         RCCHK(timed_end(m));
         hp.hs = m->d_hs32;
     } hp.wc = m->wc; hp.bc = m->bc; hp.w1 = m->w1; hp.b1 = m->b1; hp.w2 = m->w2; hp.b2 = m->b2;
@@ -1259,7 +1260,7 @@ static int guarded(const char* what, F&& body) {
 }
 extern "C" {
 
-const char* opd_version(void) { return "opd_hip 0.1 gfx950 (fp16 MFMA, fp32 accumulate)"; }
+const char* opd_version(void) { return "opd_hip 0.2 gfx950 (fp16 MFMA operands, fp32 accumulate; OPD_FLAG_BF16: bf16 operands)"; }
 
 int opd_detr_create(const opd_config* cfg, const char* weights_path, int device_ordinal, opd_detr** out) {
     ApiScope api_scope;
@@ -1284,6 +1285,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     rc = infer_arch(sd, &m->arch, &err);
     if (rc) return fail(rc, err);
     m->cfg = *cfg;
+    m->dtype = (cfg->flags & OPD_FLAG_BF16) ? OPD_DT_BF16 : OPD_DT_F16;
     if (const char* v = getenv("OPD_TRUNK_SUBBATCH")) m->trunk_subbatch = atoi(v);   // A/B switches for benchmarking
     if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
@@ -1329,7 +1331,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     if (!src || !out) return fail(OPD_EINVAL, "opd_detr_clone: null argument");
     *out = nullptr;
     std::unique_ptr<opd_detr> m(new opd_detr());
-    m->arch = src->arch; m->cfg = src->cfg; m->device = src->device;
+    m->arch = src->arch; m->cfg = src->cfg; m->device = src->device; m->dtype = src->dtype;
     // everything build_weights produced: device pointers into the shared WeightSet and the host copies the plans are folded from
     m->weights = src->weights; m->weights_sealed = true; m->weight_bytes = src->weight_bytes;
     m->stem = src->stem; m->blocks = src->blocks; m->stage_first = src->stage_first; m->proj = src->proj;
@@ -1633,7 +1635,7 @@ int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int32_t* que
     const f16_t* k = m->d_memkv16 + (size_t)frame * hw * NKV + (size_t)layer * 2 * D;
     const float scale = 1.0f / sqrtf((float)(D / m->arch.heads));
     HIPCHK(opd_launch_attention_map(q, D, k, NKV, m->d_amap_sel, (int)sel.size(), m->arch.heads, hw, scale,
-                                    m->last_ragged ? m->d_key_valid + 2 * frame : nullptr, m->last_fw, m->d_amap_stat, m->d_amap, m->stream));
+                                    m->last_ragged ? m->d_key_valid + 2 * frame : nullptr, m->last_fw, m->d_amap_stat, m->d_amap, m->stream, m->dtype));
     HIPCHK(hipMemcpyAsync(out, m->d_amap, (size_t)hw * 4, hipMemcpyDeviceToHost, m->stream));
     HIPCHK(hipStreamSynchronize(m->stream));
     return OPD_OK;

@@ -113,6 +113,7 @@ struct WeightSet {
 struct opd_detr {
     Arch arch;
     opd_config cfg{};
+    int dtype = 0;                          // OPD_DT_F16 / OPD_DT_BF16 (cfg.flags & OPD_FLAG_BF16): the 16-bit operand type of every activation buffer and GEMM weight
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t stream2 = nullptr;   // second branch of the forward (stage-3 frame split, see enqueue_forward); joins the capture of `stream`

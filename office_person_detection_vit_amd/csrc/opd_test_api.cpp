@@ -42,7 +42,9 @@ extern "C" {
 // Launch options of the hooks below (test infrastructure only; the kernel tests are single-threaded): bits 8-10 = forced tile height
 // (4 / 5 / 6 x 32 rows), bit 5 = flat-address tile staging (the path tensors beyond 2 GiB take), bit 0 of the second word = k-loop
 // gemm + LayerNorm kernel also for K == 256.
-static int g_conv_flags = 0, g_gemm_ln_kloop = 0;
+static int g_conv_flags = 0, g_gemm_ln_kloop = 0, g_test_dtype = 0;
+// the 16-bit operand type the kernel hooks below launch with: their uint16 buffers then hold bfloat16 bit patterns (OPD_DT_BF16)
+int opd_test_set_elem_bf16(int on) { g_test_dtype = on ? OPD_DT_BF16 : OPD_DT_F16; return OPD_OK; }
 int opd_test_set_conv_flags(int flags) { g_conv_flags = flags; return OPD_OK; }
 int opd_test_set_gemm_ln_kloop(int on) { g_gemm_ln_kloop = on ? 1 : 0; return OPD_OK; }
 static void apply_conv_flags(ConvGemmParams& p, int flags) {
@@ -59,7 +61,7 @@ int opd_test_conv_gemm(const uint16_t* x, const uint16_t* w, const float* bias, 
     const size_t M = (size_t)B * OH * OW;
     const int K = stem ? 256 : KH * KW * Cin;
     const size_t xin = (size_t)B * H * W * (stem ? 4 : Cin);
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = g_test_dtype;
     p.x = dm.up(x, xin);
     p.w = dm.up(w, (size_t)N * K);
     p.bias = dm.up(bias, (size_t)N * (bias_period > 0 ? bias_period : 1));
@@ -94,7 +96,7 @@ int opd_test_conv_dual(const uint16_t* x, const uint16_t* w1, const uint16_t* x2
         memcpy(&wc[(size_t)n * K], w1 + (size_t)n * K1, (size_t)K1 * 2);
         memcpy(&wc[(size_t)n * K + K1], w2 + (size_t)n * Cin2, (size_t)Cin2 * 2);
     }
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = g_test_dtype;
     p.x = dm.up(x, (size_t)B * H * W * Cin);
     p.x2 = dm.up(x2, (size_t)B * H2 * W2 * Cin2);
     p.w = dm.up(wc.data(), wc.size());
@@ -116,7 +118,7 @@ int opd_test_gemm_splitk_ln(const uint16_t* x, const uint16_t* w, const float* b
                             const float* beta, float* y, uint16_t* y16, int M, int K, int splits) {
     DevMem dm;
     const int N = 256;
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = g_test_dtype;
     p.x = dm.up(x, (size_t)M * K);
     p.w = dm.up(w, (size_t)N * K);
     p.bias = dm.up(bias, N);
@@ -144,7 +146,7 @@ int opd_test_gemm_splitk_ln(const uint16_t* x, const uint16_t* w, const float* b
 int opd_test_gemm_ln(const uint16_t* x, const uint16_t* w, const float* bias, const float* res32, const float* gamma,
                      const float* beta, float* y, uint16_t* y16, int M, int K) {
     DevMem dm;
-    GemmLnParams p{};
+    GemmLnParams p{}; p.dtype = g_test_dtype;
     p.x = dm.up(x, (size_t)M * K);
     p.w = dm.up(w, (size_t)256 * K);
     p.bias = dm.up(bias, 256);
@@ -166,7 +168,7 @@ int opd_test_gemm_ln(const uint16_t* x, const uint16_t* w, const float* bias, co
 int opd_test_gemm_ln_deep(const uint16_t* x, const uint16_t* w, const float* bias, const float* res32, const float* gamma, const float* beta,
                           const float* pos, int period, float* y, uint16_t* y16, uint16_t* yp16, int M, int K, int in_place) {
     DevMem dm;
-    GemmLnParams p{};
+    GemmLnParams p{}; p.dtype = g_test_dtype;
     p.x = dm.up(x, (size_t)M * K);
     p.w = dm.up(w, (size_t)256 * K);
     p.bias = dm.up(bias, 256);
@@ -193,7 +195,7 @@ int opd_test_gemm_ln_deep(const uint16_t* x, const uint16_t* w, const float* bia
 // Times `iters` launches of Linear(K -> 256) + residual + LayerNorm (deep != 0: the row-owner ring kernel) on M rows of arbitrary data.
 int opd_test_bench_gemm_ln(int M, int K, int deep, int iters, float* us_out) {
     DevMem dm;
-    GemmLnParams p{};
+    GemmLnParams p{}; p.dtype = g_test_dtype;
     uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)M * K);
     uint16_t* w = dm.up<uint16_t>(nullptr, (size_t)256 * K);
     float* f = dm.up<float>(nullptr, 1024);
@@ -222,7 +224,7 @@ int opd_test_bench_gemm_ln(int M, int K, int deep, int iters, float* us_out) {
 int opd_test_gemm_k256(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* out16, float* out32, int M, int N,
                        int K, int bias_period, int relu) {
     DevMem dm;
-    GemmK256Params p{};
+    GemmK256Params p{}; p.dtype = g_test_dtype;
     const int slices = K / 256;
     p.x = dm.up(x, (size_t)M * K);
     p.w = dm.up(w, (size_t)N * K);
@@ -251,7 +253,7 @@ int opd_test_bench_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     DevMem dm;
     const int pad = KH / 2, OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const size_t M = (size_t)B * OH * OW, K = (size_t)KH * KH * Cin;
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = g_test_dtype;
     uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)B * H * W * Cin);
     uint16_t* w = dm.up<uint16_t>(nullptr, (size_t)N * K);
     float* bias = dm.up<float>(nullptr, N);
@@ -290,7 +292,7 @@ int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
     DevMem dm;
     const int pad = KH / 2, OH = (H + 2 * pad - KH) / stride + 1, OW = (W + 2 * pad - KH) / stride + 1;
     const size_t M = (size_t)B * OH * OW, K = (size_t)KH * KH * Cin;
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = g_test_dtype;
     uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)B * H * W * Cin);
     uint16_t* w = dm.up<uint16_t>(nullptr, (size_t)N * K);
     float* bias = dm.up<float>(nullptr, N);
@@ -340,7 +342,7 @@ int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, cons
     std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)(C3 ? C3 : 1) * C2);
     opd_permute_k32(w2, w2p.data(), C2, C1);
     if (C3) opd_permute_k32(w3, w3p.data(), C3, C2);
-    BtailParams p{};
+    BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = dm.up(x1, (size_t)B * H * W * C1);
     p.w1 = dm.up(w1, (size_t)C1 * 9 * C1);
     p.b1 = dm.up(b1, C1);
@@ -374,7 +376,7 @@ int opd_test_btail_repeat(const uint16_t* x1, const uint16_t* w1, const float* b
     std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)C3 * C2);
     opd_permute_k32(w2, w2p.data(), C2, C1);
     opd_permute_k32(w3, w3p.data(), C3, C2);
-    BtailParams p{};
+    BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = dm.up(x1, M * C1); p.w1 = dm.up(w1, (size_t)C1 * 9 * C1); p.b1 = dm.up(b1, C1); p.w2p = dm.up(w2p.data(), w2p.size());
     p.b2 = dm.up(b2, C2); p.res = dm.up(res, M * C2); p.y = dm.up<uint16_t>(nullptr, M * C2); p.w3p = dm.up(w3p.data(), w3p.size());
     p.b3 = dm.up(b3, C3); p.z = dm.up<uint16_t>(nullptr, M * C3);
@@ -415,7 +417,7 @@ int opd_test_btail_sc(const uint16_t* x1, const uint16_t* w1, const float* b1, c
     std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)C3 * C2);
     opd_permute_k32(w2, w2p.data(), C2, C1);
     opd_permute_k32(w3, w3p.data(), C3, C2);
-    BtailParams p{};
+    BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = dm.up(x1, M * C1);
     p.w1 = dm.up(w1, (size_t)C1 * 9 * C1);
     p.b1 = dm.up(b1, C1);
@@ -463,7 +465,7 @@ int opd_test_trace_btail(int B, int H, int W, int C1, int C3, int dbg, unsigned 
     TCHK(hipMemset(bias, 0, (size_t)C2 * 4));
     TCHK(hipMemset(res, 0x2c, M * C2 * 2));
     TCHK(hipMemset(tr, 0, (size_t)wgs * 128));
-    BtailParams p{};
+    BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = x1; p.w1 = w1; p.b1 = bias; p.w2p = w2; p.b2 = bias; p.res = res; p.y = y; p.w3p = w3; p.b3 = bias; p.z = z;
     p.B = B; p.H = H; p.W = W; p.OH = H; p.OW = W; p.stride = 1; p.M = (int)M; p.C1 = C1; p.C3 = C3; p.dbg = dbg;
     for (int i = 0; i < 2; ++i) TCHK(opd_launch_btail(p, nullptr));
@@ -498,7 +500,7 @@ int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int db
     TCHK(hipMemset(bias, 0, (size_t)C2 * 4));
     TCHK(hipMemset(res, 0x2c, M * C2 * 2));
     TCHK(hipMemset(zero, 0, 4096 * 4));
-    BtailParams p{};
+    BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = x1; p.w1 = w1; p.b1 = bias; p.w2p = w2; p.b2 = bias; p.res = res; p.y = y; p.w3p = w3; p.b3 = bias; p.z = z;
     p.B = B; p.H = H; p.W = W; p.OH = OH; p.OW = OW; p.stride = stride; p.M = (int)M; p.C1 = C1; p.C3 = C3; p.dbg = dbg;
     ConvGemmParams c[3] = {};
@@ -533,7 +535,7 @@ int opd_test_bench_btail(int B, int H, int W, int C1, int C3, int stride, int db
 int opd_test_bench_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, int B, int heads, int Lq, int Lk, int ldq, int ldkv,
                              float scale, int iters, float* us_out) {
     DevMem dm;
-    AttnParams p{};
+    AttnParams p{}; p.dtype = g_test_dtype;
     p.q = dm.up(q, (size_t)B * Lq * ldq);
     p.k = dm.up(k, (size_t)B * Lk * ldkv);
     p.v = dm.up(v, (size_t)B * Lk * ldkv);
@@ -559,7 +561,7 @@ int opd_test_bench_attention(const uint16_t* q, const uint16_t* k, const uint16_
 int opd_test_trace_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, int B, int heads, int Lq, int Lk, int ldq, int ldkv,
                              float scale, unsigned long long* trace_out, int max_wgs, int* wgs_out) {
     DevMem dm;
-    AttnParams p{};
+    AttnParams p{}; p.dtype = g_test_dtype;
     p.q = dm.up(q, (size_t)B * Lq * ldq);
     p.k = dm.up(k, (size_t)B * Lk * ldkv);
     p.v = dm.up(v, (size_t)B * Lk * ldkv);
@@ -583,7 +585,7 @@ int opd_test_attention(const uint16_t* q, const uint16_t* k, const uint16_t* v, 
                        float scale) {
     DevMem dm;
     const int D = heads * 32;
-    AttnParams p{};
+    AttnParams p{}; p.dtype = g_test_dtype;
     p.q = dm.up(q, (size_t)B * Lq * D);
     p.k = dm.up(k, (size_t)B * Lk * D);
     p.v = dm.up(v, (size_t)B * Lk * D);
@@ -601,7 +603,7 @@ int opd_test_attention_masked(const uint16_t* q, const uint16_t* k, const uint16
                               int Lk, float scale, const int32_t* key_valid, int key_row) {
     DevMem dm;
     const int D = heads * 32;
-    AttnParams p{};
+    AttnParams p{}; p.dtype = g_test_dtype;
     p.q = dm.up(q, (size_t)B * Lq * D);
     p.k = dm.up(k, (size_t)B * Lk * D);
     p.v = dm.up(v, (size_t)B * Lk * D);
@@ -658,7 +660,7 @@ int opd_test_preprocess_u8(const uint8_t* frames, uint16_t* out, int B, int H, i
 // Stem on the zero-bordered NHWC4 image through the LDS-DMA kernel (stem mode 2): x4p [B][Hp][Wp][4], w [64][8][8][4].
 int opd_test_stem2(const uint16_t* x4p, const uint16_t* w, const float* bias, uint16_t* out, int B, int Hp, int Wp, int OH, int OW) {
     DevMem dm;
-    ConvGemmParams p{};
+    ConvGemmParams p{}; p.dtype = g_test_dtype;
     const size_t M = (size_t)B * OH * OW;
     p.x = dm.up(x4p, (size_t)B * Hp * Wp * 4);
     p.w = dm.up(w, (size_t)64 * 256);
@@ -993,7 +995,7 @@ int opd_test_attention_split(const uint16_t* q, const uint16_t* k, const uint16_
                              const int32_t* key_valid, int key_row, float* part_o, float* part_ml) {
     DevMem dm;
     const int D = heads * 32;
-    AttnParams p{};
+    AttnParams p{}; p.dtype = g_test_dtype;
     p.q = dm.up(q, (size_t)B * Lq * D); p.k = dm.up(k, (size_t)B * Lk * D); p.v = dm.up(v, (size_t)B * Lk * D);
     p.key_valid = key_valid ? dm.up(key_valid, (size_t)B * 2) : nullptr;
     const size_t no = (size_t)splits * B * Lq * D, nm = (size_t)splits * B * Lq * heads * 2;

@@ -78,6 +78,7 @@ class HipDetrDetector:
         use_graph: bool = True,
         streams: int = 1,
         pinned_staging: bool = True,
+        dtype: str = "fp16",
     ):
         """
         Args mirror ``config.yaml.disabled:33-44`` (``model_name``, ``confidence_threshold``, ``nms_threshold``,
@@ -90,6 +91,8 @@ class HipDetrDetector:
         ``device``: ``"hip"``, ``"hip:N"``, ``"cuda"``, ``"cuda:N"`` or None (= GPU 0).  ``"cpu"``/``"mps"`` are refused.
         ``streams``: detector handles (each with its own HIP stream and workspace; the weights are shared) that
         ``detect_batch`` keeps busy at once when a call spans several ``max_batch`` chunks; 1 = strictly serial.
+        ``dtype``: 16-bit operand type of the device path: ``"fp16"`` (default: meets the 1e-3 box tolerance) or ``"bf16"``
+        (``OPD_FLAG_BF16``: the type the DETR-era config's deployment target names; same speed, 8 mantissa bits: boxes drift ~4x more).
         ``pinned_staging``: stack the caller's frames into page-locked memory (``opd_host_alloc``) so that the upload is
         one DMA; False stacks into ordinary numpy memory.
         """
@@ -106,6 +109,9 @@ class HipDetrDetector:
         self.resize = resize
         self.device_resize = device_resize  # resize camera-resolution frames on the GPU (False: PIL on the host)
         self.use_graph = use_graph  # replay the forward as a captured hipGraph (False: launch every kernel eagerly)
+        if dtype not in ("fp16", "bf16"):
+            raise ValueError("dtype must be 'fp16' or 'bf16'")
+        self.dtype = dtype
         self.streams = max(1, int(streams))
         self.model: Optional[int] = None  # opaque opd_detr* once loaded (handle 0)
         self._handles: List[int] = []  # all handles, handle 0 first
@@ -155,7 +161,7 @@ class HipDetrDetector:
             path = self._resolve_weights()
             cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=self.max_batch,
                                   max_height=self.max_size[0], max_width=self.max_size[1],
-                                  flags=(0 if self.use_graph else _capi.OPD_FLAG_NO_GRAPH) |
+                                  flags=(0 if self.use_graph else _capi.OPD_FLAG_NO_GRAPH) | (_capi.OPD_FLAG_BF16 if self.dtype == "bf16" else 0) |
                                         (_capi.OPD_FLAG_MULTI_STREAM if self.streams > 1 else 0))
             self._lib = lib
             handle = C.c_void_p()
