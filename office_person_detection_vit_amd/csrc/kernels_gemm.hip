@@ -840,9 +840,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) bias2[nt] = *reinterpret_cast<const float4v*>(p.bias + wn * 32 + nt * 16 + g * 4);
 
+    // The kernel is bound by LDS fragment reads (49 KiB per wave and tile against 70 MFMAs), and the weights are the same for every tile of
+    // the workgroup: their 14 fragments per wave (7 filter rows x 2 column tiles, 56 VGPRs) are read ONCE, after the first barrier, and stay
+    // in registers for the up to six tiles — 35 KiB of fragment reads per wave and tile instead of 49 (round 4).
+    half8 wf[7][2];
     for (int tx = tx_first; tx < tx_end; ++tx) {
         const int buf = (tx - tx_first) & 1;
         __syncthreads();   // vmcnt(0): this tile's patch (and, first time, the weights) landed; the previous tile's pooling is done
+        if (tx == tx_first) {
+#pragma unroll
+            for (int kh = 0; kh < 7; ++kh)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+                    wf[kh][nt] = *reinterpret_cast<const half8*>(Wl + kh * 4096 + swz_t<32>(wn * 32 + nt * 16 + li, g));
+        }
         if (tx + 1 < tx_end) {
             if constexpr (U8) load_patch(tx + 1);
             else issue_patch(tx + 1, buf ^ 1);
@@ -856,10 +867,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
         const unsigned char* P = Pin + buf * STEM_PATCH + (li + g) * 16;
 #pragma unroll
         for (int kh = 0; kh < 7; ++kh) {
-            half8 wf[2], xf[5];
-#pragma unroll
-            for (int nt = 0; nt < 2; ++nt)
-                wf[nt] = *reinterpret_cast<const half8*>(Wl + kh * 4096 + swz_t<32>(wn * 32 + nt * 16 + li, g));
+            half8 xf[5];
 #pragma unroll
             for (int mt = 0; mt < 5; ++mt) {
                 const int m10 = wm * 5 + mt;      // m-tile: convolution row m10 >> 1, column half m10 & 1
@@ -868,7 +876,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-                for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
+                for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[kh][nt], xf[mt], acc[nt][mt]);
         }
         // ---- ReLU -> fp16 patch [160 pixels][64 ch] (pixels outside the image: -65504 so that the max ignores them) -------
 #pragma unroll
