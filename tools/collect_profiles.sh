@@ -15,7 +15,7 @@ python tools/pmc_mfma.py $(ls -t $O/pmc_sq/*/*_counter_collection.csv | head -n 
 for f in bench_gloo2:bench_gloo2_selflaunch_rehearsal bench_r101_1066x1920:bench_r101_1066x1920 bench_r50_tile1080p_b4:bench_r50_tile1080p_b4; do
   [ -f $O/${f%%:*}.json ] && tail -n 1 $O/${f%%:*}.json > $P/${R}_${f##*:}.json
 done
-for f in host_rate:host_boundary_rate trace_gemm:trace_gemm bench_layers:bench_layers bench_btail:bench_btail bench_btail3:bench_btail3 trace_btail3:trace_btail3 bench_attn:bench_attn trace_attn:trace_attn bench_gemm_ln:bench_gemm_ln clock_vs_window:clock_vs_window; do
+for f in host_rate:host_boundary_rate trace_gemm:trace_gemm bench_layers:bench_layers bench_btail:bench_btail bench_btail3:bench_btail3 trace_btail3:trace_btail3 bench_attn:bench_attn trace_attn:trace_attn bench_gemm_ln:bench_gemm_ln; do
   [ -f $O/${f%%:*}.txt ] && cp $O/${f%%:*}.txt $P/${R}_${f##*:}.txt
 done
 cp $O/smoke.log $P/${R}_smoke_parity.txt

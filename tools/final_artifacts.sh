@@ -33,6 +33,5 @@ timeout -k 10 120 python tools/bench_gemm_ln.py > $O/bench_gemm_ln.txt 2>&1 &&
 timeout -k 10 120 python tools/trace_gemm.py > $O/trace_gemm.txt 2>&1 &&
 timeout -k 10 300 python tools/bench_layers.py 0 > $O/bench_layers.txt 2>&1 &&
 timeout -k 10 300 python tools/bench_btail.py --ablate > $O/bench_btail.txt 2>&1 &&
-timeout -k 10 300 python tools/clock_vs_window.py 20 200 1000 > $O/clock_vs_window.txt 2>&1 &&
 du -sh $O
 fi
