@@ -15,10 +15,12 @@
 // Work decomposition: a workgroup owns 128 output pixels, wave w the 32 pixels 32w..32w+31 with ALL channels, so every
 // reduction of the two 1x1s is wave-local.  MFMA orientation as in kernels_gemm.hip: weights are the A operand, pixels
 // the B operand, D[row = channel][col = pixel]: lane (g = lane>>4, i = lane&15) holds channels 4g..4g+3 of pixel i.
-// Two such 16-channel accumulator tiles, rounded to fp16, ARE a B operand of the next 16x16x32 MFMA (8 k-slots per
-// lane) under the k-permutation  slot 8g+e -> channel 4g+e, slot 8g+4+e -> channel 16+4g+e  (e < 4) of each 32-channel
-// block; the 1x1 weights are stored with that permutation applied along K at load time (`opd_permute_k32`), so their A
-// fragments are plain 16-byte LDS reads.
+// Channel ownership: the weight rows of every 32-channel block are STAGED into LDS in the order  LDS row 16t+4g+r <- channel 8g+4t+r
+// (`own_row`; the staging offsets are per lane, so the permutation costs nothing), i.e. accumulator tile t of the block holds, in lane
+// (g, i), channels 8g+4t .. +3 of pixel i.  The two tiles of a block, rounded to fp16, are then 8 CONSECUTIVE channels per lane:
+// (1) they ARE the B operand of the next 16x16x32 MFMA in natural k order (no K-permuted weight copies), (2) y, z and the residual move as
+// 16 bytes per lane with the four lanes of a pixel covering 64 contiguous bytes (16 pixels x 64 B per wave instruction; the accumulator
+// layout of plain row order gives 8 bytes per lane, and a lane-pair exchange 32 rows x 32 B).
 //
 // Pipeline: the 3x3 main loop is the LDS-DMA loop of conv_gemm_dma_kernel (two stage buffers, buffer-descriptor
 // staging, XOR-swizzled 128-byte rows).  It continues seamlessly into C2/64 "chunk steps": chunk j stages the 64 rows of
@@ -54,6 +56,11 @@ __device__ __forceinline__ int xcd_logical_block(int bid, int nblocks) {
     const int x = bid & 7, k = bid >> 3;
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + k;
 }
+
+// LDS row -> weight row (output channel) of the tails' channel ownership: bits [t][g1 g0][r1 r0] <- [g1 g0][t][r1 r0] within a 32-block
+__device__ __forceinline__ int own_row(const int rho) { return (rho & ~31) | (((rho >> 2) & 3) << 3) | (((rho >> 4) & 1) << 2) | (rho & 3); }
+// first of the four consecutive channels lane group g holds in accumulator tile nt
+__device__ __forceinline__ int own_ch(const int nt, const int g) { return (nt >> 1) * 32 + g * 8 + (nt & 1) * 4; }
 
 __device__ __forceinline__ int fdiv(const int m, const FastDiv& f) {   // m >= 0
     return f.one ? m : (int)(__umulhi((unsigned)m, f.mul) >> f.shift);
@@ -152,8 +159,8 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(C3 ? p.w3p : p.w2p), 0, (unsigned)((C3 ? C3 : 1) * C2 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(SC ? p.wsc : p.w2p), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
     unsigned rowoff[4], rowmask[4], woff1[W1_PIECES], woff2[W2_PIECES], woff3[W3_PIECES ? W3_PIECES : 1], woffsc[2];
-    woffsc[0] = (unsigned)((wave * 16 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;        // rows 8 (2 wave) + lrow of the 64-row chunk
-    woffsc[1] = (unsigned)((wave * 16 + 8 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;
+    woffsc[0] = (unsigned)(own_row(wave * 16 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;        // rows 8 (2 wave) + lrow of the 64-row chunk
+    woffsc[1] = (unsigned)(own_row(wave * 16 + 8 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;
     {
         const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -177,15 +184,15 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         }
 #pragma unroll
         for (int i = 0; i < W1_PIECES; ++i)
-            woff1[i] = (unsigned)(((wave * W1_PIECES + i) * 8 + lrow) * (9 * C1)) * 2u + (unsigned)lchunk * 16u;
+            woff1[i] = (unsigned)(own_row((wave * W1_PIECES + i) * 8 + lrow) * (9 * C1)) * 2u + (unsigned)lchunk * 16u;
 #pragma unroll
         for (int i = 0; i < W2_PIECES; ++i) {
             const int q = wave * W2_PIECES + i;   // sub-tile q>>3 (64 k each), rows 8*(q&7)..+7 of the 64-row chunk
-            woff2[i] = (unsigned)(((q & 7) * 8 + lrow) * C1 + (q >> 3) * 64) * 2u + (unsigned)lchunk * 16u;
+            woff2[i] = (unsigned)(own_row((q & 7) * 8 + lrow) * C1 + (q >> 3) * 64) * 2u + (unsigned)lchunk * 16u;
         }
 #pragma unroll
         for (int i = 0; i < W3_PIECES; ++i)
-            woff3[i] = (unsigned)(((wave * W3_PIECES + i) * 8 + lrow) * C2) * 2u + (unsigned)lchunk * 16u;
+            woff3[i] = (unsigned)(own_row((wave * W3_PIECES + i) * 8 + lrow) * C2) * 2u + (unsigned)lchunk * 16u;
     }
 
     constexpr int kpc = C1 / 64;   // k-steps per filter tap
@@ -232,10 +239,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                                                          woffsc[i], j * (64 * 64 * 2), 0, 0);
         }
     };
-    // fp16 residual of y-chunk j in the paired 16-byte layout: lane (g, li) -> row (g&1)*16 + li, 8 channels at (g>>1)*8
-    const int pr_m = wm0 + (g & 1) * 16 + li;
-    const bool pr_ok = pr_m < p.M;
-    const size_t pr_row = (size_t)pr_m * C2 + (g >> 1) * 8;
+    // y / z / residual: lane (g, li) moves 8 channels (16 B) at 8g of each 32-channel block, for its pixels li and 16 + li
+    const bool pr_ok[2] = {wm0 + li < p.M, wm0 + 16 + li < p.M};
+    const size_t pr_row[2] = {(size_t)(wm0 + li) * C2 + g * 8, (size_t)(wm0 + 16 + li) * C2 + g * 8};
     // RDMA: wave-private residual staging: rows of this wave, whole 128-byte rows, swizzled like every other tile
     unsigned char* const res_lds = smem + 2 * STAGE_BYTES + wave * 4096;   // + (j & 1) * 16384 for chunk j
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
@@ -257,9 +263,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             if (has_res) issue_res(j);
         } else {
 #pragma unroll
-            for (int nt = 0; nt < 4; ++nt) {
-                r[nt] = make_uint4(0u, 0u, 0u, 0u);
-                if (has_res && pr_ok) r[nt] = *reinterpret_cast<const uint4*>(p.res + pr_row + j * 64 + nt * 16);
+            for (int i = 0; i < 4; ++i) {   // i = 2 q + mt: 32-channel block q of the chunk, pixel half mt
+                r[i] = make_uint4(0u, 0u, 0u, 0u);
+                if (has_res && pr_ok[i & 1]) r[i] = *reinterpret_cast<const uint4*>(p.res + pr_row[i & 1] + j * 64 + (i >> 1) * 32);
             }
         }
     };
@@ -287,7 +293,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     float4v acc1[NT1][2];
 #pragma unroll
     for (int nt = 0; nt < NT1; ++nt) {
-        const float4v b = *reinterpret_cast<const float4v*>(p.b1 + nt * 16 + g * 4);
+        const float4v b = *reinterpret_cast<const float4v*>(p.b1 + own_ch(nt, g));
         acc1[nt][0] = b;
         acc1[nt][1] = b;
     }
@@ -348,7 +354,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     if constexpr (C3 > 0) {
 #pragma unroll
         for (int nt = 0; nt < NT3; ++nt) {
-            const float4v b = *reinterpret_cast<const float4v*>(p.b3 + nt * 16 + g * 4);
+            const float4v b = *reinterpret_cast<const float4v*>(p.b3 + own_ch(nt, g));
             accz[nt][0] = b;
             accz[nt][1] = b;
         }
@@ -365,8 +371,8 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         if constexpr (RDMA) {
             if (has_res) {   // paired layout out of this wave's rows of the staged chunk; then the buffer is free for chunk j+2
 #pragma unroll
-                for (int nt = 0; nt < 4; ++nt)
-                    res_cur[nt] = *reinterpret_cast<const uint4*>(res_lds + (j & 1) * 16384 + swz((g & 1) * 16 + li, nt * 2 + (g >> 1)));
+                for (int i = 0; i < 4; ++i)
+                    res_cur[i] = *reinterpret_cast<const uint4*>(res_lds + (j & 1) * 16384 + swz((i & 1) * 16 + li, (i >> 1) * 4 + g));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (j + 2 < NCH) issue_res(j + 2);
             }
@@ -378,7 +384,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         float4v acc2[4][2];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
-            const float4v b = *reinterpret_cast<const float4v*>(p.b2 + j * 64 + nt * 16 + g * 4);
+            const float4v b = *reinterpret_cast<const float4v*>(p.b2 + j * 64 + own_ch(nt, g));
             acc2[nt][0] = b;
             acc2[nt][1] = b;
         }
@@ -406,47 +412,39 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                     for (int mt = 0; mt < 2; ++mt) acc2[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xs[mt][kk], acc2[nt][mt]);
             }
         }
-        // residual (paired layout -> accumulator layout), ReLU, fp16; store y; keep the fp16 values as the next B operand
-        unsigned pk[4][2][2];
+        // residual, ReLU, fp16; store y; keep the fp16 values as the next B operand (block q of the chunk = k-block q of W3's slice)
+        half8 yf[2][2];   // [q][mt]
 #pragma unroll
-        for (int nt = 0; nt < 4; ++nt) {
-            float4v v0 = acc2[nt][0], v1 = acc2[nt][1];
-            if (has_res) {
-                const uint4 r = res_cur[nt];
-                const uint2v s0 = __builtin_amdgcn_permlane16_swap(r.x, r.z, false, false);
-                const uint2v s1 = __builtin_amdgcn_permlane16_swap(r.y, r.w, false, false);
-                float a, b;
-                unpack2h(s0[0], a, b); v0[0] += a; v0[1] += b;
-                unpack2h(s1[0], a, b); v0[2] += a; v0[3] += b;
-                unpack2h(s0[1], a, b); v1[0] += a; v1[1] += b;
-                unpack2h(s1[1], a, b); v1[2] += a; v1[3] += b;
-            }
+        for (int q = 0; q < 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
-                v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+            for (int mt = 0; mt < 2; ++mt) {
+                float4v v0 = acc2[2 * q][mt], v1 = acc2[2 * q + 1][mt];
+                if (has_res) {
+                    const uint4 r = res_cur[2 * q + mt];
+                    float a, b;
+                    unpack2h(r.x, a, b); v0[0] += a; v0[1] += b;
+                    unpack2h(r.y, a, b); v0[2] += a; v0[3] += b;
+                    unpack2h(r.z, a, b); v1[0] += a; v1[1] += b;
+                    unpack2h(r.w, a, b); v1[2] += a; v1[3] += b;
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
+                    v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+                }
+                const uint4 o = make_uint4(pack2h(v0[0], v0[1]), pack2h(v0[2], v0[3]), pack2h(v1[0], v1[1]), pack2h(v1[2], v1[3]));
+                yf[q][mt] = as_half8(o.x, o.y, o.z, o.w);
+                if (pr_ok[mt] && !(p.dbg & 2)) *reinterpret_cast<uint4*>(p.y + pr_row[mt] + j * 64 + q * 32) = o;
             }
-            pk[nt][0][0] = pack2h(v0[0], v0[1]);
-            pk[nt][0][1] = pack2h(v0[2], v0[3]);
-            pk[nt][1][0] = pack2h(v1[0], v1[1]);
-            pk[nt][1][1] = pack2h(v1[2], v1[3]);
-            const uint2v s0 = __builtin_amdgcn_permlane16_swap(pk[nt][0][0], pk[nt][1][0], false, false);
-            const uint2v s1 = __builtin_amdgcn_permlane16_swap(pk[nt][0][1], pk[nt][1][1], false, false);
-            if (pr_ok && !(p.dbg & 2)) *reinterpret_cast<uint4*>(p.y + pr_row + j * 64 + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-        }
         if constexpr (C3 > 0) {
             const unsigned char* W3s = W2s + W2C_BYTES;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                half8 yf[2];
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-                    yf[mt] = as_half8(pk[2 * kk][mt][0], pk[2 * kk][mt][1], pk[2 * kk + 1][mt][0], pk[2 * kk + 1][mt][1]);
 #pragma unroll
                 for (int nt = 0; nt < NT3; ++nt) {
                     const half8 wf = *reinterpret_cast<const half8*>(W3s + swz(nt * 16 + li, kk * 4 + g));
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) accz[nt][mt] = OPD_MFMA_16x16x32(wf, yf[mt], accz[nt][mt]);
+                    for (int mt = 0; mt < 2; ++mt) accz[nt][mt] = OPD_MFMA_16x16x32(wf, yf[kk][mt], accz[nt][mt]);
                 }
             }
         }
@@ -464,19 +462,20 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 
     // ---- z = relu(c0') -----------------------------------------------------------------------------------------------------
     if constexpr (C3 > 0) {
-        const size_t zrow = (size_t)pr_m * C3 + (g >> 1) * 8;
 #pragma unroll
-        for (int nt = 0; nt < NT3; ++nt) {
-            float4v v0 = accz[nt][0], v1 = accz[nt][1];
+        for (int q = 0; q < NT3 / 2; ++q)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
-                v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+            for (int mt = 0; mt < 2; ++mt) {
+                float4v v0 = accz[2 * q][mt], v1 = accz[2 * q + 1][mt];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
+                    v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+                }
+                if (pr_ok[mt] && !(p.dbg & 2))
+                    *reinterpret_cast<uint4*>(p.z + (size_t)(wm0 + mt * 16 + li) * C3 + q * 32 + g * 8) =
+                        make_uint4(pack2h(v0[0], v0[1]), pack2h(v0[2], v0[3]), pack2h(v1[0], v1[1]), pack2h(v1[2], v1[3]));
             }
-            const uint2v s0 = __builtin_amdgcn_permlane16_swap(pack2h(v0[0], v0[1]), pack2h(v1[0], v1[1]), false, false);
-            const uint2v s1 = __builtin_amdgcn_permlane16_swap(pack2h(v0[2], v0[3]), pack2h(v1[2], v1[3]), false, false);
-            if (pr_ok && !(p.dbg & 2)) *reinterpret_cast<uint4*>(p.z + zrow + nt * 16) = make_uint4(s0[0], s1[0], s0[1], s1[1]);
-        }
     }
     if constexpr (TRACE) {
         stamp(4 + NCH);

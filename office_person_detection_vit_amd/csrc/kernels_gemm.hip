@@ -210,7 +210,9 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
         auto stage_quad = [&](const int nt, const int slot, const float4v& v) {
             const int r = slot * 16 + li;
             const int cb = nt * 32 + g * 8;  // byte offset of this quad inside the row
-            const int off = r * WROW + ((((cb >> 4) ^ row_swz(r)) << 4) | (cb & 8));
+            // (rows r and r + 8 share swizzle and bank line: their 8-byte halves trade places, so the 16 lanes of a ds_write_b64 lane
+            // group touch 32 different banks: the SQ pass of round 3 read 44-87 % conflict cycles on the pointwise variants without)
+            const int off = r * WROW + ((((cb >> 4) ^ row_swz(r)) << 4) | ((cb & 8) ^ (r & 8)));
             *reinterpret_cast<uint2*>(wave_stage + off) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
         };
 #pragma unroll
@@ -234,7 +236,8 @@ __device__ __forceinline__ void epilogue_regs(const ConvGemmParams& p, void* out
 #pragma unroll
             for (int i = 0; i < gt * 16 / RPI; ++i) {
                 const int r = r0 + i * RPI;
-                const uint4 v = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ row_swz(r)) << 4));
+                const uint4 t = *reinterpret_cast<const uint4*>(wave_stage + r * WROW + ((c ^ row_swz(r)) << 4));
+                const uint4 v = (r & 8) ? make_uint4(t.z, t.w, t.x, t.y) : t;
                 const int m = m0 + g0 * 16 + r;
                 if (m < p.M && !(p.dbg & 64)) *reinterpret_cast<uint4*>(o16 + (size_t)m * p.N + n0 + c * 8) = v;   // (dbg 64: timing ablation)
             }
@@ -662,8 +665,8 @@ hipError_t launch_dma(const ConvGemmParams& p, hipStream_t stream) {
 // row/column recomputed by the neighbours: 1.33x the stem FLOPs, which are 2.5 % of the model).
 //   * the implicit-GEMM part is conv_gemm_dma_kernel<64, BUF, 5> with a 2-D row map instead of the flat m index:
 //     tile row r (0..159) <-> convolution pixel (2*py0 - 1 + r / 32, 2*px0 - 1 + r % 32) of the zero-bordered NHWC4 image;
-//   * epilogue: bias + ReLU -> fp16 patch in LDS (out-of-map pixels = -65504 so the max ignores them, which is exactly
-//     MaxPool2d's implicit -inf padding) -> barrier -> 240 threads each reduce one (pooled pixel, 8-channel group).
+//   * epilogue: bias -> fp16 patch in LDS (out-of-map pixels = -65504 so the max ignores them, which is exactly
+//     MaxPool2d's implicit -inf padding) -> barrier -> 240 threads each reduce one (pooled pixel, 8-channel group), then ReLU.
 // ---------------------------------------------------------------------------------------------------------------------
 struct StemPoolParams {
     const f16_t* x4p;   // [B][Hp][Wp][4] zero-bordered normalised image
@@ -696,7 +699,7 @@ __device__ __forceinline__ int swz_t(int row, int chunk) {
 //     the B fragment of output pixel (r, c), filter row kh, column pair g is the 16 bytes at patch[(2r + kh)][2c + 2g], so
 //     the 7 k-steps (K = 7 x 32 = 224 instead of 256) run straight from LDS without a barrier between them.
 // Tile: 5 x 32 convolution outputs -> 2 x 15 pooled pixels (+1 halo row / column recomputed by the neighbours: 1.33x the stem
-// FLOPs, which are 2.5 % of the model).  Epilogue: bias + ReLU -> fp16 patch in LDS (out-of-map pixels = -65504 so the max ignores
+// FLOPs, which are 2.5 % of the model).  Epilogue: bias -> fp16 patch in LDS (out-of-map pixels = -65504 so the max ignores
 // them, which is exactly MaxPool2d's implicit -inf padding) -> barrier -> 240 threads each reduce one (pooled pixel, 8 channels).
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr int STEM_TPW = 6;              // tiles per workgroup
@@ -714,6 +717,13 @@ constexpr int STEM_W_BYTES = 7 * 64 * 64;
 //  LDS-bound stem +43 us, more than the 34 us the removed launch took.)
 constexpr float STEM_NA[3] = {0.017124755308032036f, 0.017507001757621765f, 0.01742919534444809f};   // RGB: (1/255) / std
 constexpr float STEM_NB[3] = {2.1179039478302f, 2.0357141494750977f, 1.804444432258606f};            // RGB: mean / std
+
+// Row placement of the pooling patch in LDS.  The pooling threads of one ds_read_b128 lane group read pixels 2 apart (pooled neighbours),
+// i.e. rows of ONE parity: in plain row order those sit in the same half of the 256-byte bank line and collide two by two; the accumulator
+// writes (ds_write_b64: 16 consecutive rows per lane group over a 128-byte bank line) collide between rows r and r + 8.  Row bits 0 and 2
+// trade places (rows 2 apart alternate between the halves): free.  The write collision stays: swapping the 8-byte halves of rows with bit 3
+// set removes it (the GEMM's staged epilogue does that) but costs the pooling 36 selects per tile, in a kernel bound by vector-ALU issue.
+__device__ __forceinline__ int stem_prow(const int r) { return (r & ~5) | ((r & 1) << 2) | ((r >> 2) & 1); }
 
 template <bool U8>
 __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
@@ -785,53 +795,51 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
     };
     // ---- U8: the same 525 chunks through registers.  Chunk c = patch row c / 35, pixel pair c % 35 <-> image pixels (y, x), (y, x + 1)
     //      with y = iy0 + row - 3, x = ix0 + 2 pair - 3; its 6 source bytes start at byte ((b H + y) W + x) 3 of the frames.
-    unsigned pre[3][3];   // three aligned dwords per chunk, fetched one tile ahead
+    unsigned pre[3][3];   // three aligned dwords per chunk, fetched TWO tiles ahead (right after the previous contents have been consumed)
+    // Branch-free: a chunk that does not exist (piece >= 9, row >= 15) or lies outside the frame is fetched from an out-of-range offset, which
+    // the descriptor's bounds check turns into zeros.  (A predicated load is a branch with its own wait; the wait counters of a block that a
+    // wave may skip are unknown at the join, and the compiler then drains vmcnt(0) -- including the pooling's global stores -- at the loop top.)
     auto load_patch = [&](int tx) {
         const int ix0 = 2 * (2 * (tx * 15) - 1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int q = wave + 4 * i;
-            pre[i][0] = pre[i][1] = pre[i][2] = 0u;
-            if (q < 9 && prow[i] < 15) {
-                const int y = iy0 + prow[i] - 3, x = ix0 + 2 * pcol[i] - 3;
-                if ((unsigned)y < (unsigned)vh && x + 1 >= 0 && x < vw) {
-                    // (a pair that starts left of the image, x = -1, is fetched from its second pixel: byte addresses never go negative
-                    //  -- hipcc merges the three loads into one dwordx3, and a start before the buffer would zero all of it)
-                    const int a = (((b * p.H + y) * p.W + (x < 0 ? 0 : x)) * 3) & ~3;
+            const int y = iy0 + prow[i] - 3, x = ix0 + 2 * pcol[i] - 3;
+            const bool ok = (tid >> 6) + 4 * i < 9 && prow[i] < 15 && (unsigned)y < (unsigned)vh && x + 1 >= 0 && x < vw;
+            // (a pair that starts left of the image, x = -1, is fetched from its second pixel: byte addresses never go negative
+            //  -- hipcc merges the three loads into one dwordx3, and a start before the buffer would zero all of it)
+            const unsigned a = ok ? (unsigned)((((b * p.H + y) * p.W + (x < 0 ? 0 : x)) * 3) & ~3) : 0x80000000u;
 #pragma unroll
-                    for (int d = 0; d < 3; ++d)
-                        pre[i][d] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, (unsigned)(a + 4 * d), 0, 0);   // past the end: zeros
-                }
-            }
+            for (int d = 0; d < 3; ++d) pre[i][d] = __builtin_amdgcn_raw_buffer_load_b32(rsrc_a, a + 4u * d, 0, 0);   // past the end: zeros
         }
     };
+    unsigned char* const sink = patch + 160 * 128 + lane * 16;   // 1 KiB per workgroup that nobody reads: target of the chunks that do not exist
     auto store_patch = [&](int tx, int buf) {
         const int ix0 = 2 * (2 * (tx * 15) - 1);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int q = wave + 4 * i;
-            if (q < 9 && prow[i] < 15) {
-                const int y = iy0 + prow[i] - 3, x = ix0 + 2 * pcol[i] - 3;
-                const bool row_ok = (unsigned)y < (unsigned)vh;
-                const bool ok0 = row_ok && (unsigned)x < (unsigned)vw, ok1 = row_ok && (unsigned)(x + 1) < (unsigned)vw;
-                const bool shifted = x < 0;   // the fetch started at the pair's second pixel
-                const unsigned sh = (unsigned)(((b * p.H + y) * p.W + (shifted ? 0 : x)) * 3) & 3u;
-                unsigned lo = __builtin_amdgcn_alignbyte(pre[i][1], pre[i][0], sh);   // source bytes 0..3: B0 G0 R0 B1
-                unsigned hi = __builtin_amdgcn_alignbyte(pre[i][2], pre[i][1], sh);   // source bytes 4..7: G1 R1 . .
-                if (shifted) { hi = lo >> 8; lo = lo << 24; }                         // bytes 0..2 are B1 G1 R1
-                auto nrm = [&](const int c, const unsigned byte) { return __builtin_fmaf((float)byte, STEM_NA[c], -STEM_NB[c]); };
-                uint4 o;
-                o.x = ok0 ? pack2h(nrm(0, (lo >> 16) & 255u), nrm(1, (lo >> 8) & 255u)) : 0u;   // R0 G0
-                o.y = ok0 ? pack2h(nrm(2, lo & 255u), 0.f) : 0u;                                // B0 0
-                o.z = ok1 ? pack2h(nrm(0, (hi >> 8) & 255u), nrm(1, hi & 255u)) : 0u;           // R1 G1
-                o.w = ok1 ? pack2h(nrm(2, lo >> 24), 0.f) : 0u;                                 // B1 0
-                *reinterpret_cast<uint4*>(Pin + buf * STEM_PATCH + q * 1024 + lane * 16) = o;
-            }
+            const int q = (tid >> 6) + 4 * i;
+            const int y = iy0 + prow[i] - 3, x = ix0 + 2 * pcol[i] - 3;
+            const bool row_ok = (unsigned)y < (unsigned)vh;
+            const bool ok0 = row_ok && (unsigned)x < (unsigned)vw, ok1 = row_ok && (unsigned)(x + 1) < (unsigned)vw;
+            const bool shifted = x < 0;   // the fetch started at the pair's second pixel
+            const unsigned sh = (unsigned)(((b * p.H + y) * p.W + (shifted ? 0 : x)) * 3) & 3u;
+            unsigned lo = __builtin_amdgcn_alignbyte(pre[i][1], pre[i][0], sh);   // source bytes 0..3: B0 G0 R0 B1
+            unsigned hi = __builtin_amdgcn_alignbyte(pre[i][2], pre[i][1], sh);   // source bytes 4..7: G1 R1 . .
+            if (shifted) { hi = lo >> 8; lo = lo << 24; }                         // bytes 0..2 are B1 G1 R1
+            auto nrm = [&](const int c, const unsigned byte) { return __builtin_fmaf((float)byte, STEM_NA[c], -STEM_NB[c]); };
+            uint4 o;
+            o.x = ok0 ? pack2h(nrm(0, (lo >> 16) & 255u), nrm(1, (lo >> 8) & 255u)) : 0u;   // R0 G0
+            o.y = ok0 ? pack2h(nrm(2, lo & 255u), 0.f) : 0u;                                // B0 0
+            o.z = ok1 ? pack2h(nrm(0, (hi >> 8) & 255u), nrm(1, hi & 255u)) : 0u;           // R1 G1
+            o.w = ok1 ? pack2h(nrm(2, lo >> 24), 0.f) : 0u;                                 // B1 0
+            unsigned char* const dst = (q < 9 && prow[i] < 15) ? Pin + buf * STEM_PATCH + q * 1024 + lane * 16 : sink;
+            *reinterpret_cast<uint4*>(dst) = o;
         }
     };
     if constexpr (U8) {
         load_patch(tx_first);
         store_patch(tx_first, 0);
+        load_patch(tx_first + 1 < tx_end ? tx_first + 1 : tx_first);
     } else {
         issue_patch(tx_first, 0);
     }
@@ -854,10 +862,8 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
                 for (int nt = 0; nt < 2; ++nt)
                     wf[kh][nt] = *reinterpret_cast<const half8*>(Wl + kh * 4096 + swz_t<32>(wn * 32 + nt * 16 + li, g));
         }
-        if (tx + 1 < tx_end) {
-            if constexpr (U8) load_patch(tx + 1);
-            else issue_patch(tx + 1, buf ^ 1);
-        }
+        if constexpr (!U8)
+            if (tx + 1 < tx_end) issue_patch(tx + 1, buf ^ 1);
         const int px0 = tx * 15, cx0 = 2 * px0 - 1;
         float4v acc[2][5];
 #pragma unroll
@@ -878,7 +884,7 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 #pragma unroll
                 for (int mt = 0; mt < 5; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[kh][nt], xf[mt], acc[nt][mt]);
         }
-        // ---- ReLU -> fp16 patch [160 pixels][64 ch] (pixels outside the image: -65504 so that the max ignores them) -------
+        // ---- fp16 patch [160 pixels][64 ch] (pixels outside the image: -65504 so that the max ignores them) -------
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
@@ -886,12 +892,21 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
                 const int r = wm * 80 + mt * 16 + li;
                 const int cy = cy0 + (r >> 5), cx = cx0 + (r & 31);
                 const bool ok = (unsigned)cy < (unsigned)p.OH && (unsigned)cx < (unsigned)p.OW;
-                float4v v = acc[nt][mt];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) v[j] = ok ? (v[j] > 0.f ? v[j] : 0.f) : -65504.f;
+                const float4v v = acc[nt][mt];   // (ReLU: after the pooling, max(relu(x)) == relu(max(x)), on 8 values per thread instead of 40)
                 const int cb = wn * 64 + nt * 32 + g * 8;  // byte offset of the quad in the 128-byte pixel row
-                const int off = r * 128 + ((((cb >> 4) ^ (r & 7)) << 4) | (cb & 8));
-                *reinterpret_cast<uint2*>(patch + off) = make_uint2(pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+                const int rr = stem_prow(r);
+                const int off = rr * 128 + ((((cb >> 4) ^ (rr & 7)) << 4) | (cb & 8));
+                // (the out-of-map select on the two packed words, not on the four floats: the kernel is bound by vector-ALU issue)
+                const unsigned lowest = pack2h(-65504.f, -65504.f);
+                *reinterpret_cast<uint2*>(patch + off) = make_uint2(ok ? pack2h(v[0], v[1]) : lowest, ok ? pack2h(v[2], v[3]) : lowest);
+            }
+        // U8: the next tile's patch goes into the buffer this tile does not use (last read in the k-loop of the tile before: every wave has
+        // passed this tile's first barrier since); its source bytes were requested a tile ago, and the request for the tile after next follows
+        // at once.  The barrier at the top of the next iteration publishes the patch.
+        if constexpr (U8)
+            if (tx + 1 < tx_end) {
+                store_patch(tx + 1, buf ^ 1);
+                load_patch(tx + 2 < tx_end ? tx + 2 : tx + 1);
             }
         __syncthreads();
         // ---- 3x3 s2 max over the patch: thread -> (pooled pixel 0..29, 8-channel group 0..7) -------------------------------
@@ -908,17 +923,20 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
 #pragma unroll
                     for (int dx = 0; dx < 3; ++dx) {
                         const int r = (2 * ly + dy) * 32 + 2 * lx + dx;
-                        const half8 v = *reinterpret_cast<const half8*>(patch + r * 128 + ((c8 ^ (r & 7)) << 4));
+                        const int rr = stem_prow(r);
+                        const half8 v = *reinterpret_cast<const half8*>(patch + rr * 128 + ((c8 ^ (rr & 7)) << 4));
+#ifdef OPD_ELEM_BF16
 #pragma unroll
                         for (int j = 0; j < 8; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+#else
+                        m = __builtin_elementwise_max(m, v);   // four v_pk_max_f16 (the element-wise select form: 8 compares + 8 selects)
+#endif
                     }
+#pragma unroll
+                for (int j = 0; j < 8; ++j) m[j] = m[j] > (elem_t)0.f ? m[j] : (elem_t)0.f;   // ReLU (a -0 from a rounded tiny negative becomes +0, as in the unfused pair)
                 *reinterpret_cast<half8*>(p.out + (((size_t)b * p.PH + py) * p.PW + px) * 64 + c8 * 8) = m;
             }
         }
-        // U8: the next tile's patch goes into the buffer this tile did not use (last read in the k-loop of the tile before: every wave
-        // has passed two barriers since); the barrier at the top of the next iteration publishes it
-        if constexpr (U8)
-            if (tx + 1 < tx_end) store_patch(tx + 1, buf ^ 1);
     }
 #endif
 }
@@ -989,7 +1007,7 @@ hipError_t OPD_SYM(opd_launch_stem_pool_u8)(const uint8_t* frames, const int32_t
     p.w = w; p.bias = bias; p.out = out; p.B = B; p.Hp = 2 * OH + 6; p.Wp = 2 * OW + 6; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
     p.tiles_y = (PH + 1) / 2;
     p.tiles_x = (PW + 14) / 15;
-    constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
+    constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES + 1024;   // (+ the sink of the U8 form)
     OPD_SET_MAX_LDS_ONCE(stem_pool2_kernel<true>, LDS2);
     const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
     hipLaunchKernelGGL(stem_pool2_kernel<true>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
@@ -1005,7 +1023,7 @@ hipError_t OPD_SYM(opd_launch_stem_pool)(const f16_t* x4p, const f16_t* w, const
     p.x4p = x4p; p.w = w; p.bias = bias; p.out = out; p.B = B; p.Hp = Hp; p.Wp = Wp; p.OH = OH; p.OW = OW; p.PH = PH; p.PW = PW;
     p.tiles_y = (PH + 1) / 2;
     p.tiles_x = (PW + 14) / 15;
-    constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES;
+    constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES + 1024;   // (+ the sink of the U8 form)
     OPD_SET_MAX_LDS_ONCE(stem_pool2_kernel<false>, LDS2);
     const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
     hipLaunchKernelGGL(stem_pool2_kernel<false>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);

@@ -81,18 +81,18 @@ hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* b
                                 int OW, int PH, int PW, hipStream_t stream, int dtype = 0);
 // fused bottleneck tail (kernels_btail.hip):  a1 = relu(conv3x3(x1, w1) + b1) ; y = relu(a1*w2 + b2 + res) ; z = relu(y*w3 + b3)
 // x1 [B][H][W][C1] fp16, y/res [M][4*C1], z [M][C3]  (M = B*OH*OW, 3x3 pad 1, stride 1 or 2).  w2p / w3p are the 1x1
-// weights with opd_permute_k32 applied along K.  C3 == 0: no z.  (C1, C3) must satisfy opd_btail_supported.
+// weights: plain K order for C1 = 64 / 128, opd_permute_k32 applied along K for C1 = 256 (kernels_btail3.hip).  C3 == 0: no z.  (C1, C3) must satisfy opd_btail_supported.
 struct BtailParams {
     const f16_t* x1;
     const f16_t* w1;   // [C1][3][3][C1]
     const float* b1;
-    const f16_t* w2p;  // [4*C1][C1], K-permuted
+    const f16_t* w2p;  // [4*C1][C1]
     const float* b2;
     const f16_t* res;  // [M][4*C1] or null
     const f16_t* xs;   // optional fused shortcut (C1 == 64, C3 == 64, stride 1, res == null): its input [M][64] fp16 ...
     const f16_t* wsc;  // ... and its folded 1x1 weights [4*C1][64] (plain K order); b2 then holds b2 + the shortcut's bias
     f16_t* y;          // [M][4*C1]
-    const f16_t* w3p;  // [C3][4*C1], K-permuted (C3 > 0)
+    const f16_t* w3p;  // [C3][4*C1] (C3 > 0)
     const float* b3;
     f16_t* z;          // [M][C3]
     int B, H, W, OH, OW, stride, M, C1, C3;

@@ -746,10 +746,10 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     if (nbk && nbk->c0.wp && nbk->c0.Cin == 4 * C1 && opd_btail_supported(C1, nbk->c0.Cout)) C3 = nbk->c0.Cout;
                     // (a sub-batch pipeline ends with stage 2: its last tail cannot hand z to stage 3 anyway — 256 channels)
                     BtailParams p{}; p.dtype = m->dtype;
-                    p.x1 = x1; p.w1 = b.c1.w; p.b1 = b.c1.bias; p.w2p = b.c2.wp; p.b2 = b.c2.bias; p.res = res; p.y = out;
+                    p.x1 = x1; p.w1 = b.c1.w; p.b1 = b.c1.bias; p.w2p = C1 == 256 ? b.c2.wp : b.c2.w; p.b2 = b.c2.bias; p.res = res; p.y = out;   // (K-permuted copies: stage-3 kernel only)
                     if (sc_in_tail) { p.res = nullptr; p.xs = cur; p.wsc = b.sc.w; p.b2 = b.bias2sc; }
                     f16_t* z = mid(1 - x1_id, (size_t)oh * ow * C3);
-                    if (C3) { p.w3p = nbk->c0.wp; p.b3 = nbk->c0.bias; p.z = z; }
+                    if (C3) { p.w3p = C1 == 256 ? nbk->c0.wp : nbk->c0.w; p.b3 = nbk->c0.bias; p.z = z; }
                     p.B = nb; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = nb * oh * ow; p.C1 = C1; p.C3 = C3;
                     p.rev = m->tail_rev ? (tail_no++ & 1) : 0;
                     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));

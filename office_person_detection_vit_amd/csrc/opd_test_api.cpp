@@ -331,7 +331,7 @@ int opd_test_trace_conv(int B, int H, int W, int Cin, int N, int KH, int stride,
 }
 
 // fused bottleneck tail vs. the caller's reference: x1 [B][H][W][C1], w1 [C1][3][3][C1], w2 [4*C1][C1], w3 [C3][4*C1]
-// (plain K order: the hook applies opd_permute_k32), res [M][4*C1] or null; outputs y [M][4*C1], z [M][C3] (C3 > 0).
+// (plain K order: the hook applies opd_permute_k32 where the kernel wants it), res [M][4*C1] or null; outputs y [M][4*C1], z [M][C3] (C3 > 0).
 int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2,
                    const uint16_t* res, const uint16_t* w3, const float* b3, uint16_t* y, uint16_t* z, int B, int H, int W,
                    int C1, int C3, int stride) {
@@ -340,8 +340,13 @@ int opd_test_btail(const uint16_t* x1, const uint16_t* w1, const float* b1, cons
     const int C2 = 4 * C1, OH = (H - 1) / stride + 1, OW = (W - 1) / stride + 1;
     const size_t M = (size_t)B * OH * OW;
     std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)(C3 ? C3 : 1) * C2);
-    opd_permute_k32(w2, w2p.data(), C2, C1);
-    if (C3) opd_permute_k32(w3, w3p.data(), C3, C2);
+    if (C1 == 256) {   // the stage-3 kernel takes K-permuted 1x1 weights, the stage 1-2 kernel plain ones
+        opd_permute_k32(w2, w2p.data(), C2, C1);
+        if (C3) opd_permute_k32(w3, w3p.data(), C3, C2);
+    } else {
+        w2p.assign(w2, w2 + (size_t)C2 * C1);
+        if (C3) w3p.assign(w3, w3 + (size_t)C3 * C2);
+    }
     BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = dm.up(x1, (size_t)B * H * W * C1);
     p.w1 = dm.up(w1, (size_t)C1 * 9 * C1);
@@ -374,8 +379,13 @@ int opd_test_btail_repeat(const uint16_t* x1, const uint16_t* w1, const float* b
     const int C2 = 4 * C1;
     const size_t M = (size_t)B * H * W;
     std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)C3 * C2);
-    opd_permute_k32(w2, w2p.data(), C2, C1);
-    opd_permute_k32(w3, w3p.data(), C3, C2);
+    if (C1 == 256) {
+        opd_permute_k32(w2, w2p.data(), C2, C1);
+        opd_permute_k32(w3, w3p.data(), C3, C2);
+    } else {
+        w2p.assign(w2, w2 + (size_t)C2 * C1);
+        w3p.assign(w3, w3 + (size_t)C3 * C2);
+    }
     BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = dm.up(x1, M * C1); p.w1 = dm.up(w1, (size_t)C1 * 9 * C1); p.b1 = dm.up(b1, C1); p.w2p = dm.up(w2p.data(), w2p.size());
     p.b2 = dm.up(b2, C2); p.res = dm.up(res, M * C2); p.y = dm.up<uint16_t>(nullptr, M * C2); p.w3p = dm.up(w3p.data(), w3p.size());
@@ -415,8 +425,13 @@ int opd_test_btail_sc(const uint16_t* x1, const uint16_t* w1, const float* b1, c
     const int C1 = 64, C2 = 256, C3 = 64;
     const size_t M = (size_t)B * H * W;
     std::vector<uint16_t> w2p((size_t)C2 * C1), w3p((size_t)C3 * C2);
-    opd_permute_k32(w2, w2p.data(), C2, C1);
-    opd_permute_k32(w3, w3p.data(), C3, C2);
+    if (C1 == 256) {
+        opd_permute_k32(w2, w2p.data(), C2, C1);
+        opd_permute_k32(w3, w3p.data(), C3, C2);
+    } else {
+        w2p.assign(w2, w2 + (size_t)C2 * C1);
+        w3p.assign(w3, w3 + (size_t)C3 * C2);
+    }
     BtailParams p{}; p.dtype = g_test_dtype;
     p.x1 = dm.up(x1, M * C1);
     p.w1 = dm.up(w1, (size_t)C1 * 9 * C1);
