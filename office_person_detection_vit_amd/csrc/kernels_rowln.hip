@@ -292,6 +292,95 @@ __global__ __launch_bounds__(64 * OS_NW, 1) void gemm_ln256_os_kernel(GemmLnPara
 #endif
 }
 
+// Rows of 256 columns held by EIGHT waves in accumulator layout (lane (g, li) of wave w: rows mt * 16 + li, columns (2 w + nt) * 16 + 4 g + r):
+// optional LayerNorm (two-pass fp32 statistics: lanes -> 4 lane groups by shuffles -> 8 waves through `red`), then y32 / y16 / the position
+// shadow yp16 = fp16(y + pos).  Shared by the deep-K ring kernel and the fused encoder FFN.
+struct RowLnOut {
+    const float* gamma; const float* beta;
+    float* y32; f16_t* y16; f16_t* yp16;
+    const float* pos; const float* const* pos_ptrs; int pos_period;
+    int M;
+};
+template <bool LN>
+__device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2][4], float (&red)[2][8][64], const int m_base, const int wave, const int g,
+                                             const int li) {
+    constexpr int NT = 2, RG_NW = 8;
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) sum[mt] += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
+        if constexpr (LN) {
+            sum[mt] += __shfl_xor(sum[mt], 16);
+            sum[mt] += __shfl_xor(sum[mt], 32);
+            if (g == 0) red[0][wave][mt * 16 + li] = sum[mt];
+        }
+    }
+    if constexpr (LN) __syncthreads();
+    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mt = 0; LN && mt < 4; ++mt) {
+        const int r = mt * 16 + li;
+        float mean = 0.f;
+#pragma unroll
+        for (int w = 0; w < RG_NW; ++w) mean += red[0][w][r];
+        mean *= (1.0f / 256.0f);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            acc[nt][mt] -= mean;
+            sq[mt] += acc[nt][mt][0] * acc[nt][mt][0] + acc[nt][mt][1] * acc[nt][mt][1] + acc[nt][mt][2] * acc[nt][mt][2] +
+                      acc[nt][mt][3] * acc[nt][mt][3];
+        }
+        sq[mt] += __shfl_xor(sq[mt], 16);
+        sq[mt] += __shfl_xor(sq[mt], 32);
+        if (g == 0) red[1][wave][r] = sq[mt];
+    }
+    if constexpr (LN) __syncthreads();
+    float4v gm[NT], bt[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        gm[nt] = LN ? *reinterpret_cast<const float4v*>(p.gamma + (wave * NT + nt) * 16 + g * 4) : float4v{1.f, 1.f, 1.f, 1.f};
+        bt[nt] = LN ? *reinterpret_cast<const float4v*>(p.beta + (wave * NT + nt) * 16 + g * 4) : float4v{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int r = mt * 16 + li;
+        const int m = m_base + r;
+        float var = 0.f;
+#pragma unroll
+        for (int w = 0; LN && w < RG_NW; ++w) var += red[1][w][r];
+        var *= (1.0f / 256.0f);
+        const float rstd = LN ? 1.0f / sqrtf(var + 1e-5f) : 1.0f;
+        const float* pos = nullptr;   // second fp16 shadow y + position embedding (encoder: the next layer's q / k projection input)
+        if (p.yp16 && m < p.M) {
+            const int fr = m / p.pos_period, t = m - fr * p.pos_period;
+            pos = (p.pos_ptrs ? p.pos_ptrs[fr] : p.pos) + (size_t)t * 256;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = (wave * NT + nt) * 16 + g * 4;
+            float4v o;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o[q] = LN ? acc[nt][mt][q] * rstd * gm[nt][q] + bt[nt][q] : acc[nt][mt][q];
+            if (m < p.M) {
+                if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
+                if (p.y16) {
+                    half4 h;
+                    h[0] = (elem_t)o[0]; h[1] = (elem_t)o[1]; h[2] = (elem_t)o[2]; h[3] = (elem_t)o[3];
+                    *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
+                }
+                if (pos) {
+                    const float4v pe = *reinterpret_cast<const float4v*>(pos + c);
+                    half4 h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) h[q] = (elem_t)(o[q] + pe[q]);
+                    *reinterpret_cast<half4*>(p.yp16 + (size_t)m * 256 + c) = h;
+                }
+            }
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Deep-K form (encoder FFN-2: K = 2048): row owners again — a workgroup of 64 rows walks the WHOLE reduction and finishes the
 // LayerNorm itself, so the split-K fp32 slabs (34 MB written and re-read per encoder layer at batch 8) and the reduce launch
@@ -316,7 +405,7 @@ template <bool LN>
 __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    __shared__ float red[2][RG_NW][RG_TM];       // [pass][wave][row]
+    __shared__ float red[2][8][64];              // [pass][wave][row]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -393,84 +482,189 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
                 for (int mt = 0; mt < 4; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc[nt][mt]);
         }
     }
-    // ---- + residual, LayerNorm over the 256 columns of each row (as in gemm_ln256_kernel) -----------------------------------
-    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    // ---- + residual, LayerNorm over the 256 columns of each row -------------------------------------------------------------
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[nt][mt] += res[nt][mt];
-            sum[mt] += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
-        }
-        if constexpr (LN) {
-            sum[mt] += __shfl_xor(sum[mt], 16);
-            sum[mt] += __shfl_xor(sum[mt], 32);
-            if (g == 0) red[0][wave][mt * 16 + li] = sum[mt];
-        }
+        for (int nt = 0; nt < NT; ++nt) acc[nt][mt] += res[nt][mt];
+    const RowLnOut o{p.gamma, p.beta, p.y32, p.y16, p.yp16, p.pos, p.pos_ptrs, p.pos_period, p.M};
+    row_ln_store<LN>(o, acc, red, m_base, wave, g, li);
+#endif
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The encoder's feed-forward block in ONE launch:  y = LayerNorm(x32 + relu(x . W1^T + b1) . W2^T + b2)  (+ the fp16 copies)
+// HF:models/detr/modeling_detr.py:646-660 (DetrEncoderLayer: fc1 -> activation -> fc2 -> residual -> final_layer_norm).
+//
+// The two-launch form (fc1 through conv_gemm_dma_kernel, fc2 through the ring kernel above) writes the [M][2048] hidden tensor (34 MB at
+// batch 8) and reads it back, and each launch pulls its whole weight matrix through every workgroup's k-loop with a workgroup barrier per
+// k-step (the ring kernel: ~0.8 us per k-step whatever its width).  Here a workgroup owns 64 rows for BOTH layers: the hidden activations of
+// one 128-wide chunk live in LDS between the two GEMMs and never reach HBM, and the weights travel as in the decoder kernels
+// (kernels_dec.hip): pre-arranged at load in MFMA-fragment order, one contiguous stream per wave (`opd_encffn_pack`), through a
+// WAVE-PRIVATE LDS-DMA ring with counted vmcnt waits -- no barrier in either k-loop, ONE barrier per chunk (the hidden chunk is double
+// buffered).  Per chunk and wave: 17 KiB of weights, 64 MFMAs, 64 fragment reads.
+//   fc1: wave w owns hidden columns 16 w .. 16 w + 15 of the chunk for the slab's four 16-row tiles (accumulators start from the bias, which
+//        travels in the stream as a piece in accumulator layout); ReLU, fp16, into H[chunk & 1];
+//   fc2: wave w owns output columns 32 w .. 32 w + 31 (two tiles) for the four row tiles; 4 k-steps per chunk.
+// LDS: x slab [64][256] (32 KiB) and H [2][64][128] (32 KiB), rows XOR-swizzled by (row & 15) in 16-byte chunks so that the four lane
+// groups of a ds_read_b128 fragment read cover all 64 banks; 8 x 11 KiB of rings: 152 KiB + 4 KiB of LayerNorm scratch.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr int EF_TM = 64;
+constexpr int EF_R = 11;                          // ring slots (1 KiB) per wave
+constexpr int EF_PPC = 17;                        // pieces per chunk and wave: bias, 8 of W1, 8 of W2
+constexpr int EF_X = EF_TM * 512;
+constexpr int EF_H = EF_TM * 256;
+constexpr int EF_RING0 = EF_X + 2 * EF_H;
+constexpr int EF_LDS = EF_RING0 + 8 * EF_R * 1024;
+
+template <int N>
+__device__ __forceinline__ void ef_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+__global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    __shared__ float red[2][8][64];
+    unsigned char* const X = smem;
+    unsigned char* const H = smem + EF_X;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15, lane16 = lane * 16;
+    const int m_base = blockIdx.x * EF_TM;
+    unsigned char* const ring = smem + EF_RING0 + wave * (EF_R * 1024);
+    const int nch = p.F / 128;
+    const unsigned total = (unsigned)nch * EF_PPC * 1024u;             // bytes of this wave's stream
+    const unsigned char* const wsrc = p.wpack + (size_t)wave * total + lane16;
+    auto dma = [&](const unsigned char* src_lane, unsigned char* slot) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
+    };
+    // ---- the slab: rows 8 w .. 8 w + 7 by this wave (1 KiB = two rows; lane -> row, position; the position holds chunk position ^ (row & 15)) --
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int row = 8 * wave + 2 * i + (lane >> 5);
+        const int c16 = (lane & 31) ^ (row & 15);
+        const int grow = m_base + row < p.M ? m_base + row : p.M - 1;     // (rows past the end: a valid address, never stored)
+        dma(reinterpret_cast<const unsigned char*>(p.x) + (size_t)grow * 512 + c16 * 16, X + (8 * wave + 2 * i) * 512);
     }
-    if constexpr (LN) __syncthreads();
-    float sq[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mt = 0; LN && mt < 4; ++mt) {
-        const int r = mt * 16 + li;
-        float mean = 0.f;
+    for (int n = 0; n < EF_R; ++n) dma(wsrc + n * 1024, ring + n * 1024);
+    unsigned noff = EF_R * 1024u;      // stream offset of the next piece to request
+    unsigned slot = 0u;                // ring offset of the next piece to consume
+    auto take = [&]() { const unsigned s_ = slot; slot = slot + 1024u == EF_R * 1024u ? 0u : slot + 1024u; return s_; };
+    // (past the end of the stream the last piece is requested again: the wait counts stay the same for every chunk, nobody reads the slot)
+    auto reissue = [&](const unsigned s_) { dma(wsrc + (noff < total ? noff : total - 1024u), ring + s_); noff += 1024u; };
+    float4v acc2[2][4];
 #pragma unroll
-        for (int w = 0; w < RG_NW; ++w) mean += red[0][w][r];
-        mean *= (1.0f / 256.0f);
+    for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            acc[nt][mt] -= mean;
-            sq[mt] += acc[nt][mt][0] * acc[nt][mt][0] + acc[nt][mt][1] * acc[nt][mt][1] + acc[nt][mt][2] * acc[nt][mt][2] +
-                      acc[nt][mt][3] * acc[nt][mt][3];
-        }
-        sq[mt] += __shfl_xor(sq[mt], 16);
-        sq[mt] += __shfl_xor(sq[mt], 32);
-        if (g == 0) red[1][wave][r] = sq[mt];
-    }
-    if constexpr (LN) __syncthreads();
-    float4v gm[NT], bt[NT];
+        for (int mt = 0; mt < 4; ++mt) acc2[j][mt] = float4v{0.f, 0.f, 0.f, 0.f};
+    const unsigned char* const xrow = X + li * 512;           // + mt * 16 rows; chunk (4 ks + g) ^ li
+    ef_wait_vm<EF_R>();                                       // the four slab pieces are older than the ring's
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        unsigned char* const Hc = H + (c & 1) * EF_H;
+        // ---- hidden chunk = relu(x . W1[chunk]^T + b1): pieces 0 (bias), 1 .. 8 (k-steps) ---------------------------------------
+        float4v acc1[4];
+        unsigned s5[5];
+        ef_wait_vm<EF_R - 5>();
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-        gm[nt] = LN ? *reinterpret_cast<const float4v*>(p.gamma + (wave * NT + nt) * 16 + g * 4) : float4v{1.f, 1.f, 1.f, 1.f};
-        bt[nt] = LN ? *reinterpret_cast<const float4v*>(p.beta + (wave * NT + nt) * 16 + g * 4) : float4v{0.f, 0.f, 0.f, 0.f};
-    }
+        for (int i = 0; i < 5; ++i) s5[i] = take();
+        // (every fragment of a group is requested before its first MFMA -- the scheduler is fenced -- so that the LDS latency is paid once per
+        //  group, with counted lgkmcnt waits, instead of once per MFMA)
+        {
+            const float4v b1 = *reinterpret_cast<const float4v*>(ring + s5[0] + lane16);
+            half8 wf[4], xf[4][4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int r = mt * 16 + li;
-        const int m = m_base + r;
-        float var = 0.f;
+            for (int ks = 0; ks < 4; ++ks) {
+                wf[ks] = *reinterpret_cast<const half8*>(ring + s5[1 + ks] + lane16);
 #pragma unroll
-        for (int w = 0; LN && w < RG_NW; ++w) var += red[1][w][r];
-        var *= (1.0f / 256.0f);
-        const float rstd = LN ? 1.0f / sqrtf(var + 1e-5f) : 1.0f;
-        const float* pos = nullptr;   // second fp16 shadow y + position embedding (encoder: the next layer's q / k projection input)
-        if (p.yp16 && m < p.M) {
-            const int fr = m / p.pos_period, t = m - fr * p.pos_period;
-            pos = (p.pos_ptrs ? p.pos_ptrs[fr] : p.pos) + (size_t)t * 256;
-        }
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const int c = (wave * NT + nt) * 16 + g * 4;
-            float4v o;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) o[q] = LN ? acc[nt][mt][q] * rstd * gm[nt][q] + bt[nt][q] : acc[nt][mt][q];
-            if (m < p.M) {
-                if (p.y32) *reinterpret_cast<float4v*>(p.y32 + (size_t)m * 256 + c) = o;
-                if (p.y16) {
-                    half4 h;
-                    h[0] = (elem_t)o[0]; h[1] = (elem_t)o[1]; h[2] = (elem_t)o[2]; h[3] = (elem_t)o[3];
-                    *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
-                }
-                if (pos) {
-                    const float4v pe = *reinterpret_cast<const float4v*>(pos + c);
-                    half4 h;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) h[q] = (elem_t)(o[q] + pe[q]);
-                    *reinterpret_cast<half4*>(p.yp16 + (size_t)m * 256 + c) = h;
-                }
+                for (int mt = 0; mt < 4; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(xrow + mt * (16 * 512) + (((ks * 4 + g) ^ li) << 4));
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc1[mt] = b1;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc1[mt] = OPD_MFMA_16x16x32(wf[ks], xf[ks][mt], acc1[mt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 5; ++i) reissue(s5[i]);
+        unsigned s4[4];
+        ef_wait_vm<EF_R - 4>();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s4[i] = take();
+        {
+            half8 wf[4], xf[4][4];
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                wf[ks] = *reinterpret_cast<const half8*>(ring + s4[ks] + lane16);
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(xrow + mt * (16 * 512) + ((((ks + 4) * 4 + g) ^ li) << 4));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt) acc1[mt] = OPD_MFMA_16x16x32(wf[ks], xf[ks][mt], acc1[mt]);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < 4; ++i) reissue(s4[i]);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {   // rows mt * 16 + li, hidden columns 16 w + 4 g .. + 3 of the chunk
+            half4 h;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h[r] = (elem_t)(acc1[mt][r] > 0.f ? acc1[mt][r] : 0.f);
+            *reinterpret_cast<half4*>(Hc + (mt * 16 + li) * 256 + (((2 * wave + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = h;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();      // the chunk is complete; (its buffer was last read two chunks ago: every wave has passed a barrier since)
+        // ---- acc2 += hidden chunk . W2[:, chunk]^T: pieces 9 .. 16 = (k-step i, tile j) at 9 + 2 i + j -----------------------------
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            ef_wait_vm<EF_R - 4>();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s4[i] = take();
+            half8 hfr[2][4], wf[4];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    hfr[i][mt] = *reinterpret_cast<const half8*>(Hc + (mt * 16 + li) * 256 + ((((2 * hf + i) * 4 + g) ^ li) << 4));
+#pragma unroll
+                for (int j = 0; j < 2; ++j) wf[2 * i + j] = *reinterpret_cast<const half8*>(ring + s4[2 * i + j] + lane16);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < 4; ++mt) acc2[j][mt] = OPD_MFMA_16x16x32(wf[2 * i + j], hfr[i][mt], acc2[j][mt]);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+            for (int i = 0; i < 4; ++i) reissue(s4[i]);
         }
     }
+    ef_wait_vm<0>();   // (the pieces requested past the end of the stream: no LDS-DMA may be in flight when the workgroup ends)
+    // ---- + b2 + residual, LayerNorm, outputs -----------------------------------------------------------------------------------
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int cidx = (2 * wave + j) * 16 + 4 * g;
+        const float4v b2 = *reinterpret_cast<const float4v*>(p.b2 + cidx);
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            const int m = m_base + mt * 16 + li;
+            float4v r = float4v{0.f, 0.f, 0.f, 0.f};
+            if (p.res32 && m < p.M) r = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + cidx);
+            acc2[j][mt] += b2 + r;
+        }
+    }
+    const RowLnOut o{p.gamma, p.beta, p.y32, p.y16, p.yp16, p.pos, p.pos_ptrs, p.pos_period, p.M};
+    row_ln_store<true>(o, acc2, red, m_base, wave, g, li);
 #endif
 }
 
@@ -498,6 +692,39 @@ hipError_t OPD_SYM(opd_launch_gemm_ln)(const GemmLnParams& p, hipStream_t stream
     hipLaunchKernelGGL(gemm_ln256_kernel, dim3((p.M + TM - 1) / TM), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
+
+hipError_t OPD_SYM(opd_launch_enc_ffn)(const EncFfnParams& p, hipStream_t stream) {
+    if (p.M <= 0 || p.F <= 0 || p.F % 128 != 0 || !p.x || !p.wpack || !p.b2 || !p.gamma || !p.beta) return hipErrorInvalidValue;
+    if (p.yp16 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
+    if ((size_t)(p.F / 128) * EF_PPC * 1024 >= 0x7fffff00ull) return hipErrorInvalidValue;   // 32-bit stream offsets
+    OPD_SET_MAX_LDS_ONCE(enc_ffn_kernel, EF_LDS);
+    hipLaunchKernelGGL(enc_ffn_kernel, dim3((p.M + EF_TM - 1) / EF_TM), dim3(512), EF_LDS, stream, p);
+    return hipGetLastError();
+}
+
+#ifndef OPD_ELEM_BF16   // (a permutation of 16-bit words and fp32 biases: the same for both element types)
+size_t opd_encffn_pack_bytes(int F) { return (size_t)8 * (F / 128) * EF_PPC * 1024; }
+// host: w1 [F][256], w2 [256][F] as 16-bit elements (fp16 or bf16), b1 [F] fp32 -> the eight per-wave streams of enc_ffn_kernel.  Stream of
+// wave w = chunks c = 0 .. F / 128 - 1, each 17 KiB: the bias piece (lane L = 16 g + li: b1[128 c + 16 w + 4 g .. + 3] as fp32), the 8 k-steps
+// of W1's tile (lane L: w1[128 c + 16 w + li][32 ks + 8 g .. + 7]), then W2's k-steps i = 0 .. 3 of the chunk for the wave's tiles j = 0, 1 at
+// 9 + 2 i + j (lane L: w2[(2 w + j) 16 + li][128 c + 32 i + 8 g .. + 7]).
+void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, unsigned char* out) {
+    const int nch = F / 128;
+    for (int w = 0; w < 8; ++w)
+        for (int c = 0; c < nch; ++c) {
+            unsigned char* base = out + ((size_t)(w * nch + c) * EF_PPC) * 1024;
+            for (int L = 0; L < 64; ++L) {
+                const int g = L >> 4, li = L & 15;
+                __builtin_memcpy(base + L * 16, b1 + 128 * c + 16 * w + 4 * g, 16);
+                for (int ks = 0; ks < 8; ++ks)
+                    __builtin_memcpy(base + (1 + ks) * 1024 + L * 16, w1 + (size_t)(128 * c + 16 * w + li) * 256 + 32 * ks + 8 * g, 16);
+                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < 2; ++j)
+                        __builtin_memcpy(base + (9 + 2 * i + j) * 1024 + L * 16, w2 + (size_t)((2 * w + j) * 16 + li) * F + 128 * c + 32 * i + 8 * g, 16);
+            }
+        }
+}
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Small-M linear layers of the decoder (M = batch x 100 queries): out = act(x[:, k0:k0+256] . W[:, k0:k0+256]^T + bias).

@@ -16,6 +16,7 @@ hipError_t opd_launch_stem_pool(const f16_t* x4p, const f16_t* w, const float* b
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t s) { return OPD_PICK(opd_launch_btail, p.dtype, p, s); }
 hipError_t opd_launch_btail256(const BtailParams& p, hipStream_t s) { return OPD_PICK(opd_launch_btail256, p.dtype, p, s); }
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t s) { return OPD_PICK(opd_launch_gemm_ln, p.dtype, p, s); }
+hipError_t opd_launch_enc_ffn(const EncFfnParams& p, hipStream_t s) { return OPD_PICK(opd_launch_enc_ffn, p.dtype, p, s); }
 hipError_t opd_launch_gemm_k256(const GemmK256Params& p, hipStream_t s) { return OPD_PICK(opd_launch_gemm_k256, p.dtype, p, s); }
 hipError_t opd_launch_attention(const AttnParams& p, hipStream_t s) { return OPD_PICK(opd_launch_attention, p.dtype, p, s); }
 hipError_t opd_launch_attention_map(const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,

@@ -133,6 +133,28 @@ struct GemmLnParams {
     int dtype;           // OPD_DT_F16 / OPD_DT_BF16: x, w, y16, yp16
 };
 hipError_t opd_launch_gemm_ln(const GemmLnParams& p, hipStream_t stream);
+// The encoder's FFN block in one launch (kernels_rowln.hip::enc_ffn_kernel): y = LayerNorm(res32 + relu(x . W1^T + b1) . W2^T + b2) over rows
+// of 256; wpack = opd_encffn_pack(W1, b1, W2): the weights in MFMA-fragment order as eight per-wave streams.  Outputs as GemmLnParams' deep_k
+// form (y32 may alias res32, y16 may alias x: a workgroup reads its own rows before it writes them).
+struct EncFfnParams {
+    const f16_t* x;               // [M][256]
+    const unsigned char* wpack;   // opd_encffn_pack_bytes(F)
+    const float* b2;              // [256]
+    const float* res32;           // [M][256] or null
+    const float* gamma;           // [256]
+    const float* beta;
+    float* y32;
+    f16_t* y16;
+    f16_t* yp16;                  // optional fp16(y + pos[row % pos_period])
+    const float* pos;
+    const float* const* pos_ptrs;
+    int pos_period;
+    int M, F;                     // F % 128 == 0
+    int dtype;
+};
+hipError_t opd_launch_enc_ffn(const EncFfnParams& p, hipStream_t stream);
+size_t opd_encffn_pack_bytes(int F);
+void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, unsigned char* out);   // host
 // Small-M linear layer, reduction cut into 256-wide slices: slice z computes x[:, 256z : 256z+256] . w[:, 256z : 256z+256]^T.
 // slices == 1: out = act(. + bias) as fp16 (out16) or fp32 (out32).  slices > 1: fp32 slabs out32[z][M][N], bias in slab 0
 // (summed by opd_launch_reduce_ln).  bias_period > 0: row-periodic bias [period][N].
@@ -319,6 +341,7 @@ OPD_DECL_ELEM(opd_launch_stem_pool, const f16_t* x4p, const f16_t* w, const floa
 OPD_DECL_ELEM(opd_launch_btail, const BtailParams& p, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_btail256, const BtailParams& p, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_gemm_ln, const GemmLnParams& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_enc_ffn, const EncFfnParams& p, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_gemm_k256, const GemmK256Params& p, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_attention, const AttnParams& p, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_attention_map, const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,

@@ -45,6 +45,19 @@ static int upload_frag(opd_detr* m, f16_t** dst, const std::vector<float>& v, in
 
 static const HostTensor& T(const StateDict& sd, const std::string& k) { return sd.at(k); }
 
+// the encoder FFN's weights as enc_ffn_kernel's per-wave fragment streams, in the handle's 16-bit operand type
+static int upload_encffn(opd_detr* m, unsigned char** dst, const std::vector<float>& w1, const std::vector<float>& b1, const std::vector<float>& w2, int F) {
+    std::vector<uint16_t> h1(w1.size()), h2(w2.size());
+    const bool bf = m->dtype == OPD_DT_BF16;
+    for (size_t i = 0; i < w1.size(); ++i) h1[i] = bf ? f32_to_bf16(w1[i]) : f32_to_f16(w1[i]);
+    for (size_t i = 0; i < w2.size(); ++i) h2[i] = bf ? f32_to_bf16(w2[i]) : f32_to_f16(w2[i]);
+    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F));
+    opd_encffn_pack(h1.data(), b1.data(), h2.data(), F, pk.data());
+    RCCHK(dalloc(m, dst, pk.size(), true));
+    HIPCHK(hipMemcpy(*dst, pk.data(), pk.size(), hipMemcpyHostToDevice));
+    return OPD_OK;
+}
+
 // conv + FrozenBN -> folded fp16 [Cout][KH][KW][Cin] + fp32 bias (HF:models/detr/modeling_detr.py:207-215)
 static int make_conv(opd_detr* m, const StateDict& sd, const std::string& prefix, int stride, Conv* c) {
     const HostTensor& w = T(sd, prefix + ".convolution.weight");
@@ -189,6 +202,8 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln2));
+        if (a.d_model == 256 && a.ffn % 128 == 0)
+            RCCHK(upload_encffn(m, &L.ffn_pack, T(sd, p + ".mlp.fc1.weight").data, T(sd, p + ".mlp.fc1.bias").data, T(sd, p + ".mlp.fc2.weight").data, a.ffn));
     }
     // decoder: query-position folds are resolution independent -> build them now with the fp32 plan GEMM
     float* d_qpos = nullptr;
@@ -889,7 +904,17 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream, m->dtype));
             RCCHK(timed_end(m));
         }
-        {
+        if (m->fused_enc_ffn && m->fuse_gemm_ln && L.ffn_pack && D == 256) {
+            // the whole FFN block as ONE row-owner launch: the [M][F] hidden tensor never leaves LDS (kernels_rowln.hip::enc_ffn_kernel)
+            EncFfnParams fp{}; fp.dtype = m->dtype;
+            fp.x = m->d_x16; fp.wpack = L.ffn_pack; fp.b2 = L.fc2.b; fp.res32 = m->d_x32; fp.gamma = L.ln2.g; fp.beta = L.ln2.b;
+            fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F;
+            if (ps) { fp.pos = ps->pos; fp.pos_ptrs = ps->pos_ptrs; fp.pos_period = ps->period; fp.yp16 = ps->yp16; }
+            RCCHK(timed_begin(m, CLS_GEMM, 4.0 * M * (double)D * F));
+            HIPCHK(opd_launch_enc_ffn(fp, m->stream));
+            RCCHK(timed_end(m));
+            RCCHK(tap(m, "enc_ffn", m->d_x32, (size_t)M * D * 4));
+        } else {
             RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
             // fc2 + residual + LayerNorm (+ the position shadow) as ONE row-owner launch of the three-stage ring kernel: 36.9 us in the
             // forward against 19.4 + 12.2 us for split-K slabs + reduce, but 514 MB less HBM traffic per forward and half the CUs left to
@@ -1296,6 +1321,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_DEEP_FC2")) m->deep_fc2 = atoi(v);
     if (const char* v = getenv("OPD_WROUND")) m->wround = atoi(v);
     if (const char* v = getenv("OPD_FUSED_DEC")) m->fused_dec = atoi(v);
+    if (const char* v = getenv("OPD_FUSED_ENC_FFN")) m->fused_enc_ffn = atoi(v);
     if (const char* v = getenv("OPD_DBG_DEC_LAYERS")) m->dbg_dec_layers = atoi(v);   // timing ablation (tools/dec_cost.sh): results are wrong
     m->device = device_ordinal;
     int ndev = 0;
@@ -1341,7 +1367,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
-    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
+    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());

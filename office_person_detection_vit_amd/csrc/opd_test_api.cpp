@@ -221,6 +221,64 @@ int opd_test_bench_gemm_ln(int M, int K, int deep, int iters, float* us_out) {
     return OPD_OK;
 }
 
+// the encoder's FFN block in one launch (enc_ffn_kernel): x [M][256], w1 [F][256], w2 [256][F] as 16-bit elements of the current test element
+// type, b1 [F], b2 / gamma / beta [256], res32 [M][256]; y = LayerNorm(res32 + relu(x . w1^T + b1) . w2^T + b2); optional position shadow as in
+// opd_test_gemm_ln_deep.  in_place: y32 aliases res32 and y16 aliases x, as in the model.
+int opd_test_enc_ffn(const uint16_t* x, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* res32, const float* gamma,
+                     const float* beta, const float* pos, int period, float* y, uint16_t* y16, uint16_t* yp16, int M, int F, int in_place) {
+    if (M <= 0 || F <= 0 || F % 128) return tfail(OPD_EINVAL, "enc_ffn: F must be a multiple of 128");
+    DevMem dm;
+    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F));
+    opd_encffn_pack(w1, b1, w2, F, pk.data());
+    EncFfnParams p{}; p.dtype = g_test_dtype;
+    uint16_t* dx = dm.up(x, (size_t)M * 256);
+    float* res = dm.up(res32, (size_t)M * 256);
+    p.x = dx; p.wpack = dm.up(pk.data(), pk.size()); p.b2 = dm.up(b2, 256); p.res32 = res; p.gamma = dm.up(gamma, 256); p.beta = dm.up(beta, 256);
+    p.y32 = in_place ? res : dm.up<float>(nullptr, (size_t)M * 256);
+    p.y16 = in_place ? dx : dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    p.pos = pos ? dm.up(pos, (size_t)period * 256) : nullptr;
+    p.pos_period = period;
+    p.yp16 = pos ? dm.up<uint16_t>(nullptr, (size_t)M * 256) : nullptr;
+    if (!p.x || !p.wpack || !p.b2 || !p.res32 || !p.gamma || !p.beta || !p.y32 || !p.y16 || (pos && (!p.pos || !p.yp16))) return tfail(OPD_ENOMEM, "test alloc failed");
+    p.M = M; p.F = F;
+    TCHK(opd_launch_enc_ffn(p, nullptr));
+    TCHK(hipDeviceSynchronize());
+    TCHK(hipMemcpy(y, p.y32, (size_t)M * 256 * 4, hipMemcpyDeviceToHost));
+    TCHK(hipMemcpy(y16, p.y16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
+    if (pos) TCHK(hipMemcpy(yp16, p.yp16, (size_t)M * 256 * 2, hipMemcpyDeviceToHost));
+    return OPD_OK;
+}
+
+// Times `iters` launches of the fused encoder FFN on M rows of arbitrary data.
+int opd_test_bench_enc_ffn(int M, int F, int iters, float* us_out) {
+    if (M <= 0 || F <= 0 || F % 128) return tfail(OPD_EINVAL, "bench_enc_ffn: F must be a multiple of 128");
+    DevMem dm;
+    EncFfnParams p{}; p.dtype = g_test_dtype;
+    uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    unsigned char* wp = dm.up<unsigned char>(nullptr, opd_encffn_pack_bytes(F));
+    float* f = dm.up<float>(nullptr, 1024);
+    float* res = dm.up<float>(nullptr, (size_t)M * 256);
+    uint16_t* y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    if (!x || !wp || !f || !res || !y16) return tfail(OPD_ENOMEM, "bench alloc failed");
+    TCHK(hipMemset(x, 0x2c, (size_t)M * 256 * 2));
+    TCHK(hipMemset(wp, 0x1c, opd_encffn_pack_bytes(F)));
+    TCHK(hipMemset(f, 0, 4096));
+    TCHK(hipMemset(res, 0, (size_t)M * 256 * 4));
+    p.x = x; p.wpack = wp; p.b2 = f; p.gamma = f + 256; p.beta = f + 512; p.res32 = res; p.y32 = res; p.y16 = y16; p.M = M; p.F = F;
+    hipEvent_t a, b;
+    TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) TCHK(opd_launch_enc_ffn(p, nullptr));
+    TCHK(hipEventRecord(a, nullptr));
+    for (int i = 0; i < iters; ++i) TCHK(opd_launch_enc_ffn(p, nullptr));
+    TCHK(hipEventRecord(b, nullptr));
+    TCHK(hipEventSynchronize(b));
+    float ms = 0.f;
+    TCHK(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *us_out = ms * 1000.f / iters;
+    return OPD_OK;
+}
+
 int opd_test_gemm_k256(const uint16_t* x, const uint16_t* w, const float* bias, uint16_t* out16, float* out32, int M, int N,
                        int K, int bias_period, int relu) {
     DevMem dm;

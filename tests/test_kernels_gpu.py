@@ -697,6 +697,41 @@ def test_gemm_ln_deep_matches_torch(lib, M, K, period, in_place, ln):
         np.testing.assert_array_equal(yp16.view(np.float16), wantp)
 
 
+@pytest.mark.parametrize("M,FF,period,in_place", [(8400, 2048, 1050, True), (100, 2048, 0, False), (333, 256, 111, True), (64, 128, 0, False),
+                                                  (1, 384, 0, True), (130, 1024, 13, False)])
+def test_enc_ffn_matches_torch(lib, M, FF, period, in_place):
+    """The encoder's FFN block in one launch (kernels_rowln.hip::enc_ffn_kernel): y = LN(res + fp16(relu(x W1^T + b1)) W2^T + b2) with the hidden
+    chunk in LDS, weights as per-wave fragment streams through wave-private LDS-DMA rings; in place on the residual stream / the fp16 copy as in
+    the model, position shadow, 1 .. 16 hidden chunks, ragged last slab.  Reference: double precision on the same fp16 operands with the hidden
+    activations rounded to fp16 once (what the two-launch form stores)."""
+    rng = np.random.default_rng(M * 7 + FF)
+    x, xb = _h(rng.standard_normal((M, 256)))
+    w1, w1b = _h(rng.standard_normal((FF, 256)) / 16.0)
+    w2, w2b = _h(rng.standard_normal((256, FF)) / np.sqrt(FF))
+    b1 = (rng.standard_normal(FF) * 0.3).astype(np.float32)
+    b2 = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    res = rng.standard_normal((M, 256)).astype(np.float32)
+    gamma = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    pos = rng.standard_normal((period, 256)).astype(np.float32) if period else None
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    yp16 = np.empty((M, 256), np.uint16)
+    _capi.check(lib.opd_test_enc_ffn(_p(xb), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(res), _p(gamma), _p(beta), _p(pos), period, _p(y), _p(y16), _p(yp16),
+                                     M, FF, int(in_place)), "opd_test_enc_ffn")
+    hid = torch.relu(torch.from_numpy(x).double() @ torch.from_numpy(w1).double().T + torch.from_numpy(b1).double())
+    hid = hid.float().half().double()                      # fp32 accumulate -> one fp16 rounding
+    pre = hid @ torch.from_numpy(w2).double().T + torch.from_numpy(b2).double() + torch.from_numpy(res).double()
+    want = F.layer_norm(pre, (256,), torch.from_numpy(gamma).double(), torch.from_numpy(beta).double(), 1e-5).float().numpy()
+    # (a hidden value whose fp32 sum lands next to an fp16 rounding boundary may round the other way than the double-precision reference:
+    #  2^-11 relative on one of FF terms)
+    np.testing.assert_allclose(y, want, atol=2e-4, rtol=1e-5)
+    np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), y, atol=2e-3, rtol=1e-3)
+    if period:
+        wantp = (y + pos[np.arange(M) % period]).astype(np.float16)
+        np.testing.assert_array_equal(yp16.view(np.float16), wantp)
+
+
 # ---- one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel) -------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,period,relu", [(800, 768, 256, 100, False), (800, 256, 256, 100, False), (800, 2048, 256, 0, True),
                                                (800, 256, 2048, 0, False), (37, 64, 256, 0, True), (130, 256, 512, 0, False)])
