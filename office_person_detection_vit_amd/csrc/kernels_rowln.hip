@@ -301,13 +301,13 @@ struct RowLnOut {
     const float* pos; const float* const* pos_ptrs; int pos_period;
     int M;
 };
-template <bool LN>
-__device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2][4], float (&red)[2][8][64], const int m_base, const int wave, const int g,
+template <bool LN, int MT = 4>
+__device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2][MT], float (&red)[2][8][16 * MT], const int m_base, const int wave, const int g,
                                              const int li) {
     constexpr int NT = 2, RG_NW = 8;
-    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+    float sum[MT] = {};
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) sum[mt] += acc[nt][mt][0] + acc[nt][mt][1] + acc[nt][mt][2] + acc[nt][mt][3];
         if constexpr (LN) {
@@ -317,9 +317,9 @@ __device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2
         }
     }
     if constexpr (LN) __syncthreads();
-    float sq[4] = {0.f, 0.f, 0.f, 0.f};
+    float sq[MT] = {};
 #pragma unroll
-    for (int mt = 0; LN && mt < 4; ++mt) {
+    for (int mt = 0; LN && mt < MT; ++mt) {
         const int r = mt * 16 + li;
         float mean = 0.f;
 #pragma unroll
@@ -343,7 +343,7 @@ __device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2
         bt[nt] = LN ? *reinterpret_cast<const float4v*>(p.beta + (wave * NT + nt) * 16 + g * 4) : float4v{0.f, 0.f, 0.f, 0.f};
     }
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         const int r = mt * 16 + li;
         const int m = m_base + r;
         float var = 0.f;
@@ -499,32 +499,52 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
 //
 // The two-launch form (fc1 through conv_gemm_dma_kernel, fc2 through the ring kernel above) writes the [M][2048] hidden tensor (34 MB at
 // batch 8) and reads it back, and each launch pulls its whole weight matrix through every workgroup's k-loop with a workgroup barrier per
-// k-step (the ring kernel: ~0.8 us per k-step whatever its width).  Here a workgroup owns 64 rows for BOTH layers: the hidden activations of
-// one 128-wide chunk live in LDS between the two GEMMs and never reach HBM, and the weights travel as in the decoder kernels
-// (kernels_dec.hip): pre-arranged at load in MFMA-fragment order, one contiguous stream per wave (`opd_encffn_pack`), through a
-// WAVE-PRIVATE LDS-DMA ring with counted vmcnt waits -- no barrier in either k-loop, ONE barrier per chunk (the hidden chunk is double
-// buffered).  Per chunk and wave: 17 KiB of weights, 64 MFMAs, 64 fragment reads.
-//   fc1: wave w owns hidden columns 16 w .. 16 w + 15 of the chunk for the slab's four 16-row tiles (accumulators start from the bias, which
+// k-step (the ring kernel: ~0.8 us per k-step whatever its width).  Here a workgroup owns 48 rows for BOTH layers (M = 8400: 175 workgroups,
+// one round): the hidden activations of one 128-wide chunk live in LDS between the two GEMMs and never reach HBM, the slab's own 24 x-fragments
+// per lane stay in REGISTERS for all 16 chunks, and the weights travel as in the decoder kernels (kernels_dec.hip): pre-arranged at load in
+// MFMA-fragment order, one contiguous stream per wave (`opd_encffn_pack`), through a WAVE-PRIVATE LDS-DMA ring with counted vmcnt waits -- no
+// barrier in either k-loop, ONE barrier per chunk.
+//   fc1: wave w owns hidden columns 16 w .. 16 w + 15 of the chunk for the slab's three 16-row tiles (accumulators start from the bias, which
 //        travels in the stream as a piece in accumulator layout); ReLU, fp16, into H[chunk & 1];
-//   fc2: wave w owns output columns 32 w .. 32 w + 31 (two tiles) for the four row tiles; 4 k-steps per chunk.
-// LDS: x slab [64][256] (32 KiB) and H [2][64][128] (32 KiB), rows XOR-swizzled by (row & 15) in 16-byte chunks so that the four lane
-// groups of a ds_read_b128 fragment read cover all 64 banks; 8 x 11 KiB of rings: 152 KiB + 4 KiB of LayerNorm scratch.
+//   fc2: wave w owns output columns 32 w .. 32 w + 31 (two tiles) for the three row tiles; 4 k-steps per chunk.
+// A wave's work is cut into GROUPS of 4-5 pieces (G0: bias + W1 k-steps 0-3, G1: W1 k-steps 4-7, G2 / G3: W2 k-steps 0-1 / 2-3 of both tiles).
+// The first form ran wait -> fragment reads -> MFMAs -> re-request per group and took the SUM of the three resources' times (41 us: LDS reads,
+// MFMAs and LDS-DMA issue are ~14 us each); this form is skewed and software pipelined:
+//   * fc1 runs one chunk AHEAD of fc2 (H is double buffered), so the barrier that publishes a hidden chunk is a whole iteration away from
+//     the reads that need it;
+//   * the fragment reads of group k + 1 (into a second register set) are issued BEFORE the MFMAs of group k and its slots are re-requested
+//     right after, so LDS latency and LDS-DMA issue of one wave overlap its own MFMAs and those of the SIMD's other wave.
+// Stream order = consumption order: G0(0) G1(0) G0(1) { G1(c+1) G2(c) G3(c) G0(c+2) } for c = 0 .. F/128 - 1, with zero blocks for the fc1
+// chunks past the end (one hidden chunk is computed in vain; every wait count is the same in every iteration).
+// LDS: x slab [48][256] (24 KiB, read once) and H [2][48][128] (24 KiB), rows XOR-swizzled by (row & 15) in 16-byte chunks so that the four
+// lane groups of a ds_read_b128 fragment read cover all 64 banks; 8 x 13 KiB of rings: 152 KiB + 3 KiB of LayerNorm scratch.
 // ---------------------------------------------------------------------------------------------------------------------
-constexpr int EF_TM = 64;
-constexpr int EF_R = 11;                          // ring slots (1 KiB) per wave
-constexpr int EF_PPC = 17;                        // pieces per chunk and wave: bias, 8 of W1, 8 of W2
+constexpr int EF_MT = 3;
+constexpr int EF_TM = 16 * EF_MT;
+constexpr int EF_R = 13;                          // ring slots (1 KiB) per wave
 constexpr int EF_X = EF_TM * 512;
 constexpr int EF_H = EF_TM * 256;
 constexpr int EF_RING0 = EF_X + 2 * EF_H;
 constexpr int EF_LDS = EF_RING0 + 8 * EF_R * 1024;
+constexpr int EF_PIECES(const int nch) { return 14 + 17 * nch; }   // per wave
 
 template <int N>
 __device__ __forceinline__ void ef_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+#define EF_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define EF_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
+struct EfFrags {
+    float4v b;
+    half8 w[4];
+    half8 h[2][EF_MT];
+};
+
+template <int DBG>   // DBG: timing ablations of tools/bench_enc_ffn.py (compile-time: 0 in the model): 1 no MFMAs, 2 no re-requests, 4 no hidden-chunk traffic, 8 no barriers
 __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    __shared__ float red[2][8][64];
+    __shared__ float red[2][8][EF_TM];
+    constexpr int MT = EF_MT;
     unsigned char* const X = smem;
     unsigned char* const H = smem + EF_X;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -533,121 +553,136 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
     const int m_base = blockIdx.x * EF_TM;
     unsigned char* const ring = smem + EF_RING0 + wave * (EF_R * 1024);
     const int nch = p.F / 128;
-    const unsigned total = (unsigned)nch * EF_PPC * 1024u;             // bytes of this wave's stream
+    const unsigned total = (unsigned)EF_PIECES(nch) * 1024u;             // bytes of this wave's stream
     const unsigned char* const wsrc = p.wpack + (size_t)wave * total + lane16;
     auto dma = [&](const unsigned char* src_lane, unsigned char* slot) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
     };
-    // ---- the slab: rows 8 w .. 8 w + 7 by this wave (1 KiB = two rows; lane -> row, position; the position holds chunk position ^ (row & 15)) --
+    // ---- the slab: rows 2 MT w .. + 2 MT - 1 by this wave (1 KiB = two rows; lane -> row, position; the position holds chunk position ^ (row & 15))
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int row = 8 * wave + 2 * i + (lane >> 5);
+    for (int i = 0; i < MT; ++i) {
+        const int row = 2 * MT * wave + 2 * i + (lane >> 5);
         const int c16 = (lane & 31) ^ (row & 15);
         const int grow = m_base + row < p.M ? m_base + row : p.M - 1;     // (rows past the end: a valid address, never stored)
-        dma(reinterpret_cast<const unsigned char*>(p.x) + (size_t)grow * 512 + c16 * 16, X + (8 * wave + 2 * i) * 512);
+        dma(reinterpret_cast<const unsigned char*>(p.x) + (size_t)grow * 512 + c16 * 16, X + (2 * MT * wave + 2 * i) * 512);
     }
 #pragma unroll
     for (int n = 0; n < EF_R; ++n) dma(wsrc + n * 1024, ring + n * 1024);
     unsigned noff = EF_R * 1024u;      // stream offset of the next piece to request
     unsigned slot = 0u;                // ring offset of the next piece to consume
     auto take = [&]() { const unsigned s_ = slot; slot = slot + 1024u == EF_R * 1024u ? 0u : slot + 1024u; return s_; };
-    // (past the end of the stream the last piece is requested again: the wait counts stay the same for every chunk, nobody reads the slot)
-    auto reissue = [&](const unsigned s_) { dma(wsrc + (noff < total ? noff : total - 1024u), ring + s_); noff += 1024u; };
-    float4v acc2[2][4];
+    // (past the end of the stream the last piece is requested again: the wait counts stay the same in every iteration, nobody reads the slot)
+    constexpr int dbg = DBG;
+    auto reissue = [&](const unsigned s_) { if constexpr (!(dbg & 2)) dma(wsrc + (noff < total ? noff : total - 1024u), ring + s_); noff += 1024u; };
+    auto frag = [&](const unsigned s_) { return *reinterpret_cast<const half8*>(ring + s_ + lane16); };
+    float4v acc1[MT], acc2[2][MT];
 #pragma unroll
     for (int j = 0; j < 2; ++j)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc2[j][mt] = float4v{0.f, 0.f, 0.f, 0.f};
-    const unsigned char* const xrow = X + li * 512;           // + mt * 16 rows; chunk (4 ks + g) ^ li
-    ef_wait_vm<EF_R>();                                       // the four slab pieces are older than the ring's
+        for (int mt = 0; mt < MT; ++mt) acc2[j][mt] = float4v{0.f, 0.f, 0.f, 0.f};
+    ef_wait_vm<EF_R>();                                       // the slab pieces are older than the ring's
     __builtin_amdgcn_s_barrier();
-#pragma unroll 1
-    for (int c = 0; c < nch; ++c) {
-        unsigned char* const Hc = H + (c & 1) * EF_H;
-        // ---- hidden chunk = relu(x . W1[chunk]^T + b1): pieces 0 (bias), 1 .. 8 (k-steps) ---------------------------------------
-        float4v acc1[4];
-        unsigned s5[5];
-        ef_wait_vm<EF_R - 5>();
+    half8 xf[8][MT];                                          // this lane's B fragments of the slab: rows mt * 16 + li, k = 32 ks + 8 g .. + 7
 #pragma unroll
-        for (int i = 0; i < 5; ++i) s5[i] = take();
-        // (every fragment of a group is requested before its first MFMA -- the scheduler is fenced -- so that the LDS latency is paid once per
-        //  group, with counted lgkmcnt waits, instead of once per MFMA)
-        {
-            const float4v b1 = *reinterpret_cast<const float4v*>(ring + s5[0] + lane16);
-            half8 wf[4], xf[4][4];
+    for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wf[ks] = *reinterpret_cast<const half8*>(ring + s5[1 + ks] + lane16);
+        for (int mt = 0; mt < MT; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(X + (mt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+    // hidden chunk in registers -> H buffer: rows mt * 16 + li, hidden columns 16 w + 4 g .. + 3 of the chunk
+    auto write_h = [&](unsigned char* Hw) {
+        if constexpr (dbg & 4) return;
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(xrow + mt * (16 * 512) + (((ks * 4 + g) ^ li) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc1[mt] = b1;
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc1[mt] = OPD_MFMA_16x16x32(wf[ks], xf[ks][mt], acc1[mt]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 5; ++i) reissue(s5[i]);
-        unsigned s4[4];
-        ef_wait_vm<EF_R - 4>();
-#pragma unroll
-        for (int i = 0; i < 4; ++i) s4[i] = take();
-        {
-            half8 wf[4], xf[4][4];
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                wf[ks] = *reinterpret_cast<const half8*>(ring + s4[ks] + lane16);
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(xrow + mt * (16 * 512) + ((((ks + 4) * 4 + g) ^ li) << 4));
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks)
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt) acc1[mt] = OPD_MFMA_16x16x32(wf[ks], xf[ks][mt], acc1[mt]);
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-        for (int i = 0; i < 4; ++i) reissue(s4[i]);
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {   // rows mt * 16 + li, hidden columns 16 w + 4 g .. + 3 of the chunk
+        for (int mt = 0; mt < MT; ++mt) {
             half4 h;
 #pragma unroll
             for (int r = 0; r < 4; ++r) h[r] = (elem_t)(acc1[mt][r] > 0.f ? acc1[mt][r] : 0.f);
-            *reinterpret_cast<half4*>(Hc + (mt * 16 + li) * 256 + (((2 * wave + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = h;
+            *reinterpret_cast<half4*>(Hw + (mt * 16 + li) * 256 + (((2 * wave + (g >> 1)) ^ li) << 4) + (g & 1) * 8) = h;
         }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();      // the chunk is complete; (its buffer was last read two chunks ago: every wave has passed a barrier since)
-        // ---- acc2 += hidden chunk . W2[:, chunk]^T: pieces 9 .. 16 = (k-step i, tile j) at 9 + 2 i + j -----------------------------
+    };
+    // one k-step of fc1 / one (k-step, tile) pair of fc2: MT MFMAs
+    auto mma_fc1 = [&](const EfFrags& f, const int ks0, const int ks, const bool first) {
+        if constexpr (dbg & 1) return;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            ef_wait_vm<EF_R - 4>();
+        for (int mt = 0; mt < MT; ++mt) acc1[mt] = OPD_MFMA_16x16x32(f.w[ks], xf[ks0 + ks][mt], (first && ks == 0) ? f.b : acc1[mt]);
+    };
+    auto mma_fc2 = [&](const EfFrags& f, const int q) {   // q = 2 i + j
+        if constexpr (dbg & 1) return;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) s4[i] = take();
-            half8 hfr[2][4], wf[4];
+        for (int mt = 0; mt < MT; ++mt) acc2[q & 1][mt] = OPD_MFMA_16x16x32(f.w[q], f.h[q >> 1][mt], acc2[q & 1][mt]);
+    };
+    auto read_h = [&](EfFrags& f, const unsigned char* Hr, const int ks0) {
+        if constexpr (dbg & 4) return;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    hfr[i][mt] = *reinterpret_cast<const half8*>(Hc + (mt * 16 + li) * 256 + ((((2 * hf + i) * 4 + g) ^ li) << 4));
+            for (int mt = 0; mt < MT; ++mt) f.h[i][mt] = *reinterpret_cast<const half8*>(Hr + (mt * 16 + li) * 256 + ((((ks0 + i) * 4 + g) ^ li) << 4));
+    };
+    // A STEP: the fragments of the next group are requested from LDS into the idle register set, then the current group's MFMAs run with the
+    // re-requests of ITS ring slots (read one step ago: no wait) placed between them -- LDS latency and LDS-DMA issue hide behind the MFMAs.
+    // Wait count of a step: R - (pieces of the group in registers) - (pieces of the group being read).
+    // (the next group's reads come AFTER the first MFMAs of the current one: the compiler guards the current operands with lgkmcnt(0), which
+    //  would otherwise also wait for the reads just issued)
+#define EF_FC1_STEP(F_, KS0, FIRST, SL, NSL, NEXT)                                \
+    do {                                                                           \
+        EF_FENCE();                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                         \
+            mma_fc1(F_, KS0, q_, FIRST);                                           \
+            EF_FENCE();                                                            \
+            if (q_ == 0) { NEXT; EF_FENCE(); }                                     \
+            reissue(SL[q_]);                                                       \
+            if (q_ == 3 && NSL == 5) reissue(SL[4]);                               \
+            EF_FENCE();                                                            \
+        }                                                                          \
+    } while (0)
+#define EF_FC2_STEP(F_, SL, NEXT)                                                 \
+    do {                                                                           \
+        EF_FENCE();                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                         \
+            mma_fc2(F_, q_);                                                       \
+            EF_FENCE();                                                            \
+            if (q_ == 0) { NEXT; EF_FENCE(); }                                     \
+            reissue(SL[q_]);                                                       \
+            EF_FENCE();                                                            \
+        }                                                                          \
+    } while (0)
+    EfFrags A, B;
+    unsigned sa[5], sb[4];
+    auto take_g0 = [&](EfFrags& f) {   // bias piece + W1 k-steps 0 .. 3 -> sa
 #pragma unroll
-                for (int j = 0; j < 2; ++j) wf[2 * i + j] = *reinterpret_cast<const half8*>(ring + s4[2 * i + j] + lane16);
-            }
-            __builtin_amdgcn_sched_barrier(0);
+        for (int i = 0; i < 5; ++i) sa[i] = take();
+        f.b = *reinterpret_cast<const float4v*>(ring + sa[0] + lane16);
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < 4; ++i) f.w[i] = frag(sa[1 + i]);
+    };
+    auto take_w4 = [&](EfFrags& f, unsigned (&sl)[4]) {
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+        for (int i = 0; i < 4; ++i) { sl[i] = take(); f.w[i] = frag(sl[i]); }
+    };
+    // ---- fc1 of chunk 0 (the pipeline fills), then the first group of chunk 1 into set A ------------------------------------------------
+    unsigned s0[5], sa4[4];
+    ef_wait_vm<EF_R - 5>();
+    take_g0(A);
 #pragma unroll
-                    for (int mt = 0; mt < 4; ++mt) acc2[j][mt] = OPD_MFMA_16x16x32(wf[2 * i + j], hfr[i][mt], acc2[j][mt]);
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-            for (int i = 0; i < 4; ++i) reissue(s4[i]);
-        }
+    for (int i = 0; i < 5; ++i) s0[i] = sa[i];
+    EF_FC1_STEP(A, 0, true, s0, 5, (ef_wait_vm<EF_R - 9>(), take_w4(B, sb)));
+    EF_FC1_STEP(B, 4, false, sb, 4, (ef_wait_vm<EF_R - 9>(), take_g0(A)));
+    write_h(H);
+    EF_LGKM0();
+    __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+    for (int c = 0; c < nch; ++c) {
+        const unsigned char* const Hr = H + (c & 1) * EF_H;        // hidden chunk c (fc2 reads it)
+        unsigned char* const Hw = H + ((c + 1) & 1) * EF_H;        // hidden chunk c + 1 (fc1 writes it)
+        // step G0(c + 1): multiply A, request G1(c + 1) into B
+        EF_FC1_STEP(A, 0, true, sa, 5, (ef_wait_vm<EF_R - 9>(), take_w4(B, sb)));
+        // step G1(c + 1): multiply B, request G2(c) into A (two k-steps of W2's tiles and of hidden chunk c), publish hidden chunk c + 1
+        EF_FC1_STEP(B, 4, false, sb, 4, (ef_wait_vm<EF_R - 8>(), take_w4(A, sa4), read_h(A, Hr, 0)));
+        write_h(Hw);
+        // step G2(c): multiply A, request G3(c) into B
+        EF_FC2_STEP(A, sa4, (ef_wait_vm<EF_R - 8>(), take_w4(B, sb), read_h(B, Hr, 2)));
+        // step G3(c): multiply B, request G0(c + 2) into A
+        EF_FC2_STEP(B, sb, (ef_wait_vm<EF_R - 9>(), take_g0(A)));
+        EF_LGKM0();
+        if constexpr (!(dbg & 8)) __builtin_amdgcn_s_barrier();   // hidden chunk c + 1 is complete, every read of chunk c has returned
     }
     ef_wait_vm<0>();   // (the pieces requested past the end of the stream: no LDS-DMA may be in flight when the workgroup ends)
     // ---- + b2 + residual, LayerNorm, outputs -----------------------------------------------------------------------------------
@@ -656,7 +691,7 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
         const int cidx = (2 * wave + j) * 16 + 4 * g;
         const float4v b2 = *reinterpret_cast<const float4v*>(p.b2 + cidx);
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
             const int m = m_base + mt * 16 + li;
             float4v r = float4v{0.f, 0.f, 0.f, 0.f};
             if (p.res32 && m < p.M) r = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + cidx);
@@ -664,7 +699,7 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
         }
     }
     const RowLnOut o{p.gamma, p.beta, p.y32, p.y16, p.yp16, p.pos, p.pos_ptrs, p.pos_period, p.M};
-    row_ln_store<true>(o, acc2, red, m_base, wave, g, li);
+    row_ln_store<true, MT>(o, acc2, red, m_base, wave, g, li);
 #endif
 }
 
@@ -696,33 +731,68 @@ hipError_t OPD_SYM(opd_launch_gemm_ln)(const GemmLnParams& p, hipStream_t stream
 hipError_t OPD_SYM(opd_launch_enc_ffn)(const EncFfnParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.F <= 0 || p.F % 128 != 0 || !p.x || !p.wpack || !p.b2 || !p.gamma || !p.beta) return hipErrorInvalidValue;
     if (p.yp16 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
-    if ((size_t)(p.F / 128) * EF_PPC * 1024 >= 0x7fffff00ull) return hipErrorInvalidValue;   // 32-bit stream offsets
-    OPD_SET_MAX_LDS_ONCE(enc_ffn_kernel, EF_LDS);
-    hipLaunchKernelGGL(enc_ffn_kernel, dim3((p.M + EF_TM - 1) / EF_TM), dim3(512), EF_LDS, stream, p);
-    return hipGetLastError();
+    if ((size_t)EF_PIECES(p.F / 128) * 1024 >= 0x7fffff00ull) return hipErrorInvalidValue;   // 32-bit stream offsets
+    const dim3 grid((p.M + EF_TM - 1) / EF_TM);
+#define EF_LAUNCH(D)                                                                   \
+    do {                                                                               \
+        OPD_SET_MAX_LDS_ONCE(enc_ffn_kernel<D>, EF_LDS);                               \
+        hipLaunchKernelGGL(enc_ffn_kernel<D>, grid, dim3(512), EF_LDS, stream, p);     \
+        return hipGetLastError();                                                      \
+    } while (0)
+    switch (p.dbg) {
+        case 0: EF_LAUNCH(0);
+        case 1: EF_LAUNCH(1);
+        case 2: EF_LAUNCH(2);
+        case 3: EF_LAUNCH(3);
+        case 4: EF_LAUNCH(4);
+        case 8: EF_LAUNCH(8);
+        case 15: EF_LAUNCH(15);
+        default: return hipErrorInvalidValue;
+    }
 }
 
 #ifndef OPD_ELEM_BF16   // (a permutation of 16-bit words and fp32 biases: the same for both element types)
-size_t opd_encffn_pack_bytes(int F) { return (size_t)8 * (F / 128) * EF_PPC * 1024; }
-// host: w1 [F][256], w2 [256][F] as 16-bit elements (fp16 or bf16), b1 [F] fp32 -> the eight per-wave streams of enc_ffn_kernel.  Stream of
-// wave w = chunks c = 0 .. F / 128 - 1, each 17 KiB: the bias piece (lane L = 16 g + li: b1[128 c + 16 w + 4 g .. + 3] as fp32), the 8 k-steps
-// of W1's tile (lane L: w1[128 c + 16 w + li][32 ks + 8 g .. + 7]), then W2's k-steps i = 0 .. 3 of the chunk for the wave's tiles j = 0, 1 at
-// 9 + 2 i + j (lane L: w2[(2 w + j) 16 + li][128 c + 32 i + 8 g .. + 7]).
+size_t opd_encffn_pack_bytes(int F) { return (size_t)8 * EF_PIECES(F / 128) * 1024; }
+// host: w1 [F][256], w2 [256][F] as 16-bit elements (fp16 or bf16), b1 [F] fp32 -> the eight per-wave streams of enc_ffn_kernel, in the order the
+// kernel consumes them: G0(0) G1(0) G0(1) { G1(c+1) G2(c) G3(c) G0(c+2) } for c = 0 .. F/128 - 1 (zeros for fc1 chunks past the end).
+//   G0(c): the bias piece (lane L = 16 g + li: b1[128 c + 16 w + 4 g .. + 3] as fp32), then k-steps 0 .. 3 of W1's tile (lane L:
+//          w1[128 c + 16 w + li][32 ks + 8 g .. + 7]);  G1(c): k-steps 4 .. 7;
+//   G2(c) / G3(c): W2's k-steps i = 0, 1 / 2, 3 of the chunk for the wave's tiles j = 0, 1 at 2 (i & 1) + j (lane L:
+//          w2[(2 w + j) 16 + li][128 c + 32 i + 8 g .. + 7]).
 void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, unsigned char* out) {
     const int nch = F / 128;
-    for (int w = 0; w < 8; ++w)
-        for (int c = 0; c < nch; ++c) {
-            unsigned char* base = out + ((size_t)(w * nch + c) * EF_PPC) * 1024;
+    __builtin_memset(out, 0, opd_encffn_pack_bytes(F));
+    for (int w = 0; w < 8; ++w) {
+        unsigned char* o = out + (size_t)w * EF_PIECES(nch) * 1024;
+        auto g0 = [&](const int c) {   // 5 pieces
+            if (c < nch)
+                for (int L = 0; L < 64; ++L) {
+                    const int g = L >> 4, li = L & 15;
+                    __builtin_memcpy(o + L * 16, b1 + 128 * c + 16 * w + 4 * g, 16);
+                    for (int ks = 0; ks < 4; ++ks) __builtin_memcpy(o + (1 + ks) * 1024 + L * 16, w1 + (size_t)(128 * c + 16 * w + li) * 256 + 32 * ks + 8 * g, 16);
+                }
+            o += 5 * 1024;
+        };
+        auto g1 = [&](const int c) {   // 4 pieces
+            if (c < nch)
+                for (int L = 0; L < 64; ++L) {
+                    const int g = L >> 4, li = L & 15;
+                    for (int ks = 4; ks < 8; ++ks) __builtin_memcpy(o + (ks - 4) * 1024 + L * 16, w1 + (size_t)(128 * c + 16 * w + li) * 256 + 32 * ks + 8 * g, 16);
+                }
+            o += 4 * 1024;
+        };
+        auto g23 = [&](const int c, const int i0) {   // 4 pieces: k-steps i0, i0 + 1
             for (int L = 0; L < 64; ++L) {
                 const int g = L >> 4, li = L & 15;
-                __builtin_memcpy(base + L * 16, b1 + 128 * c + 16 * w + 4 * g, 16);
-                for (int ks = 0; ks < 8; ++ks)
-                    __builtin_memcpy(base + (1 + ks) * 1024 + L * 16, w1 + (size_t)(128 * c + 16 * w + li) * 256 + 32 * ks + 8 * g, 16);
-                for (int i = 0; i < 4; ++i)
+                for (int i = 0; i < 2; ++i)
                     for (int j = 0; j < 2; ++j)
-                        __builtin_memcpy(base + (9 + 2 * i + j) * 1024 + L * 16, w2 + (size_t)((2 * w + j) * 16 + li) * F + 128 * c + 32 * i + 8 * g, 16);
+                        __builtin_memcpy(o + (2 * i + j) * 1024 + L * 16, w2 + (size_t)((2 * w + j) * 16 + li) * F + 128 * c + 32 * (i0 + i) + 8 * g, 16);
             }
-        }
+            o += 4 * 1024;
+        };
+        g0(0); g1(0); g0(1);
+        for (int c = 0; c < nch; ++c) { g1(c + 1); g23(c, 0); g23(c, 2); g0(c + 2); }
+    }
 }
 #endif
 

@@ -151,6 +151,7 @@ struct EncFfnParams {
     int pos_period;
     int M, F;                     // F % 128 == 0
     int dtype;
+    int dbg;                      // tools only: timing ablations (0 in the model)
 };
 hipError_t opd_launch_enc_ffn(const EncFfnParams& p, hipStream_t stream);
 size_t opd_encffn_pack_bytes(int F);

@@ -250,7 +250,7 @@ int opd_test_enc_ffn(const uint16_t* x, const uint16_t* w1, const float* b1, con
 }
 
 // Times `iters` launches of the fused encoder FFN on M rows of arbitrary data.
-int opd_test_bench_enc_ffn(int M, int F, int iters, float* us_out) {
+int opd_test_bench_enc_ffn(int M, int F, int iters, int dbg, float* us_out) {
     if (M <= 0 || F <= 0 || F % 128) return tfail(OPD_EINVAL, "bench_enc_ffn: F must be a multiple of 128");
     DevMem dm;
     EncFfnParams p{}; p.dtype = g_test_dtype;
@@ -264,7 +264,7 @@ int opd_test_bench_enc_ffn(int M, int F, int iters, float* us_out) {
     TCHK(hipMemset(wp, 0x1c, opd_encffn_pack_bytes(F)));
     TCHK(hipMemset(f, 0, 4096));
     TCHK(hipMemset(res, 0, (size_t)M * 256 * 4));
-    p.x = x; p.wpack = wp; p.b2 = f; p.gamma = f + 256; p.beta = f + 512; p.res32 = res; p.y32 = res; p.y16 = y16; p.M = M; p.F = F;
+    p.x = x; p.wpack = wp; p.b2 = f; p.gamma = f + 256; p.beta = f + 512; p.res32 = res; p.y32 = res; p.y16 = y16; p.M = M; p.F = F; p.dbg = dbg;
     hipEvent_t a, b;
     TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));
     for (int i = 0; i < 3; ++i) TCHK(opd_launch_enc_ffn(p, nullptr));
