@@ -26,8 +26,8 @@
 // staging, XOR-swizzled 128-byte rows).  It continues seamlessly into C2/64 "chunk steps": chunk j stages the 64 rows of
 // W2 and the 64-column slice of W3 that chunk needs into the stage buffer the previous step has left, computes 64
 // channels of y for the wave's 32 pixels, applies bias/residual/ReLU, stores them, and feeds them straight into the z
-// accumulators.  The residual for chunk j+2 is fetched during chunk j; waits are counted (`s_waitcnt vmcnt(N)`) so that
-// the y stores and the youngest residual loads stay in flight across the stage barriers.
+// accumulators.  The residual for chunk j+2 is fetched during chunk j; the wait that ends a chunk step counts only younger LDS-DMA
+// requests (see `res_dma` below), and the step's y stores are issued behind it.
 //
 // Measured (tools/bench_btail.py, batch 8): stage-1 tail 188 us against 287 us for the three launches it replaces,
 // stage-2 tail 135 against 170.  What does NOT move it further (each built, measured, removed):
@@ -254,10 +254,13 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                                                      res_voff + (unsigned)(i * 8 * C2 * 2), j * 128, 0, 0);
     };
     const bool has_res = !SC && p.res != nullptr && !(p.dbg & 4);
-    // Counted waits (below) rely on every wave issuing exactly 4 residual loads and 4 stores per chunk: true on full
-    // tiles with a residual (SC: no residual loads, 4 stores); otherwise (ragged last tile, no residual) the waits fall back
-    // to vmcnt(0).
-    const bool counted = (SC || has_res) && m_base + 128 <= p.M && !(p.dbg & 2);
+    // Counted waits: `s_waitcnt vmcnt(N)` proves that an LDS-DMA request has landed only if the N operations allowed to stay in flight are
+    // YOUNGER LDS-DMA requests.  Stores and loads into registers retire out of order with respect to an older LDS-DMA request
+    // (tools/microbench/vmorder.hip: with 4 younger stores, or 4 younger register loads, vmcnt(4) returns while the older request's data is
+    // still on its way in > 90 % of the cases; with 4 younger LDS-DMA requests in none), so they must not be counted -- rounds 2-3 did, and
+    // were saved only by the operands having been requested a whole chunk step earlier.  Hence: N = the residual pieces of chunk j + 2 when
+    // they travel by LDS-DMA, otherwise 0; and the y stores of a step are issued AFTER its wait, so that a vmcnt(0) never waits for them.
+    const bool res_dma = RDMA && has_res;
     auto load_res = [&](int j, uint4 (&r)[4]) {
         if constexpr (RDMA) {
             if (has_res) issue_res(j);
@@ -328,9 +331,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     load_res(1, res[1]);
     compiler_fence();
     compute_main((nk - 1) & 1);
-    if (SC) wait_vmcnt<0>();                     // chunk 0 operands landed (nothing else is in flight)
-    else if (RDMA && counted) wait_vmcnt<4>();   // chunk 0 operands and residual chunk 0 landed (chunk 1's 4 pieces may still fly)
-    else if (counted) wait_vmcnt<8>();           // chunk 0 operands landed (the 8 residual loads may still fly)
+    if (res_dma) wait_vmcnt<4>();   // chunk 0 operands and residual chunk 0 landed (chunk 1's 4 pieces, younger LDS-DMA requests, may still fly)
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     stamp(3);
@@ -432,9 +433,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                     v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
                     v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
                 }
-                const uint4 o = make_uint4(pack2h(v0[0], v0[1]), pack2h(v0[2], v0[3]), pack2h(v1[0], v1[1]), pack2h(v1[2], v1[3]));
-                yf[q][mt] = as_half8(o.x, o.y, o.z, o.w);
-                if (pr_ok[mt] && !(p.dbg & 2)) *reinterpret_cast<uint4*>(p.y + pr_row[mt] + j * 64 + q * 32) = o;
+                yf[q][mt] = as_half8(pack2h(v0[0], v0[1]), pack2h(v0[2], v0[3]), pack2h(v1[0], v1[1]), pack2h(v1[2], v1[3]));
             }
         if constexpr (C3 > 0) {
             const unsigned char* W3s = W2s + W2C_BYTES;
@@ -449,14 +448,18 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             }
         }
         if (j + 1 < NCH) {
-            // chunk j+1's operands (issued at the top of this step) have landed; this step's y stores and the residual
-            // loads of chunk j+2 stay in flight across the barrier (vmcnt retires in issue order)
-            if (!counted) wait_vmcnt<0>();
-            else if (SC) wait_vmcnt<4>();            // (this step's 4 stores)
-            else if (j + 2 < NCH) wait_vmcnt<8>();
-            else wait_vmcnt<4>();
+            // chunk j+1's operands (requested at the top of this step) have landed; only the residual pieces of chunk j+2 (LDS-DMA requests
+            // younger than the operands') may stay in flight
+            if (res_dma && j + 2 < NCH) wait_vmcnt<4>();
+            else wait_vmcnt<0>();
             __builtin_amdgcn_s_barrier();
         }
+        // the y stores go out behind the wait: they fly during the next chunk step
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+                if (pr_ok[mt] && !(p.dbg & 2)) *reinterpret_cast<half8*>(p.y + pr_row[mt] + j * 64 + q * 32) = yf[q][mt];
         stamp(4 + j);
     }
 

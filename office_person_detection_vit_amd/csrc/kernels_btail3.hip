@@ -395,6 +395,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
         // residual (paired layout -> accumulator layout), ReLU, fp16; store y; the fp16 values are this wave's k-block of the chunk
         uint4v (&res_cur)[2] = res[j % 3];
         unsigned pk[2][2][2];
+        uint4v yo[2];   // this step's y values in store layout: written behind the wait below
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
             float4v v0 = acc2[nt][0], v1 = acc2[nt][1];
@@ -421,8 +422,7 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
             pk[nt][1][1] = pack2h(v1[2], v1[3]);
             const uint2v s0 = __builtin_amdgcn_permlane16_swap(pk[nt][0][0], pk[nt][1][0], false, false);
             const uint2v s1 = __builtin_amdgcn_permlane16_swap(pk[nt][0][1], pk[nt][1][1], false, false);
-            const uint4v o = {s0[0], s1[0], s0[1], s1[1]};
-            __builtin_amdgcn_raw_buffer_store_b128(o, rsrc_y, pr_off + (unsigned)(j * 64 + nt * 16) * 2u, 0, 0);
+            yo[nt] = uint4v{s0[0], s1[0], s0[1], s1[1]};
         }
         half8 yf[2][2];   // [own / partner][m-tile]
         if constexpr (C3 > 0) {
@@ -432,16 +432,22 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
                 *reinterpret_cast<half8*>(smem + XBUF + (j & 1) * 16384 + wave * 2048 + mt * 1024 + lane * 16) = yf[0][mt];
             }
         }
-        // barrier j: W3_j and W2_{j+1} (requested after barrier j-1; before the loop for j = 0) have landed; younger operations that may
-        // stay in flight: the residual loads of chunk j+1 (2, absent in the last step) and this step's 2 stores
-        if (j + 1 < NCH) wait_vmcnt<4>();
-        else wait_vmcnt<2>();
+        // barrier j: W3_j and W2_{j+1} (requested after barrier j-1; before the loop for j = 0) have landed.  vmcnt(0): a counted wait proves an
+        // LDS-DMA request only against YOUNGER LDS-DMA requests -- stores and register loads retire out of order with respect to it
+        // (tools/microbench/vmorder.hip; rounds 2-3 let the residual loads of chunk j+1 and this step's stores stay in flight here, which
+        // held only because the operands had been requested a whole step earlier).  The residual loads are a phase old by now, and this
+        // step's y stores go out BEHIND the barrier, so the wait does not stand on them.
+        wait_vmcnt<0>();
         lds_barrier();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) __builtin_amdgcn_raw_buffer_store_b128(yo[nt], rsrc_y, pr_off + (unsigned)(j * 64 + nt * 16) * 2u, 0, 0);
+        // the residual of chunk j + 2 right away (its registers were read two steps ago): it is a whole step old when barrier j + 1 drains it
+        if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]);
         if (j + 1 < NCH) load_bias2(j + 1);
         compiler_fence();
         if constexpr (C3 > 0) {
             // z: 2 k-blocks x 8 tiles x 2 MFMAs; weight fragments run four tiles ahead; the 8 DMA requests of this step (W3 of chunk j+1, W2 of
-            // chunk j+2) go out one per tile over the first half, then the residual loads of chunk j+2
+            // chunk j+2) go out one per tile over the first half
             const unsigned char* W3s = smem + W3BUF + (j & 1) * 32768;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {   // the chunk's two k-blocks in order: block `half` is this wave's, the other one the partner's
@@ -467,7 +473,6 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
                 if (p.dbg & 16) {}   // timing ablation: no weight requests in the chunk loop (tools only)
                 else if (idx < 4) { if (j + 1 < NCH) issue_w3_piece(j + 1, idx); }
                 else if (idx < 8) { if (j + 2 < NCH) issue_w2_piece(j + 2, idx - 4); }
-                else if (idx == 8) { if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]); }
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else {
@@ -475,8 +480,6 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) issue_w2_piece(j + 2, i);
             }
-            compiler_fence();
-            if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]);
             compiler_fence();
         }
         if (j & 1) stamp(5 + (j >> 1));

@@ -104,9 +104,11 @@ __device__ __forceinline__ float acc3_get(const Acc3& a, const int j, const int 
 // ---- wave-private LDS-DMA ring ------------------------------------------------------------------------------------------------------
 // A wave consumes a fixed SEQUENCE of 1-KiB pieces (weight fragment blocks, rows of fp32 partial sums) in order; piece n lives in slot
 // n mod R of the wave's ring.  R pieces are requested up front; when pieces [first, first + count) have been consumed (their LDS reads
-// have returned: lgkmcnt(0)) pieces [first + R, ...) are requested into the freed slots.  vmcnt retires in issue order, so piece `last`
-// has landed once at most (pieces issued so far) - 1 - last requests are outstanding; other, younger vector-memory operations of the
-// wave only make that wait longer than necessary, never shorter.  Every index is a compile-time constant after unrolling.
+// have returned: lgkmcnt(0)) pieces [first + R, ...) are requested into the freed slots.  LDS-DMA requests retire in issue order AMONG
+// THEMSELVES, so piece `last` has landed once at most (pieces issued so far) - 1 - last requests are outstanding.  Stores and loads into
+// registers retire out of order with respect to an older request (tools/microbench/vmorder.hip): they are never part of a count, and as
+// extra outstanding operations they only make a wait longer than necessary, never shorter.  Every index is a compile-time constant after
+// unrolling.
 __device__ __forceinline__ void dma1k(const unsigned char* src_lane, unsigned char* slot) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
 }

@@ -300,6 +300,10 @@ struct RowLnOut {
     float* y32; f16_t* y16; f16_t* yp16;
     const float* pos; const float* const* pos_ptrs; int pos_period;
     int M;
+    // optional (fused encoder FFN with a tail projection): fp16(y) and fp16(y + pos) also as [rows][256] B-operand images in LDS, 16-byte chunks
+    // XOR-swizzled by (row & 15)
+    unsigned char* img_x = nullptr;
+    unsigned char* img_xp = nullptr;
 };
 template <bool LN, int MT = 4>
 __device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2][MT], float (&red)[2][8][16 * MT], const int m_base, const int wave, const int g,
@@ -352,7 +356,7 @@ __device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2
         var *= (1.0f / 256.0f);
         const float rstd = LN ? 1.0f / sqrtf(var + 1e-5f) : 1.0f;
         const float* pos = nullptr;   // second fp16 shadow y + position embedding (encoder: the next layer's q / k projection input)
-        if (p.yp16 && m < p.M) {
+        if ((p.yp16 || p.img_xp) && p.pos_period > 0 && m < p.M) {
             const int fr = m / p.pos_period, t = m - fr * p.pos_period;
             pos = (p.pos_ptrs ? p.pos_ptrs[fr] : p.pos) + (size_t)t * 256;
         }
@@ -369,13 +373,23 @@ __device__ __forceinline__ void row_ln_store(const RowLnOut& p, float4v (&acc)[2
                     h[0] = (elem_t)o[0]; h[1] = (elem_t)o[1]; h[2] = (elem_t)o[2]; h[3] = (elem_t)o[3];
                     *reinterpret_cast<half4*>(p.y16 + (size_t)m * 256 + c) = h;
                 }
-                if (pos) {
+                if (pos && p.yp16) {
                     const float4v pe = *reinterpret_cast<const float4v*>(pos + c);
                     half4 h;
 #pragma unroll
                     for (int q = 0; q < 4; ++q) h[q] = (elem_t)(o[q] + pe[q]);
                     *reinterpret_cast<half4*>(p.yp16 + (size_t)m * 256 + c) = h;
                 }
+            }
+            if (p.img_x) {   // (rows past M: finite values nobody stores)
+                const int ioff = r * 512 + ((((c >> 3) ^ li) << 4) | ((c & 4) << 1));
+                half4 h, hp;
+                float4v pe = float4v{0.f, 0.f, 0.f, 0.f};
+                if (pos) pe = *reinterpret_cast<const float4v*>(pos + c);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { h[q] = (elem_t)o[q]; hp[q] = (elem_t)(o[q] + pe[q]); }
+                *reinterpret_cast<half4*>(p.img_x + ioff) = h;
+                *reinterpret_cast<half4*>(p.img_xp + ioff) = hp;
             }
         }
     }
@@ -445,7 +459,8 @@ __global__ __launch_bounds__(64 * RG_NW, 1) void gemm_ln256_ring_kernel(GemmLnPa
     float4v res[NT][4];
 #pragma unroll 1
     for (int ks = 0; ks < nk; ++ks) {
-        // k-step ks has landed once at most the pieces of k-step ks + 1 are outstanding (vmcnt retires in issue order)
+        // k-step ks has landed once at most the pieces of k-step ks + 1 are outstanding (LDS-DMA requests retire in issue order among themselves;
+        // nothing else is in flight here: the residual rows are requested behind the last wait)
         if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();       // everybody's pieces of ks are in LDS; everybody has finished multiplying stage (ks - 1) % 3
@@ -526,7 +541,7 @@ constexpr int EF_X = EF_TM * 512;
 constexpr int EF_H = EF_TM * 256;
 constexpr int EF_RING0 = EF_X + 2 * EF_H;
 constexpr int EF_LDS = EF_RING0 + 8 * EF_R * 1024;
-constexpr int EF_PIECES(const int nch) { return 14 + 17 * nch; }   // per wave
+constexpr int EF_PIECES(const int nch, const int tail) { return 14 + 17 * nch + (tail ? 17 * tail + 5 : 0); }   // per wave
 
 template <int N>
 __device__ __forceinline__ void ef_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -534,7 +549,7 @@ __device__ __forceinline__ void ef_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 #define EF_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 
 struct EfFrags {
-    float4v b;
+    float4v b, b2;
     half8 w[4];
     half8 h[2][EF_MT];
 };
@@ -553,7 +568,7 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
     const int m_base = blockIdx.x * EF_TM;
     unsigned char* const ring = smem + EF_RING0 + wave * (EF_R * 1024);
     const int nch = p.F / 128;
-    const unsigned total = (unsigned)EF_PIECES(nch) * 1024u;             // bytes of this wave's stream
+    const unsigned total = (unsigned)EF_PIECES(nch, p.pack_tail) * 1024u;   // bytes of this wave's stream
     const unsigned char* const wsrc = p.wpack + (size_t)wave * total + lane16;
     auto dma = [&](const unsigned char* src_lane, unsigned char* slot) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
@@ -684,7 +699,12 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
         EF_LGKM0();
         if constexpr (!(dbg & 8)) __builtin_amdgcn_s_barrier();   // hidden chunk c + 1 is complete, every read of chunk c has returned
     }
-    ef_wait_vm<0>();   // (the pieces requested past the end of the stream: no LDS-DMA may be in flight when the workgroup ends)
+    const int T = p.tail;
+    if (T == 0) ef_wait_vm<0>();   // (the pieces requested past the end of the stream: no LDS-DMA may be in flight when the workgroup ends)
+    else {
+#pragma unroll
+        for (int i = 0; i < 5; ++i) reissue(sa[i]);   // (the slots of the last, empty fc1 group: the stream continues with the tail's weights)
+    }
     // ---- + b2 + residual, LayerNorm, outputs -----------------------------------------------------------------------------------
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -698,8 +718,87 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
             acc2[j][mt] += b2 + r;
         }
     }
-    const RowLnOut o{p.gamma, p.beta, p.y32, p.y16, p.yp16, p.pos, p.pos_ptrs, p.pos_period, p.M};
+    RowLnOut o{p.gamma, p.beta, p.y32, p.y16, p.yp16, p.pos, p.pos_ptrs, p.pos_period, p.M};
+    if (T) { o.img_x = X; o.img_xp = H; }   // (the slab and the hidden chunks are dead: their 48 KiB take the two images)
     row_ln_store<true, MT>(o, acc2, red, m_base, wave, g, li);
+    if (T == 0) return;
+    // ---- tail projection: out[:, col_t .. + 255] = (y or y + pos) . Wt_t^T + bias_t for T passes of 256 columns (the next layer's q / k / v, or
+    //      the decoder's memory keys / values): the wave's tiles 2 w, 2 w + 1 of every pass, 16 pieces per pass (4 groups of two k-steps x two
+    //      tiles, as fc2's), the y fragments in registers; the first `tail_pos` passes multiply y + pos.  Same pipeline as above.
+    EF_LGKM0();
+    __builtin_amdgcn_s_barrier();      // both images are complete
+    auto load_img = [&](const unsigned char* img) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(img + (mt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+    };
+    auto mma_tail = [&](const EfFrags& f, const int ks0, const int q) {   // q = 2 i + j: k-step ks0 + i, tile j
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc2[q & 1][mt] = OPD_MFMA_16x16x32(f.w[q], xf[ks0 + (q >> 1)][mt], acc2[q & 1][mt]);
+    };
+#define EF_TAIL_STEP(F_, KS0, SL, NEXT)                                            \
+    do {                                                                           \
+        EF_FENCE();                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                         \
+            mma_tail(F_, KS0, q_);                                                 \
+            EF_FENCE();                                                            \
+            if (q_ == 0) { NEXT; EF_FENCE(); }                                     \
+            reissue(SL[q_]);                                                       \
+            EF_FENCE();                                                            \
+        }                                                                          \
+    } while (0)
+    // Every pass = 17 pieces: the biases of the wave's two tiles (accumulator layout: lane (g, li < 8) tile 0, (g, li >= 8) tile 1) + 16 weight
+    // pieces; nothing but LDS-DMA requests and the output stores touch vector memory inside the loop (a global load here makes the compiler
+    // drain vmcnt(0) -- the whole ring -- at every use).
+    // The wait counts are those of the FFN loop: they count LDS-DMA requests only.  The output stores of a pass are in flight meanwhile; they
+    // retire out of order with respect to the requests (tools/microbench/vmorder.hip) and so can neither be relied on nor be in the way.
+    const bool full = m_base + EF_TM <= p.M;
+    auto take_t0 = [&](EfFrags& f) {   // bias piece + the first group (k-steps 0, 1 of both tiles) -> sa
+#pragma unroll
+        for (int i = 0; i < 5; ++i) sa[i] = take();
+        f.b = *reinterpret_cast<const float4v*>(ring + sa[0] + g * 256);
+        f.b2 = *reinterpret_cast<const float4v*>(ring + sa[0] + g * 256 + 128);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) f.w[i] = frag(sa[1 + i]);
+    };
+    load_img(p.tail_pos > 0 ? H : X);
+    ef_wait_vm<0>();                  // (once: the epilogue's stores; the ring is full)
+    take_t0(A);
+#pragma unroll 1
+    for (int t = 0; t < T; ++t) {
+        if (t == p.tail_pos && t > 0) load_img(X);
+        const float4v bias[2] = {A.b, A.b2};
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[j][mt] = float4v{0.f, 0.f, 0.f, 0.f};
+        unsigned s1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s1[i] = sa[1 + i];
+        const unsigned sbias = sa[0];
+        // (slots are re-requested in ring order: the stream's next piece belongs into the slot that `take` will visit next)
+        EF_TAIL_STEP(A, 0, s1, (ef_wait_vm<EF_R - 9>(), take_w4(B, sb), reissue(sbias)));
+        EF_TAIL_STEP(B, 2, sb, (ef_wait_vm<EF_R - 8>(), take_w4(A, sa4)));
+        EF_TAIL_STEP(A, 4, sa4, (ef_wait_vm<EF_R - 8>(), take_w4(B, sb)));
+        EF_TAIL_STEP(B, 6, sb, (ef_wait_vm<EF_R - 9>(), take_t0(A)));   // (the next pass's bias + first group; after the last pass: five zero pieces)
+        f16_t* const orow = p.tail_out + p.tail_col[t] + (2 * wave) * 16 + 4 * g;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const int m = m_base + mt * 16 + li;
+            if (full || m < p.M) {
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    half4 h;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) h[r] = (elem_t)(acc2[j][mt][r] + bias[j][r]);
+                    *reinterpret_cast<half4*>(orow + (size_t)m * p.tail_ld + j * 16) = h;
+                }
+            }
+        }
+        EF_FENCE();
+    }
+    ef_wait_vm<0>();
 #endif
 }
 
@@ -731,7 +830,9 @@ hipError_t OPD_SYM(opd_launch_gemm_ln)(const GemmLnParams& p, hipStream_t stream
 hipError_t OPD_SYM(opd_launch_enc_ffn)(const EncFfnParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.F <= 0 || p.F % 128 != 0 || !p.x || !p.wpack || !p.b2 || !p.gamma || !p.beta) return hipErrorInvalidValue;
     if (p.yp16 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
-    if ((size_t)EF_PIECES(p.F / 128) * 1024 >= 0x7fffff00ull) return hipErrorInvalidValue;   // 32-bit stream offsets
+    if ((size_t)EF_PIECES(p.F / 128, p.pack_tail) * 1024 >= 0x7fffff00ull) return hipErrorInvalidValue;   // 32-bit stream offsets
+    if (p.pack_tail < 0 || p.pack_tail > 16 || (p.tail != 0 && p.tail != p.pack_tail) || p.tail < 0 || p.tail > 16 || p.tail_pos < 0 || p.tail_pos > p.tail || (p.tail && (!p.tail_out || p.tail_ld < 256))) return hipErrorInvalidValue;
+    if (p.tail_pos > 0 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
     const dim3 grid((p.M + EF_TM - 1) / EF_TM);
 #define EF_LAUNCH(D)                                                                   \
     do {                                                                               \
@@ -752,18 +853,21 @@ hipError_t OPD_SYM(opd_launch_enc_ffn)(const EncFfnParams& p, hipStream_t stream
 }
 
 #ifndef OPD_ELEM_BF16   // (a permutation of 16-bit words and fp32 biases: the same for both element types)
-size_t opd_encffn_pack_bytes(int F) { return (size_t)8 * EF_PIECES(F / 128) * 1024; }
+size_t opd_encffn_pack_bytes(int F, int tail) { return (size_t)8 * EF_PIECES(F / 128, tail) * 1024; }
 // host: w1 [F][256], w2 [256][F] as 16-bit elements (fp16 or bf16), b1 [F] fp32 -> the eight per-wave streams of enc_ffn_kernel, in the order the
 // kernel consumes them: G0(0) G1(0) G0(1) { G1(c+1) G2(c) G3(c) G0(c+2) } for c = 0 .. F/128 - 1 (zeros for fc1 chunks past the end).
 //   G0(c): the bias piece (lane L = 16 g + li: b1[128 c + 16 w + 4 g .. + 3] as fp32), then k-steps 0 .. 3 of W1's tile (lane L:
 //          w1[128 c + 16 w + li][32 ks + 8 g .. + 7]);  G1(c): k-steps 4 .. 7;
 //   G2(c) / G3(c): W2's k-steps i = 0, 1 / 2, 3 of the chunk for the wave's tiles j = 0, 1 at 2 (i & 1) + j (lane L:
 //          w2[(2 w + j) 16 + li][128 c + 32 i + 8 g .. + 7]).
-void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, unsigned char* out) {
+// Tail (optional): wt [tail * 256][256] = the weight rows of the tail projection in PASS order, bt [tail * 256] its biases; per pass the bias piece
+// (lane (g, li): bt[256 t + (2 w + (li >> 3)) 16 + 4 g .. + 3]) and 16 pieces in fc2's group format (group q: k-steps 2 q, 2 q + 1 of the wave's
+// tiles 2 w, 2 w + 1 of that pass); five zero pieces at the end.
+void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, const uint16_t* wt, const float* bt, int tail, unsigned char* out) {
     const int nch = F / 128;
-    __builtin_memset(out, 0, opd_encffn_pack_bytes(F));
+    __builtin_memset(out, 0, opd_encffn_pack_bytes(F, tail));
     for (int w = 0; w < 8; ++w) {
-        unsigned char* o = out + (size_t)w * EF_PIECES(nch) * 1024;
+        unsigned char* o = out + (size_t)w * EF_PIECES(nch, tail) * 1024;
         auto g0 = [&](const int c) {   // 5 pieces
             if (c < nch)
                 for (int L = 0; L < 64; ++L) {
@@ -792,6 +896,19 @@ void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, in
         };
         g0(0); g1(0); g0(1);
         for (int c = 0; c < nch; ++c) { g1(c + 1); g23(c, 0); g23(c, 2); g0(c + 2); }
+        for (int t = 0; t < tail; ++t) {
+            for (int L = 0; L < 64; ++L) __builtin_memcpy(o + L * 16, bt + 256 * t + (2 * w + ((L & 15) >> 3)) * 16 + 4 * (L >> 4), 16);
+            o += 1024;
+            for (int q = 0; q < 4; ++q) {
+                for (int L = 0; L < 64; ++L) {
+                    const int g = L >> 4, li = L & 15;
+                    for (int i = 0; i < 2; ++i)
+                        for (int j = 0; j < 2; ++j)
+                            __builtin_memcpy(o + (2 * i + j) * 1024 + L * 16, wt + (size_t)(t * 256 + (2 * w + j) * 16 + li) * 256 + 32 * (2 * q + i) + 8 * g, 16);
+                }
+                o += 4 * 1024;
+            }
+        }
     }
 }
 #endif

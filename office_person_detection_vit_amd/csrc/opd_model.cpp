@@ -45,14 +45,17 @@ static int upload_frag(opd_detr* m, f16_t** dst, const std::vector<float>& v, in
 
 static const HostTensor& T(const StateDict& sd, const std::string& k) { return sd.at(k); }
 
-// the encoder FFN's weights as enc_ffn_kernel's per-wave fragment streams, in the handle's 16-bit operand type
-static int upload_encffn(opd_detr* m, unsigned char** dst, const std::vector<float>& w1, const std::vector<float>& b1, const std::vector<float>& w2, int F) {
-    std::vector<uint16_t> h1(w1.size()), h2(w2.size());
+// the encoder FFN's weights (+ the rows of its tail projection, pass order) as enc_ffn_kernel's per-wave fragment streams, in the handle's 16-bit
+// operand type
+static int upload_encffn(opd_detr* m, unsigned char** dst, const std::vector<float>& w1, const std::vector<float>& b1, const std::vector<float>& w2, int F,
+                         const std::vector<float>& wt, const std::vector<float>& bt, int tail) {
+    std::vector<uint16_t> h1(w1.size()), h2(w2.size()), ht(wt.size());
     const bool bf = m->dtype == OPD_DT_BF16;
-    for (size_t i = 0; i < w1.size(); ++i) h1[i] = bf ? f32_to_bf16(w1[i]) : f32_to_f16(w1[i]);
-    for (size_t i = 0; i < w2.size(); ++i) h2[i] = bf ? f32_to_bf16(w2[i]) : f32_to_f16(w2[i]);
-    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F));
-    opd_encffn_pack(h1.data(), b1.data(), h2.data(), F, pk.data());
+    auto cv = [&](const std::vector<float>& v, std::vector<uint16_t>& h) { for (size_t i = 0; i < v.size(); ++i) h[i] = bf ? f32_to_bf16(v[i]) : f32_to_f16(v[i]); };
+    cv(w1, h1); cv(w2, h2); cv(wt, ht);
+    if (ht.size() != (size_t)tail * 256 * 256 || bt.size() != (size_t)tail * 256) return fail(OPD_ESCHEMA, "encoder tail projection: unexpected weight shape");
+    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F, tail));
+    opd_encffn_pack(h1.data(), b1.data(), h2.data(), F, ht.data(), bt.data(), tail, pk.data());
     RCCHK(dalloc(m, dst, pk.size(), true));
     HIPCHK(hipMemcpy(*dst, pk.data(), pk.size(), hipMemcpyHostToDevice));
     return OPD_OK;
@@ -202,8 +205,6 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
         RCCHK(make_lin(m, sd, p + ".mlp.fc1", &L.fc1));
         RCCHK(make_lin(m, sd, p + ".mlp.fc2", &L.fc2));
         RCCHK(make_ln(m, sd, p + ".final_layer_norm", &L.ln2));
-        if (a.d_model == 256 && a.ffn % 128 == 0)
-            RCCHK(upload_encffn(m, &L.ffn_pack, T(sd, p + ".mlp.fc1.weight").data, T(sd, p + ".mlp.fc1.bias").data, T(sd, p + ".mlp.fc2.weight").data, a.ffn));
     }
     // decoder: query-position folds are resolution independent -> build them now with the fp32 plan GEMM
     float* d_qpos = nullptr;
@@ -254,6 +255,30 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
     }
     RCCHK(upload_f16(m, &m->wkv_all, kv_full));
     RCCHK(upload_f32(m, &m->bkv_all, m->h_kv_cat_b));
+    if (a.d_model == 256 && a.ffn % 128 == 0) {   // the encoder FFN blocks as single launches, each with the projection that consumes its output
+        const int D = 256, L = a.dec_layers;
+        for (int i = 0; i < a.enc_layers; ++i) {
+            EncLayer& E = m->enc[i];
+            const std::string p = "model.encoder.layers." + std::to_string(i);
+            std::vector<float> wt, bt;
+            if (i + 1 < a.enc_layers) {   // the next layer's q, k (on x + pos), v
+                const std::string n = "model.encoder.layers." + std::to_string(i + 1) + ".self_attn.";
+                for (const char* pr : {"q_proj", "k_proj", "v_proj"}) { append(wt, T(sd, n + pr + ".weight").data); append(bt, T(sd, n + pr + ".bias").data); }
+                E.tail = 3; E.tail_pos = 2; E.tail_ld = 3 * D;
+                for (int t = 0; t < 3; ++t) E.tail_col[t] = t * D;
+            } else if (2 * L <= 16 && kv_full.size() == (size_t)L * 2 * D * D && m->h_kv_cat_b.size() == (size_t)L * 2 * D) {
+                // the decoder's memory projections, [k_l | v_l] per layer in wkv_all: passes k_0 .. k_{L-1} (on x + pos), then v_0 .. v_{L-1}
+                for (int kv = 0; kv < 2; ++kv)
+                    for (int l = 0; l < L; ++l) {
+                        wt.insert(wt.end(), kv_full.begin() + (size_t)(2 * l + kv) * D * D, kv_full.begin() + (size_t)(2 * l + kv + 1) * D * D);
+                        bt.insert(bt.end(), m->h_kv_cat_b.begin() + (size_t)(2 * l + kv) * D, m->h_kv_cat_b.begin() + (size_t)(2 * l + kv + 1) * D);
+                        E.tail_col[kv * L + l] = (2 * l + kv) * D;
+                    }
+                E.tail = 2 * L; E.tail_pos = L; E.tail_ld = 2 * L * D;
+            }
+            RCCHK(upload_encffn(m, &E.ffn_pack, T(sd, p + ".mlp.fc1.weight").data, T(sd, p + ".mlp.fc1.bias").data, T(sd, p + ".mlp.fc2.weight").data, a.ffn, wt, bt, E.tail));
+        }
+    }
     {   // The decoder starts from h = 0 (HF:models/detr/modeling_detr.py:1243-1251), so in layer 0 the self-attention values are the
         // same row for every query, v = 0 . Wv^T + bv, the softmax weights of a row sum to one, and the block's output
         // LN(0 + Wo . bv + bo) is ONE vector, whatever the frame shows: computed here once in fp32, broadcast at run time instead of
@@ -889,9 +914,12 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         RCCHK(run_deep(cur, nullptr, m->proj.w, m->proj.bias, m->proj.K, nullptr, nullptr, CLS_CONV));
     else
         RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV, ps));
+    bool qkv_done = false, kv_done = false;
+    const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
     for (int i = 0; i < a.enc_layers; ++i) {
         const EncLayer& L = m->enc[i];
-        if (shadow)
+        if (qkv_done) {   // written by the previous layer's FFN launch (its tail projection)
+        } else if (shadow)
             RCCHK(run_gemm(m, m->d_xp16, L.wqkv, L.bqkv, 0, M, 3 * D, D, m->d_qkv16, false, false, nullptr, nullptr, 0, 0, m->d_x16, 3 * D, 2 * D));
         else
             RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i], 3 * D, 2 * D));   // (pos enters q and k only)
@@ -908,13 +936,23 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             // the whole FFN block as ONE row-owner launch: the [M][F] hidden tensor never leaves LDS (kernels_rowln.hip::enc_ffn_kernel)
             EncFfnParams fp{}; fp.dtype = m->dtype;
             fp.x = m->d_x16; fp.wpack = L.ffn_pack; fp.b2 = L.fc2.b; fp.res32 = m->d_x32; fp.gamma = L.ln2.g; fp.beta = L.ln2.b;
-            fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F;
+            fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F; fp.pack_tail = L.tail;
             if (ps) { fp.pos = ps->pos; fp.pos_ptrs = ps->pos_ptrs; fp.pos_period = ps->period; fp.yp16 = ps->yp16; }
-            RCCHK(timed_begin(m, CLS_GEMM, 4.0 * M * (double)D * F));
+            const bool last = i + 1 == a.enc_layers;
+            qkv_done = false;
+            // the tail projection: what consumes this block's output (only on the position-shadow path: x + pos with plain bias vectors)
+            if (ps && m->enc_tail && L.tail && L.tail_ld == (last ? NKV : 3 * D) && (last ? (size_t)M * NKV * 2 < (1ull << 32) : true)) {
+                fp.tail = L.tail; fp.tail_pos = L.tail_pos; fp.tail_ld = L.tail_ld;
+                fp.tail_out = last ? m->d_memkv16 : m->d_qkv16;
+                for (int t = 0; t < L.tail; ++t) fp.tail_col[t] = L.tail_col[t];
+                (last ? kv_done : qkv_done) = true;
+            }
+            RCCHK(timed_begin(m, CLS_GEMM, 4.0 * M * (double)D * F + 2.0 * M * (double)D * 256 * fp.tail));
             HIPCHK(opd_launch_enc_ffn(fp, m->stream));
             RCCHK(timed_end(m));
             RCCHK(tap(m, "enc_ffn", m->d_x32, (size_t)M * D * 4));
         } else {
+            qkv_done = false;
             RCCHK(run_gemm(m, m->d_x16, L.fc1.w, L.fc1.b, 0, M, F, D, m->d_ffn16, false, true, nullptr));
             // fc2 + residual + LayerNorm (+ the position shadow) as ONE row-owner launch of the three-stage ring kernel: 36.9 us in the
             // forward against 19.4 + 12.2 us for split-K slabs + reduce, but 514 MB less HBM traffic per forward and half the CUs left to
@@ -928,8 +966,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     }
     MARK(6);
     // ---- decoder -----------------------------------------------------------------------------------------------
-    const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
-    if (shadow)
+    if (kv_done) {   // written by the last encoder layer's FFN launch
+    } else if (shadow)
         RCCHK(run_gemm(m, m->d_xp16, m->wkv_all, m->bkv_all, 0, M, NKV, D, m->d_memkv16, false, false, nullptr, nullptr, 0, 0, m->d_x16, 2 * D, D));
     else
         RCCHK(run_gemm(m, m->d_x16, m->wkv_all, plan->rb_kv, hw, M, NKV, D, m->d_memkv16, false, false, nullptr, kv_bias_ptrs, 2 * D, D));   // (per layer [k | v]: pos enters k only)
@@ -1322,6 +1360,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_WROUND")) m->wround = atoi(v);
     if (const char* v = getenv("OPD_FUSED_DEC")) m->fused_dec = atoi(v);
     if (const char* v = getenv("OPD_FUSED_ENC_FFN")) m->fused_enc_ffn = atoi(v);
+    if (const char* v = getenv("OPD_ENC_TAIL")) m->enc_tail = atoi(v);
     if (const char* v = getenv("OPD_DBG_DEC_LAYERS")) m->dbg_dec_layers = atoi(v);   // timing ablation (tools/dec_cost.sh): results are wrong
     m->device = device_ordinal;
     int ndev = 0;
@@ -1367,7 +1406,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
-    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
+    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());

@@ -717,8 +717,12 @@ def test_enc_ffn_matches_torch(lib, M, FF, period, in_place):
     y = np.empty((M, 256), np.float32)
     y16 = np.empty((M, 256), np.uint16)
     yp16 = np.empty((M, 256), np.uint16)
+    tail, tail_pos = (3, 2) if period else ((12, 6) if M == 100 else (0, 0))     # the next layer's q / k / v; the decoder's memory k / v (no pos table: y)
+    wt, wtb = _h(rng.standard_normal((max(tail, 1) * 256, 256)) / 16.0)
+    tb = (rng.standard_normal(max(tail, 1) * 256) * 0.2).astype(np.float32)
+    tout = np.empty((M, max(tail, 1) * 256), np.uint16)
     _capi.check(lib.opd_test_enc_ffn(_p(xb), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(res), _p(gamma), _p(beta), _p(pos), period, _p(y), _p(y16), _p(yp16),
-                                     M, FF, int(in_place)), "opd_test_enc_ffn")
+                                     M, FF, int(in_place), _p(wtb), _p(tb), tail, tail_pos if period else 0, _p(tout)), "opd_test_enc_ffn")
     hid = torch.relu(torch.from_numpy(x).double() @ torch.from_numpy(w1).double().T + torch.from_numpy(b1).double())
     hid = hid.float().half().double()                      # fp32 accumulate -> one fp16 rounding
     pre = hid @ torch.from_numpy(w2).double().T + torch.from_numpy(b2).double() + torch.from_numpy(res).double()
@@ -730,6 +734,14 @@ def test_enc_ffn_matches_torch(lib, M, FF, period, in_place):
     if period:
         wantp = (y + pos[np.arange(M) % period]).astype(np.float16)
         np.testing.assert_array_equal(yp16.view(np.float16), wantp)
+    if tail:   # tail projection of the kernel's own fp16 outputs: pass t < tail_pos on fp16(y + pos), the others on fp16(y); fp32 accumulate, one rounding
+        xin = y16.view(np.float16).astype(np.float64)
+        xpin = yp16.view(np.float16).astype(np.float64) if period else xin
+        got = tout.view(np.float16).astype(np.float32)
+        for t in range(tail):
+            src = xpin if (period and t < tail_pos) else xin
+            want_t = src @ wt[256 * t:256 * t + 256].astype(np.float64).T + tb[256 * t:256 * t + 256]
+            np.testing.assert_allclose(got[:, 256 * t:256 * t + 256], want_t, atol=2e-3, rtol=1.2e-3)
 
 
 # ---- one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel) -------------------------------------------------------
