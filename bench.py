@@ -440,7 +440,7 @@ def main() -> int:
             if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333) and args.arch == "r50":
                 traffic = round(json.load(open(tpath))["conv_gemm_family"]["bytes_per_launch"])
                 break
-        roof = {"bound": "mfma", "kernel": "implicit-GEMM family (conv_gemm_dma_kernel, btail_kernel, btail256_kernel, gemm_ln256_ring/os_kernel, gemm_k256_kernel, stem_pool2_kernel)",
+        roof = {"bound": "mfma", "kernel": "implicit-GEMM family (conv_gemm_dma_kernel, btail_kernel, btail256_kernel, gemm_ln256_ring/os_kernel, enc_ffn_kernel, gemm_k256_kernel, stem_pool2_kernel)",
                 "achieved": round(achieved, 2), "peak": PEAK_MFMA_TFLOPS,
                 "unit": "TFLOP/s", "frac": round(achieved / PEAK_MFMA_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": k_n, "avg_launch_us": round(1e3 * k_ms / max(k_n, 1), 2),

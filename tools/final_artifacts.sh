@@ -33,5 +33,10 @@ timeout -k 10 120 python tools/bench_gemm_ln.py > $O/bench_gemm_ln.txt 2>&1 &&
 timeout -k 10 120 python tools/trace_gemm.py > $O/trace_gemm.txt 2>&1 &&
 timeout -k 10 300 python tools/bench_layers.py 0 > $O/bench_layers.txt 2>&1 &&
 timeout -k 10 300 python tools/bench_btail.py --ablate > $O/bench_btail.txt 2>&1 &&
+timeout -k 10 200 python tools/bench_enc_ffn.py --ablate > $O/bench_enc_ffn.txt 2>&1 &&
+timeout -k 10 200 python tools/bench_dec.py > $O/bench_dec.txt 2>&1 &&
+timeout -k 10 120 tools/microbench/vmorder > $O/microbench_vmorder.txt 2>&1 &&
+timeout -k 10 300 python tools/host_rate_ref_pattern.py > $O/host_rate_ref_pattern.txt 2>&1 &&
+timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline --steps 300 > $O/bench_bf16.json 2> $O/bench_bf16.err &&
 du -sh $O
 fi

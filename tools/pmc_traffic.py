@@ -14,7 +14,7 @@ import sys
 
 
 # the kernels bench.py times as the "implicit-GEMM family" (classes conv + linear of opd_detr_kernel_times)
-GEMM_FAMILY = ("conv_gemm", "btail_kernel", "btail256_kernel", "gemm_ln256", "gemm_k256_kernel", "stem_pool")
+GEMM_FAMILY = ("conv_gemm", "btail_kernel", "btail256_kernel", "gemm_ln256", "enc_ffn_kernel", "gemm_k256_kernel", "stem_pool")
 
 
 def per_kernel(path, counter):
