@@ -541,7 +541,7 @@ constexpr int EF_X = EF_TM * 512;
 constexpr int EF_H = EF_TM * 256;
 constexpr int EF_RING0 = EF_X + 2 * EF_H;
 constexpr int EF_LDS = EF_RING0 + 8 * EF_R * 1024;
-constexpr int EF_PIECES(const int nch, const int tail) { return 14 + 17 * nch + (tail ? 17 * tail + 5 : 0); }   // per wave
+constexpr int EF_PIECES(const int nch, const int tail, const int front) { return (front ? 16 : 0) + 14 + 17 * nch + (tail ? 17 * tail + 5 : 0); }   // per wave
 
 template <int N>
 __device__ __forceinline__ void ef_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
@@ -568,8 +568,10 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
     const int m_base = blockIdx.x * EF_TM;
     unsigned char* const ring = smem + EF_RING0 + wave * (EF_R * 1024);
     const int nch = p.F / 128;
-    const unsigned total = (unsigned)EF_PIECES(nch, p.pack_tail) * 1024u;   // bytes of this wave's stream
-    const unsigned char* const wsrc = p.wpack + (size_t)wave * total + lane16;
+    const unsigned stride = (unsigned)EF_PIECES(nch, p.pack_tail, p.pack_front) * 1024u;   // bytes of a wave's stream
+    const unsigned skip = (p.pack_front && !p.attn) ? 16u * 1024u : 0u;                    // (a stream packed with the front projection, run without it)
+    const unsigned total = stride - skip;
+    const unsigned char* const wsrc = p.wpack + (size_t)wave * stride + skip + lane16;
     auto dma = [&](const unsigned char* src_lane, unsigned char* slot) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src_lane, (__attribute__((address_space(3))) void*)slot, 16, 0, 0);
     };
@@ -579,7 +581,7 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
         const int row = 2 * MT * wave + 2 * i + (lane >> 5);
         const int c16 = (lane & 31) ^ (row & 15);
         const int grow = m_base + row < p.M ? m_base + row : p.M - 1;     // (rows past the end: a valid address, never stored)
-        dma(reinterpret_cast<const unsigned char*>(p.x) + (size_t)grow * 512 + c16 * 16, X + (2 * MT * wave + 2 * i) * 512);
+        dma(reinterpret_cast<const unsigned char*>(p.attn ? p.attn : p.x) + (size_t)grow * 512 + c16 * 16, X + (2 * MT * wave + 2 * i) * 512);
     }
 #pragma unroll
     for (int n = 0; n < EF_R; ++n) dma(wsrc + n * 1024, ring + n * 1024);
@@ -672,10 +674,65 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { sl[i] = take(); f.w[i] = frag(sl[i]); }
     };
+    auto load_img = [&](const unsigned char* img) {
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(img + (mt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
+    };
+    auto mma_tail = [&](const EfFrags& f, const int ks0, const int q) {   // q = 2 i + j: k-step ks0 + i, tile j
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc2[q & 1][mt] = OPD_MFMA_16x16x32(f.w[q], xf[ks0 + (q >> 1)][mt], acc2[q & 1][mt]);
+    };
+#define EF_TAIL_STEP(F_, KS0, SL, NEXT)                                            \
+    do {                                                                           \
+        EF_FENCE();                                                                \
+        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                         \
+            mma_tail(F_, KS0, q_);                                                 \
+            EF_FENCE();                                                            \
+            if (q_ == 0) { NEXT; EF_FENCE(); }                                     \
+            reissue(SL[q_]);                                                       \
+            EF_FENCE();                                                            \
+        }                                                                          \
+    } while (0)
     // ---- fc1 of chunk 0 (the pipeline fills), then the first group of chunk 1 into set A ------------------------------------------------
     unsigned s0[5], sa4[4];
-    ef_wait_vm<EF_R - 5>();
-    take_g0(A);
+    if (p.attn == nullptr) {
+        ef_wait_vm<EF_R - 5>();
+        take_g0(A);
+    } else {
+        // ---- FRONT phase (the slab holds the ATTENTION output): x = LayerNorm(res + attn . Wo^T + bo), HF:models/detr/modeling_detr.py:640-645.
+        //      The stream starts with Wo's 16 pieces for this wave's two tiles (fc2's group format); same pipeline; x goes to y32 (the residual the
+        //      epilogue reads back) and, as fp16, into the slab's place in LDS -- it never exists as a tensor of its own.
+        ef_wait_vm<EF_R - 4>();
+        take_w4(A, sa4);
+        EF_TAIL_STEP(A, 0, sa4, (ef_wait_vm<EF_R - 8>(), take_w4(B, sb)));
+        EF_TAIL_STEP(B, 2, sb, (ef_wait_vm<EF_R - 8>(), take_w4(A, sa4)));
+        EF_TAIL_STEP(A, 4, sa4, (ef_wait_vm<EF_R - 8>(), take_w4(B, sb)));
+        EF_TAIL_STEP(B, 6, sb, (ef_wait_vm<EF_R - 9>(), take_g0(A)));   // (the FFN's first group)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int cidx = (2 * wave + j) * 16 + 4 * g;
+            const float4v bo = *reinterpret_cast<const float4v*>(p.bo + cidx);
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = m_base + mt * 16 + li;
+                float4v r = float4v{0.f, 0.f, 0.f, 0.f};
+                if (p.res32 && m < p.M) r = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + cidx);
+                acc2[j][mt] += bo + r;
+            }
+        }
+        RowLnOut o1{p.gamma1, p.beta1, p.y32, nullptr, nullptr, nullptr, nullptr, 0, p.M};
+        o1.img_x = X; o1.img_xp = H;      // (no position table here: both images are fp16(x); H is not in use yet)
+        row_ln_store<true, MT>(o1, acc2, red, m_base, wave, g, li);   // (its barriers separate every wave's slab reads from the image writes)
+        EF_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        load_img(X);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc2[j][mt] = float4v{0.f, 0.f, 0.f, 0.f};
+    }
 #pragma unroll
     for (int i = 0; i < 5; ++i) s0[i] = sa[i];
     EF_FC1_STEP(A, 0, true, s0, 5, (ef_wait_vm<EF_R - 9>(), take_w4(B, sb)));
@@ -727,27 +784,6 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
     //      tiles, as fc2's), the y fragments in registers; the first `tail_pos` passes multiply y + pos.  Same pipeline as above.
     EF_LGKM0();
     __builtin_amdgcn_s_barrier();      // both images are complete
-    auto load_img = [&](const unsigned char* img) {
-#pragma unroll
-        for (int ks = 0; ks < 8; ++ks)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) xf[ks][mt] = *reinterpret_cast<const half8*>(img + (mt * 16 + li) * 512 + (((ks * 4 + g) ^ li) << 4));
-    };
-    auto mma_tail = [&](const EfFrags& f, const int ks0, const int q) {   // q = 2 i + j: k-step ks0 + i, tile j
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc2[q & 1][mt] = OPD_MFMA_16x16x32(f.w[q], xf[ks0 + (q >> 1)][mt], acc2[q & 1][mt]);
-    };
-#define EF_TAIL_STEP(F_, KS0, SL, NEXT)                                            \
-    do {                                                                           \
-        EF_FENCE();                                                                \
-        _Pragma("unroll") for (int q_ = 0; q_ < 4; ++q_) {                         \
-            mma_tail(F_, KS0, q_);                                                 \
-            EF_FENCE();                                                            \
-            if (q_ == 0) { NEXT; EF_FENCE(); }                                     \
-            reissue(SL[q_]);                                                       \
-            EF_FENCE();                                                            \
-        }                                                                          \
-    } while (0)
     // Every pass = 17 pieces: the biases of the wave's two tiles (accumulator layout: lane (g, li < 8) tile 0, (g, li >= 8) tile 1) + 16 weight
     // pieces; nothing but LDS-DMA requests and the output stores touch vector memory inside the loop (a global load here makes the compiler
     // drain vmcnt(0) -- the whole ring -- at every use).
@@ -828,9 +864,12 @@ hipError_t OPD_SYM(opd_launch_gemm_ln)(const GemmLnParams& p, hipStream_t stream
 }
 
 hipError_t OPD_SYM(opd_launch_enc_ffn)(const EncFfnParams& p, hipStream_t stream) {
-    if (p.M <= 0 || p.F <= 0 || p.F % 128 != 0 || !p.x || !p.wpack || !p.b2 || !p.gamma || !p.beta) return hipErrorInvalidValue;
+    if (p.M <= 0 || p.F <= 0 || p.F % 128 != 0 || (!p.x && !p.attn) || !p.wpack || !p.b2 || !p.gamma || !p.beta) return hipErrorInvalidValue;
+    // front phase (attention output projection + LayerNorm in front of the FFN): its weights lead the stream; x is then made inside, and the
+    // residual the epilogue adds is what the front phase wrote (y32 == res32)
+    if ((p.attn && !p.pack_front) || (p.attn && (!p.bo || !p.gamma1 || !p.beta1 || !p.y32 || p.y32 != p.res32))) return hipErrorInvalidValue;
     if (p.yp16 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
-    if ((size_t)EF_PIECES(p.F / 128, p.pack_tail) * 1024 >= 0x7fffff00ull) return hipErrorInvalidValue;   // 32-bit stream offsets
+    if ((size_t)EF_PIECES(p.F / 128, p.pack_tail, p.pack_front) * 1024 >= 0x7fffff00ull) return hipErrorInvalidValue;   // 32-bit stream offsets
     if (p.pack_tail < 0 || p.pack_tail > 16 || (p.tail != 0 && p.tail != p.pack_tail) || p.tail < 0 || p.tail > 16 || p.tail_pos < 0 || p.tail_pos > p.tail || (p.tail && (!p.tail_out || p.tail_ld < 256))) return hipErrorInvalidValue;
     if (p.tail_pos > 0 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
     const dim3 grid((p.M + EF_TM - 1) / EF_TM);
@@ -853,7 +892,7 @@ hipError_t OPD_SYM(opd_launch_enc_ffn)(const EncFfnParams& p, hipStream_t stream
 }
 
 #ifndef OPD_ELEM_BF16   // (a permutation of 16-bit words and fp32 biases: the same for both element types)
-size_t opd_encffn_pack_bytes(int F, int tail) { return (size_t)8 * EF_PIECES(F / 128, tail) * 1024; }
+size_t opd_encffn_pack_bytes(int F, int tail, int front) { return (size_t)8 * EF_PIECES(F / 128, tail, front) * 1024; }
 // host: w1 [F][256], w2 [256][F] as 16-bit elements (fp16 or bf16), b1 [F] fp32 -> the eight per-wave streams of enc_ffn_kernel, in the order the
 // kernel consumes them: G0(0) G1(0) G0(1) { G1(c+1) G2(c) G3(c) G0(c+2) } for c = 0 .. F/128 - 1 (zeros for fc1 chunks past the end).
 //   G0(c): the bias piece (lane L = 16 g + li: b1[128 c + 16 w + 4 g .. + 3] as fp32), then k-steps 0 .. 3 of W1's tile (lane L:
@@ -863,11 +902,23 @@ size_t opd_encffn_pack_bytes(int F, int tail) { return (size_t)8 * EF_PIECES(F /
 // Tail (optional): wt [tail * 256][256] = the weight rows of the tail projection in PASS order, bt [tail * 256] its biases; per pass the bias piece
 // (lane (g, li): bt[256 t + (2 w + (li >> 3)) 16 + 4 g .. + 3]) and 16 pieces in fc2's group format (group q: k-steps 2 q, 2 q + 1 of the wave's
 // tiles 2 w, 2 w + 1 of that pass); five zero pieces at the end.
-void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, const uint16_t* wt, const float* bt, int tail, unsigned char* out) {
+// Front (optional): wo [256][256] = the attention output projection; its 16 pieces (fc2's group format) lead every wave's stream.
+void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, const uint16_t* wt, const float* bt, int tail, const uint16_t* wo, unsigned char* out) {
     const int nch = F / 128;
-    __builtin_memset(out, 0, opd_encffn_pack_bytes(F, tail));
+    const int front = wo != nullptr;
+    __builtin_memset(out, 0, opd_encffn_pack_bytes(F, tail, front));
     for (int w = 0; w < 8; ++w) {
-        unsigned char* o = out + (size_t)w * EF_PIECES(nch, tail) * 1024;
+        unsigned char* o = out + (size_t)w * EF_PIECES(nch, tail, front) * 1024;
+        if (front)
+            for (int q = 0; q < 4; ++q) {
+                for (int L = 0; L < 64; ++L) {
+                    const int g = L >> 4, li = L & 15;
+                    for (int i = 0; i < 2; ++i)
+                        for (int j = 0; j < 2; ++j)
+                            __builtin_memcpy(o + (2 * i + j) * 1024 + L * 16, wo + (size_t)((2 * w + j) * 16 + li) * 256 + 32 * (2 * q + i) + 8 * g, 16);
+                }
+                o += 4 * 1024;
+            }
         auto g0 = [&](const int c) {   // 5 pieces
             if (c < nch)
                 for (int L = 0; L < 64; ++L) {

@@ -154,6 +154,13 @@ struct EncFfnParams {
     int dbg;                      // tools only: timing ablations (0 in the model)
     // optional tail projection of the block's output, `tail` passes of 256 output columns (the next layer's q / k / v, or the decoder's memory
     // keys / values): tail_out[m][tail_col[t] .. + 255] = fp16((t < tail_pos ? y + pos : y)[m] . Wt_t^T + bias_t); Wt and the biases travel in wpack
+    // optional FRONT phase: x = LayerNorm1(res32 + attn . Wo^T + bo) computed inside from the attention output (then `x` above is unused, y32 must be
+    // res32: the front phase writes x there and the epilogue reads it back as the FFN's residual); Wo leads wpack (pack_front)
+    const f16_t* attn;            // [M][256] or null
+    const float* bo;              // [256]
+    const float* gamma1;          // [256]
+    const float* beta1;
+    int pack_front;
     int pack_tail;                // the number of tail passes wpack was built with (stream stride); tail is 0 or pack_tail
     int tail, tail_pos;           // 0 .. 16 passes; the first tail_pos of them multiply y + pos (pos / pos_ptrs / pos_period as for yp16)
     f16_t* tail_out;
@@ -161,8 +168,9 @@ struct EncFfnParams {
     int tail_col[16];
 };
 hipError_t opd_launch_enc_ffn(const EncFfnParams& p, hipStream_t stream);
-size_t opd_encffn_pack_bytes(int F, int tail);
-void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, const uint16_t* wt, const float* bt, int tail, unsigned char* out);   // host
+size_t opd_encffn_pack_bytes(int F, int tail, int front);
+void opd_encffn_pack(const uint16_t* w1, const float* b1, const uint16_t* w2, int F, const uint16_t* wt, const float* bt, int tail, const uint16_t* wo,
+                     unsigned char* out);   // host
 // Small-M linear layer, reduction cut into 256-wide slices: slice z computes x[:, 256z : 256z+256] . w[:, 256z : 256z+256]^T.
 // slices == 1: out = act(. + bias) as fp16 (out16) or fp32 (out32).  slices > 1: fp32 slabs out32[z][M][N], bias in slab 0
 // (summed by opd_launch_reduce_ln).  bias_period > 0: row-periodic bias [period][N].

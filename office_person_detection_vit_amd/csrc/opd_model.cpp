@@ -48,14 +48,15 @@ static const HostTensor& T(const StateDict& sd, const std::string& k) { return s
 // the encoder FFN's weights (+ the rows of its tail projection, pass order) as enc_ffn_kernel's per-wave fragment streams, in the handle's 16-bit
 // operand type
 static int upload_encffn(opd_detr* m, unsigned char** dst, const std::vector<float>& w1, const std::vector<float>& b1, const std::vector<float>& w2, int F,
-                         const std::vector<float>& wt, const std::vector<float>& bt, int tail) {
-    std::vector<uint16_t> h1(w1.size()), h2(w2.size()), ht(wt.size());
+                         const std::vector<float>& wt, const std::vector<float>& bt, int tail, const std::vector<float>& wo) {
+    std::vector<uint16_t> h1(w1.size()), h2(w2.size()), ht(wt.size()), ho(wo.size());
     const bool bf = m->dtype == OPD_DT_BF16;
     auto cv = [&](const std::vector<float>& v, std::vector<uint16_t>& h) { for (size_t i = 0; i < v.size(); ++i) h[i] = bf ? f32_to_bf16(v[i]) : f32_to_f16(v[i]); };
-    cv(w1, h1); cv(w2, h2); cv(wt, ht);
+    cv(w1, h1); cv(w2, h2); cv(wt, ht); cv(wo, ho);
+    if (!ho.empty() && ho.size() != (size_t)256 * 256) return fail(OPD_ESCHEMA, "encoder front projection: unexpected weight shape");
     if (ht.size() != (size_t)tail * 256 * 256 || bt.size() != (size_t)tail * 256) return fail(OPD_ESCHEMA, "encoder tail projection: unexpected weight shape");
-    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F, tail));
-    opd_encffn_pack(h1.data(), b1.data(), h2.data(), F, ht.data(), bt.data(), tail, pk.data());
+    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F, tail, ho.empty() ? 0 : 1));
+    opd_encffn_pack(h1.data(), b1.data(), h2.data(), F, ht.data(), bt.data(), tail, ho.empty() ? nullptr : ho.data(), pk.data());
     RCCHK(dalloc(m, dst, pk.size(), true));
     HIPCHK(hipMemcpy(*dst, pk.data(), pk.size(), hipMemcpyHostToDevice));
     return OPD_OK;
@@ -276,7 +277,9 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
                     }
                 E.tail = 2 * L; E.tail_pos = L; E.tail_ld = 2 * L * D;
             }
-            RCCHK(upload_encffn(m, &E.ffn_pack, T(sd, p + ".mlp.fc1.weight").data, T(sd, p + ".mlp.fc1.bias").data, T(sd, p + ".mlp.fc2.weight").data, a.ffn, wt, bt, E.tail));
+            RCCHK(upload_encffn(m, &E.ffn_pack, T(sd, p + ".mlp.fc1.weight").data, T(sd, p + ".mlp.fc1.bias").data, T(sd, p + ".mlp.fc2.weight").data, a.ffn, wt, bt, E.tail,
+                                T(sd, p + ".self_attn.o_proj.weight").data));
+            E.front = 1;
         }
     }
     {   // The decoder starts from h = 0 (HF:models/detr/modeling_detr.py:1243-1251), so in layer 0 the self-attention values are the
@@ -924,7 +927,10 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         else
             RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i], 3 * D, 2 * D));   // (pos enters q and k only)
         RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw, d_keyv, cw));
-        if (m->fuse_gemm_ln && D == 256) {
+        const bool ffn_fused = m->fused_enc_ffn && m->fuse_gemm_ln && L.ffn_pack && D == 256;
+        const bool front = ffn_fused && L.front && m->enc_front;   // the output projection + LayerNorm run inside the FFN launch
+        if (front) {
+        } else if (m->fuse_gemm_ln && D == 256) {
             RCCHK(run_gemm_ln(m, m->d_attn16, L.o.w, L.o.b, M, D, m->d_x32, L.ln1, m->d_x32, m->d_x16));
         } else {
             RCCHK(run_gemm(m, m->d_attn16, L.o.w, L.o.b, 0, M, D, D, m->d_y32, true, false, m->d_x32));
@@ -932,11 +938,12 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             HIPCHK(opd_launch_layernorm(m->d_y32, L.ln1.g, L.ln1.b, m->d_x32, m->d_x16, M, m->stream, m->dtype));
             RCCHK(timed_end(m));
         }
-        if (m->fused_enc_ffn && m->fuse_gemm_ln && L.ffn_pack && D == 256) {
+        if (ffn_fused) {
             // the whole FFN block as ONE row-owner launch: the [M][F] hidden tensor never leaves LDS (kernels_rowln.hip::enc_ffn_kernel)
             EncFfnParams fp{}; fp.dtype = m->dtype;
             fp.x = m->d_x16; fp.wpack = L.ffn_pack; fp.b2 = L.fc2.b; fp.res32 = m->d_x32; fp.gamma = L.ln2.g; fp.beta = L.ln2.b;
-            fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F; fp.pack_tail = L.tail;
+            fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F; fp.pack_tail = L.tail; fp.pack_front = L.front;
+            if (front) { fp.attn = m->d_attn16; fp.bo = L.o.b; fp.gamma1 = L.ln1.g; fp.beta1 = L.ln1.b; }
             if (ps) { fp.pos = ps->pos; fp.pos_ptrs = ps->pos_ptrs; fp.pos_period = ps->period; fp.yp16 = ps->yp16; }
             const bool last = i + 1 == a.enc_layers;
             qkv_done = false;
@@ -947,7 +954,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 for (int t = 0; t < L.tail; ++t) fp.tail_col[t] = L.tail_col[t];
                 (last ? kv_done : qkv_done) = true;
             }
-            RCCHK(timed_begin(m, CLS_GEMM, 4.0 * M * (double)D * F + 2.0 * M * (double)D * 256 * fp.tail));
+            RCCHK(timed_begin(m, CLS_GEMM, 4.0 * M * (double)D * F + 2.0 * M * (double)D * 256 * (fp.tail + (front ? 1 : 0))));
             HIPCHK(opd_launch_enc_ffn(fp, m->stream));
             RCCHK(timed_end(m));
             RCCHK(tap(m, "enc_ffn", m->d_x32, (size_t)M * D * 4));
@@ -1361,6 +1368,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_FUSED_DEC")) m->fused_dec = atoi(v);
     if (const char* v = getenv("OPD_FUSED_ENC_FFN")) m->fused_enc_ffn = atoi(v);
     if (const char* v = getenv("OPD_ENC_TAIL")) m->enc_tail = atoi(v);
+    if (const char* v = getenv("OPD_ENC_FRONT")) m->enc_front = atoi(v);
     if (const char* v = getenv("OPD_DBG_DEC_LAYERS")) m->dbg_dec_layers = atoi(v);   // timing ablation (tools/dec_cost.sh): results are wrong
     m->device = device_ordinal;
     int ndev = 0;
@@ -1406,7 +1414,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
-    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
+    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());

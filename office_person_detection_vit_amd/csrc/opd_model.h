@@ -68,6 +68,7 @@ struct EncLayer {
     // ... followed by the weights of the block's TAIL projection: the next layer's q / k / v (3 passes of 256 columns, the first 2 on x + pos), or,
     // after the last layer, the decoder's memory keys and values (k of every decoder layer on x + pos, then v of every layer)
     int tail = 0, tail_pos = 0, tail_ld = 0;
+    int front = 0;                       // the stream leads with the attention output projection (front phase of the launch)
     int tail_col[16] = {};
 };
 struct DecLayer {
@@ -140,6 +141,7 @@ struct opd_detr {
     float* dec0_h = nullptr;   // [256]: decoder state after the self-attention block of layer 0 (input independent, see build_weights)
     int fuse_dec0 = 1;         // use it (0: run that block's four launches on the zero state like every other layer)
     f16_t* qc0 = nullptr;      // [Q][256]: layer 0's cross-attention queries (dec0_h + qpos) . Wq_c^T + bq_c: input independent as well (fp32 at load)
+    int enc_front = 1;         // ... with the attention output projection + LayerNorm in front, from the attention output (env OPD_ENC_FRONT)
     int enc_tail = 0;          // ... with the next layer's q / k / v projection (last layer: the decoder's memory k / v) as its tail (env OPD_ENC_TAIL)
     int fused_enc_ffn = 1;     // the encoder's FFN block as one launch (kernels_rowln.hip::enc_ffn_kernel; 0: fc1 GEMM + deep-K ring launch; env OPD_FUSED_ENC_FFN)
     int fused_dec = 1;         // the decoder as five launches per layer on split fp16 operands (kernels_dec.hip; 0: the round-3 chain of nine launches

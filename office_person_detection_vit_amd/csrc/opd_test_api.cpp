@@ -224,24 +224,37 @@ int opd_test_bench_gemm_ln(int M, int K, int deep, int iters, float* us_out) {
 // the encoder's FFN block in one launch (enc_ffn_kernel): x [M][256], w1 [F][256], w2 [256][F] as 16-bit elements of the current test element
 // type, b1 [F], b2 / gamma / beta [256], res32 [M][256]; y = LayerNorm(res32 + relu(x . w1^T + b1) . w2^T + b2); optional position shadow as in
 // opd_test_gemm_ln_deep.  in_place: y32 aliases res32 and y16 aliases x, as in the model.  Optional tail projection: wt [tail * 256][256],
-// tail_bias [tail * 256], the first tail_pos passes on y + pos; tail_out [M][tail * 256] (pass t at columns 256 t).
+// tail_bias [tail * 256], the first tail_pos passes on y + pos; tail_out [M][tail * 256] (pass t at columns 256 t).  Optional FRONT phase
+// (wo != null): x is the ATTENTION output; x' = LayerNorm1(res32 + x . wo^T + bo) * g1 + be1 is computed inside, returned in x1_out [M][256]
+// (fp32), and the FFN runs on fp16(x') with the residual x' (always in place on res32 then).
 int opd_test_enc_ffn(const uint16_t* x, const uint16_t* w1, const float* b1, const uint16_t* w2, const float* b2, const float* res32, const float* gamma,
                      const float* beta, const float* pos, int period, float* y, uint16_t* y16, uint16_t* yp16, int M, int F, int in_place,
-                     const uint16_t* wt, const float* tail_bias, int tail, int tail_pos, uint16_t* tail_out) {
+                     const uint16_t* wt, const float* tail_bias, int tail, int tail_pos, uint16_t* tail_out, const uint16_t* wo, const float* bo,
+                     const float* g1, const float* be1, int pack_front) {
     if (M <= 0 || F <= 0 || F % 128 || tail < 0 || tail > 16) return tfail(OPD_EINVAL, "enc_ffn: F must be a multiple of 128, tail <= 16");
+    if (wo && !pack_front) return tfail(OPD_EINVAL, "enc_ffn: the front phase needs a stream packed with it");
     DevMem dm;
-    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F, tail));
-    opd_encffn_pack(w1, b1, w2, F, wt, tail_bias, tail, pk.data());
+    std::vector<unsigned char> pk(opd_encffn_pack_bytes(F, tail, pack_front));
+    std::vector<uint16_t> wo_dummy((size_t)256 * 256, 0);
+    opd_encffn_pack(w1, b1, w2, F, wt, tail_bias, tail, pack_front ? (wo ? wo : wo_dummy.data()) : nullptr, pk.data());
     EncFfnParams p{}; p.dtype = g_test_dtype;
     uint16_t* dx = dm.up(x, (size_t)M * 256);
     float* res = dm.up(res32, (size_t)M * 256);
-    p.x = dx; p.wpack = dm.up(pk.data(), pk.size()); p.b2 = dm.up(b2, 256); p.res32 = res; p.gamma = dm.up(gamma, 256); p.beta = dm.up(beta, 256);
+    p.wpack = dm.up(pk.data(), pk.size()); p.b2 = dm.up(b2, 256); p.res32 = res; p.gamma = dm.up(gamma, 256); p.beta = dm.up(beta, 256);
+    p.pack_front = pack_front;
+    if (wo) {
+        p.attn = dx; p.bo = dm.up(bo, 256); p.gamma1 = dm.up(g1, 256); p.beta1 = dm.up(be1, 256);
+        if (!p.bo || !p.gamma1 || !p.beta1) return tfail(OPD_ENOMEM, "test alloc failed");
+        in_place = 1;
+    } else {
+        p.x = dx;
+    }
     p.y32 = in_place ? res : dm.up<float>(nullptr, (size_t)M * 256);
-    p.y16 = in_place ? dx : dm.up<uint16_t>(nullptr, (size_t)M * 256);
+    p.y16 = (in_place && !wo) ? dx : dm.up<uint16_t>(nullptr, (size_t)M * 256);
     p.pos = pos ? dm.up(pos, (size_t)period * 256) : nullptr;
     p.pos_period = period;
     p.yp16 = pos ? dm.up<uint16_t>(nullptr, (size_t)M * 256) : nullptr;
-    if (!p.x || !p.wpack || !p.b2 || !p.res32 || !p.gamma || !p.beta || !p.y32 || !p.y16 || (pos && (!p.pos || !p.yp16))) return tfail(OPD_ENOMEM, "test alloc failed");
+    if (!dx || !p.wpack || !p.b2 || !p.res32 || !p.gamma || !p.beta || !p.y32 || !p.y16 || (pos && (!p.pos || !p.yp16))) return tfail(OPD_ENOMEM, "test alloc failed");
     p.M = M; p.F = F; p.pack_tail = tail; p.tail = tail; p.tail_pos = tail_pos;
     if (tail) {
         p.tail_ld = tail * 256;
@@ -259,12 +272,12 @@ int opd_test_enc_ffn(const uint16_t* x, const uint16_t* w1, const float* b1, con
 }
 
 // Times `iters` launches of the fused encoder FFN on M rows of arbitrary data.
-int opd_test_bench_enc_ffn(int M, int F, int iters, int dbg, int tail, float* us_out) {
+int opd_test_bench_enc_ffn(int M, int F, int iters, int dbg, int tail, int front, float* us_out) {
     if (M <= 0 || F <= 0 || F % 128) return tfail(OPD_EINVAL, "bench_enc_ffn: F must be a multiple of 128");
     DevMem dm;
     EncFfnParams p{}; p.dtype = g_test_dtype;
     uint16_t* x = dm.up<uint16_t>(nullptr, (size_t)M * 256);
-    unsigned char* wp = dm.up<unsigned char>(nullptr, opd_encffn_pack_bytes(F, tail));
+    unsigned char* wp = dm.up<unsigned char>(nullptr, opd_encffn_pack_bytes(F, tail, 1));
     uint16_t* tout = tail ? dm.up<uint16_t>(nullptr, (size_t)M * tail * 256) : nullptr;
     if (tail && !tout) return tfail(OPD_ENOMEM, "bench alloc failed");
     float* f = dm.up<float>(nullptr, 1024);
@@ -272,11 +285,12 @@ int opd_test_bench_enc_ffn(int M, int F, int iters, int dbg, int tail, float* us
     uint16_t* y16 = dm.up<uint16_t>(nullptr, (size_t)M * 256);
     if (!x || !wp || !f || !res || !y16) return tfail(OPD_ENOMEM, "bench alloc failed");
     TCHK(hipMemset(x, 0x2c, (size_t)M * 256 * 2));
-    TCHK(hipMemset(wp, 0x1c, opd_encffn_pack_bytes(F, tail)));
+    TCHK(hipMemset(wp, 0x1c, opd_encffn_pack_bytes(F, tail, 1)));
     TCHK(hipMemset(f, 0, 4096));
     TCHK(hipMemset(res, 0, (size_t)M * 256 * 4));
     p.x = x; p.wpack = wp; p.b2 = f; p.gamma = f + 256; p.beta = f + 512; p.res32 = res; p.y32 = res; p.y16 = y16; p.M = M; p.F = F; p.dbg = dbg;
-    p.pack_tail = tail; p.tail = tail; p.tail_pos = 0; p.tail_out = tout; p.tail_ld = tail * 256;
+    p.pack_tail = tail; p.tail = tail; p.tail_pos = 0; p.tail_out = tout; p.tail_ld = tail * 256; p.pack_front = 1;
+    if (front) { p.attn = x; p.x = nullptr; p.bo = f; p.gamma1 = f + 256; p.beta1 = f + 512; }
     for (int t = 0; t < tail && t < 16; ++t) p.tail_col[t] = 256 * t;
     hipEvent_t a, b;
     TCHK(hipEventCreate(&a)); TCHK(hipEventCreate(&b));

@@ -721,8 +721,10 @@ def test_enc_ffn_matches_torch(lib, M, FF, period, in_place):
     wt, wtb = _h(rng.standard_normal((max(tail, 1) * 256, 256)) / 16.0)
     tb = (rng.standard_normal(max(tail, 1) * 256) * 0.2).astype(np.float32)
     tout = np.empty((M, max(tail, 1) * 256), np.uint16)
+    # the stream is packed WITH the front projection's pieces in every case (as the model's is) and run without the front phase here
     _capi.check(lib.opd_test_enc_ffn(_p(xb), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(res), _p(gamma), _p(beta), _p(pos), period, _p(y), _p(y16), _p(yp16),
-                                     M, FF, int(in_place), _p(wtb), _p(tb), tail, tail_pos if period else 0, _p(tout)), "opd_test_enc_ffn")
+                                     M, FF, int(in_place), _p(wtb), _p(tb), tail, tail_pos if period else 0, _p(tout), None, None, None, None, 1),
+                "opd_test_enc_ffn")
     hid = torch.relu(torch.from_numpy(x).double() @ torch.from_numpy(w1).double().T + torch.from_numpy(b1).double())
     hid = hid.float().half().double()                      # fp32 accumulate -> one fp16 rounding
     pre = hid @ torch.from_numpy(w2).double().T + torch.from_numpy(b2).double() + torch.from_numpy(res).double()
@@ -742,6 +744,42 @@ def test_enc_ffn_matches_torch(lib, M, FF, period, in_place):
             src = xpin if (period and t < tail_pos) else xin
             want_t = src @ wt[256 * t:256 * t + 256].astype(np.float64).T + tb[256 * t:256 * t + 256]
             np.testing.assert_allclose(got[:, 256 * t:256 * t + 256], want_t, atol=2e-3, rtol=1.2e-3)
+
+
+@pytest.mark.parametrize("M,FF,period", [(8400, 2048, 1050), (100, 2048, 0), (333, 256, 111), (1, 128, 0)])
+def test_enc_ffn_with_front_projection_matches_torch(lib, M, FF, period):
+    """enc_ffn_kernel with its FRONT phase: the attention output goes in, x = LN1(res + attn Wo^T + bo) is made inside (fp32 to the residual
+    stream, fp16 into LDS as the FFN's operand) and y = LN2(x + fp16(relu(fp16(x) W1^T + b1)) W2^T + b2) comes out: what the model runs per
+    encoder layer after the attention (HF:models/detr/modeling_detr.py:640-660)."""
+    rng = np.random.default_rng(M * 11 + FF)
+    at, atb = _h(rng.standard_normal((M, 256)))
+    wo, wob = _h(rng.standard_normal((256, 256)) / 16.0)
+    bo = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    g1 = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    be1 = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    w1, w1b = _h(rng.standard_normal((FF, 256)) / 16.0)
+    w2, w2b = _h(rng.standard_normal((256, FF)) / np.sqrt(FF))
+    b1 = (rng.standard_normal(FF) * 0.3).astype(np.float32)
+    b2 = (rng.standard_normal(256) * 0.1).astype(np.float32)
+    res = rng.standard_normal((M, 256)).astype(np.float32)
+    gamma = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(256)).astype(np.float32)
+    pos = rng.standard_normal((period, 256)).astype(np.float32) if period else None
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    yp16 = np.empty((M, 256), np.uint16)
+    _capi.check(lib.opd_test_enc_ffn(_p(atb), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(res), _p(gamma), _p(beta), _p(pos), period, _p(y), _p(y16), _p(yp16),
+                                     M, FF, 1, None, None, 0, 0, None, _p(wob), _p(bo), _p(g1), _p(be1), 1), "opd_test_enc_ffn")
+    T = lambda a: torch.from_numpy(a).double()
+    x1 = F.layer_norm(T(at) @ T(wo).T + T(bo) + T(res), (256,), T(g1), T(be1), 1e-5)
+    x16 = x1.float().half().double()
+    hid = torch.relu(x16 @ T(w1).T + T(b1)).float().half().double()
+    want = F.layer_norm(hid @ T(w2).T + T(b2) + x1, (256,), T(gamma), T(beta), 1e-5).float().numpy()
+    # (fp16 roundings of x and of the hidden activations that land next to a boundary may go the other way than in the double-precision chain)
+    np.testing.assert_allclose(y, want, atol=6e-4, rtol=1e-5)
+    np.testing.assert_allclose(y16.view(np.float16).astype(np.float32), y, atol=2e-3, rtol=1e-3)
+    if period:
+        np.testing.assert_array_equal(yp16.view(np.float16), (y + pos[np.arange(M) % period]).astype(np.float16))
 
 
 # ---- one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel) -------------------------------------------------------
