@@ -397,3 +397,36 @@ def test_r50_tile_1080x1920_matches_live_oracle(mild_path, parity_log):
         assert float(np.abs(bx1[0] - bx2[1]).max()) <= 1e-6   # a frame does not depend on the batch it travels in
     finally:
         det.close()
+
+
+@pytest.mark.parametrize("env", [{"OPD_ENC_FRONT": "0"}, {"OPD_FUSED_ENC_FFN": "0"}, {"OPD_ENC_TAIL": "1"}, {"OPD_FUSED_DEC": "0"}])
+def test_alternative_launch_plans_agree_with_the_default(mild_path, parity_log, monkeypatch, env):
+    """Every encoder / decoder launch plan the library can take for the same weights — the attention output projection as its own launch,
+    the FFN block as two launches, the next layer's q / k / v (and the decoder's memory k / v) inside the FFN launch, the decoder as the
+    round-3 chain — computes the same function: each against the live oracle at the north-star tolerance (800x1333, ragged second frame:
+    padding mask and per-frame position tables go through every plan), and against the default plan within the fp16 noise of two equally
+    precise summation orders."""
+    frames = structured_frames(2, 800, 1333, seed=5151)
+    frames[1] = np.ascontiguousarray(frames[1][:640, :1100])
+
+    def run():
+        det = HipDetrDetector(model_path=mild_path, max_batch=2, max_size=(800, 1333), resize=False)
+        det.load_model()
+        try:
+            return det.forward_raw(frames)
+        finally:
+            det.close()
+
+    lg0, bx0, enc0 = run()
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    lg1, bx1, enc1 = run()
+    w = O.to_torch(load_safetensors(mild_path))
+    pv, pm = O.preprocess(frames)
+    lg, bx, mem = O.forward(w, pv, pm)
+    sm = lambda t: torch.softmax(torch.as_tensor(t), -1).numpy()
+    dbox = float(np.abs(bx1 - bx.numpy()).max())
+    parity_log(f"r50 mild 800x1333 + ragged 640x1100, plan {env} vs live oracle", dbox, float(np.abs(sm(lg1) - sm(lg.numpy())).max()), None, 1e-3,
+               f"default plan on the same frames {float(np.abs(bx0 - bx.numpy()).max()):.1e}; plans apart {float(np.abs(bx1 - bx0).max()):.1e}")
+    assert dbox <= 1e-3
+    assert float(np.abs(bx1 - bx0).max()) <= 8e-4
