@@ -403,14 +403,15 @@ def main() -> int:
         stage_graph = None
         _capi.check(lib.opd_detr_set_profiling(phandle, 2), "opd_detr_set_profiling")
         sg = np.zeros(8)
-        for it in range(2 + 5):   # eager, capture, then five replays
+        NREP = 20
+        for it in range(2 + NREP):   # eager, capture, then NREP replays (the serial leg's own 30-step window: averaged over as many steps)
             detect_blocking(phandle, d_flats[0])
             if it >= 2:
                 s8 = (C.c_float * 8)()
                 _capi.check(lib.opd_detr_stage_times(phandle, s8), "opd_detr_stage_times")
                 sg += np.asarray(list(s8))
         if sg.sum() > 0:
-            stage_graph = [round(float(v), 4) for v in sg / 5]
+            stage_graph = [round(float(v), 4) for v in sg / NREP]
         # roofline of the dominant kernel: HIP event pairs around every launch on the library's stream (eager, serial)
         handle = phandle
         _capi.check(lib.opd_detr_set_profiling(handle, 1), "opd_detr_set_profiling")

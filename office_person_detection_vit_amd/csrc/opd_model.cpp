@@ -421,8 +421,9 @@ static int build_workspace(opd_detr* m) {
     RCCHK(fill_qc0(m));
     RCCHK(dalloc(m, &m->d_logits, Md * a.ncls, false));
     RCCHK(dalloc(m, &m->d_boxes, Md * 4, false));
-    RCCHK(dalloc(m, &m->d_records, Md, false));
-    RCCHK(dalloc(m, &m->d_counts, B, false));
+    // records of max_batch frames, the per-frame counts right behind them: ONE device-to-host copy fetches both
+    RCCHK(dalloc(m, &m->d_records, Md + ((size_t)B * 4 + sizeof(opd_det) - 1) / sizeof(opd_det), false));
+    m->d_counts = reinterpret_cast<int32_t*>(m->d_records + Md);
     RCCHK(dalloc(m, &m->d_orig_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_valid_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_key_valid, B * 2, false));
@@ -1273,8 +1274,14 @@ int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, op
 static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kind) {
     const int B = m->last_B, Q = m->arch.queries;
     if (!outputs_on_device(mem_kind)) {   // (device callers had the post-process kernel write into their buffers)
-        HIPCHK(hipMemcpyAsync(counts, m->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(hipMemcpyAsync(out, m->d_records, (size_t)B * Q * sizeof(opd_det), hipMemcpyDeviceToHost, m->stream));
+        // one copy of [records of max_batch frames | counts] into page-locked memory (a copy into the caller's pageable arrays is staged by
+        // the runtime anyway, once per call), handed over after the wait
+        const size_t rec_bytes = (size_t)m->cfg.max_batch * Q * sizeof(opd_det);
+        if (!m->sync_pinned) HIPCHK(hipHostMalloc(&m->sync_pinned, rec_bytes + (size_t)m->cfg.max_batch * 4, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(m->sync_pinned, m->d_records, rec_bytes + (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipStreamSynchronize(m->stream));
+        memcpy(out, m->sync_pinned, (size_t)B * Q * sizeof(opd_det));
+        memcpy(counts, static_cast<char*>(m->sync_pinned) + rec_bytes, (size_t)B * 4);
     }
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->profiling) {
@@ -1446,6 +1453,7 @@ void opd_detr_destroy(opd_detr* m) {
         if (e) (void)hipEventDestroy(e);
     for (auto& a : m->async_host)
         if (a.pinned) (void)hipHostFree(a.pinned);
+    if (m->sync_pinned) { (void)hipHostFree(m->sync_pinned); m->sync_pinned = nullptr; }
     for (auto& e : m->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto& e : m->event_pool) (void)hipEventDestroy(e);
@@ -1566,8 +1574,7 @@ int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int
         RCCHK(enqueue_postprocess(m, threshold, orig_hw));
         const size_t rec_bytes = (size_t)m->cfg.max_batch * Q * sizeof(opd_det);
         if (!slot.pinned) HIPCHK(hipHostMalloc(&slot.pinned, rec_bytes + (size_t)m->cfg.max_batch * 4, hipHostMallocDefault));
-        HIPCHK(hipMemcpyAsync(slot.pinned, m->d_records, (size_t)B * Q * sizeof(opd_det), hipMemcpyDeviceToHost, m->stream));
-        HIPCHK(hipMemcpyAsync(static_cast<char*>(slot.pinned) + rec_bytes, m->d_counts, (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        HIPCHK(hipMemcpyAsync(slot.pinned, m->d_records, rec_bytes + (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));   // (records | counts: one copy)
         slot.out = out; slot.counts = counts; slot.B = B;
     }
     HIPCHK(hipEventRecord(m->ev_async[t], m->stream));

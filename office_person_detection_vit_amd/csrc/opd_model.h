@@ -184,6 +184,7 @@ struct opd_detr {
     // host-output submissions: the records travel device -> pinned slot (asynchronous) -> caller buffer (in opd_detr_wait)
     struct AsyncHost { void* pinned = nullptr; opd_det* out = nullptr; int32_t* counts = nullptr; int B = 0; };
     AsyncHost async_host[4];
+    void* sync_pinned = nullptr;   // page-locked staging of the blocking entry points: [records of max_batch frames | counts]
     // device-side resize (camera resolution -> model resolution): source staging (grown on demand) and coefficient tables
     uint8_t* d_src = nullptr;
     size_t src_bytes = 0;
