@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         acc1[nt][0] = b;
         acc1[nt][1] = b;
     }
-    __syncthreads();
+    OPD_DMA_BARRIER();   // (the bias loads above are younger than the first stage's requests: the compiler's own wait would let them fly)
     uint4 res[3][4];  // residual of chunk j lives in res[j % 3], fetched two chunk steps ahead
     auto compute_main = [&](int buf) {
         const unsigned char* As = smem + buf * STAGE_BYTES;

@@ -854,7 +854,11 @@ __global__ __launch_bounds__(256, 2) void stem_pool2_kernel(StemPoolParams p) {
     half8 wf[7][2];
     for (int tx = tx_first; tx < tx_end; ++tx) {
         const int buf = (tx - tx_first) & 1;
-        __syncthreads();   // vmcnt(0): this tile's patch (and, first time, the weights) landed; the previous tile's pooling is done
+        // this tile's patch (and, first time, the weights) landed; the previous tile's pooling is done.  LDS-DMA data (the weights; the patch of
+        // the fp16 form) is published behind an explicit drain; the uint8 form's later tiles have nothing of that kind in flight and must not
+        // wait for the pooling's stores
+        if (!U8 || tx == tx_first) OPD_DMA_BARRIER();
+        else __syncthreads();
         if (tx == tx_first) {
 #pragma unroll
             for (int kh = 0; kh < 7; ++kh)

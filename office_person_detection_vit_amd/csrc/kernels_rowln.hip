@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256, 2) void gemm_ln256_kernel(GemmLnParams p) {
         acc[nt][0] = b;
         acc[nt][1] = b;
     }
-    __syncthreads();
+    OPD_DMA_BARRIER();   // (the bias loads above are younger than the first stage's requests)
     const int nk = p.K / 64;
     for (int ks = 0; ks < nk; ++ks) {
         if (ks + 1 < nk) issue(ks + 1, (ks + 1) & 1);
@@ -210,7 +210,7 @@ __global__ __launch_bounds__(64 * OS_NW, 1) void gemm_ln256_os_kernel(GemmLnPara
             if (p.res32 && m < p.M) res[nt][mt] = *reinterpret_cast<const float4v*>(p.res32 + (size_t)m * 256 + (wave * NT + nt) * 16 + g * 4);
         }
     }
-    __syncthreads();   // vmcnt(0) + barrier: everything is in LDS
+    OPD_DMA_BARRIER();   // drain + barrier: everything is in LDS (the bias / residual loads above are younger than the requests)
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
@@ -1019,7 +1019,7 @@ __global__ __launch_bounds__(256, 2) void gemm_k256_kernel(GemmK256Params p) {
             if (z == 0 && m < p.M)
                 acc[nt][mt] = *reinterpret_cast<const float4v*>(p.bias + (p.bias_period ? (size_t)(m % p.bias_period) * p.N : 0) + n);
         }
-    __syncthreads();   // vmcnt(0) + barrier: both tiles are in LDS
+    OPD_DMA_BARRIER();   // drain + barrier: both tiles are in LDS
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll

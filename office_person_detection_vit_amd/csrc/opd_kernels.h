@@ -21,6 +21,21 @@ enum { OPD_DT_F16 = 0, OPD_DT_BF16 = 1 };   // operand type of a launch: every k
         if (err_[dev_] != hipSuccess) return err_[dev_];                                                                     \
     } while (0)
 
+// Publishing LDS-DMA data through a workgroup barrier.  hipcc models vector memory as ONE in-order queue: behind [LDS-DMA requests, loads into
+// registers] it guards `__syncthreads()` with e.g. `s_waitcnt vmcnt(2)` -- "everything but the two youngest loads".  On gfx950 loads into registers
+// (and stores) retire out of order with respect to an older LDS-DMA request (tools/microbench/vmorder.hip), so that wait proves nothing about the
+// requests.  Every barrier that publishes LDS-DMA data with younger register loads possibly in flight is therefore written OPD_DMA_BARRIER():
+// an explicit drain, then the barrier (tools/scan_dma_waits.py checks the compiled code for the pattern).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define OPD_DMA_BARRIER()                                        \
+    do {                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         \
+        __syncthreads();                                         \
+    } while (0)
+#else
+#define OPD_DMA_BARRIER() __syncthreads()
+#endif
+
 // ---- implicit-GEMM convolution / linear layer (kernels_gemm.hip) ---------------------------------------------------
 // out[m][n] = act( sum_k A[m][k] * Wt[n][k] + bias + residual ),  m = (b,oh,ow), k = (kh,kw,cin), NHWC fp16 input.
 // Division of a 31-bit unsigned value by a launch constant: q = one ? m : umulhi(m, mul) >> shift, exact for m < 2^31 (mul =
