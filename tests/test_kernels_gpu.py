@@ -782,6 +782,38 @@ def test_enc_ffn_with_front_projection_matches_torch(lib, M, FF, period):
         np.testing.assert_array_equal(yp16.view(np.float16), (y + pos[np.arange(M) % period]).astype(np.float16))
 
 
+def test_enc_ffn_is_reproducible_under_load(lib):
+    """Race screen for enc_ffn_kernel (wave-private LDS-DMA rings with hand-counted waits, a barrier per chunk, front and tail phases): 12
+    launches on the same operands at the encoder's full size -- 175 workgroups, every CU streaming weights -- must agree bit for bit; a
+    misplaced wait shows as a slab that comes and goes with timing."""
+    M, FF, period, tail = 8400, 2048, 1050, 3
+    rng = np.random.default_rng(77)
+    _, atb = _h(rng.standard_normal((M, 256)))
+    _, wob = _h(rng.standard_normal((256, 256)) / 16.0)
+    _, w1b = _h(rng.standard_normal((FF, 256)) / 16.0)
+    _, w2b = _h(rng.standard_normal((256, FF)) / np.sqrt(FF))
+    _, wtb = _h(rng.standard_normal((tail * 256, 256)) / 16.0)
+    f32 = lambda n, s=0.1: (rng.standard_normal(n) * s).astype(np.float32)
+    b1, b2, bo, tb = f32(FF, 0.3), f32(256), f32(256), f32(tail * 256, 0.2)
+    g1, be1, gamma, beta = 1.0 + f32(256), f32(256), 1.0 + f32(256), f32(256)
+    res = rng.standard_normal((M, 256)).astype(np.float32)
+    pos = rng.standard_normal((period, 256)).astype(np.float32)
+    first = None
+    for rep in range(12):
+        y = np.empty((M, 256), np.float32)
+        y16 = np.empty((M, 256), np.uint16)
+        yp16 = np.empty((M, 256), np.uint16)
+        tout = np.empty((M, tail * 256), np.uint16)
+        _capi.check(lib.opd_test_enc_ffn(_p(atb), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(res), _p(gamma), _p(beta), _p(pos), period, _p(y), _p(y16), _p(yp16),
+                                         M, FF, 1, _p(wtb), _p(tb), tail, 2, _p(tout), _p(wob), _p(bo), _p(g1), _p(be1), 1), "opd_test_enc_ffn")
+        assert np.isfinite(y).all()
+        cur = (y.tobytes(), y16.tobytes(), yp16.tobytes(), tout.tobytes())
+        if first is None:
+            first = cur
+        else:
+            assert cur == first, f"launch {rep} differs from launch 0"
+
+
 # ---- one-shot small-M linear layer (kernels_rowln.hip::gemm_k256_kernel) -------------------------------------------------------
 @pytest.mark.parametrize("M,N,K,period,relu", [(800, 768, 256, 100, False), (800, 256, 256, 100, False), (800, 2048, 256, 0, True),
                                                (800, 256, 2048, 0, False), (37, 64, 256, 0, True), (130, 256, 512, 0, False)])
