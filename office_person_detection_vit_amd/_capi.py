@@ -96,6 +96,7 @@ TEST_API = {
     "opd_test_gemm_ln": (C.c_int, [C.c_void_p] * 8 + [C.c_int] * 2),
     "opd_test_bench_gemm_ln": (C.c_int, [C.c_int] * 4 + [C.POINTER(C.c_float)]),
     "opd_test_gemm_ln_deep": (C.c_int, [C.c_void_p] * 7 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3),
+    "opd_test_set_heads2": (C.c_int, [C.c_int]),
     "opd_test_enc_ffn": (C.c_int, [C.c_void_p] * 9 + [C.c_int] + [C.c_void_p] * 3 + [C.c_int] * 3 + [C.c_void_p] * 2 + [C.c_int] * 2 + [C.c_void_p] * 5 + [C.c_int]),
     "opd_test_bench_enc_ffn": (C.c_int, [C.c_int] * 6 + [C.POINTER(C.c_float)]),
     "opd_test_bench_conv": (C.c_int, [C.c_int] * 11 + [C.POINTER(C.c_float)]),

@@ -674,6 +674,150 @@ __global__ __launch_bounds__(512) void dec_ffn_kernel(DecFfnParams p) {
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// heads2_kernel: the class head (256 -> ncls <= 128) and the box MLP (256 -> 256 -> 256 -> 4, ReLU, sigmoid) on split fp16 operands
+// (HF:models/detr/modeling_detr.py:1284-1300, 1567-1583), grid = slabs of 16 rows, 512 threads.  The fp32-MFMA form (kernels_misc.hip::
+// heads_kernel) pulls 620 KB of fp32 weights per workgroup through register loads in fragment shape -- the slow path of
+// tools/microbench/oneshot.hip -- and takes 34 us; here the three 256-wide layers travel like every other decoder weight: fragment-order
+// hi / lo pairs through the wave-private rings.  Prologue as heads_kernel's (the last layer's FFN sum + LN3, the final decoder LayerNorm).
+// A wave's piece sequence: 16 pieces of its class tile (the class matrix is padded to 128 rows: waves 6, 7 multiply zeros), 32 of layer 1's
+// two tiles, 32 of layer 2's.  The hidden activations pass through the slab's X area (barrier - rewrite - barrier); the last layer
+// (256 -> 4) is 64 dot products split over the waves, in fp32 from LDS.
+// ---------------------------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512) void heads2_kernel(HeadParams p) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    unsigned char* const Xhi = smem;
+    unsigned char* const Xlo = smem + 16 * XP;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15, lane16 = lane * 16;
+    const int row0 = blockIdx.x * 16;
+    const int row = row0 + li;
+    const bool ok = row < p.rows;
+    PieceRing<SLAB_R, 80> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
+    const unsigned char* const wc = reinterpret_cast<const unsigned char*>(p.wc_f) + (size_t)wave * 16384;
+    const unsigned char* const w1 = reinterpret_cast<const unsigned char*>(p.w1_f) + (size_t)(2 * wave) * 16384;
+    const unsigned char* const w2 = reinterpret_cast<const unsigned char*>(p.w2_f) + (size_t)(2 * wave) * 16384;
+    auto src = [&](const int n) -> const unsigned char* { return n < 16 ? wc + (size_t)n * 1024 : n < 48 ? w1 + (size_t)(n - 16) * 1024 : w2 + (size_t)(n - 48) * 1024; };
+    {   // rows -> X hi / lo: 32 threads per row, 8 consecutive columns each; every load that does not depend on computed data up front
+        const int r = tid >> 5, c0 = (tid & 31) * 8;
+        const size_t rc = (size_t)(row0 + r < p.rows ? row0 + r : p.rows - 1) * 256 + c0;
+        float v[8];
+        const float4v h0 = *reinterpret_cast<const float4v*>(p.hs + rc), h1 = *reinterpret_cast<const float4v*>(p.hs + rc + 4);
+        float4v pa[16], pb[16];
+        if (p.partials) {
+#pragma unroll
+            for (int sp = 0; sp < 16; ++sp) {
+                const float* ps = p.partials + (size_t)(sp < p.nsplit ? sp : p.nsplit - 1) * p.rows * 256 + rc;
+                pa[sp] = *reinterpret_cast<const float4v*>(ps);
+                pb[sp] = *reinterpret_cast<const float4v*>(ps + 4);
+            }
+        }
+        const float* z = p.ffn_b2 ? p.ffn_b2 : p.b1;   // (any valid address: unused without partials)
+        const float4v fb0 = *reinterpret_cast<const float4v*>(z + c0), fb1 = *reinterpret_cast<const float4v*>(z + c0 + 4);
+        const float* g3 = p.ln3_gamma ? p.ln3_gamma : p.b1;
+        const float* b3 = p.ln3_beta ? p.ln3_beta : p.b1;
+        const float4v g30 = *reinterpret_cast<const float4v*>(g3 + c0), g31 = *reinterpret_cast<const float4v*>(g3 + c0 + 4);
+        const float4v b30 = *reinterpret_cast<const float4v*>(b3 + c0), b31 = *reinterpret_cast<const float4v*>(b3 + c0 + 4);
+        const float* gf = p.ln_gamma ? p.ln_gamma : p.b1;
+        const float* bf = p.ln_beta ? p.ln_beta : p.b1;
+        const float4v gf0 = *reinterpret_cast<const float4v*>(gf + c0), gf1 = *reinterpret_cast<const float4v*>(gf + c0 + 4);
+        const float4v bf0 = *reinterpret_cast<const float4v*>(bf + c0), bf1 = *reinterpret_cast<const float4v*>(bf + c0 + 4);
+        rg.prime(src);
+        DEC_FENCE();
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { v[j] = h0[j]; v[4 + j] = h1[j]; }
+        if (p.partials) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { v[j] += fb0[j]; v[4 + j] += fb1[j]; }
+#pragma unroll
+            for (int sp = 0; sp < 16; ++sp)
+                if (sp < p.nsplit) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { v[j] += pa[sp][j]; v[4 + j] += pb[sp][j]; }
+                }
+            layernorm_row32(v, g30, g31, b30, b31);
+        }
+        if (p.ln_gamma) layernorm_row32(v, gf0, gf1, bf0, bf1);
+        if (row0 + r >= p.rows) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        }
+        store_split8(Xhi, Xlo, XP, r, c0, v);
+    }
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    // ---- class logits: this wave's tile (columns 16 w .. + 15) -------------------------------------------------------------------------
+    {
+        Acc3 c;
+        acc3_zero(c);
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            rg.wait(8 * hf, 8 * hf + 7);
+            gemm_group(rg, 8 * hf, Xhi, Xlo, li, 4 * hf, lane16, g, c.h[0], c.l[0], c.m[0]);
+            rg.advance(src, 8 * hf, 8);
+        }
+        const int n = wave * 16 + 4 * g;
+        if (ok) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (n + r < p.ncls) p.logits[(size_t)row * p.ncls + n + r] = acc3_get(c, 0, r) + p.bc[n + r];
+        }
+    }
+    // ---- box MLP layer 1 ------------------------------------------------------------------------------------------------------------------
+    Acc3 a;
+    acc3_zero(a);
+    gemm256(rg, src, 16, Xhi, Xlo, lane16, g, li, a);
+    float4v t[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.b1 + (2 * wave + j) * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float x = acc3_get(a, j, r) + b[r]; t[j][r] = x > 0.f ? x : 0.f; }
+    }
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();          // every wave has read the rows: the first hidden layer takes their place
+#pragma unroll
+    for (int j = 0; j < 2; ++j) store_split4(Xhi, Xlo, XP, li, (2 * wave + j) * 16 + 4 * g, t[j]);
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    // ---- layer 2 ---------------------------------------------------------------------------------------------------------------------------
+    acc3_zero(a);
+    gemm256(rg, src, 48, Xhi, Xlo, lane16, g, li, a);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.b2 + (2 * wave + j) * 16 + 4 * g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { const float x = acc3_get(a, j, r) + b[r]; t[j][r] = x > 0.f ? x : 0.f; }
+    }
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();          // the X area is free: the second hidden layer as fp32 [16][264]
+    float* const h2 = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) *reinterpret_cast<float4v*>(h2 + li * 264 + (2 * wave + j) * 16 + 4 * g) = t[j];
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    // ---- last layer: 64 outputs (row = lane >> 2, coordinate = lane & 3), the reduction split over the 8 waves (32 k each), summed in order ----
+    float* const part = reinterpret_cast<float*>(smem + SLAB_RING);   // (the rings are drained: every piece has been consumed)
+    {
+        const int r = lane >> 2, c = lane & 3;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int kk = 0; kk < 32; ++kk) acc = fmaf(h2[r * 264 + wave * 32 + kk], p.w3[(wave * 32 + kk) * 4 + c], acc);
+        part[wave * 64 + lane] = acc;
+    }
+    DEC_LGKM0();
+    __builtin_amdgcn_s_barrier();
+    if (tid < 64) {
+        const int r = tid >> 2, c = tid & 3;
+        float acc = part[tid];
+#pragma unroll
+        for (int w = 1; w < 8; ++w) acc += part[w * 64 + tid];
+        if (row0 + r < p.rows) p.boxes[(size_t)(row0 + r) * 4 + c] = 1.0f / (1.0f + expf(-(acc + p.b3[c])));
+    }
+}
+
 }  // namespace
 
 // host: [N][K] fp32 -> the split pair in MFMA-fragment order: for every (16-row tile nt, 32-wide k-step ks) 1 KiB of hi = fp16(w) followed by
@@ -694,6 +838,15 @@ void opd_split_f16_frag(const float* w, int N, int K, f16_t* out) {
         }
 }
 
+hipError_t opd_launch_heads2(const HeadParams& p, hipStream_t stream) {
+    if (p.rows <= 0 || p.ncls <= 0 || p.ncls > 128 || !p.hs || !p.wc_f || !p.w1_f || !p.w2_f || !p.bc || !p.b1 || !p.b2 || !p.w3 || !p.b3 || !p.logits || !p.boxes)
+        return hipErrorInvalidValue;
+    if (p.partials && (p.nsplit < 1 || p.nsplit > 16 || !p.ffn_b2 || !p.ln3_gamma || !p.ln3_beta)) return hipErrorInvalidValue;
+    if ((p.ln_gamma != nullptr) != (p.ln_beta != nullptr)) return hipErrorInvalidValue;
+    OPD_SET_MAX_LDS_ONCE(heads2_kernel, SLAB_LDS);
+    hipLaunchKernelGGL(heads2_kernel, dim3((p.rows + 15) / 16), dim3(512), SLAB_LDS, stream, p);
+    return hipGetLastError();
+}
 hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.Q <= 0 || !p.h_out || !p.w || !p.bias || !p.q16 || !p.k16 || !p.vT) return hipErrorInvalidValue;
     if (p.partials && (!p.h_in || !p.b2 || !p.ln_g || !p.ln_b || p.nsplit < 1 || p.nsplit > QKV_MAXS)) return hipErrorInvalidValue;

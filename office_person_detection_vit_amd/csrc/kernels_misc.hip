@@ -677,6 +677,7 @@ hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bia
 
 #ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
+    if (p.wc_f && p.w1_f && p.w2_f && p.ncls <= 128) return opd_launch_heads2(p, stream);   // split fp16 operands through the decoder's rings
     if (p.ncls > 256 || p.rows <= 0) return hipErrorInvalidValue;
     if (p.partials && (p.nsplit < 1 || p.nsplit > 16 || !p.ffn_b2 || !p.ln3_gamma || !p.ln3_beta)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(512), 0, stream, p);

@@ -245,12 +245,16 @@ struct HeadParams {
     int nsplit;
     const float *ffn_b2, *ln3_gamma, *ln3_beta;   // that FFN-2's bias, LN3
     const float *ln_gamma, *ln_beta;  // optional: hs is the decoder state BEFORE its final LayerNorm, applied here first
-    const float *wc, *bc, *w1, *b1, *w2, *b2, *w3, *b3;
+    const float *wc, *bc, *w1, *b1, *w2, *b2, *w3, *b3;   // weights transposed: wc [256][ncls], w1 / w2 [256][256], w3 [256][4]
+    // optional: the three 256-wide layers as split fp16 pairs in MFMA-fragment order (opd_split_f16_frag; the class matrix padded with zero
+    // rows to 128): all three set -> kernels_dec.hip::heads2_kernel (wc / w1 / w2 are then unused)
+    const f16_t *wc_f, *w1_f, *w2_f;
     float* logits;    // [rows][ncls]
     float* boxes;     // [rows][4]
     int rows, ncls;
 };
 hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream);
+hipError_t opd_launch_heads2(const HeadParams& p, hipStream_t stream);   // kernels_dec.hip (reached through opd_launch_heads)
 // post-process: softmax / max over first ncls-1 / cxcywh->xyxy*scale / threshold -> fixed-slot records + counts.
 struct PostParams {
     const float* logits;  // [B][Q][ncls]

@@ -331,6 +331,14 @@ static int build_weights(opd_detr* m, const StateDict& sd) {
     };
     RCCHK(upload_f32(m, &m->wc, transposed("class_labels_classifier.weight")));
     RCCHK(upload_f32(m, &m->bc, T(sd, "class_labels_classifier.bias").data));
+    if (a.d_model == 256 && a.ncls <= 128) {   // the heads on split fp16 operands (kernels_dec.hip::heads2_kernel): class matrix padded to 128 rows
+        std::vector<float> wcp((size_t)128 * 256, 0.f);
+        const auto& wcs = T(sd, "class_labels_classifier.weight").data;
+        std::copy(wcs.begin(), wcs.end(), wcp.begin());
+        RCCHK(upload_frag(m, &m->wc_f, wcp, 128, 256));
+        RCCHK(upload_frag(m, &m->w1_f, T(sd, "bbox_predictor.layers.0.weight").data, 256, 256));
+        RCCHK(upload_frag(m, &m->w2_f, T(sd, "bbox_predictor.layers.1.weight").data, 256, 256));
+    }
     RCCHK(upload_f32(m, &m->w1, transposed("bbox_predictor.layers.0.weight")));
     RCCHK(upload_f32(m, &m->b1, T(sd, "bbox_predictor.layers.0.bias").data));
     RCCHK(upload_f32(m, &m->w2, transposed("bbox_predictor.layers.1.weight")));
@@ -1098,6 +1106,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         hp.hs = m->d_hs32;
     } hp.wc = m->wc; hp.bc = m->bc; hp.w1 = m->w1; hp.b1 = m->b1; hp.w2 = m->w2; hp.b2 = m->b2;
     hp.w3 = m->w3; hp.b3 = m->b3; hp.logits = m->d_logits; hp.boxes = m->d_boxes; hp.rows = Md; hp.ncls = a.ncls;
+    if (m->heads2 && m->wc_f && m->w1_f && m->w2_f) { hp.wc_f = m->wc_f; hp.w1_f = m->w1_f; hp.w2_f = m->w2_f; }
     RCCHK(timed_begin(m, CLS_OTHER, 2.0 * Md * 256.0 * (a.ncls + 256 + 256 + 4)));
     HIPCHK(opd_launch_heads(hp, m->stream));
     RCCHK(timed_end(m));
@@ -1376,6 +1385,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_FUSED_ENC_FFN")) m->fused_enc_ffn = atoi(v);
     if (const char* v = getenv("OPD_ENC_TAIL")) m->enc_tail = atoi(v);
     if (const char* v = getenv("OPD_ENC_FRONT")) m->enc_front = atoi(v);
+    if (const char* v = getenv("OPD_HEADS2")) m->heads2 = atoi(v);
     if (const char* v = getenv("OPD_DBG_DEC_LAYERS")) m->dbg_dec_layers = atoi(v);   // timing ablation (tools/dec_cost.sh): results are wrong
     m->device = device_ordinal;
     int ndev = 0;
@@ -1416,7 +1426,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->weights = src->weights; m->weights_sealed = true; m->weight_bytes = src->weight_bytes;
     m->stem = src->stem; m->blocks = src->blocks; m->stage_first = src->stage_first; m->proj = src->proj;
     m->enc = src->enc; m->dec = src->dec; m->wkv_all = src->wkv_all; m->bkv_all = src->bkv_all; m->dec_ln = src->dec_ln;
-    m->wc = src->wc; m->bc = src->bc; m->w1 = src->w1; m->b1 = src->b1; m->w2 = src->w2; m->b2 = src->b2; m->w3 = src->w3; m->b3 = src->b3;
+    m->wc = src->wc; m->bc = src->bc; m->w1 = src->w1; m->b1 = src->b1; m->w2 = src->w2; m->b2 = src->b2; m->w3 = src->w3; m->b3 = src->b3; m->wc_f = src->wc_f; m->w1_f = src->w1_f; m->w2_f = src->w2_f; m->heads2 = src->heads2;
     m->zero_bias = src->zero_bias;
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;

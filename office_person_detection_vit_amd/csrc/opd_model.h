@@ -150,6 +150,8 @@ struct opd_detr {
     int dbg_dec_layers = 1 << 20;   // timing ablation only (OPD_DBG_DEC_LAYERS): run this many decoder layers
     LNp dec_ln;
     float *wc = nullptr, *bc = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
+    f16_t *wc_f = nullptr, *w1_f = nullptr, *w2_f = nullptr;   // the heads' 256-wide layers as split fp16 pairs in fragment order (heads2_kernel)
+    int heads2 = 1;            // the heads through kernels_dec.hip::heads2_kernel (0: kernels_misc.hip::heads_kernel on the fp32 matrix pipe; env OPD_HEADS2)
     float* zero_bias = nullptr;  // [3072] zeros
 
     // host copies needed to build plans for new resolutions

@@ -817,6 +817,23 @@ int opd_test_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const 
 
 // heads_kernel alone: hs [rows][256] fp32 (+ optional final LayerNorm), weights in the reference's [out][in] layout (the hook
 // transposes them as opd_model.cpp does); logits [rows][ncls], boxes [rows][4]
+static int g_test_heads2 = 1;   // heads hooks: 1 = heads2_kernel (split fp16 operands), 0 = heads_kernel (fp32 matrix pipe)
+int opd_test_set_heads2(int on) { g_test_heads2 = on; return OPD_OK; }
+// (the three 256-wide layers as split fp16 pairs in fragment order, class matrix padded to 128 rows)
+static bool heads_frags(DevMem& dm, HeadParams& p, const float* wc, const float* w1, const float* w2, int ncls) {
+    if (!g_test_heads2 || ncls > 128) return true;
+    std::vector<float> wcp((size_t)128 * 256, 0.f);
+    std::copy(wc, wc + (size_t)ncls * 256, wcp.begin());
+    std::vector<uint16_t> f((size_t)2 * 128 * 256);
+    opd_split_f16_frag(wcp.data(), 128, 256, f.data());
+    p.wc_f = dm.up(f.data(), f.size());
+    std::vector<uint16_t> f2((size_t)2 * 256 * 256);
+    opd_split_f16_frag(w1, 256, 256, f2.data());
+    p.w1_f = dm.up(f2.data(), f2.size());
+    opd_split_f16_frag(w2, 256, 256, f2.data());
+    p.w2_f = dm.up(f2.data(), f2.size());
+    return p.wc_f && p.w1_f && p.w2_f;
+}
 int opd_test_heads(const float* hs, const float* ln_g, const float* ln_b, const float* wc, const float* bc, const float* w1, const float* b1,
                    const float* w2, const float* b2, const float* w3, const float* b3, float* logits, float* boxes, int rows, int ncls) {
     DevMem dm;
@@ -838,6 +855,7 @@ int opd_test_heads(const float* hs, const float* ln_g, const float* ln_b, const 
     p.boxes = dm.up<float>(nullptr, (size_t)rows * 4);
     if (!p.hs || !p.wc || !p.bc || !p.w1 || !p.b1 || !p.w2 || !p.b2 || !p.w3 || !p.b3 || !p.logits || !p.boxes) return tfail(OPD_ENOMEM, "test alloc failed");
     p.rows = rows; p.ncls = ncls;
+    if (!heads_frags(dm, p, wc, w1, w2, ncls)) return tfail(OPD_ENOMEM, "test alloc failed");
     TCHK(opd_launch_heads(p, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(logits, p.logits, (size_t)rows * ncls * 4, hipMemcpyDeviceToHost));
@@ -1230,6 +1248,7 @@ int opd_test_heads_fused(const float* hs, const float* partials, int nsplit, con
         !p.w3 || !p.b3 || !p.logits || !p.boxes)
         return tfail(OPD_ENOMEM, "test alloc failed");
     p.rows = rows; p.ncls = ncls;
+    if (!heads_frags(dm, p, wc, w1, w2, ncls)) return tfail(OPD_ENOMEM, "test alloc failed");
     TCHK(opd_launch_heads(p, nullptr));
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(logits, p.logits, (size_t)rows * ncls * 4, hipMemcpyDeviceToHost));

@@ -230,8 +230,11 @@ def test_dec_ffn_kernel(lib, M, Fh):
     np.testing.assert_allclose(parts[c], (hid[:, c * 128:(c + 1) * 128] @ t(w2)[:, c * 128:(c + 1) * 128].T).numpy(), atol=1e-5, rtol=1e-5)
 
 
-def test_heads_kernel_with_ffn_prologue(lib):
-    """heads_kernel fed by the fused decoder: rows = LN3(hs + b2 + sum of the FFN's partial slabs), final LayerNorm, heads."""
+@pytest.mark.parametrize("split", [1, 0])
+def test_heads_kernel_with_ffn_prologue(lib, split):
+    """The heads fed by the fused decoder: rows = LN3(hs + b2 + sum of the FFN's partial slabs), final LayerNorm, heads; through
+    heads2_kernel (split fp16 operands, the model's default) and heads_kernel (fp32 matrix pipe)."""
+    lib.opd_test_set_heads2(split)
     rng = np.random.default_rng(9)
     rows, ns = 800, 16
     hs = rng.standard_normal((rows, D)).astype(np.float32)
@@ -251,5 +254,6 @@ def test_heads_kernel_with_ffn_prologue(lib):
         x = x + t(parts[s])
     x = F.layer_norm(F.layer_norm(x, (D,), t(g3), t(b3_), 1e-5), (D,), t(g), t(b), 1e-5)
     y = F.relu(F.relu(x @ t(w1).T + t(b1)) @ t(w2).T + t(b2))
+    lib.opd_test_set_heads2(1)
     np.testing.assert_allclose(logits, (x @ t(wc).T + t(bc)).numpy(), atol=3e-5, rtol=1e-5)
     np.testing.assert_allclose(boxes, torch.sigmoid(y @ t(w3).T + t(b3)).numpy(), atol=2e-6)

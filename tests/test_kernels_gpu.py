@@ -904,10 +904,13 @@ def test_conv_dual_source_integer_exact(lib):
 
 
 # ---- output kernels in isolation (kernels_misc.hip): heads, post-process, ROI features ---------------------------------------------
+@pytest.mark.parametrize("split", [1, 0])
 @pytest.mark.parametrize("rows,ln", [(800, True), (100, False), (37, True), (1, True)])
-def test_heads_kernel_matches_torch(lib, rows, ln):
+def test_heads_kernel_matches_torch(lib, rows, ln, split):
     """class_labels_classifier + DetrMLPPredictionHead + sigmoid (HF:models/detr/modeling_detr.py:1284-1300, 1410-1411), with and
-    without the decoder's final LayerNorm inside; fp32 on the matrix pipe (exact fp32 fma chains) against float64 torch."""
+    without the decoder's final LayerNorm inside, against float64 torch.  split = 1: kernels_dec.hip::heads2_kernel (the 256-wide layers
+    on split fp16 pairs through the decoder's rings: fp32-grade products); split = 0: kernels_misc.hip::heads_kernel (fp32 matrix pipe)."""
+    lib.opd_test_set_heads2(split)
     rng = np.random.default_rng(rows)
     hs = rng.standard_normal((rows, 256)).astype(np.float32) * 1.5
     g = (1.0 + 0.1 * rng.standard_normal(256)).astype(np.float32)
@@ -928,6 +931,7 @@ def test_heads_kernel_matches_torch(lib, rows, ln):
     y = F.relu(x @ t(w1).T + t(b1))
     y = F.relu(y @ t(w2).T + t(b2))
     want_boxes = torch.sigmoid(y @ t(w3).T + t(b3))
+    lib.opd_test_set_heads2(1)
     np.testing.assert_allclose(logits, want_logits.numpy(), atol=2e-5, rtol=1e-5)
     np.testing.assert_allclose(boxes, want_boxes.numpy(), atol=2e-6)
 
