@@ -28,7 +28,8 @@
 //      dec_cross_out_kernel  combine key splits + o-proj + residual + LN2                                               (slab)
 //      dec_ffn_kernel        fc1 chunk + ReLU + fc2 partial sums over a 128-wide slice of the hidden layer    (64-row slab x 16 chunks)
 //    The FFN's hidden tensor never leaves the CU; its 16 fp32 partial sums per row are summed in fixed order by the consumer
-//    (dec_qkv_kernel of the next layer / heads_kernel), so results are deterministic.
+//    (dec_qkv_kernel of the next layer / heads2_kernel), so results are deterministic.  heads2_kernel (end of this file) runs the class
+//    head and the box MLP the same way.
 //
 // MFMA operand layout used throughout (as in kernels_gemm.hip): v_mfma_f32_16x16x32_f16(A = weight rows, B = data rows): lane
 // (g = lane >> 4, li = lane & 15) feeds A[n0 + li][k0 + 8g .. 8g + 7] and B[row li][k0 + 8g .. 8g + 7] and receives

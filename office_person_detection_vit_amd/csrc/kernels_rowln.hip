@@ -12,6 +12,11 @@
 // buffers); every wave stages the 8 weight pieces of its own columns plus one activation piece.  LayerNorm statistics are
 // two-pass (mean, then centred variance) in fp32 like layernorm256_kernel: lane partials -> 4 lane groups (shuffles) ->
 // 4 waves (LDS).
+//
+// Also in this file, same row-owner idea: gemm_ln256_os_kernel (K = 256 in one staging batch), gemm_ln256_ring_kernel (deep K through a
+// three-stage ring: the input projection), enc_ffn_kernel (round 4: everything behind an encoder layer's attention -- output projection +
+// LayerNorm + fc1 + ReLU + fc2 + LayerNorm -- in one launch, weights as per-wave fragment streams through wave-private rings) and
+// gemm_k256_kernel (small-M linears of the unfused decoder chain).
 #include <hip/hip_runtime.h>
 #include "opd_kernels.h"
 #include "opd_elem.h"
