@@ -842,6 +842,9 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
     ef_wait_vm<0>();
 #endif
 }
+#undef EF_FC1_STEP
+#undef EF_FC2_STEP
+#undef EF_TAIL_STEP
 
 }  // namespace
 
