@@ -124,3 +124,39 @@ def test_bf16_mode_end_to_end_bound(weight_cache, parity_log, size, bound):
     assert dbox <= bound
     assert dbox16 < dbox                      # the default mode is the tighter one
     assert np.isfinite(lg).all() and len(dets) == 2
+
+
+@pytest.mark.parametrize("M,FF,front", [(8400, 2048, True), (130, 1024, False)])
+def test_enc_ffn_bf16(bf16_hooks, M, FF, front):
+    """enc_ffn_kernel, bf16 instantiation (x, the weight streams, the hidden chunk and the fp16-typed outputs in bf16; accumulators, residual
+    stream and LayerNorm in fp32), with and without its front phase, against double precision on the same bf16 operands with the same
+    intermediate roundings."""
+    lib = bf16_hooks
+    rng = np.random.default_rng(M + FF)
+    xin, xinb = _bf(rng.standard_normal((M, 256)))
+    wo, wob = _bf(rng.standard_normal((256, 256)) / 16.0)
+    w1, w1b = _bf(rng.standard_normal((FF, 256)) / 16.0)
+    w2, w2b = _bf(rng.standard_normal((256, FF)) / np.sqrt(FF))
+    f32 = lambda n, s=0.1: (rng.standard_normal(n) * s).astype(np.float32)
+    b1, b2, bo = f32(FF, 0.3), f32(256), f32(256)
+    g1, be1, gamma, beta = 1.0 + f32(256), f32(256), 1.0 + f32(256), f32(256)
+    res = rng.standard_normal((M, 256)).astype(np.float32)
+    y = np.empty((M, 256), np.float32)
+    y16 = np.empty((M, 256), np.uint16)
+    yp16 = np.empty((M, 256), np.uint16)
+    _capi.check(lib.opd_test_enc_ffn(_p(xinb), _p(w1b), _p(b1), _p(w2b), _p(b2), _p(res), _p(gamma), _p(beta), None, 0, _p(y), _p(y16), _p(yp16), M, FF, 1,
+                                     None, None, 0, 0, None, _p(wob) if front else None, _p(bo) if front else None, _p(g1) if front else None,
+                                     _p(be1) if front else None, 1), "opd_test_enc_ffn")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).double()
+    rb = lambda t: t.float().to(torch.bfloat16).double()      # one rounding to bf16
+    if front:
+        x1 = F.layer_norm(T(xin) @ T(wo).T + T(bo) + T(res), (256,), T(g1), T(be1), 1e-5)
+        x16, r32 = rb(x1), x1
+    else:
+        x16, r32 = T(xin), T(res)
+    hid = rb(torch.relu(x16 @ T(w1).T + T(b1)))
+    want = F.layer_norm(hid @ T(w2).T + T(b2) + r32, (256,), T(gamma), T(beta), 1e-5).float().numpy()
+    # (bf16 roundings of x and of the hidden activations next to a boundary may go the other way than in the double-precision chain: 2^-8 of
+    #  one of 2048 terms)
+    np.testing.assert_allclose(y, want, atol=4e-3, rtol=1e-4)
+    np.testing.assert_allclose(_from_bf(y16), y, atol=1e-2, rtol=2.0 ** -8)
