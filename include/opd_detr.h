@@ -228,9 +228,16 @@ OPD_API int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int3
  * rank 0 to the other ranks by whatever launched them (file, socket, MPI, a torch.distributed store): the library does no rendezvous. */
 typedef struct opd_comm opd_comm;
 #define OPD_COMM_ID_BYTES 128
+OPD_API int opd_comm_available(void);          /* OPD_OK when librccl could be resolved in this process: every rank checks BEFORE any rank enters the collective set-up */
 OPD_API int opd_comm_unique_id(void* id128);   /* rank 0 only: ncclGetUniqueId */
 /* collective over the `world` ranks (ncclCommInitRank): every rank passes the same id, its rank, and its OWN handle (device and stream) */
 OPD_API int opd_comm_create(const void* id128, int rank, int world, opd_detr* m, opd_comm** out);
+/* A further LANE on `parent`'s communicator for another detector handle of the same device (a rank that keeps several batches in flight):
+ * own send / receive buffers and events, the SAME RCCL communicator.  All all-gathers of a rank are enqueued on the communicator's own
+ * stream in the order opd_comm_exchange was called, so every rank must call it in the same order across its lanes.  Local, not collective. */
+OPD_API int opd_comm_attach(opd_comm* parent, opd_detr* m, opd_comm** out);
+/* Lanes may be destroyed in any order; the communicator goes with the last one.  Destroying the detector handle first is allowed: its lanes
+ * then return OPD_ESTATE from every call and only opd_comm_destroy remains valid on them. */
 OPD_API void opd_comm_destroy(opd_comm* c);
 OPD_API int opd_comm_info(const opd_comm* c, int* rank, int* world);
 /* One exchange = begin(slots) ; detect(slot0, frames ...) once or several times (a shard larger than max_batch goes in chunks) ; exchange ;

@@ -75,8 +75,10 @@ API = {
     "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_detr_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "opd_detr_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "opd_comm_available": (C.c_int, []),
     "opd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "opd_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "opd_comm_attach": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p)]),
     "opd_comm_destroy": (None, [C.c_void_p]),
     "opd_comm_info": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "opd_comm_begin": (C.c_int, [C.c_void_p, C.c_int]),
@@ -126,6 +128,7 @@ TEST_API = {
     "opd_test_sine_pos_embed": (C.c_int, [C.c_int] * 5 + [C.c_void_p]),
     "opd_test_conv_dual": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 13),
     "opd_test_btail_sc": (C.c_int, [C.c_void_p] * 11 + [C.c_int] * 3),
+    "opd_test_btail_chain": (C.c_int, [C.c_void_p] * 13 + [C.c_int] * 4),
     "opd_test_bench_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_int, C.POINTER(C.c_float)]),
     "opd_test_trace_attention": (C.c_int, [C.c_void_p] * 3 + [C.c_int] * 6 + [C.c_float, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "opd_test_heads": (C.c_int, [C.c_void_p] * 13 + [C.c_int] * 2),

@@ -113,7 +113,12 @@ __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory")
 // rounded to fp16 on the way (one rounding fewer than the unfused path; the reference rounds nothing).
 // TRACE (tools/trace_btail.py): wave 0 stamps the shader clock at the phase boundaries and writes p.trace[blockIdx.x][16] at the end:
 // {wall clock in, entry, prologue done, 3x3 loop done, chunk 0 .. NCH-1 done, stores retired, ..., [15] wall clock out}.
-template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false>
+// RC = 1 (round 5; second block of stage 1): the residual is not read but REBUILT.  The previous block's output y' = relu(W2' . a1' + Wsc . xs +
+// b') is 256 channels wide, its ingredients a1' and xs 64 each, and a 1x1 needs no halo: this kernel reads a1' and xs of its own 32 pixels per
+// wave as B fragments (32 KiB per workgroup instead of the 64-KiB residual), streams the 64 x 64 slices of W2' and Wsc with its own chunk
+// operands and runs the previous tail's chunk arithmetic -- same operands, same MFMA order, same fp16 rounding -- so the residual it adds has
+// the bits that tail would have stored.  The previous tail then stores a1' (68 MB at batch 8) instead of y' (274 MB), and nobody reads y'.
+template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false, int RC = 0>
 __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long tstamp[16] = {};
@@ -123,13 +128,14 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     if constexpr (TRACE) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tstamp[0])::"memory");
     stamp(1);
     static_assert(!RDMA || C1 == 64, "residual staging buffers are budgeted for C1 == 64 (80 KiB of LDS per workgroup)");
+    static_assert(!RDMA || RC == 0, "a rebuilt residual is not staged");
     static_assert(!SC || (C1 == 64 && !RDMA), "fused shortcut: 64-channel tails only; it replaces the residual");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     constexpr int C2 = 4 * C1;
     constexpr int NT1 = C1 / 16;               // c1 accumulator tiles per wave (all C1 channels)
     constexpr int KK1 = C1 / 32;               // 32-channel k-blocks of a1
     constexpr int A_BYTES = 128 * ROW_BYTES;   // 128 pixels x 64 halfs
-    constexpr int STAGE_BYTES = A_BYTES + C1 * ROW_BYTES;
+    constexpr int RC_BYTES = RC ? 2 * 64 * ROW_BYTES : 0;    // chunks of the previous block's W2 and Wsc: [64 rows][64 halfs] each
     constexpr int W1_PIECES = C1 / 32;         // 1-KiB pieces of the W1 tile per wave
     constexpr int NCH = C2 / 64;               // 64-channel chunks of y
     constexpr int W2C_BYTES = 64 * C1 * 2;     // chunk of W2: C1/64 sub-tiles of [64 rows][64 halfs]
@@ -137,7 +143,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     constexpr int W3_PIECES = C3 / 32;         // slice of W3: [C3 rows][64 halfs]
     constexpr int NT3 = C3 / 16;
     constexpr int WSC_BYTES = SC ? 64 * ROW_BYTES : 0;   // chunk of Wsc: [64 rows][64 halfs]
-    static_assert(W2C_BYTES + C3 * ROW_BYTES + WSC_BYTES <= STAGE_BYTES, "chunk operands must fit a stage buffer");
+    constexpr int CHUNK_BYTES = W2C_BYTES + C3 * ROW_BYTES + WSC_BYTES + RC_BYTES;
+    constexpr int STAGE_BYTES = (A_BYTES + C1 * ROW_BYTES) > CHUNK_BYTES ? (A_BYTES + C1 * ROW_BYTES) : CHUNK_BYTES;   // a stage buffer holds a 3x3 k-step's tiles or a chunk's operands
+    static_assert(RC == 0 || (RC == 1 && C1 == 64 && !RDMA && !SC), "residual rebuild: second block of stage 1");
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -157,7 +165,8 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w1), 0, (unsigned)(C1 * 9 * C1 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w2p), 0, (unsigned)(C2 * C1 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(C3 ? p.w3p : p.w2p), 0, (unsigned)((C3 ? C3 : 1) * C2 * 2), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(SC ? p.wsc : p.w2p), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(SC ? p.wsc : RC ? p.rc_wsc : p.w2p), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(RC ? p.rc_w2[0] : p.w2p), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
     unsigned rowoff[4], rowmask[4], woff1[W1_PIECES], woff2[W2_PIECES], woff3[W3_PIECES ? W3_PIECES : 1], woffsc[2];
     woffsc[0] = (unsigned)(own_row(wave * 16 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;        // rows 8 (2 wave) + lrow of the 64-row chunk
     woffsc[1] = (unsigned)(own_row(wave * 16 + 8 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;
@@ -238,9 +247,30 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, (__attribute__((address_space(3))) void*)(Wscs + (wave * 2 + i) * 1024), 16,
                                                          woffsc[i], j * (64 * 64 * 2), 0, 0);
         }
+        if constexpr (RC) {   // the previous block's expand and shortcut slices: [64 rows][64 k] each, rows in this kernel's ownership order
+            unsigned char* Wr = W2s + W2C_BYTES + C3 * ROW_BYTES;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_rw, (__attribute__((address_space(3))) void*)(Wr + (wave * 2 + i) * 1024), 16,
+                                                         woffsc[i], j * (64 * 64 * 2), 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, (__attribute__((address_space(3))) void*)(Wr + 8192 + (wave * 2 + i) * 1024), 16,
+                                                         woffsc[i], j * (64 * 64 * 2), 0, 0);
+            }
+        }
     };
     // y / z / residual: lane (g, li) moves 8 channels (16 B) at 8g of each 32-channel block, for its pixels li and 16 + li
     const bool pr_ok[2] = {wm0 + li < p.M, wm0 + 16 + li < p.M};
+    // y: not stored at all (p.y == null: the consumer rebuilds it), or only where a stride-2 1x1 of the next stage reads it (even oh, ow)
+    bool y_ok[2] = {pr_ok[0] && p.y != nullptr, pr_ok[1] && p.y != nullptr};
+    if (p.y_stride2) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = wm0 + mt * 16 + li;
+            const int r = m - fdiv(m, p.fd_ohw) * (p.OH * p.OW);
+            const int oh = fdiv(r, p.fd_ow), ow = r - oh * p.OW;
+            y_ok[mt] = y_ok[mt] && !((oh | ow) & 1);
+        }
+    }
     const size_t pr_row[2] = {(size_t)(wm0 + li) * C2 + g * 8, (size_t)(wm0 + 16 + li) * C2 + g * 8};
     // RDMA: wave-private residual staging: rows of this wave, whole 128-byte rows, swizzled like every other tile
     unsigned char* const res_lds = smem + 2 * STAGE_BYTES + wave * 4096;   // + (j & 1) * 16384 for chunk j
@@ -253,7 +283,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (__attribute__((address_space(3))) void*)(res_lds + (j & 1) * 16384 + i * 1024), 16,
                                                      res_voff + (unsigned)(i * 8 * C2 * 2), j * 128, 0, 0);
     };
-    const bool has_res = !SC && p.res != nullptr && !(p.dbg & 4);
+    const bool has_res = RC ? true : (!SC && p.res != nullptr && !(p.dbg & 4));
     // Counted waits: `s_waitcnt vmcnt(N)` proves that an LDS-DMA request has landed only if the N operations allowed to stay in flight are
     // YOUNGER LDS-DMA requests.  Stores and loads into registers retire out of order with respect to an older LDS-DMA request
     // (tools/microbench/vmorder.hip: with 4 younger stores, or 4 younger register loads, vmcnt(4) returns while the older request's data is
@@ -278,16 +308,20 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     if (ks_first) { tap_kh = 2; tap_kw = 2; tap_c = kpc - 1; }
     // SC: the shortcut's input channels of this wave's 32 pixels as B fragments (k in natural order: Wsc is not permuted);
     // loaded in front of everything else, complete at the first barrier's vmcnt(0)
-    half8 xs[2][2];
-    if constexpr (SC) {
+    half8 xs[2][2], a1p[2][2];   // RC: the same for the previous block: its shortcut input and its a1
+    if constexpr (SC || RC != 0) {
+        const f16_t* xsrc = SC ? p.xs : p.rc_xs;
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int m = wm0 + mt * 16 + li;
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk) {
-                half8 v = {};
-                if (m < p.M) v = *reinterpret_cast<const half8*>(p.xs + (size_t)m * 64 + kk * 32 + g * 8);
+                half8 v = {}, u = {};
+                if (m < p.M) v = *reinterpret_cast<const half8*>(xsrc + (size_t)m * 64 + kk * 32 + g * 8);
+                if constexpr (RC != 0)
+                    if (m < p.M) u = *reinterpret_cast<const half8*>(p.rc_a1[0] + (size_t)m * 64 + kk * 32 + g * 8);
                 xs[mt][kk] = v;
+                a1p[mt][kk] = u;
             }
         }
     }
@@ -327,8 +361,10 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     // last k-step: the free stage buffer receives chunk 0's operands; residual chunks 0 and 1 start their trip
     issue_chunk(0, nk & 1);
     compiler_fence();
-    load_res(0, res[0]);
-    load_res(1, res[1]);
+    if constexpr (RC == 0) {
+        load_res(0, res[0]);
+        load_res(1, res[1]);
+    }
     compiler_fence();
     compute_main((nk - 1) & 1);
     if (res_dma) wait_vmcnt<4>();   // chunk 0 operands and residual chunk 0 landed (chunk 1's 4 pieces, younger LDS-DMA requests, may still fly)
@@ -350,6 +386,14 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             }
             a1[mt][kk] = as_half8(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(v[0], v[1]), pack2h(v[2], v[3]));
         }
+
+    if (p.a1_out) {   // for the next tail, which rebuilds this block's output from it (lane (g, li): channels 32 kk + 8 g .. + 7 of its two pixels)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int kk = 0; kk < KK1; ++kk)
+                if (pr_ok[mt]) *reinterpret_cast<half8*>(p.a1_out + (size_t)(wm0 + mt * 16 + li) * C1 + kk * 32 + g * 8) = a1[mt][kk];
+    }
 
     float4v accz[NT3 ? NT3 : 1][2];
     if constexpr (C3 > 0) {
@@ -377,11 +421,45 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (j + 2 < NCH) issue_res(j + 2);
             }
-        } else {
+        } else if constexpr (RC == 0) {
             if (j + 2 < NCH) load_res(j + 2, res[(j + 2) % 3]);
         }
         compiler_fence();
         const unsigned char* W2s = smem + buf * STAGE_BYTES;
+        if constexpr (RC != 0) {   // the previous block's chunk, as its own tail computes it (btail_kernel<64, 64, false, SC>): bias, W2' . a1', Wsc . xs
+            const unsigned char* Wr = W2s + W2C_BYTES + C3 * ROW_BYTES;
+            float4v accr[4][2];
+#pragma unroll
+            for (int nt = 0; nt < 4; ++nt) {
+                const float4v b = *reinterpret_cast<const float4v*>(p.rc_b[0] + j * 64 + own_ch(nt, g));
+                accr[nt][0] = b;
+                accr[nt][1] = b;
+            }
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    half8 wf[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Wr + half * 8192 + swz(nt * 16 + li, kk * 4 + g));
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+                        for (int mt = 0; mt < 2; ++mt) accr[nt][mt] = OPD_MFMA_16x16x32(wf[nt], half ? xs[mt][kk] : a1p[mt][kk], accr[nt][mt]);
+                }
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    float4v v0 = accr[2 * q][mt], v1 = accr[2 * q + 1][mt];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
+                        v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+                    }
+                    res_cur[2 * q + mt] = make_uint4(pack2h(v0[0], v0[1]), pack2h(v0[2], v0[3]), pack2h(v1[0], v1[1]), pack2h(v1[2], v1[3]));
+                }
+        }
         float4v acc2[4][2];
 #pragma unroll
         for (int nt = 0; nt < 4; ++nt) {
@@ -459,7 +537,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
-                if (pr_ok[mt] && !(p.dbg & 2)) *reinterpret_cast<half8*>(p.y + pr_row[mt] + j * 64 + q * 32) = yf[q][mt];
+                if (y_ok[mt] && !(p.dbg & 2)) *reinterpret_cast<half8*>(p.y + pr_row[mt] + j * 64 + q * 32) = yf[q][mt];
         stamp(4 + j);
     }
 
@@ -493,11 +571,12 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #endif
 }
 
-template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false>
+template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false, int RC = 0>
 hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
-    constexpr int LDS = 2 * (128 + C1) * ROW_BYTES + (RDMA ? 2 * 16384 : 0);
-    OPD_SET_MAX_LDS_ONCE((btail_kernel<C1, C3, RDMA, SC, TRACE>), LDS);
-    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA, SC, TRACE>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+    constexpr int MAIN = (128 + C1) * ROW_BYTES, CHUNK = 64 * C1 * 2 + C3 * ROW_BYTES + (SC ? 64 * ROW_BYTES : 0) + (RC ? 2 * 64 * ROW_BYTES : 0);
+    constexpr int LDS = 2 * (MAIN > CHUNK ? MAIN : CHUNK) + (RDMA ? 2 * 16384 : 0);
+    OPD_SET_MAX_LDS_ONCE((btail_kernel<C1, C3, RDMA, SC, TRACE, RC>), LDS);
+    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA, SC, TRACE, RC>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -518,6 +597,14 @@ hipError_t OPD_SYM(opd_launch_btail)(const BtailParams& p_in, hipStream_t stream
     if ((size_t)p.B * p.H * p.W * p.C1 * 2 + (size_t)(p.W + 1) * p.C1 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
     if ((size_t)p.M * p.C1 * 8 >= 0x7fffff00ull) return hipErrorInvalidValue;
     if (p.C1 == 256) return OPD_SYM(opd_launch_btail256)(p, stream);   // stage 3: kernels_btail3.hip
+    if (p.y_stride2 && (p.stride != 1 || p.C3 == 0)) return hipErrorInvalidValue;   // (only next to a fused reduce: nobody else may need y)
+    if (!p.y && !p.a1_out) return hipErrorInvalidValue;   // an output nobody could rebuild
+    if (p.rc) {   // residual rebuilt from the previous block's a1 and shortcut input (second block of stage 1)
+        if (p.rc != 1 || p.C1 != 64 || p.C3 != 64 || p.stride != 1 || p.res || p.xs || !p.rc_a1[0] || !p.rc_xs || !p.rc_w2[0] || !p.rc_wsc || !p.rc_b[0] ||
+            p.trace || (size_t)p.M * 64 * 2 >= 0x7fffff00ull)
+            return hipErrorInvalidValue;
+        return launch_btail_t<64, 64, false, false, false, 1>(p, stream);
+    }
     if (p.xs) {   // fused shortcut convolution: stride 1, 64 -> 256 channels next to a 64-channel 3x3 (first block of stage 1)
         if (p.C1 != 64 || p.C3 != 64 || p.stride != 1 || !p.wsc || p.res || (size_t)p.M * 64 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
         return launch_btail_t<64, 64, false, true>(p, stream);

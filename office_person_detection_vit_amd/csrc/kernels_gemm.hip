@@ -988,7 +988,8 @@ hipError_t OPD_SYM(opd_launch_conv_gemm)(const ConvGemmParams& p_in, hipStream_t
                                                                                                      : launch_dma<64>(p, stream);
     }
     const int tiles_m = (p.M + BM - 1) / BM;
-    const bool wide = (p.N % 128 == 0) && ((long long)tiles_m * (p.N / 128) >= 384);
+    static const int wide_min = [] { const char* v = getenv("OPD_WIDE_MIN"); return v ? atoi(v) : 384; }();   // (A/B switch: 128-column tiles from this many tiles on)
+    const bool wide = (p.N % 128 == 0) && ((long long)tiles_m * (p.N / 128) >= wide_min);
     if (p.bias_ptrs) {  // per-frame periodic bias: implemented by the LDS-DMA kernel's accumulator initialisation only
         if (p.bias_period <= 0 || p.stem || !p.zero16) return hipErrorInvalidValue;
         return wide ? launch_dma<128>(p, stream) : launch_dma<64>(p, stream);

@@ -5,9 +5,20 @@
 // batched detectors is DetectorPort.detect(frames: Sequence[FrameDTO]) (src/core/interfaces.py:30-34).  Rounds 1-3 did the exchange in
 // Python on torch.distributed: two host synchronisations per step (wait for the post-process kernel, then all_gather_into_tensor on
 // torch's stream, then .cpu()), and a reference-side ctypes binding could not run the sharded configurations without importing torch.
-// Here a communicator is bound to ONE detector handle and everything is enqueued on that handle's stream:
-//     forward -> post-process kernel (writes the records into the send buffer) -> ncclAllGather -> copy to page-locked host memory -> event
-// and the host waits once, on the event.  RCCL is resolved at run time (dlopen of librccl.so.1: the copy a host process has already
+// Here the step is enqueued without a host wait in between:
+//     handle's stream:        forward -> post-process kernel (writes the records into the lane's send buffer) -> event `ready`
+//     communicator's stream:  wait(ready) -> ncclAllGather -> copy to page-locked host memory -> event `done`
+// and the host waits once, on `done`.
+//
+// ONE communicator per rank, any number of LANES (round 5).  A rank that keeps several batches in flight has several detector handles
+// (own stream, workspace, graph).  Round 4 gave each handle a communicator of its own and enqueued its all-gather on the handle's stream:
+// three communicators per rank whose collectives run on three unordered streams -- RCCL requires every rank to issue the collectives of a
+// communicator in the same order, and says nothing good about the device-side order of collectives on DIFFERENT communicators that share
+// links (a documented deadlock hazard), and that arrangement had never run on more than one GPU.  Now an `opd_comm` is a lane: a handle's
+// send / receive buffers and events on a communicator shared by all lanes of the rank (`opd_comm_attach`).  Every all-gather of the rank is
+// enqueued on the communicator's own stream under its mutex, i.e. in the order the host submitted the exchanges, and every rank submits
+// them in the same order (step i uses lane i mod N everywhere): one communicator, one in-order stream, one order -- RCCL's contract as
+// written.  The handles' streams never wait for a collective: the next forward of a handle starts while its records are still travelling.  RCCL is resolved at run time (dlopen of librccl.so.1: the copy a host process has already
 // loaded, e.g. PyTorch's, or ROCm's), so libopd_hip.so itself does not link it and single-GPU callers never touch it.
 // Whoever launches the ranks carries the 128-byte unique id from rank 0 to the others (a file, a socket, MPI, torch.distributed: the
 // Python layer uses its process-group store); the library does no rendezvous of its own.
@@ -64,18 +75,67 @@ Rccl& rccl() {
 
 }  // namespace
 
-struct opd_comm {
+// what the lanes of one rank share: the RCCL communicator and the one stream its collectives are enqueued on
+struct CommShared {
     ncclComm_t comm = nullptr;
-    opd_detr* m = nullptr;      // the handle this communicator is bound to: its device, its stream
-    int rank = 0, world = 1;
+    hipStream_t xstream = nullptr;
+    int device = 0, rank = 0, world = 1;
+    std::mutex mu;   // serialises [wait(ready), all-gather, copy, record(done)] of the lanes: submission order = enqueue order
+    ~CommShared() {
+        (void)hipSetDevice(device);
+        if (xstream) (void)hipStreamSynchronize(xstream);
+        if (comm && rccl().CommDestroy) (void)rccl().CommDestroy(comm);
+        if (xstream) (void)hipStreamDestroy(xstream);
+    }
+};
+
+struct opd_comm {
+    std::shared_ptr<CommShared> sh;
+    opd_detr* m = nullptr;      // the handle this lane is bound to (its stream produces the records); null once that handle has been destroyed
     int slots = 0;              // frame slots per rank of the current exchange
     int32_t* d_send = nullptr;  // [slots * Q * 8 record words][slots counts]
     int32_t* d_recv = nullptr;  // [world] x the same
     int32_t* h_recv = nullptr;  // page-locked copy of d_recv
     size_t cap_words = 0;       // words per rank the buffers hold
-    hipEvent_t done = nullptr;
+    hipEvent_t ready = nullptr; // recorded on the handle's stream behind the post-process kernel(s) of an exchange
+    hipEvent_t done = nullptr;  // recorded on the communicator's stream behind the copy to h_recv
     bool pending = false;
 };
+
+namespace {
+std::mutex g_lanes_mu;   // guards opd_detr::comms (the lanes bound to a handle)
+
+int make_lane(std::shared_ptr<CommShared> sh, opd_detr* m, opd_comm** out) {
+    std::unique_ptr<opd_comm> c(new (std::nothrow) opd_comm());
+    if (!c) return fail(OPD_ENOMEM, "opd_comm: out of host memory");
+    c->sh = std::move(sh); c->m = m;
+    if (hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
+        if (c->ready) (void)hipEventDestroy(c->ready);
+        return fail(OPD_EHIP, "opd_comm: hipEventCreate failed");
+    }
+    {
+        std::lock_guard<std::mutex> lk(g_lanes_mu);
+        m->comms.push_back(c.get());
+    }
+    *out = c.release();
+    return OPD_OK;
+}
+#define LANE_ALIVE(c, what)                                                                                                      \
+    do {                                                                                                                         \
+        if (!(c)->m) return fail(OPD_ESTATE, what ": the detector handle this communicator lane was bound to has been destroyed"); \
+    } while (0)
+}  // namespace
+
+// opd_detr_destroy: the handle's stream is about to go.  Its lanes stay valid objects (opd_comm_destroy still frees them) but refuse work.
+void opd::comm_detach_all(opd_detr* m) {
+    std::lock_guard<std::mutex> lk(g_lanes_mu);
+    for (opd_comm* c : m->comms) {
+        if (c->sh && c->sh->xstream) (void)hipStreamSynchronize(c->sh->xstream);   // (an exchange still in flight reads this handle's records)
+        c->m = nullptr;
+        c->pending = false;
+    }
+    m->comms.clear();
+}
 
 extern "C" {
 
@@ -90,56 +150,78 @@ int opd_comm_unique_id(void* id128) {
     return OPD_OK;
 }
 
+int opd_comm_available(void) {
+    Rccl& r = rccl();
+    if (!r.error.empty()) return fail(OPD_EHIP, "RCCL unavailable: " + r.error);
+    return OPD_OK;
+}
+
 int opd_comm_create(const void* id128, int rank, int world, opd_detr* m, opd_comm** out) {
+    // (the API lock stays held across ncclCommInitRank: it allocates device memory, which must not run beside another thread's stream capture;
+    //  set-up only.  A rank whose peers never arrive blocks here: callers bound the set-up with a watchdog, see sharding.py / bench.py)
     ApiScope api_scope;
     if (out) *out = nullptr;
     if (!id128 || !m || !out || world < 1 || rank < 0 || rank >= world) return fail(OPD_EINVAL, "opd_comm_create: bad argument");
     Rccl& r = rccl();
     if (!r.error.empty()) return fail(OPD_EHIP, "RCCL unavailable: " + r.error);
     HIPCHK(hipSetDevice(m->device));
-    std::unique_ptr<opd_comm> c(new (std::nothrow) opd_comm());
-    if (!c) return fail(OPD_ENOMEM, "opd_comm_create: out of host memory");
+    std::shared_ptr<CommShared> sh(new (std::nothrow) CommShared());
+    if (!sh) return fail(OPD_ENOMEM, "opd_comm_create: out of host memory");
+    sh->device = m->device; sh->rank = rank; sh->world = world;
+    HIPCHK(hipStreamCreateWithFlags(&sh->xstream, hipStreamNonBlocking));
     ncclUniqueId id;
     memcpy(&id, id128, sizeof(id));
-    NCCLCHK(r.CommInitRank(&c->comm, world, id, rank));
-    c->m = m; c->rank = rank; c->world = world;
-    if (hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
-        (void)r.CommDestroy(c->comm);
-        return fail(OPD_EHIP, "opd_comm_create: hipEventCreate failed");
-    }
-    *out = c.release();
-    return OPD_OK;
+    NCCLCHK(r.CommInitRank(&sh->comm, world, id, rank));
+    return make_lane(std::move(sh), m, out);
+}
+
+int opd_comm_attach(opd_comm* parent, opd_detr* m, opd_comm** out) {
+    ApiScope api_scope;
+    if (out) *out = nullptr;
+    if (!parent || !m || !out) return fail(OPD_EINVAL, "opd_comm_attach: null argument");
+    if (m->device != parent->sh->device) return fail(OPD_EINVAL, "opd_comm_attach: the handle lives on another device than the communicator");
+    HIPCHK(hipSetDevice(m->device));
+    return make_lane(parent->sh, m, out);
 }
 
 void opd_comm_destroy(opd_comm* c) {
     ApiScope api_scope;
     if (!c) return;
-    (void)hipSetDevice(c->m->device);
-    (void)hipStreamSynchronize(c->m->stream);
-    if (c->comm && rccl().CommDestroy) (void)rccl().CommDestroy(c->comm);
+    (void)hipSetDevice(c->sh->device);
+    (void)hipStreamSynchronize(c->sh->xstream);   // this lane's exchange, if any, is over
+    if (c->m) {
+        (void)hipStreamSynchronize(c->m->stream);
+        std::lock_guard<std::mutex> lk(g_lanes_mu);
+        auto& v = c->m->comms;
+        for (size_t i = 0; i < v.size(); ++i)
+            if (v[i] == c) { v.erase(v.begin() + i); break; }
+    }
     if (c->d_send) (void)hipFree(c->d_send);
     if (c->d_recv) (void)hipFree(c->d_recv);
     if (c->h_recv) (void)hipHostFree(c->h_recv);
+    if (c->ready) (void)hipEventDestroy(c->ready);
     if (c->done) (void)hipEventDestroy(c->done);
-    delete c;
+    delete c;   // (the communicator and its stream go with the last lane: ~CommShared)
 }
 
 int opd_comm_begin(opd_comm* c, int slots) {
     ApiScope api_scope;
     if (!c || slots < 1) return fail(OPD_EINVAL, "opd_comm_begin: bad argument");
+    LANE_ALIVE(c, "opd_comm_begin");
     if (c->pending) return fail(OPD_ESTATE, "opd_comm_begin: the previous exchange has not been waited for");
     opd_detr* m = c->m;
     HIPCHK(hipSetDevice(m->device));
     const size_t Q = (size_t)m->arch.queries, words = (size_t)slots * Q * 8 + (size_t)slots;
     if (words > c->cap_words) {   // (grow only; not on the steady-state path)
         HIPCHK(hipStreamSynchronize(m->stream));
+        HIPCHK(hipStreamSynchronize(c->sh->xstream));
         if (c->d_send) (void)hipFree(c->d_send);
         if (c->d_recv) (void)hipFree(c->d_recv);
         if (c->h_recv) (void)hipHostFree(c->h_recv);
         c->d_send = c->d_recv = c->h_recv = nullptr; c->cap_words = 0;
         void *a = nullptr, *b = nullptr, *h = nullptr;
-        if (hipMalloc(&a, words * 4) != hipSuccess || hipMalloc(&b, words * 4 * c->world) != hipSuccess ||
-            hipHostMalloc(&h, words * 4 * c->world, hipHostMallocDefault) != hipSuccess) {
+        if (hipMalloc(&a, words * 4) != hipSuccess || hipMalloc(&b, words * 4 * c->sh->world) != hipSuccess ||
+            hipHostMalloc(&h, words * 4 * c->sh->world, hipHostMallocDefault) != hipSuccess) {
             if (a) (void)hipFree(a);
             if (b) (void)hipFree(b);
             return fail(OPD_ENOMEM, "opd_comm_begin: exchange buffers");
@@ -157,6 +239,7 @@ int opd_comm_detect(opd_comm* c, int slot0, const void* pixels, int pixel_format
                     const int32_t* orig_hw) {
     ApiScope api_scope;
     if (!c) return fail(OPD_EINVAL, "opd_comm_detect: null communicator");
+    LANE_ALIVE(c, "opd_comm_detect");
     opd_detr* m = c->m;
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     if (c->slots < 1 || slot0 < 0 || slot0 + B > c->slots) return fail(OPD_EINVAL, "opd_comm_detect: frames do not fit the slots of opd_comm_begin");
@@ -173,6 +256,7 @@ int opd_comm_detect(opd_comm* c, int slot0, const void* pixels, int pixel_format
 
 int opd_comm_buffers(opd_comm* c, int slot0, void** records, void** counts) {
     if (!c || !records || !counts) return fail(OPD_EINVAL, "opd_comm_buffers: null argument");
+    LANE_ALIVE(c, "opd_comm_buffers");
     if (c->slots < 1 || slot0 < 0 || slot0 >= c->slots) return fail(OPD_EINVAL, "opd_comm_buffers: slot outside the exchange begun");
     const size_t Q = (size_t)c->m->arch.queries;
     *records = reinterpret_cast<opd_det*>(c->d_send) + (size_t)slot0 * Q;
@@ -183,13 +267,20 @@ int opd_comm_buffers(opd_comm* c, int slot0, void** records, void** counts) {
 int opd_comm_exchange(opd_comm* c) {
     ApiScope api_scope;
     if (!c || c->slots < 1) return fail(OPD_EINVAL, "opd_comm_exchange: no exchange begun");
+    LANE_ALIVE(c, "opd_comm_exchange");
     if (c->pending) return fail(OPD_ESTATE, "opd_comm_exchange: the previous exchange has not been waited for");
     opd_detr* m = c->m;
+    CommShared& sh = *c->sh;
     HIPCHK(hipSetDevice(m->device));
     const size_t words = (size_t)c->slots * m->arch.queries * 8 + (size_t)c->slots;
-    NCCLCHK(rccl().AllGather(c->d_send, c->d_recv, words, ncclInt32, c->comm, m->stream));   // right behind the post-process kernel, same stream
-    HIPCHK(hipMemcpyAsync(c->h_recv, c->d_recv, words * 4 * c->world, hipMemcpyDeviceToHost, m->stream));
-    HIPCHK(hipEventRecord(c->done, m->stream));
+    HIPCHK(hipEventRecord(c->ready, m->stream));   // behind the post-process kernel(s) that filled the send buffer
+    {
+        std::lock_guard<std::mutex> lk(sh.mu);     // the rank's collectives in ONE order: the order the exchanges were submitted in
+        HIPCHK(hipStreamWaitEvent(sh.xstream, c->ready, 0));
+        NCCLCHK(rccl().AllGather(c->d_send, c->d_recv, words, ncclInt32, sh.comm, sh.xstream));
+        HIPCHK(hipMemcpyAsync(c->h_recv, c->d_recv, words * 4 * sh.world, hipMemcpyDeviceToHost, sh.xstream));
+        HIPCHK(hipEventRecord(c->done, sh.xstream));
+    }
     c->pending = true;
     return OPD_OK;
 }
@@ -197,11 +288,15 @@ int opd_comm_exchange(opd_comm* c) {
 int opd_comm_wait(opd_comm* c, opd_det* out_all, int32_t* counts_all) {
     ApiScope api_scope;
     if (!c || !out_all || !counts_all) return fail(OPD_EINVAL, "opd_comm_wait: null argument");
+    LANE_ALIVE(c, "opd_comm_wait");
     if (!c->pending) return fail(OPD_ESTATE, "opd_comm_wait: no exchange outstanding");
     HIPCHK(hipSetDevice(c->m->device));
-    HIPCHK(hipEventSynchronize(c->done));   // the step's ONE host wait
+    {
+        ApiUnlocked unlocked;   // the step's ONE host wait -- for the remote ranks too: another thread's graph capture must not queue behind it
+        HIPCHK(hipEventSynchronize(c->done));
+    }
     const size_t Q = (size_t)c->m->arch.queries, nrec = (size_t)c->slots * Q * 8, words = nrec + c->slots;
-    for (int r = 0; r < c->world; ++r) {
+    for (int r = 0; r < c->sh->world; ++r) {
         memcpy(out_all + (size_t)r * c->slots * Q, c->h_recv + (size_t)r * words, nrec * 4);
         memcpy(counts_all + (size_t)r * c->slots, c->h_recv + (size_t)r * words + nrec, (size_t)c->slots * 4);
     }
@@ -211,7 +306,7 @@ int opd_comm_wait(opd_comm* c, opd_det* out_all, int32_t* counts_all) {
 
 int opd_comm_info(const opd_comm* c, int* rank, int* world) {
     if (!c || !rank || !world) return fail(OPD_EINVAL, "opd_comm_info: null argument");
-    *rank = c->rank; *world = c->world;
+    *rank = c->sh->rank; *world = c->sh->world;
     return OPD_OK;
 }
 

@@ -116,6 +116,22 @@ struct BtailParams {
     unsigned long long* trace;   // tools only: per-workgroup phase stamps [grid][16] (btail_kernel<..., TRACE>); null in the model
     int rev;           // 1: each XCD walks its tiles in descending order (results identical; see kernels_btail.hip)
     int dtype;         // OPD_DT_F16 / OPD_DT_BF16
+    // Round 5, stage 1 (C1 == 64): the block output y = relu(W2 . a1 + residual) is 4x wider than a1, and a 1x1 has no halo, so the NEXT
+    // tail can rebuild the y it needs as its residual from the 64-channel tensors that made it instead of reading 274 MB back:
+    //   y == null      -> y is not stored at all (the consumer recomputes it);
+    //   a1_out         -> [M][C1] fp16: this block's a1 = relu(3x3), stored for that consumer (natural channel order);
+    //   rc = 1         -> residual = relu(rc_b0 + rc_w2[0] . rc_a1[0] + rc_wsc . rc_xs), the previous block's output rebuilt per 64-channel
+    //                     chunk with that block's own instruction order (bit-identical to what its tail would have stored); res must be null;
+    //   y_stride2 = 1  -> y is stored only at pixels with even (oh, ow): the only ones a stride-2 1x1 shortcut of the next stage reads
+    //                     (valid when the next block's reduce is fused as z, i.e. nobody else reads y).
+    f16_t* a1_out;
+    const f16_t* rc_a1[2];
+    const f16_t* rc_xs;
+    const f16_t* rc_w2[2];
+    const f16_t* rc_wsc;
+    const float* rc_b[2];
+    int rc;
+    int y_stride2;
 };
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);

@@ -537,7 +537,7 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
     p.x = x; p.w = c.w; p.bias = c.bias; p.res16 = res16; p.res32 = nullptr; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = B; p.H = H; p.W = W; p.Cin = c.Cin; p.OH = OH; p.OW = OW; p.N = c.Cout; p.KH = c.KH; p.KW = c.KW;
     p.stride = c.stride; p.pad = c.pad; p.M = B * OH * OW; p.K = c.K; p.relu = relu ? 1 : 0; p.bias_period = 0;
-    p.out_f32 = 0; p.stem = c.stem ? 1 : 0;
+    p.out_f32 = 0; p.stem = c.stem ? 1 : 0; p.dbg = m->dbg_gemm;
     // algorithmic FLOPs (2 x MAC over the real taps/channels; the stem's zero padding is not counted)
     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)c.Cout * c.KH * c.KW * c.Cin));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
@@ -555,7 +555,7 @@ static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bi
     p.x_alt = x_alt; p.alt_mod = alt_mod; p.alt_cols = alt_cols;
     p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
-    p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0;
+    p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0; p.dbg = m->dbg_gemm;
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
@@ -739,6 +739,8 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     // ones touch (per-frame sizes shrink from stage to stage).
     struct TrunkState { int cur_id; int ch, cw; int z_id; };   // cur_id 0 = pool, 1 = t0, 2 = t1; z_id -1 / 0 = m0 / 1 = m1
     int tail_no = 0;   // consecutive fused tails walk the tiles in alternating directions (tail_rev)
+    int rc_prev = -1;            // block whose tail stored a1 instead of y (its successor rebuilds the residual: BtailParams::rc)
+    const f16_t* rc_xs = nullptr;
     auto run_blocks = [&](int s_begin, int s_end, int b0, int nb, TrunkState& st, int l_begin = 0, int l_end = 1 << 30) -> int {
         auto trunk = [&](int id, size_t per_frame) { return (id == 0 ? m->d_pool : id == 1 ? m->d_t0 : m->d_t1) + (size_t)b0 * per_frame; };
         auto mid = [&](int id, size_t per_frame) { return (id ? m->d_m1 : m->d_m0) + (size_t)b0 * per_frame; };
@@ -802,12 +804,29 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     if (sc_in_tail) { p.res = nullptr; p.xs = cur; p.wsc = b.sc.w; p.b2 = b.bias2sc; }
                     f16_t* z = mid(1 - x1_id, (size_t)oh * ow * C3);
                     if (C3) { p.w3p = C1 == 256 ? nbk->c0.wp : nbk->c0.w; p.b3 = nbk->c0.bias; p.z = z; }
+                    // Stage 1, residual rebuild (BtailParams::rc): block 0 stores its a1 (64 channels) instead of its output (256), block 1 rebuilds
+                    // that output chunk by chunk from a1 and the pooled map (the shortcut's input) as its residual.  Bit-identical results
+                    // (tests/test_kernels_gpu.py, OPD_TAIL_RC=0/1 end to end); 344 MB less HBM traffic per forward at batch 8.  The a1 tensor lives in
+                    // the shortcut buffer, which a fused shortcut leaves unused.
+                    const bool rc_ok = m->tail_rc && s == 0 && C1 == 64 && C3 == 64 && a.depths[0] >= 2 && !m->taps;
+                    f16_t* a1_keep = m->d_sc + (size_t)b0 * oh * ow * 64;
+                    if (rc_ok && sc_in_tail && l == 0) { p.y = nullptr; p.a1_out = a1_keep; rc_prev = bi; rc_xs = cur; }
+                    else if (rc_ok && l == 1 && rc_prev == bi - 1 && !b.has_sc) {
+                        const Block& pb = m->blocks[bi - 1];
+                        p.res = nullptr; p.rc = 1; p.rc_a1[0] = a1_keep; p.rc_xs = rc_xs; p.rc_w2[0] = pb.c2.w; p.rc_wsc = pb.sc.w; p.rc_b[0] = pb.bias2sc;
+                    }
+                    // The last block of stage 1 hands the next stage its reduce output z (fused above); the block output itself is then read
+                    // by that stage's stride-2 shortcut only, i.e. at even (oh, ow): the other three quarters of its 274 MB are not stored.
+                    if (m->y_stride2 && C3 && b.c1.stride == 1 && l + 1 == a.depths[s] && nbk && nbk->has_sc && nbk->sc.stride == 2 && nbk->sc.KH == 1 &&
+                        nbk->c1.stride == 2 && !m->taps)
+                        p.y_stride2 = 1;
                     p.B = nb; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = nb * oh * ow; p.C1 = C1; p.C3 = C3;
                     p.rev = m->tail_rev ? (tail_no++ & 1) : 0;
+                    p.dbg = m->dbg_btail;
                     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));
                     HIPCHK(opd_launch_btail(p, m->stream));
                     RCCHK(timed_end(m));
-                    RCCHK(tap(m, "btail_y", out, (size_t)p.M * 4 * C1 * 2));
+                    if (p.y) RCCHK(tap(m, "btail_y", out, (size_t)p.M * 4 * C1 * 2));
                     if (C3) RCCHK(tap(m, "btail_z", z, (size_t)p.M * C3 * 2));
                     if (C3) st.z_id = 1 - x1_id;
                 } else {
@@ -818,7 +837,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                         p.x = a1; p.w = b.w2sc; p.bias = b.bias2sc; p.out = out; p.zero16 = m->zero_bias;
                         p.B = nb; p.H = oh; p.W = ow; p.Cin = C1; p.OH = oh; p.OW = ow; p.N = C2; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
                         p.M = nb * oh * ow; p.K1 = C1; p.K = C1 + b.sc.Cin; p.relu = 1;
-                        p.x2 = cur; p.H2 = ch; p.W2 = cw; p.Cin2 = b.sc.Cin; p.stride2 = b.sc.stride;
+                        p.x2 = cur; p.H2 = ch; p.W2 = cw; p.Cin2 = b.sc.Cin; p.stride2 = b.sc.stride; p.dbg = m->dbg_gemm;
                         RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)C2 * p.K));
                         HIPCHK(opd_launch_conv_gemm(p, m->stream));
                         RCCHK(timed_end(m));
@@ -1376,6 +1395,8 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_DUAL_OVER_TAIL")) m->dual_over_tail = atoi(v);
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
     if (const char* v = getenv("OPD_TAIL3")) m->tail3 = atoi(v);
+    if (const char* v = getenv("OPD_TAIL_RC")) m->tail_rc = atoi(v);
+    if (const char* v = getenv("OPD_Y_STRIDE2")) m->y_stride2 = atoi(v);
     if (const char* v = getenv("OPD_TAIL3_SPLIT")) m->tail3_split = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
     if (const char* v = getenv("OPD_POS_SHADOW")) m->pos_shadow = atoi(v);
@@ -1387,6 +1408,8 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_ENC_FRONT")) m->enc_front = atoi(v);
     if (const char* v = getenv("OPD_HEADS2")) m->heads2 = atoi(v);
     if (const char* v = getenv("OPD_DBG_DEC_LAYERS")) m->dbg_dec_layers = atoi(v);   // timing ablation (tools/dec_cost.sh): results are wrong
+    if (const char* v = getenv("OPD_DBG_BTAIL")) m->dbg_btail = atoi(v);             // timing ablations of the whole forward: BtailParams::dbg / ConvGemmParams::dbg
+    if (const char* v = getenv("OPD_DBG_GEMM")) m->dbg_gemm = atoi(v);               // of every fused tail / implicit-GEMM launch (results are wrong)
     m->device = device_ordinal;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -1432,6 +1455,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
+    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());
@@ -1457,6 +1481,7 @@ void opd_detr_destroy(opd_detr* m) {
     if (!m) return;
     (void)hipSetDevice(m->device);
     if (m->stream) (void)hipStreamSynchronize(m->stream);
+    comm_detach_all(m);   // communicator lanes bound to this handle refuse work from here on (their own destroy still frees them)
     for (void* p : m->allocs) (void)hipFree(p);
     if (m->d_src) (void)hipFree(m->d_src);
     for (auto& e : m->ev_async)

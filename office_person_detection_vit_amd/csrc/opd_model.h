@@ -147,6 +147,7 @@ struct opd_detr {
     int fused_dec = 1;         // the decoder as five launches per layer on split fp16 operands (kernels_dec.hip; 0: the round-3 chain of nine launches
                                // per layer on single fp16 operands, also taken when the architecture does not fit: d_model != 256, heads != 8, queries % 4)
     int dec_splits = 3;        // key ranges of the fused decoder's cross-attention
+    int dbg_btail = 0, dbg_gemm = 0;   // timing ablations only (OPD_DBG_BTAIL / OPD_DBG_GEMM): the kernels' dbg bits for every launch of the forward
     int dbg_dec_layers = 1 << 20;   // timing ablation only (OPD_DBG_DEC_LAYERS): run this many decoder layers
     LNp dec_ln;
     float *wc = nullptr, *bc = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
@@ -212,6 +213,8 @@ struct opd_detr {
     int tail_rev = 1;        // consecutive fused tails walk their tiles in opposite directions (Infinity Cache reuse of the block output)
     int tail3 = 1;           // stage 3 (256-channel blocks) through the eight-wave fused tail (kernels_btail3.hip) where it pays (see run_blocks);
                              // 0: never (three launches per block), 2: always
+    int tail_rc = 1;         // stage 1: block 0 stores a1 instead of y, block 1 rebuilds y as its residual (kernels_btail.hip, RC; env OPD_TAIL_RC)
+    int y_stride2 = 1;       // last tail of stage 1: y stored only where the next stage's stride-2 shortcut reads it (env OPD_Y_STRIDE2)
     int num_cus = 256;
     int tail3_split = 1;     // stage 3: frames beyond whole rounds of the fused tail run as a second chain on `stream2` (0: one launch per tail)
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
@@ -236,6 +239,8 @@ struct opd_detr {
     float class_ms[4] = {};
     int class_launches[4] = {};
     double class_flops[4] = {};
+
+    std::vector<struct opd_comm*> comms;   // communicator lanes bound to this handle (opd_comm.cpp; detached when the handle is destroyed)
 
     // diagnostic taps (opd_test_set_taps): a checksum launch after every launch of the forward, captured into the graph with it
     int taps = 0;
@@ -273,6 +278,7 @@ inline int dalloc(opd_detr* m, T** p, size_t count, bool weight) {
     return OPD_OK;
 }
 
+void comm_detach_all(opd_detr* m);   // opd_comm.cpp: called by opd_detr_destroy
 int fill_qc0(opd_detr* m);   // opd_model.cpp
 // forward / post-process building blocks shared with opd_comm.cpp (all enqueue on m->stream; none synchronises unless it must)
 int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int H, int W, const int32_t* valid_hw = nullptr);
@@ -319,6 +325,11 @@ struct ApiScope {   // first statement of every HIP-calling entry point; entry p
         if (outer) { lk.lock(); tl_api_lock = &lk; }
     }
     ~ApiScope() { if (outer) tl_api_lock = nullptr; }
+};
+struct ApiUnlocked {   // a blocking host wait inside an entry point (an event of another rank's making): the shared hold is dropped meanwhile
+    std::shared_lock<std::shared_mutex>* s;
+    ApiUnlocked() : s(tl_api_lock && tl_api_lock->owns_lock() ? tl_api_lock : nullptr) { if (s) s->unlock(); }
+    ~ApiUnlocked() { if (s) s->lock(); }
 };
 struct CaptureExclusive {   // the calling thread's shared hold is handed back for the duration
     std::shared_lock<std::shared_mutex>* s;

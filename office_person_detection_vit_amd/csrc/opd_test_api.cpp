@@ -538,6 +538,66 @@ int opd_test_btail_sc(const uint16_t* x1, const uint16_t* w1, const float* b1, c
     return OPD_OK;
 }
 
+// Stage 1's first two tails and its last one, both ways (kernels_btail.hip, round 5).  Blocks a (shortcut inside), b, c on x1 [B][H][W][64] /
+// xs [M][64]; weights as in opd_test_btail_sc / opd_test_btail (w3a, w3b: [64][256], w3c: [128][256]).
+//   old: tail a stores y_a -> tail b reads it back as its residual -> tail c stores all of y_c;
+//   new: tail a stores a1 only -> tail b REBUILDS y_a (rc = 1) -> tail c stores y_c at even (oh, ow) only (y_stride2; the buffer is pre-filled
+//        with `fill` so the caller sees what was not written).
+// Outputs: yb / zb [M][256] / [M][64], yc / zc [M][256] / [M][128], once per route (index 0 old, 1 new).
+int opd_test_btail_chain(const uint16_t* x1, const uint16_t* xs, const uint16_t* const* w1, const float* const* b1, const uint16_t* const* w2,
+                         const float* const* b2, const uint16_t* wsc, const uint16_t* const* w3, const float* const* b3, uint16_t* const* yb,
+                         uint16_t* const* zb, uint16_t* const* yc, uint16_t* const* zc, int B, int H, int W, int fill) {
+    DevMem dm;
+    const size_t M = (size_t)B * H * W;
+    const uint16_t* d_x1 = dm.up(x1, M * 64);
+    const uint16_t* d_xs = dm.up(xs, M * 64);
+    const uint16_t* d_wsc = dm.up(wsc, (size_t)256 * 64);
+    const uint16_t *d_w1[3], *d_w2[3], *d_w3[3];
+    const float *d_b1[3], *d_b2[3], *d_b3[3];
+    for (int i = 0; i < 3; ++i) {
+        const int c3 = i == 2 ? 128 : 64;
+        d_w1[i] = dm.up(w1[i], (size_t)64 * 9 * 64); d_b1[i] = dm.up(b1[i], 64);
+        d_w2[i] = dm.up(w2[i], (size_t)256 * 64); d_b2[i] = dm.up(b2[i], 256);
+        d_w3[i] = dm.up(w3[i], (size_t)c3 * 256); d_b3[i] = dm.up(b3[i], c3);
+        if (!d_w1[i] || !d_b1[i] || !d_w2[i] || !d_b2[i] || !d_w3[i] || !d_b3[i]) return tfail(OPD_ENOMEM, "test alloc failed");
+    }
+    uint16_t* ya = dm.up<uint16_t>(nullptr, M * 256);
+    uint16_t* za = dm.up<uint16_t>(nullptr, M * 64);
+    uint16_t* a1a = dm.up<uint16_t>(nullptr, M * 64);
+    uint16_t* d_yb = dm.up<uint16_t>(nullptr, M * 256);
+    uint16_t* d_zb = dm.up<uint16_t>(nullptr, M * 64);
+    uint16_t* d_yc = dm.up<uint16_t>(nullptr, M * 256);
+    uint16_t* d_zc = dm.up<uint16_t>(nullptr, M * 128);
+    if (!d_x1 || !d_xs || !d_wsc || !ya || !za || !a1a || !d_yb || !d_zb || !d_yc || !d_zc) return tfail(OPD_ENOMEM, "test alloc failed");
+    for (int route = 0; route < 2; ++route) {
+        TCHK(hipMemset(ya, 0xEE, M * 256 * 2));
+        TCHK(hipMemset(d_yc, fill, M * 256 * 2));
+        auto base = [&](int i, const uint16_t* in, uint16_t* y, uint16_t* z, int c3) {
+            BtailParams p{}; p.dtype = g_test_dtype;
+            p.x1 = in; p.w1 = d_w1[i]; p.b1 = d_b1[i]; p.w2p = d_w2[i]; p.b2 = d_b2[i]; p.y = y; p.w3p = d_w3[i]; p.b3 = d_b3[i]; p.z = z;
+            p.B = B; p.H = H; p.W = W; p.OH = H; p.OW = W; p.stride = 1; p.M = (int)M; p.C1 = 64; p.C3 = c3;
+            return p;
+        };
+        BtailParams pa = base(0, d_x1, ya, za, 64);
+        pa.xs = d_xs; pa.wsc = d_wsc;
+        if (route) { pa.y = nullptr; pa.a1_out = a1a; }
+        TCHK(opd_launch_btail(pa, nullptr));
+        BtailParams pb = base(1, za, d_yb, d_zb, 64);
+        if (route) { pb.rc = 1; pb.rc_a1[0] = a1a; pb.rc_xs = d_xs; pb.rc_w2[0] = d_w2[0]; pb.rc_wsc = d_wsc; pb.rc_b[0] = d_b2[0]; }
+        else pb.res = ya;
+        TCHK(opd_launch_btail(pb, nullptr));
+        BtailParams pc = base(2, d_zb, d_yc, d_zc, 128);
+        pc.res = d_yb; pc.y_stride2 = route;
+        TCHK(opd_launch_btail(pc, nullptr));
+        TCHK(hipDeviceSynchronize());
+        TCHK(hipMemcpy(yb[route], d_yb, M * 256 * 2, hipMemcpyDeviceToHost));
+        TCHK(hipMemcpy(zb[route], d_zb, M * 64 * 2, hipMemcpyDeviceToHost));
+        TCHK(hipMemcpy(yc[route], d_yc, M * 256 * 2, hipMemcpyDeviceToHost));
+        TCHK(hipMemcpy(zc[route], d_zc, M * 128 * 2, hipMemcpyDeviceToHost));
+    }
+    return OPD_OK;
+}
+
 // Times the fused tail (us_out[0]) and the three unfused launches it replaces (us_out[1..3]: c1, c2, c0') on
 // device-resident data of the given shape.
 // Two warm launches, then one traced launch of a fused tail: trace_out [wgs][16] (kernels_btail.hip, TRACE), *wgs_out = grid size

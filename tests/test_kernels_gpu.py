@@ -597,6 +597,45 @@ def test_btail_with_fused_shortcut(lib, B, H, W):
     np.testing.assert_allclose(z, zr, atol=4e-3, rtol=2e-3)
 
 
+@pytest.mark.parametrize("B,H,W", [(1, 10, 14), (2, 13, 17), (1, 64, 64), (2, 200, 334)])
+def test_btail_residual_rebuild_and_strided_output_are_bit_identical(lib, B, H, W):
+    """Stage 1's three tails both ways (kernels_btail.hip, round 5).  New route: the first tail stores its a1 (64 channels) instead of its
+    output (256), the second REBUILDS that output chunk by chunk as its residual (BtailParams::rc) and the third stores its own output
+    only at even (oh, ow), which is all the next stage's stride-2 shortcut reads.  Everything the old route stores must come out with the
+    same bits: y / z of the second tail everywhere, z of the third everywhere, y of the third where it is stored -- and nothing else of
+    that buffer may be touched (it is pre-filled with 0xA5 bytes)."""
+    rng = np.random.default_rng(1000 * B + 10 * H + W)
+    M = B * H * W
+    f16 = lambda a: np.ascontiguousarray(a.astype(np.float16).view(np.uint16))
+    f32 = lambda a: np.ascontiguousarray(a.astype(np.float32))
+    x1 = f16(np.abs(rng.standard_normal((B, H, W, 64))))
+    xs = f16(np.abs(rng.standard_normal((M, 64))))
+    wsc = f16(rng.standard_normal((256, 64)) / 8)
+    w1 = [f16((rng.standard_normal((64, 64, 3, 3)) / 24).transpose(0, 2, 3, 1).reshape(64, 576)) for _ in range(3)]
+    w2 = [f16(rng.standard_normal((256, 64)) / 8) for _ in range(3)]
+    w3 = [f16(rng.standard_normal((c3, 256)) / 16) for c3 in (64, 64, 128)]
+    b1 = [f32(0.1 * rng.standard_normal(64)) for _ in range(3)]
+    b2 = [f32(0.1 * rng.standard_normal(256)) for _ in range(3)]
+    b3 = [f32(0.1 * rng.standard_normal(c3)) for c3 in (64, 64, 128)]
+    arr = lambda xs_: (C.c_void_p * len(xs_))(*[x.ctypes.data for x in xs_])
+    yb = [np.empty((M, 256), np.uint16) for _ in range(2)]
+    zb = [np.empty((M, 64), np.uint16) for _ in range(2)]
+    yc = [np.empty((B, H, W, 256), np.uint16) for _ in range(2)]
+    zc = [np.empty((M, 128), np.uint16) for _ in range(2)]
+    rc = lib.opd_test_btail_chain(_p(x1), _p(xs), arr(w1), arr(b1), arr(w2), arr(b2), _p(wsc), arr(w3), arr(b3), arr(yb), arr(zb), arr(yc), arr(zc),
+                                  B, H, W, 0xA5)
+    _capi.check(rc, "opd_test_btail_chain")
+    assert np.isfinite(yb[0].view(np.float16)).all() and float(np.abs(yb[0].view(np.float16).astype(np.float32)).max()) > 0.5
+    assert np.array_equal(yb[0], yb[1]), "second tail: y differs between a residual read back and a residual rebuilt"
+    assert np.array_equal(zb[0], zb[1])
+    assert np.array_equal(zc[0], zc[1])
+    assert np.array_equal(yc[0][:, ::2, ::2], yc[1][:, ::2, ::2]), "third tail: y at the positions a stride-2 1x1 reads"
+    untouched = np.ones((B, H, W), bool)
+    untouched[:, ::2, ::2] = False
+    assert (yc[1][untouched] == 0xA5A5).all(), "third tail stored y at positions nobody reads"
+    assert not (yc[0] == 0xA5A5).all()
+
+
 def test_btail_fused_shortcut_integer_exact(lib):
     """Integer operands: bit-exact against the exact sums, and against the unfused route (shortcut launch -> residual tail)."""
     rng = np.random.default_rng(77)
