@@ -230,31 +230,58 @@ def main() -> int:
     # step); torch.distributed carries the 128-byte unique ids at set-up, the barriers and the max-over-ranks of the timing.  The
     # torch.distributed all-gather of rounds 1-3 remains for the gloo rehearsal (ranks sharing one device cannot form an RCCL
     # communicator) and as the fallback should communicator creation fail on a node.
+    # ONE communicator per rank (default): handle 0 creates it, the other handles attach LANES to it (opd_comm_attach); every all-gather of
+    # the rank is enqueued on the communicator's own stream in submission order, the same order on every rank (step i uses lane i mod NS).
+    # OPD_BENCH_COMMS=per-handle: one communicator per handle (round 4's arrangement: collectives of different communicators on unordered
+    # streams; kept as a switch for a node where it can be compared, never the default).
+    # Set-up protocol: (1) every rank checks that librccl can be resolved and the ranks AGREE on it (all_reduce) before anyone enters a
+    # collective initialisation -- a rank that cannot take part must not leave its peers blocked in ncclCommInitRank; (2) rank 0's unique
+    # id(s) travel through the process group; (3) ncclCommInitRank under a watchdog: failure or a stall past OPD_BENCH_COMM_TIMEOUT seconds
+    # ends this rank with a non-zero exit code (the parent stops the others) -- there is no fallback from a half-initialised communicator.
     comms, exchange = [], "none"
+    force_comm = os.environ.get("OPD_BENCH_FORCE_COMM") == "1"   # test switch: the native exchange over a ONE-rank communicator
     if world > 1:
         exchange = "torch.distributed"
-        if backend == "nccl" and os.environ.get("OPD_BENCH_EXCHANGE", "native") == "native":
-            try:
-                ids = [[bytes(_capi_unique_id(lib)) for _ in handles] if rank == 0 else None]
+    if not rehearsal and ((world > 1 and backend == "nccl") or (world == 1 and force_comm)) and os.environ.get("OPD_BENCH_EXCHANGE", "native") == "native":
+        avail = 1 if lib.opd_comm_available() == 0 else 0
+        if not avail:
+            print(f"bench.py: rank {rank}: {lib.opd_last_error().decode()}", file=sys.stderr, flush=True)
+        if world > 1:
+            t_av = torch.tensor([avail], device="cuda")
+            dist.all_reduce(t_av, op=dist.ReduceOp.MIN)   # every rank or none, decided before any collective set-up
+            avail = int(t_av.item())
+        if avail:
+            per_handle = os.environ.get("OPD_BENCH_COMMS", "shared") == "per-handle"
+            ids = [[bytes(_capi_unique_id(lib)) for _ in range(NS if per_handle else 1)] if rank == 0 else None]
+            if world > 1:
                 dist.broadcast_object_list(ids, src=0)
-                for hx, uid in zip(handles, ids[0]):
+            import threading
+            limit = float(os.environ.get("OPD_BENCH_COMM_TIMEOUT", "120"))
+
+            def stalled():
+                print(f"bench.py: rank {rank}: communicator set-up did not finish within {limit:.0f} s; giving up", file=sys.stderr, flush=True)
+                os._exit(3)
+
+            dog = threading.Timer(limit, stalled)
+            dog.daemon = True
+            dog.start()
+            try:
+                for k, hx in enumerate(handles):
                     cx = C.c_void_p()
-                    _capi.check(lib.opd_comm_create(uid, rank, world, hx, C.byref(cx)), "opd_comm_create")
+                    if per_handle or k == 0:
+                        _capi.check(lib.opd_comm_create(ids[0][k if per_handle else 0], rank, world, hx, C.byref(cx)), "opd_comm_create")
+                    else:
+                        _capi.check(lib.opd_comm_attach(comms[0], hx, C.byref(cx)), "opd_comm_attach")
                     comms.append(cx)
-                exchange = "native (opd_comm_*: ncclAllGather on the handle's stream)"
-            except Exception as e:   # noqa: BLE001 — any failure: say so and use the torch path
-                print(f"bench.py: native exchange unavailable on rank {rank} ({e}); using torch.distributed", file=sys.stderr, flush=True)
-                for cx in comms:
-                    lib.opd_comm_destroy(cx)
-                comms = []
-            ok = torch.tensor([1 if comms else 0], device="cuda")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # every rank or none
-            if int(ok.item()) == 0 and comms:
-                for cx in comms:
-                    lib.opd_comm_destroy(cx)
-                comms, exchange = [], "torch.distributed"
-            elif int(ok.item()) == 0:
-                exchange = "torch.distributed"
+            except Exception as e:   # noqa: BLE001 -- inside a collective initialisation there is nothing to fall back to
+                print(f"bench.py: rank {rank}: communicator set-up failed: {e}", file=sys.stderr, flush=True)
+                os._exit(3)
+            finally:
+                dog.cancel()
+            exchange = ("native (opd_comm_*: one communicator per handle)" if per_handle else
+                        f"native (opd_comm_*: ONE communicator per rank, {NS} lane(s), all-gathers on its own stream in submission order)")
+        else:
+            print("bench.py: librccl not available on every rank; the exchange runs on torch.distributed", file=sys.stderr, flush=True)
 
     # synthetic office-camera frames, resident in HBM before the timed region (torch = device memory plumbing only)
     d_frames = None
@@ -375,6 +402,25 @@ def main() -> int:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- sustained leg: the same handles over a window of >= 2 s.  The driver's --steps 20 times 55 ms of GPU work; this leg, in the same
+    # JSON line, shows whether that burst is representative (all ranks take part: it is bracketed like the timed region).
+    sustained = None
+    if not rehearsal and args.steps < 750 and os.environ.get("OPD_BENCH_SUSTAINED", "1") != "0":
+        n_sus = max(750, int(2.2 / max(elapsed / args.steps, 1e-6)))
+        sync()
+        ts0 = time.perf_counter()
+        run_steps(n_sus, args.sync_steps)
+        sync()
+        e_sus = time.perf_counter() - ts0
+        if world > 1:
+            t = torch.tensor([e_sus], dtype=torch.float64, device=gdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e_sus = float(t.item())
+        f_sus = B * world * n_sus / e_sus
+        ratio = f_sus / (B * world * args.steps / elapsed)
+        sustained = {"steps": n_sus, "seconds": round(e_sus, 3), "ms_per_step": round(1e3 * e_sus / n_sus, 3), "frames_per_s": round(f_sus, 2),
+                     "ratio_to_value": round(ratio, 4), "agrees_within_3pct": bool(abs(ratio - 1.0) <= 0.03)}
+
     # ---- rank-local legs (no collective from here to the final barrier: the other ranks wait there) ---------------------
     roof = serial = stage_ms = None
     if rank == 0 and not rehearsal:
@@ -430,6 +476,12 @@ def main() -> int:
             _capi.check(lib.opd_detr_stage_times(handle, s8), "opd_detr_stage_times")
             ms_acc += np.asarray(list(ms4)); fl = np.asarray(list(f4)); ln = np.asarray(list(l4)); st_acc += np.asarray(list(s8))
         ms_avg = ms_acc / reps
+        # the same event pairs by kernel instantiation (opd_detr_kernel_table; the last of the `reps` forwards): the single largest kernel
+        ktab = (_capi.OpdKernelStat * 64)()
+        kcount = C.c_int(0)
+        _capi.check(lib.opd_detr_kernel_table(handle, ktab, 64, C.byref(kcount)), "opd_detr_kernel_table")
+        krows = [{"kernel": ktab[i].name.decode(), "launches": int(ktab[i].launches), "ms": float(ktab[i].ms), "flops": float(ktab[i].flops)}
+                 for i in range(min(kcount.value, 64))]
         stage_eager = [round(float(v), 4) for v in st_acc / reps]
         stage_ms = stage_graph if stage_graph is not None else stage_eager
         _capi.check(lib.opd_detr_set_profiling(handle, 0), "opd_detr_set_profiling")
@@ -441,7 +493,7 @@ def main() -> int:
         # HBM bytes per launch of the same kernel family from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE
         # in separate runs, gfx950 x2 fetch correction: tools/pmc_traffic.py) — valid for the default 8 x 800x1333 workload
         traffic = None
-        for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
+        for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json", "r01_pmc_traffic.json"):
             tpath = os.path.join(ROOT, "profiles", name)
             if os.path.exists(tpath) and (B, H, W) == (8, 800, 1333) and args.arch == "r50":
                 traffic = round(json.load(open(tpath))["conv_gemm_family"]["bytes_per_launch"])
@@ -456,7 +508,21 @@ def main() -> int:
                 "graph_ms_per_step": round(float(sum(stage_graph)), 4) if stage_graph else None,   # the same forward inside the replayed graph (stage marks in the graph)
                 "stage_ms_eager": stage_eager,
                 "by_class_ms": {"conv": round(float(ms_avg[0]), 4), "linear": round(float(ms_avg[1]), 4),
-                                "attention": round(float(ms_avg[2]), 4), "other": round(float(ms_avg[3]), 4)}}
+                                "attention": round(float(ms_avg[2]), 4), "other": round(float(ms_avg[3]), 4)},
+                "traffic_source": "committed profile (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload: profiles/*_pmc_traffic.json), not measured in this run",
+                "peak_note": "peak = 2500 TFLOP/s is 1024 FLOP/clk/SIMD at 2.4 GHz; back-to-back MFMAs from registers on random fp16 operands hold "
+                             "1.90-1.91 PFLOP/s at 1.91-1.97 GHz on this part (tools/microbench/mfma_peak.hip, profiles/r05_microbench_mfma_peak.txt): "
+                             "no k-loop can read above 0.76 of `peak`"}
+        gemm_rows = [r for r in krows if r["flops"] > 0 and r["ms"] > 0]
+        if gemm_rows:
+            d = max(gemm_rows, key=lambda r: r["ms"])
+            d_tf = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            roof["dominant"] = {"kernel": d["kernel"], "launches_per_step": d["launches"], "avg_us": round(1e3 * d["ms"] / d["launches"], 2),
+                                "flops_per_launch": round(d["flops"] / d["launches"]), "achieved": round(d_tf, 2), "unit": "TFLOP/s",
+                                "frac": round(d_tf / PEAK_MFMA_TFLOPS, 4),
+                                "source": "HIP event pairs around every launch of one eagerly launched serial forward (opd_detr_kernel_table); "
+                                          "compare with the kernel's AverageNs in profiles/*_bench_streams1_kernel_stats.csv"}
+            roof["kernels"] = [{"kernel": r["kernel"], "launches": r["launches"], "ms": round(r["ms"], 4), "gflop": round(r["flops"] / 1e9, 2)} for r in krows[:12]]
         if (B, H, W) == (8, 800, 1333) and args.arch == "r50":
             # achieved HBM GB/s of the convolution stages: SURVEY.md section 8(d)'s unfused per-layer minimum bytes of each stage (MB per
             # frame, bf16/fp16) x 8 frames / the stage's duration measured live with HIP events on the library's stream (profiling mode:
@@ -469,11 +535,11 @@ def main() -> int:
                  "frac_of_peak": round(mb * B / 1e3 / (stage_ms[i] * 1e-3) / PEAK_HBM_GBS, 3) if stage_ms[i] > 0 else None}
                 for i, (name, mb) in enumerate(stage_mb.items())]
             # MFMA-pipe utilisation of the attention / linear kernels from the committed SQ counter pass of the same build
-            sq_path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r04_pmc_sq.json", "r03_pmc_sq.json")) if os.path.exists(q)), "")
+            sq_path = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r05_pmc_sq.json", "r04_pmc_sq.json", "r03_pmc_sq.json")) if os.path.exists(q)), "")
             if sq_path:
                 sq = json.load(open(sq_path))
                 pick = lambda sub: {k: v["mfma_busy_pct"] for k, v in sq["kernels"].items() if sub in k}
-                roof["mfma_busy_pct"] = {"source": f"profiles/{os.path.basename(sq_path)} (rocprofv3 --pmc SQ pass, one serial forward)",
+                roof["mfma_busy_pct"] = {"source": f"committed profile, not measured in this run: profiles/{os.path.basename(sq_path)} (rocprofv3 --pmc SQ pass, one serial forward)",
                                          "whole_forward": sq["whole_forward_mfma_busy_pct"], "attention": pick("attention_kernel"),
                                          "row_owner_linears": pick("gemm_ln256"), "implicit_gemm": pick("conv_gemm_dma_kernel"),
                                          "fused_tails": {**pick("btail_kernel"), **pick("btail256_kernel")}}
@@ -502,6 +568,7 @@ def main() -> int:
                        "batches_in_flight_per_gpu": 1 if args.sync_steps else NS},
             "roofline": roof,
             "serial": serial,
+            "sustained": sustained,
             "stage_ms": stage_ms,   # inside the replayed graph of a single-stream handle (eager per-launch form: roofline.stage_ms_eager)
             "exchange": exchange,
             "detections_last_step": int(np.asarray(counts).clip(min=0).sum()) if counts is not None else None,

@@ -253,7 +253,7 @@ OPD_API int opd_comm_buffers(opd_comm* c, int slot0, void** records, void** coun
 OPD_API int opd_comm_exchange(opd_comm* c);
 OPD_API int opd_comm_wait(opd_comm* c, opd_det* out_all, int32_t* counts_all);
 
-/* Device time (ms) of the last forward/detect per stage, measured with HIP events on the handle's stream:
+/* Device time (ms) of the last DETECT call (opd_detr_detect and its variants: forward + post-process) per stage, measured with HIP events on the handle's stream:
  * [0] preprocess+stem+pool, [1] stage1, [2] stage2, [3] stage3, [4] stage4, [5] projection+encoder, [6] decoder+heads,
  * [7] post-process.  Only filled when profiling is on: opd_detr_set_profiling(m, 1) = the forward is launched EAGERLY with an event pair
  * around every launch (opd_detr_kernel_times; the eager launches and their events add ~10 us per launch to the stage times), (m, 2) =
@@ -265,6 +265,12 @@ OPD_API int opd_detr_stage_times(const opd_detr* m, float* ms8);
  * transformer linear layer, 2 = attention_kernel, 3 = reserved.  ms4[c] = summed device time, launches4[c] = number of
  * launches, flops4[c] = summed ALGORITHMIC FLOPs (2 x MAC) of those launches. */
 OPD_API int opd_detr_kernel_times(const opd_detr* m, float* ms4, int32_t* launches4, double* flops4);
+/* The same event pairs by KERNEL: one row per kernel instantiation of the last profiled forward (mode 1), longest first -- `name` as rocprofv3
+ * prints it minus namespace and signature (e.g. "btail256_kernel<256, false>"), so a row can be checked against a kernel-trace summary;
+ * launches, summed device time (ms) and summed algorithmic FLOPs (0 for launches that are not GEMM-shaped).  *count = rows available;
+ * at most `capacity` are written. */
+typedef struct opd_kernel_stat { char name[96]; int32_t launches; float ms; double flops; } opd_kernel_stat;
+OPD_API int opd_detr_kernel_table(const opd_detr* m, opd_kernel_stat* out, int capacity, int* count);
 
 /* Thread-local description of the last error returned on this thread ("" if none). */
 OPD_API const char* opd_last_error(void);

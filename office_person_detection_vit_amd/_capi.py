@@ -23,11 +23,16 @@ OPD_FLAG_NO_GRAPH = 1
 OPD_FLAG_MULTI_STREAM = 2
 OPD_FLAG_BF16 = 4
 OPD_COMM_ID_BYTES = 128
+OPD_OK, OPD_EINVAL, OPD_EIO, OPD_ESCHEMA, OPD_EHIP, OPD_ENOMEM, OPD_ESTATE = 0, -1, -2, -3, -4, -5, -6   # include/opd_detr.h
 
 
 class OpdConfig(C.Structure):
     _fields_ = [("struct_size", C.c_int32), ("max_batch", C.c_int32), ("max_height", C.c_int32),
                 ("max_width", C.c_int32), ("flags", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+class OpdKernelStat(C.Structure):   # opd_kernel_stat (include/opd_detr.h)
+    _fields_ = [("name", C.c_char * 96), ("launches", C.c_int32), ("ms", C.c_float), ("flops", C.c_double)]
 
 
 class OpdDet(C.Structure):
@@ -75,6 +80,7 @@ API = {
     "opd_detr_set_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "opd_detr_stage_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float)]),
     "opd_detr_kernel_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_float), C.POINTER(C.c_int32), C.POINTER(C.c_double)]),
+    "opd_detr_kernel_table": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "opd_comm_available": (C.c_int, []),
     "opd_comm_unique_id": (C.c_int, [C.c_void_p]),
     "opd_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -13,11 +13,23 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 PKG = os.path.dirname(HERE)
-SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_dec.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_comm.cpp", "opd_dispatch.cpp", "opd_test_api.cpp"]
+SOURCES = ["kernels_gemm.hip", "kernels_w8.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip", "kernels_dec.hip", "opd_loader.cpp", "opd_host.cpp", "opd_model.cpp", "opd_comm.cpp", "opd_dispatch.cpp", "opd_test_api.cpp"]
 TEST_ONLY = {"opd_test_api.cpp"}
 # kernel files with 16-bit operands: ONE source, compiled for fp16 and (-DOPD_ELEM_BF16) for bf16 (opd_elem.h)
-ELEM_SOURCES = ["kernels_gemm.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip"]
+ELEM_SOURCES = ["kernels_gemm.hip", "kernels_w8.hip", "kernels_btail.hip", "kernels_btail3.hip", "kernels_rowln.hip", "kernels_attn.hip", "kernels_misc.hip"]
 HEADERS = ["opd_kernels.h", "opd_elem.h", "opd_loader.h", "opd_host.h", "opd_model.h", os.path.join("..", "..", "include", "opd_detr.h")]
+# code-generation flags of every translation unit, and per file: the attention kernel consumes its S = K.Q^T accumulators with VALU right
+# away, so its MFMAs should write VGPRs (the default AGPR form costs 56 v_accvgpr moves per key tile in a VALU-bound loop).
+# tools/scan_dma_waits.py imports these: the ISA it checks must be the ISA that ships.
+COMMON_FLAGS = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-fvisibility=hidden"]
+EXTRA_FLAGS = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+BF16_FLAGS = ["-DOPD_ELEM_BF16=1"]
+
+
+def hipcc_path() -> str:
+    return os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+
+
 LIB = os.path.join(PKG, "libopd_hip.so")
 TEST_LIB = os.path.join(PKG, "libopd_hip_test.so")
 
@@ -30,15 +42,12 @@ def _stale(target: str, deps) -> bool:
 
 
 def build(verbose: bool = False, force: bool = False) -> str:
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    hipcc = hipcc_path()
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
     hdrs = [os.path.join(HERE, h) for h in HEADERS]
     objs = []
-    common = ["-O3", "-fPIC", "-std=c++17", "--offload-arch=gfx950", "-Wall", "-Wno-unused-function", "-fvisibility=hidden"]
-    # per-file code-generation options: the attention kernel consumes its S = K.Q^T accumulators with VALU right away, so its
-    # MFMAs should write VGPRs (the default AGPR form costs 56 v_accvgpr moves per key tile in a VALU-bound loop)
-    extra = {"kernels_attn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form"]}
+    common, extra = COMMON_FLAGS, EXTRA_FLAGS
     jobs = []
     for src in SOURCES:
         sp = os.path.join(HERE, src)
@@ -50,7 +59,7 @@ def build(verbose: bool = False, force: bool = False) -> str:
             obj16 = os.path.join(objdir, os.path.splitext(src)[0] + "_bf16.o")
             objs.append(obj16)
             if force or _stale(obj16, [sp] + hdrs):
-                jobs.append([hipcc] + common + extra.get(src, []) + ["-DOPD_ELEM_BF16=1", "-c", sp, "-o", obj16])
+                jobs.append([hipcc] + common + extra.get(src, []) + BF16_FLAGS + ["-c", sp, "-o", obj16])
 
     def compile_one(cmd):
         if verbose:

@@ -317,8 +317,8 @@ hipError_t OPD_SYM(opd_launch_attention)(const AttnParams& p, hipStream_t stream
         if ((size_t)p.B * p.Lk * p.ldk * 2 >= (1ull << 32) || (size_t)p.B * p.Lk * p.ldv * 2 >= (1ull << 32)) return hipErrorInvalidValue;
         const int total = ((p.Lq + 63) / 64) * p.heads * p.B * p.splits;
         dim3 grid(8 * ((total + 7) / 8));
-        if (p.key_valid) hipLaunchKernelGGL((attention_kernel<true, 128, false, true>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attention_kernel<false, 128, false, true>), grid, dim3(256), 0, stream, p);
+        if (p.key_valid) OPD_LAUNCH((attention_kernel<true, 128, false, true>), grid, dim3(256), 0, stream, p);
+        else OPD_LAUNCH((attention_kernel<false, 128, false, true>), grid, dim3(256), 0, stream, p);
         return hipGetLastError();
     }
     if ((p.ldq % 8) || (p.ldk % 8) || (p.ldv % 8) || (p.ldo % 4)) return hipErrorInvalidValue;  // 16-byte row chunks
@@ -328,13 +328,13 @@ hipError_t OPD_SYM(opd_launch_attention)(const AttnParams& p, hipStream_t stream
     dim3 grid(8 * ((total + 7) / 8));   // 8 XCDs x their share of the tiles (attention_kernel's tile map)
     const bool wide = p.Lq <= 128 && p.Lk > 128;   // few query tiles, long key loop: decoder cross-attention
     if (p.trace) {
-        hipLaunchKernelGGL((attention_kernel<false, 64, true>), grid, dim3(256), 0, stream, p);
+        OPD_LAUNCH((attention_kernel<false, 64, true>), grid, dim3(256), 0, stream, p);
     } else if (p.key_valid) {
-        if (wide) hipLaunchKernelGGL((attention_kernel<true, 128>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attention_kernel<true, 64>), grid, dim3(256), 0, stream, p);
+        if (wide) OPD_LAUNCH((attention_kernel<true, 128>), grid, dim3(256), 0, stream, p);
+        else OPD_LAUNCH((attention_kernel<true, 64>), grid, dim3(256), 0, stream, p);
     } else {
-        if (wide) hipLaunchKernelGGL((attention_kernel<false, 128>), grid, dim3(256), 0, stream, p);
-        else hipLaunchKernelGGL((attention_kernel<false, 64>), grid, dim3(256), 0, stream, p);
+        if (wide) OPD_LAUNCH((attention_kernel<false, 128>), grid, dim3(256), 0, stream, p);
+        else OPD_LAUNCH((attention_kernel<false, 64>), grid, dim3(256), 0, stream, p);
     }
     return hipGetLastError();
 }

@@ -576,7 +576,9 @@ hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
     constexpr int MAIN = (128 + C1) * ROW_BYTES, CHUNK = 64 * C1 * 2 + C3 * ROW_BYTES + (SC ? 64 * ROW_BYTES : 0) + (RC ? 2 * 64 * ROW_BYTES : 0);
     constexpr int LDS = 2 * (MAIN > CHUNK ? MAIN : CHUNK) + (RDMA ? 2 * 16384 : 0);
     OPD_SET_MAX_LDS_ONCE((btail_kernel<C1, C3, RDMA, SC, TRACE, RC>), LDS);
-    hipLaunchKernelGGL((btail_kernel<C1, C3, RDMA, SC, TRACE, RC>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+    OPD_LAUNCH((btail_kernel<C1, C3, RDMA, SC, TRACE, RC>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+    static const char* const kname = opd_kernel_name("btail_kernel<%d, %d, %s, %s, %s, %d>", C1, C3, OPD_BOOLSTR(RDMA), OPD_BOOLSTR(SC), OPD_BOOLSTR(TRACE), RC);
+    opd_last_kernel_name = kname;
     return hipGetLastError();
 }
 

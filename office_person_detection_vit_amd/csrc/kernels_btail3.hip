@@ -519,7 +519,9 @@ __global__ __launch_bounds__(512) void btail256_kernel(BtailParams p) {
 template <int C3, bool TRACE = false>
 hipError_t launch_btail256_t(const BtailParams& p, hipStream_t stream) {
     OPD_SET_MAX_LDS_ONCE((btail256_kernel<C3, TRACE>), LDS_BYTES);
-    hipLaunchKernelGGL((btail256_kernel<C3, TRACE>), dim3((p.M + 127) / 128), dim3(512), LDS_BYTES, stream, p);
+    OPD_LAUNCH((btail256_kernel<C3, TRACE>), dim3((p.M + 127) / 128), dim3(512), LDS_BYTES, stream, p);
+    static const char* const kname = opd_kernel_name("btail256_kernel<%d, %s>", C3, OPD_BOOLSTR(TRACE));
+    opd_last_kernel_name = kname;
     return hipGetLastError();
 }
 

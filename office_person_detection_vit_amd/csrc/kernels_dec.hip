@@ -85,13 +85,19 @@ __device__ __forceinline__ void store_split4(unsigned char* Xhi, unsigned char* 
 // neither sinks them to their uses nor hoists the consumers' waits.
 #define DEC_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define DEC_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
-// tools only: wave 0 stamps the shader clock (s_memtime) into trace[block][i]
+// tools only: wave 0 stamps the shader clock (s_memtime) into dec_ts[i]; DEC_STAMP_FLUSH writes trace[block][0..7] when the kernel ends.
+// (Round 5: the stamps used to be stored where they were taken -- a store between the ring's requests, inside the window of its counted
+//  waits, which tools/scan_dma_waits.py flags once no kernel is exempted by name: stores retire out of order with respect to LDS-DMA requests.)
 #define DEC_STAMP(tr, i)                                                                                   \
     do {                                                                                                   \
-        if (tr) {                                                                                          \
-            unsigned long long now_;                                                                       \
-            asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(now_)::"memory");                    \
-            if (threadIdx.x == 0) (tr)[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + (i)] = now_;     \
+        if (tr) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(dec_ts[i])::"memory");          \
+    } while (0)
+#define DEC_STAMP_FLUSH(tr)                                                                                \
+    do {                                                                                                   \
+        if ((tr) && threadIdx.x == 0) {                                                                    \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                               \
+            _Pragma("unroll") for (int i_ = 0; i_ < 8; ++i_)                                               \
+                (tr)[(size_t)(blockIdx.y * gridDim.x + blockIdx.x) * 8 + i_] = dec_ts[i_];                 \
         }                                                                                                  \
     } while (0)
 
@@ -363,6 +369,7 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
     const size_t row = (size_t)b * Q + (q_ok ? q0 + li : Q - 1);   // this lane's data row (clamped: padding lanes compute on a valid row, store nothing)
     const int h = wave;
     unsigned long long* const tr = p.trace;
+    unsigned long long dec_ts[8] = {};
     DEC_STAMP(tr, 0);
     PieceRing<SLAB_R, 80> rg{smem + SLAB_RING + wave * SLAB_R * 1024, lane16};
     const unsigned char* const wo = reinterpret_cast<const unsigned char*>(p.wo) + (size_t)(2 * wave) * 16384;
@@ -490,6 +497,7 @@ __global__ __launch_bounds__(512) void dec_self_kernel(DecSelfParams p) {
             }
         }
     }
+    DEC_STAMP_FLUSH(tr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
@@ -845,7 +853,7 @@ hipError_t opd_launch_heads2(const HeadParams& p, hipStream_t stream) {
     if (p.partials && (p.nsplit < 1 || p.nsplit > 16 || !p.ffn_b2 || !p.ln3_gamma || !p.ln3_beta)) return hipErrorInvalidValue;
     if ((p.ln_gamma != nullptr) != (p.ln_beta != nullptr)) return hipErrorInvalidValue;
     OPD_SET_MAX_LDS_ONCE(heads2_kernel, SLAB_LDS);
-    hipLaunchKernelGGL(heads2_kernel, dim3((p.rows + 15) / 16), dim3(512), SLAB_LDS, stream, p);
+    OPD_LAUNCH(heads2_kernel, dim3((p.rows + 15) / 16), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream) {
@@ -854,27 +862,27 @@ hipError_t opd_launch_dec_qkv(const DecQkvParams& p, hipStream_t stream) {
     if (p.Q > 128 || p.M % p.Q != 0) return hipErrorInvalidValue;   // v^T rows hold 128 keys; rows are (frame, query)
     OPD_SET_MAX_LDS_ONCE(dec_qkv_kernel<true>, SLAB_LDS);
     OPD_SET_MAX_LDS_ONCE(dec_qkv_kernel<false>, SLAB_LDS);
-    if (p.partials) hipLaunchKernelGGL(dec_qkv_kernel<true>, dim3((p.M + 15) / 16, 3), dim3(512), SLAB_LDS, stream, p);
-    else hipLaunchKernelGGL(dec_qkv_kernel<false>, dim3((p.M + 15) / 16, 3), dim3(512), SLAB_LDS, stream, p);
+    if (p.partials) OPD_LAUNCH(dec_qkv_kernel<true>, dim3((p.M + 15) / 16, 3), dim3(512), SLAB_LDS, stream, p);
+    else OPD_LAUNCH(dec_qkv_kernel<false>, dim3((p.M + 15) / 16, 3), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_self(const DecSelfParams& p, hipStream_t stream) {
     if (p.B <= 0 || p.Q <= 0 || p.Q > 128 || (p.Q & 3) || !p.q16 || !p.k16 || !p.vT || !p.h || !p.wo || !p.bo || !p.ln_g || !p.ln_b || !p.wq || !p.rbq || !p.qc16)
         return hipErrorInvalidValue;
     OPD_SET_MAX_LDS_ONCE(dec_self_kernel, SLAB_LDS);
-    hipLaunchKernelGGL(dec_self_kernel, dim3((p.Q + 15) / 16, p.B), dim3(512), SLAB_LDS, stream, p);
+    OPD_LAUNCH(dec_self_kernel, dim3((p.Q + 15) / 16, p.B), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_cross_out(const DecCrossOutParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.splits < 1 || p.splits > CROSS_MAXS || !p.part_o || !p.part_ml || !p.res || !p.h || !p.wo || !p.bo || !p.ln_g || !p.ln_b || p.res_period < 0)
         return hipErrorInvalidValue;
     OPD_SET_MAX_LDS_ONCE(dec_cross_out_kernel, SLAB_LDS);
-    hipLaunchKernelGGL(dec_cross_out_kernel, dim3((p.M + 15) / 16), dim3(512), SLAB_LDS, stream, p);
+    OPD_LAUNCH(dec_cross_out_kernel, dim3((p.M + 15) / 16), dim3(512), SLAB_LDS, stream, p);
     return hipGetLastError();
 }
 hipError_t opd_launch_dec_ffn(const DecFfnParams& p, hipStream_t stream) {
     if (p.M <= 0 || p.F <= 0 || p.F % OPD_DEC_FFN_CHUNK != 0 || !p.h || !p.w1 || !p.b1 || !p.w2 || !p.partials) return hipErrorInvalidValue;
     OPD_SET_MAX_LDS_ONCE(dec_ffn_kernel, FFN_LDS);
-    hipLaunchKernelGGL(dec_ffn_kernel, dim3((p.M + FFN_ROWS - 1) / FFN_ROWS, p.F / OPD_DEC_FFN_CHUNK), dim3(512), FFN_LDS, stream, p);
+    OPD_LAUNCH(dec_ffn_kernel, dim3((p.M + FFN_ROWS - 1) / FFN_ROWS, p.F / OPD_DEC_FFN_CHUNK), dim3(512), FFN_LDS, stream, p);
     return hipGetLastError();
 }

@@ -501,6 +501,23 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_dma_kernel(ConvGemmParams p)
     const int wm0 = m_base + wm * (MT * 16), wn0 = n_base + wn * (BN / 2);
     stamp(2);
     issue(0, 0);
+    // Cooperative L2 warm-up of the weights (round 5).  Inside the forward a layer's weights are in nobody's L2 when its launch starts, and all
+    // workgroups of an XCD ask for the same weight tile at the same k-step: a cold miss (~2 us) in front of EVERY k-step of the first round,
+    // with one tile of prefetch distance.  Each workgroup therefore touches a 1 / n-th share of the whole [N][K] matrix at once -- one dword
+    // per 128-byte line, LDS-DMA requests whose bytes land in the second stage buffer before its first real tile is requested (the barrier
+    // below drains them) -- so that the matrix is on its way into the XCD's L2 within the first microseconds.  n = workgroups sharing the XCD
+    // (blockIdx mod 8; placement is speed only).
+    if constexpr (BUF) {
+        if (p.wprefetch && nk >= 2) {
+            const unsigned wbytes = (unsigned)((size_t)p.N * p.K * 2);
+            const unsigned nx = (gridDim.x + 7u) >> 3, xi = blockIdx.x >> 3;
+            const unsigned seg = ((wbytes + nx - 1u) / nx + 127u) & ~127u;
+            const unsigned lo = xi * seg, hi = lo + seg < wbytes ? lo + seg : wbytes;
+            unsigned char* const dump = smem + STAGE_BYTES + wave * 256;
+            for (unsigned off = lo + (unsigned)tid * 128u; off < hi; off += 256u * 128u)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_b, (__attribute__((address_space(3))) void*)dump, 4, off, 0, 0, 0);
+        }
+    }
     float4v acc[NT][MT];
     init_acc_bias<NT, MT>(p, bias_ptr, acc, wm0, wn0, lane);
     uint4 res[NT][(MT + 1) / 2];
@@ -575,7 +592,9 @@ hipError_t launch_dma_t(const ConvGemmParams& p_in, hipStream_t stream) {
     // a single k-step per workgroup (K = 64 layers, split-K slices of one step) needs no second stage buffer: half the
     // LDS -> three workgroups per CU instead of two, which is what hides the DMA / residual / store round trips there
     const int lds = ((p.K / BK) / splits == 1) ? LDS / 2 : LDS;
-    hipLaunchKernelGGL((conv_gemm_dma_kernel<BN, BUF, MT, DUAL, TRACE, PW>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
+    OPD_LAUNCH((conv_gemm_dma_kernel<BN, BUF, MT, DUAL, TRACE, PW>), dim3(tiles_m * tiles_n * splits), dim3(256), lds, stream, p);
+    static const char* const kname = opd_kernel_name("conv_gemm_dma_kernel<%d, %s, %d, %s, %s, %s>", BN, OPD_BOOLSTR(BUF), MT, OPD_BOOLSTR(DUAL), OPD_BOOLSTR(TRACE), OPD_BOOLSTR(PW));
+    opd_last_kernel_name = kname;
     return hipGetLastError();
 }
 
@@ -1015,7 +1034,7 @@ hipError_t OPD_SYM(opd_launch_stem_pool_u8)(const uint8_t* frames, const int32_t
     constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES + 1024;   // (+ the sink of the U8 form)
     OPD_SET_MAX_LDS_ONCE(stem_pool2_kernel<true>, LDS2);
     const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
-    hipLaunchKernelGGL(stem_pool2_kernel<true>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
+    OPD_LAUNCH(stem_pool2_kernel<true>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
     return hipGetLastError();
 }
 
@@ -1031,6 +1050,6 @@ hipError_t OPD_SYM(opd_launch_stem_pool)(const f16_t* x4p, const f16_t* w, const
     constexpr int LDS2 = STEM_W_BYTES + 2 * STEM_PATCH + 160 * ROW_BYTES + 1024;   // (+ the sink of the U8 form)
     OPD_SET_MAX_LDS_ONCE(stem_pool2_kernel<false>, LDS2);
     const int nseg = (p.tiles_x + STEM_TPW - 1) / STEM_TPW;
-    hipLaunchKernelGGL(stem_pool2_kernel<false>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
+    OPD_LAUNCH(stem_pool2_kernel<false>, dim3(B * p.tiles_y * nseg), dim3(256), LDS2, stream, p);
     return hipGetLastError();
 }

@@ -569,9 +569,9 @@ inline unsigned blocks_for(size_t n, unsigned threads) { return (unsigned)((n + 
 hipError_t OPD_SYM(opd_launch_attention_map)(const f16_t* q, int ldq, const f16_t* k, int ldk, const int32_t* sel, int nsel, int heads, int Lk, float scale,
                                     const int32_t* key_valid2, int key_row, void* stat, float* out, hipStream_t stream) {
     if (nsel <= 0 || heads <= 0 || Lk <= 0 || key_row <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_map_rowstat_kernel, dim3((nsel * heads + 3) / 4), dim3(256), 0, stream, q, ldq, k, ldk, sel, nsel, heads, Lk, scale,
+    OPD_LAUNCH(attn_map_rowstat_kernel, dim3((nsel * heads + 3) / 4), dim3(256), 0, stream, q, ldq, k, ldk, sel, nsel, heads, Lk, scale,
                        key_valid2, key_row, reinterpret_cast<float2*>(stat));
-    hipLaunchKernelGGL(attn_map_mean_kernel, dim3((Lk + 255) / 256), dim3(256), 0, stream, q, ldq, k, ldk, sel, nsel, heads, Lk, scale, key_valid2,
+    OPD_LAUNCH(attn_map_mean_kernel, dim3((Lk + 255) / 256), dim3(256), 0, stream, q, ldq, k, ldk, sel, nsel, heads, Lk, scale, key_valid2,
                        key_row, reinterpret_cast<const float2*>(stat), out);
     return hipGetLastError();
 }
@@ -580,7 +580,7 @@ hipError_t OPD_SYM(opd_launch_preprocess_u8)(const uint8_t* frames, f16_t* out, 
                                     hipStream_t stream) {
     if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
     const size_t ngroups = (size_t)B * Hp * ((Wp + 3) / 4);
-    hipLaunchKernelGGL(preprocess_u8_kernel, dim3(blocks_for(ngroups, 256)), dim3(256), 0, stream, frames, out, B, H, W, Hp, Wp, valid_hw);
+    OPD_LAUNCH(preprocess_u8_kernel, dim3(blocks_for(ngroups, 256)), dim3(256), 0, stream, frames, out, B, H, W, Hp, Wp, valid_hw);
     return hipGetLastError();
 }
 
@@ -588,7 +588,7 @@ hipError_t OPD_SYM(opd_launch_preprocess_f32)(const float* pv, f16_t* out, int B
                                      hipStream_t stream) {
     if (Hp < H + 6 || Wp < W + 6) return hipErrorInvalidValue;
     const size_t npix = (size_t)B * Hp * Wp;
-    hipLaunchKernelGGL(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H, W, Hp, Wp, valid_hw);
+    OPD_LAUNCH(preprocess_f32_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, pv, out, B, H, W, Hp, Wp, valid_hw);
     return hipGetLastError();
 }
 
@@ -598,7 +598,7 @@ hipError_t opd_launch_resize_u8(const uint8_t* in, uint8_t* out, int B, int h, i
                                 hipStream_t stream) {
     if (B <= 0 || h <= 0 || w <= 0 || oh <= 0 || ow <= 0) return hipErrorInvalidValue;
     const size_t npix = (size_t)B * oh * ow;
-    hipLaunchKernelGGL(resize_bilinear_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, in, out, B, h, w, oh, ow, bounds_h,
+    OPD_LAUNCH(resize_bilinear_u8_kernel, dim3(blocks_for(npix, 256)), dim3(256), 0, stream, in, out, B, h, w, oh, ow, bounds_h,
                        coeff_h, ksize_h, bounds_v, coeff_v, ksize_v);
     return hipGetLastError();
 }
@@ -608,20 +608,20 @@ hipError_t OPD_SYM(opd_launch_maxpool)(const f16_t* x, f16_t* out, int B, int H,
                               hipStream_t stream) {
     if (C % 8 != 0) return hipErrorInvalidValue;
     const size_t total = (size_t)B * OH * OW * (C / 8);
-    hipLaunchKernelGGL(maxpool_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, out, B, H, W, C, OH, OW);
+    OPD_LAUNCH(maxpool_kernel, dim3(blocks_for(total, 256)), dim3(256), 0, stream, x, out, B, H, W, C, OH, OW);
     return hipGetLastError();
 }
 
 hipError_t OPD_SYM(opd_launch_layernorm)(const float* x, const float* gamma, const float* beta, float* y, f16_t* y16, int rows,
                                 hipStream_t stream) {
     if (rows <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, y16, rows);
+    OPD_LAUNCH(layernorm256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, x, gamma, beta, y, y16, rows);
     return hipGetLastError();
 }
 
 hipError_t OPD_SYM(opd_launch_broadcast_rows)(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream) {
     if (rows <= 0 || !c || !y || !y16) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(broadcast_rows256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, c, y, y16, rows);
+    OPD_LAUNCH(broadcast_rows256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, c, y, y16, rows);
     return hipGetLastError();
 }
 
@@ -635,7 +635,7 @@ hipError_t OPD_SYM(opd_launch_reduce_ln_pos)(const float* partials, int nsplit, 
                                     const float* beta, float* y, f16_t* y16, int rows, const float* pos, const float* const* pos_ptrs,
                                     int period, f16_t* yp16, hipStream_t stream) {
     if (rows <= 0 || nsplit < 1 || (yp16 && (period <= 0 || (!pos && !pos_ptrs)))) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(reduce_ln256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, partials, nsplit, slab_stride, residual,
+    OPD_LAUNCH(reduce_ln256_kernel, dim3((rows + 3) / 4), dim3(256), 0, stream, partials, nsplit, slab_stride, residual,
                        gamma, beta, y, y16, rows, pos, pos_ptrs, period, yp16);
     return hipGetLastError();
 }
@@ -657,20 +657,20 @@ static __global__ void checksum_kernel(const uint32_t* __restrict__ buf, size_t 
 
 #ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_checksum(const void* buf, size_t bytes, unsigned long long* slots, hipStream_t stream) {
-    hipLaunchKernelGGL(checksum_kernel, dim3(OPD_TAP_BLOCKS), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(buf), bytes / 4, slots);
+    OPD_LAUNCH(checksum_kernel, dim3(OPD_TAP_BLOCKS), dim3(256), 0, stream, reinterpret_cast<const uint32_t*>(buf), bytes / 4, slots);
     return hipGetLastError();
 }
 #endif
 
 hipError_t OPD_SYM(opd_launch_cast_f16)(const float* x, f16_t* y, size_t n, hipStream_t stream) {
-    hipLaunchKernelGGL(cast_f16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, y, n);
+    OPD_LAUNCH(cast_f16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, y, n);
     return hipGetLastError();
 }
 
 #ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_gemm_f32(const float* A, const float* Wt, const float* bias, float* C, int M, int N, int K, int ldc,
                                hipStream_t stream) {
-    hipLaunchKernelGGL(gemm_f32_kernel, dim3((N + 63) / 64, M), dim3(64), 0, stream, A, Wt, bias, C, M, N, K, ldc);
+    OPD_LAUNCH(gemm_f32_kernel, dim3((N + 63) / 64, M), dim3(64), 0, stream, A, Wt, bias, C, M, N, K, ldc);
     return hipGetLastError();
 }
 #endif
@@ -680,7 +680,7 @@ hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
     if (p.wc_f && p.w1_f && p.w2_f && p.ncls <= 128) return opd_launch_heads2(p, stream);   // split fp16 operands through the decoder's rings
     if (p.ncls > 256 || p.rows <= 0) return hipErrorInvalidValue;
     if (p.partials && (p.nsplit < 1 || p.nsplit > 16 || !p.ffn_b2 || !p.ln3_gamma || !p.ln3_beta)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(512), 0, stream, p);
+    OPD_LAUNCH(heads_kernel, dim3((p.rows + HEAD_ROWS - 1) / HEAD_ROWS), dim3(512), 0, stream, p);
     return hipGetLastError();
 }
 #endif
@@ -688,7 +688,7 @@ hipError_t opd_launch_heads(const HeadParams& p, hipStream_t stream) {
 #ifndef OPD_ELEM_BF16   // (no 16-bit operands: defined once)
 hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream) {
     if (p.Q > 128 || p.ncls > 128 || p.B <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(postprocess_kernel, dim3(p.B), dim3(1024), 0, stream, p);
+    OPD_LAUNCH(postprocess_kernel, dim3(p.B), dim3(1024), 0, stream, p);
     return hipGetLastError();
 }
 #endif
@@ -751,7 +751,7 @@ hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const 
                                         const uint8_t* has2, int n2, int D, double aw, double mw, int as_distance, float* out,
                                         hipStream_t stream) {
     if (n1 <= 0 || n2 <= 0 || D <= 0 || !b1 || !b2 || !out) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(similarity_matrix_kernel, dim3((n1 * n2 + 127) / 128), dim3(128), 0, stream, f1, b1, has1, n1, f2, b2, has2, n2, D, aw,
+    OPD_LAUNCH(similarity_matrix_kernel, dim3((n1 * n2 + 127) / 128), dim3(128), 0, stream, f1, b1, has1, n1, f2, b2, has2, n2, D, aw,
                        mw, as_distance, out);
     return hipGetLastError();
 }
@@ -761,7 +761,7 @@ hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const 
 hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois, float* out, int n, int h, int w,
                                    hipStream_t stream) {
     if (n <= 0) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(roi_features_kernel, dim3(n), dim3(256), 0, stream, enc, rois, out, h, w);
+    OPD_LAUNCH(roi_features_kernel, dim3(n), dim3(256), 0, stream, enc, rois, out, h, w);
     return hipGetLastError();
 }
 #endif

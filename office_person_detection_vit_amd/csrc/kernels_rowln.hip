@@ -591,6 +591,25 @@ __global__ __launch_bounds__(512, 1) void enc_ffn_kernel(EncFfnParams p) {
 #pragma unroll
     for (int n = 0; n < EF_R; ++n) dma(wsrc + n * 1024, ring + n * 1024);
     unsigned noff = EF_R * 1024u;      // stream offset of the next piece to request
+    // Cooperative L2 warm-up of the weight stream (round 5).  Inside the forward the layer's 2.4 MB of weights are in nobody's L2 when the launch
+    // starts, and every workgroup of an XCD walks the SAME stream from the same end: the leader takes every miss (13 KiB in flight per wave
+    // against a ~2-us round trip), the others follow in its wake -- 53 us in the graph against 35-39 us back to back on warm caches.  So each
+    // wave first TOUCHES a 1 / n-th share of its stream, n = the workgroups that share its XCD (blockIdx mod 8: placement is speed only), one
+    // dword per 128-byte line through an LDS-DMA request whose 256 bytes land in the hidden-chunk buffer long before that is first written
+    // (requests return in order, and these are older than every piece re-requested below).  The ring's counted waits stay conservative: they
+    // assume fewer requests in flight than there are.
+    if (p.wprefetch) {
+        const unsigned nx = (gridDim.x + 7u) >> 3, xi = blockIdx.x >> 3;
+        const unsigned seg = ((total + nx - 1u) / nx + 127u) & ~127u;
+        const unsigned lo = xi * seg, hi = lo + seg < total ? lo + seg : total;
+        const unsigned char* const wbase = p.wpack + (size_t)wave * stride + skip;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const unsigned off = lo + (unsigned)(q * 64 + lane) * 128u;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wbase + (off < hi ? off : total - 128u)),
+                                             (__attribute__((address_space(3))) void*)(H + wave * 512 + q * 256), 4, 0, 0);
+        }
+    }
     unsigned slot = 0u;                // ring offset of the next piece to consume
     auto take = [&]() { const unsigned s_ = slot; slot = slot + 1024u == EF_R * 1024u ? 0u : slot + 1024u; return s_; };
     // (past the end of the stream the last piece is requested again: the wait counts stay the same in every iteration, nobody reads the slot)
@@ -855,19 +874,19 @@ hipError_t OPD_SYM(opd_launch_gemm_ln)(const GemmLnParams& p, hipStream_t stream
         if (p.yp16 && (p.pos_period <= 0 || (!p.pos && !p.pos_ptrs))) return hipErrorInvalidValue;
         OPD_SET_MAX_LDS_ONCE(gemm_ln256_ring_kernel<true>, RG_LDS);
         OPD_SET_MAX_LDS_ONCE(gemm_ln256_ring_kernel<false>, RG_LDS);
-        if (p.gamma) hipLaunchKernelGGL(gemm_ln256_ring_kernel<true>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
-        else hipLaunchKernelGGL(gemm_ln256_ring_kernel<false>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
+        if (p.gamma) OPD_LAUNCH(gemm_ln256_ring_kernel<true>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
+        else OPD_LAUNCH(gemm_ln256_ring_kernel<false>, dim3((p.M + RG_TM - 1) / RG_TM), dim3(64 * RG_NW), RG_LDS, stream, p);
         return hipGetLastError();
     }
     if (p.yp16) return hipErrorInvalidValue;   // (the position shadow is written by the deep-K form only)
     if (p.K == 256 && !p.kloop) {
         OPD_SET_MAX_LDS_ONCE(gemm_ln256_os_kernel, OS_LDS);
-        hipLaunchKernelGGL(gemm_ln256_os_kernel, dim3((p.M + OS_TM - 1) / OS_TM), dim3(64 * OS_NW), OS_LDS, stream, p);
+        OPD_LAUNCH(gemm_ln256_os_kernel, dim3((p.M + OS_TM - 1) / OS_TM), dim3(64 * OS_NW), OS_LDS, stream, p);
         return hipGetLastError();
     }
     constexpr int LDS = 2 * STAGE_BYTES;
     OPD_SET_MAX_LDS_ONCE(gemm_ln256_kernel, LDS);
-    hipLaunchKernelGGL(gemm_ln256_kernel, dim3((p.M + TM - 1) / TM), dim3(256), LDS, stream, p);
+    OPD_LAUNCH(gemm_ln256_kernel, dim3((p.M + TM - 1) / TM), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }
 
@@ -884,7 +903,8 @@ hipError_t OPD_SYM(opd_launch_enc_ffn)(const EncFfnParams& p, hipStream_t stream
 #define EF_LAUNCH(D)                                                                   \
     do {                                                                               \
         OPD_SET_MAX_LDS_ONCE(enc_ffn_kernel<D>, EF_LDS);                               \
-        hipLaunchKernelGGL(enc_ffn_kernel<D>, grid, dim3(512), EF_LDS, stream, p);     \
+        OPD_LAUNCH(enc_ffn_kernel<D>, grid, dim3(512), EF_LDS, stream, p);     \
+        opd_last_kernel_name = "enc_ffn_kernel<" #D ">";                               \
         return hipGetLastError();                                                      \
     } while (0)
     switch (p.dbg) {
@@ -1074,6 +1094,6 @@ hipError_t OPD_SYM(opd_launch_gemm_k256)(const GemmK256Params& p, hipStream_t st
     if ((size_t)p.M * p.ldx * 2 >= 0x7fffff00ull || (size_t)p.N * p.ldw * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
     constexpr int LDS = 8 * 64 * ROW_BYTES;
     OPD_SET_MAX_LDS_ONCE(gemm_k256_kernel, LDS);
-    hipLaunchKernelGGL(gemm_k256_kernel, dim3(p.N / 64, (p.M + 63) / 64, p.slices), dim3(256), LDS, stream, p);
+    OPD_LAUNCH(gemm_k256_kernel, dim3(p.N / 64, (p.M + 63) / 64, p.slices), dim3(256), LDS, stream, p);
     return hipGetLastError();
 }

@@ -5,6 +5,7 @@
 #define OPD_PICK(name, dtype, ...) ((dtype) == OPD_DT_BF16 ? name##_bf16(__VA_ARGS__) : name##_f16(__VA_ARGS__))
 
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t s) { return OPD_PICK(opd_launch_conv_gemm, p.dtype, p, s); }
+hipError_t opd_launch_conv_w8(const ConvGemmParams& p, hipStream_t s) { return OPD_PICK(opd_launch_conv_w8, p.dtype, p, s); }
 hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H, int W, int OH,
                                    int OW, int PH, int PW, hipStream_t s, int dtype) {
     return OPD_PICK(opd_launch_stem_pool_u8, dtype, frames, valid_hw, w, bias, out, B, H, W, OH, OW, PH, PW, s);

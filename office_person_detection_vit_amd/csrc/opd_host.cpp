@@ -11,6 +11,18 @@
 #include "opd_host.h"
 #include "opd_loader.h"
 
+#include <stdarg.h>
+#include <stdio.h>
+thread_local const char* opd_last_kernel_name = nullptr;
+const char* opd_kernel_name(const char* fmt, ...) {
+    char buf[160];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return strdup(buf);   // (one per kernel instantiation, kept for the life of the process)
+}
+
 namespace opd {
 
 thread_local std::string g_err;

@@ -21,6 +21,17 @@ enum { OPD_DT_F16 = 0, OPD_DT_BF16 = 1 };   // operand type of a launch: every k
         if (err_[dev_] != hipSuccess) return err_[dev_];                                                                     \
     } while (0)
 
+// Every launch notes the kernel's name for the per-kernel timing table (opd_detr_kernel_table: profiling mode 1).  Templates whose arguments are
+// template parameters of the launcher format the instantiation's name the way rocprofv3 prints it (opd_kernel_name).
+extern thread_local const char* opd_last_kernel_name;          // opd_host.cpp
+const char* opd_kernel_name(const char* fmt, ...);             // a process-lifetime string (call once per instantiation: function-local static)
+#define OPD_LAUNCH(kernel, ...)                       \
+    do {                                              \
+        opd_last_kernel_name = #kernel;               \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);      \
+    } while (0)
+#define OPD_BOOLSTR(b) ((b) ? "true" : "false")
+
 // Publishing LDS-DMA data through a workgroup barrier.  hipcc models vector memory as ONE in-order queue: behind [LDS-DMA requests, loads into
 // registers] it guards `__syncthreads()` with e.g. `s_waitcnt vmcnt(2)` -- "everything but the two youngest loads".  On gfx950 loads into registers
 // (and stores) retire out of order with respect to an older LDS-DMA request (tools/microbench/vmorder.hip), so that wait proves nothing about the
@@ -85,10 +96,14 @@ struct ConvGemmParams {
     FastDiv fd_tilesn, fd_ntiles;      // filled by the LDS-DMA launcher: column tiles, tiles per split-K slice
     unsigned long long* trace;  // tools only: per-workgroup phase stamps [grid][8] (conv_gemm_dma_kernel<..., TRACE>); null in the model
     int force_mt;        // tools only (tools/sweep_tiles.py): 4 / 5 / 6 = tile height 128 / 160 / 192 rows instead of the quantisation-aware choice
+    int wprefetch;       // 1: the workgroups of an XCD first touch a share each of the weight matrix (L2 warm-up at launch start; speed only)
     int flat_staging;    // tools / tests: 1 = stage tiles through flat global addresses (the path tensors beyond 2 GiB take) instead of buffer descriptors
     int dtype;           // OPD_DT_F16 / OPD_DT_BF16: the 16-bit operand type of x / w / res16 / out (opd_elem.h)
 };
 hipError_t opd_launch_conv_gemm(const ConvGemmParams& p, hipStream_t stream);
+// eight-wave form for wide layers (kernels_w8.hip: 128 x 256 tiles, one workgroup per CU, three-stage ring); bit-identical results
+bool opd_conv_w8_supported(const ConvGemmParams& p);
+hipError_t opd_launch_conv_w8(const ConvGemmParams& p, hipStream_t stream);
 // fused stem: 7x7 s2 conv + FrozenBN + ReLU + 3x3 s2 max-pool on the zero-bordered NHWC4 image -> pooled NHWC fp16
 hipError_t opd_launch_stem_pool_u8(const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H,
                                    int W, int OH, int OW, int PH, int PW, hipStream_t stream, int dtype = 0);   // pre-processing inside the stem
@@ -183,6 +198,7 @@ struct EncFfnParams {
     int M, F;                     // F % 128 == 0
     int dtype;
     int dbg;                      // tools only: timing ablations (0 in the model)
+    int wprefetch;                // 1: the workgroups of an XCD warm its L2 with the weight stream at launch start (speed only)
     // optional tail projection of the block's output, `tail` passes of 256 output columns (the next layer's q / k / v, or the decoder's memory
     // keys / values): tail_out[m][tail_col[t] .. + 255] = fp16((t < tail_pos ? y + pos : y)[m] . Wt_t^T + bias_t); Wt and the biases travel in wpack
     // optional FRONT phase: x = LayerNorm1(res32 + attn . Wo^T + bo) computed inside from the attention output (then `x` above is unused, y32 must be
@@ -385,6 +401,7 @@ hipError_t opd_launch_attention(const AttnParams& p, hipStream_t stream);
     hipError_t name##_f16(__VA_ARGS__);   \
     hipError_t name##_bf16(__VA_ARGS__);
 OPD_DECL_ELEM(opd_launch_conv_gemm, const ConvGemmParams& p, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_conv_w8, const ConvGemmParams& p, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_stem_pool_u8, const uint8_t* frames, const int32_t* valid_hw, const f16_t* w, const float* bias, f16_t* out, int B, int H, int W, int OH,
               int OW, int PH, int PW, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_stem_pool, const f16_t* x4p, const f16_t* w, const float* bias, f16_t* out, int B, int Hp, int Wp, int OH, int OW, int PH, int PW,

@@ -499,12 +499,14 @@ static int timed_begin(opd_detr* m, int cls, double flops) {
         e[i] = m->event_pool[m->pool_next++];
     }
     HIPCHK(hipEventRecord(e[0], m->stream));
-    m->timed.push_back({cls, e[0], e[1], flops});
+    m->timed.push_back({cls, e[0], e[1], flops, nullptr});
+    opd_last_kernel_name = nullptr;
     return OPD_OK;
 }
 static int timed_end(opd_detr* m) {
     if (m->profiling != 1) return OPD_OK;
     HIPCHK(hipEventRecord(m->timed.back().b, m->stream));
+    m->timed.back().name = opd_last_kernel_name;   // what the launcher just launched (OPD_LAUNCH): the name rocprofv3 prints, minus namespace and signature
     return OPD_OK;
 }
 static void timed_reset(opd_detr* m) {
@@ -513,14 +515,24 @@ static void timed_reset(opd_detr* m) {
 }
 static void timed_collect(opd_detr* m) {
     for (int c = 0; c < 4; ++c) { m->class_ms[c] = 0.f; m->class_launches[c] = 0; m->class_flops[c] = 0.0; }
+    m->ktable.clear();
+    static const char* const cls_name[4] = {"(convolution)", "(linear layer)", "(attention)", "(other)"};
     for (const auto& t : m->timed) {
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) {
             m->class_ms[t.cls] += ms;
             m->class_launches[t.cls] += 1;
             m->class_flops[t.cls] += t.flops;
+            std::string nm = t.name ? t.name : cls_name[t.cls];
+            if (!nm.empty() && nm.front() == '(' && nm.back() == ')' && t.name) nm = nm.substr(1, nm.size() - 2);   // OPD_LAUNCH((kernel<a, b>), ...)
+            opd_detr::KernelRow* row = nullptr;
+            for (auto& r : m->ktable)
+                if (r.name == nm) { row = &r; break; }
+            if (!row) { m->ktable.push_back({nm, 0, 0.f, 0.0}); row = &m->ktable.back(); }
+            row->launches += 1; row->ms += ms; row->flops += t.flops;
         }
     }
+    std::sort(m->ktable.begin(), m->ktable.end(), [](const opd_detr::KernelRow& a, const opd_detr::KernelRow& b) { return a.ms > b.ms; });
 }
 
 static int tap(opd_detr* m, const char* name, const void* p, size_t bytes) {
@@ -537,10 +549,19 @@ static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, in
     p.x = x; p.w = c.w; p.bias = c.bias; p.res16 = res16; p.res32 = nullptr; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = B; p.H = H; p.W = W; p.Cin = c.Cin; p.OH = OH; p.OW = OW; p.N = c.Cout; p.KH = c.KH; p.KW = c.KW;
     p.stride = c.stride; p.pad = c.pad; p.M = B * OH * OW; p.K = c.K; p.relu = relu ? 1 : 0; p.bias_period = 0;
-    p.out_f32 = 0; p.stem = c.stem ? 1 : 0; p.dbg = m->dbg_gemm;
+    p.out_f32 = 0; p.stem = c.stem ? 1 : 0; p.dbg = m->dbg_gemm; p.wprefetch = m->wprefetch & 1;
     // algorithmic FLOPs (2 x MAC over the real taps/channels; the stem's zero padding is not counted)
     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)c.Cout * c.KH * c.KW * c.Cin));
-    HIPCHK(opd_launch_conv_gemm(p, m->stream));
+    // Wide layers with few row tiles (stage 4) through the eight-wave kernel (kernels_w8.hip; identical bits).  The choice follows the handle's
+    // CONFIGURATION (max_batch and the layer), never the batch at hand.  OPD_W8: bit 0 = 3x3, bit 1 = 1x1 with K >= 1024, bit 2 = 1x1 with K = 512.
+    bool w8 = false;
+    if (m->w8 && c.Cout % 256 == 0 && c.Cout >= 512) {
+        const long long tiles = (((long long)OH * OW * m->cfg.max_batch + 127) / 128) * (c.Cout / 256);
+        const bool few = tiles <= 3LL * m->num_cus;
+        const int kind = c.KH == 3 ? (m->w8 & 1) : (c.K >= 1024 ? (m->w8 & 2) : (c.K == 512 ? (m->w8 & 4) : 0));
+        w8 = few && kind && opd_conv_w8_supported(p);
+    }
+    HIPCHK(w8 ? opd_launch_conv_w8(p, m->stream) : opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
     RCCHK(tap(m, c.KH == 3 ? "conv3x3" : "conv1x1", out, (size_t)p.M * c.Cout * 2));
     return OPD_OK;
@@ -555,7 +576,7 @@ static int run_gemm(opd_detr* m, const f16_t* x, const f16_t* w, const float* bi
     p.x_alt = x_alt; p.alt_mod = alt_mod; p.alt_cols = alt_cols;
     p.x = x; p.w = w; p.bias = bias; p.res16 = nullptr; p.res32 = res32; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = M; p.H = 1; p.W = 1; p.Cin = K; p.OH = 1; p.OW = 1; p.N = N; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
-    p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0; p.dbg = m->dbg_gemm;
+    p.M = M; p.K = K; p.relu = relu ? 1 : 0; p.bias_period = bias_period; p.out_f32 = out_f32 ? 1 : 0; p.stem = 0; p.dbg = m->dbg_gemm; p.wprefetch = m->wprefetch & 1;
     RCCHK(timed_begin(m, CLS_GEMM, 2.0 * M * (double)N * K));
     HIPCHK(opd_launch_conv_gemm(p, m->stream));
     RCCHK(timed_end(m));
@@ -837,7 +858,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                         p.x = a1; p.w = b.w2sc; p.bias = b.bias2sc; p.out = out; p.zero16 = m->zero_bias;
                         p.B = nb; p.H = oh; p.W = ow; p.Cin = C1; p.OH = oh; p.OW = ow; p.N = C2; p.KH = 1; p.KW = 1; p.stride = 1; p.pad = 0;
                         p.M = nb * oh * ow; p.K1 = C1; p.K = C1 + b.sc.Cin; p.relu = 1;
-                        p.x2 = cur; p.H2 = ch; p.W2 = cw; p.Cin2 = b.sc.Cin; p.stride2 = b.sc.stride; p.dbg = m->dbg_gemm;
+                        p.x2 = cur; p.H2 = ch; p.W2 = cw; p.Cin2 = b.sc.Cin; p.stride2 = b.sc.stride; p.dbg = m->dbg_gemm; p.wprefetch = m->wprefetch & 1;
                         RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)C2 * p.K));
                         HIPCHK(opd_launch_conv_gemm(p, m->stream));
                         RCCHK(timed_end(m));
@@ -968,7 +989,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         }
         if (ffn_fused) {
             // the whole FFN block as ONE row-owner launch: the [M][F] hidden tensor never leaves LDS (kernels_rowln.hip::enc_ffn_kernel)
-            EncFfnParams fp{}; fp.dtype = m->dtype;
+            EncFfnParams fp{}; fp.dtype = m->dtype; fp.wprefetch = (m->wprefetch >> 1) & 1;
             fp.x = m->d_x16; fp.wpack = L.ffn_pack; fp.b2 = L.fc2.b; fp.res32 = m->d_x32; fp.gamma = L.ln2.g; fp.beta = L.ln2.b;
             fp.y32 = m->d_x32; fp.y16 = m->d_x16; fp.M = M; fp.F = F; fp.pack_tail = L.tail; fp.pack_front = L.front;
             if (front) { fp.attn = m->d_attn16; fp.bo = L.o.b; fp.gamma1 = L.ln1.g; fp.beta1 = L.ln1.b; }
@@ -1396,6 +1417,8 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_TAIL_REV")) m->tail_rev = atoi(v);
     if (const char* v = getenv("OPD_TAIL3")) m->tail3 = atoi(v);
     if (const char* v = getenv("OPD_TAIL_RC")) m->tail_rc = atoi(v);
+    if (const char* v = getenv("OPD_WPREFETCH")) m->wprefetch = atoi(v);
+    if (const char* v = getenv("OPD_W8")) m->w8 = atoi(v);
     if (const char* v = getenv("OPD_Y_STRIDE2")) m->y_stride2 = atoi(v);
     if (const char* v = getenv("OPD_TAIL3_SPLIT")) m->tail3_split = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
@@ -1455,7 +1478,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
-    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm;
+    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());
@@ -1775,6 +1798,19 @@ int opd_detr_stage_times(const opd_detr* m, float* ms8) {
     ApiScope api_scope;
     if (!m || !ms8) return fail(OPD_EINVAL, "opd_detr_stage_times: null argument");
     for (int i = 0; i < 8; ++i) ms8[i] = m->stage_ms[i];
+    return OPD_OK;
+}
+
+int opd_detr_kernel_table(const opd_detr* m, opd_kernel_stat* out, int capacity, int* count) {
+    ApiScope api_scope;
+    if (!m || !count || capacity < 0 || (capacity > 0 && !out)) return fail(OPD_EINVAL, "opd_detr_kernel_table: bad argument");
+    *count = (int)m->ktable.size();
+    for (int i = 0; i < capacity && i < (int)m->ktable.size(); ++i) {
+        const auto& r = m->ktable[i];
+        memset(&out[i], 0, sizeof out[i]);
+        snprintf(out[i].name, sizeof out[i].name, "%s", r.name.c_str());
+        out[i].launches = r.launches; out[i].ms = r.ms; out[i].flops = r.flops;
+    }
     return OPD_OK;
 }
 

@@ -215,6 +215,8 @@ struct opd_detr {
                              // 0: never (three launches per block), 2: always
     int tail_rc = 1;         // stage 1: block 0 stores a1 instead of y, block 1 rebuilds y as its residual (kernels_btail.hip, RC; env OPD_TAIL_RC)
     int y_stride2 = 1;       // last tail of stage 1: y stored only where the next stage's stride-2 shortcut reads it (env OPD_Y_STRIDE2)
+    int wprefetch = 3;       // L2 warm-up of a launch's weights by its own workgroups: bit 0 implicit GEMM, bit 1 the encoder's FFN launch (env OPD_WPREFETCH)
+    int w8 = 0;              // wide stage-4 layers through the eight-wave GEMM (kernels_w8.hip): bit 0 3x3, bit 1 1x1 K >= 1024, bit 2 1x1 K = 512 (env OPD_W8)
     int num_cus = 256;
     int tail3_split = 1;     // stage 3: frames beyond whole rounds of the fused tail run as a second chain on `stream2` (0: one launch per tail)
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
@@ -232,7 +234,9 @@ struct opd_detr {
     std::vector<GraphEntry> graphs;
 
     // per-kernel-class timing (profiling mode only): event pairs around every launch of the last forward
-    struct Timed { int cls; hipEvent_t a, b; double flops; };
+    struct Timed { int cls; hipEvent_t a, b; double flops; const char* name; };
+    struct KernelRow { std::string name; int launches; float ms; double flops; };
+    std::vector<KernelRow> ktable;      // the last profiled forward by kernel (opd_detr_kernel_table), longest first
     std::vector<Timed> timed;           // pairs used by the current forward
     std::vector<hipEvent_t> event_pool;  // all events ever created (reused across forwards)
     size_t pool_next = 0;

@@ -77,7 +77,12 @@ int opd_test_conv_gemm(const uint16_t* x, const uint16_t* w, const float* bias, 
     p.B = B; p.H = H; p.W = W; p.Cin = Cin; p.OH = OH; p.OW = OW; p.N = N; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
     p.M = (int)M; p.K = K; p.relu = relu; p.bias_period = bias_period; p.out_f32 = out_f32; p.stem = stem;
     apply_conv_flags(p, g_conv_flags);
-    TCHK(opd_launch_conv_gemm(p, nullptr));
+    if (g_conv_flags & (1 << 12)) {   // the eight-wave kernel (kernels_w8.hip)
+        if (!opd_conv_w8_supported(p)) return tfail(OPD_EINVAL, "conv_w8: shape outside the kernel's contract");
+        TCHK(opd_launch_conv_w8(p, nullptr));
+    } else {
+        TCHK(opd_launch_conv_gemm(p, nullptr));
+    }
     TCHK(hipDeviceSynchronize());
     TCHK(hipMemcpy(out, p.out, obytes, hipMemcpyDeviceToHost));
     return OPD_OK;

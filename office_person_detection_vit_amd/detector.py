@@ -182,6 +182,11 @@ class HipDetrDetector:
             raise RuntimeError(f"Failed to load DETR model: {e}") from e
 
     def close(self) -> None:
+        # communicator lanes bound to this detector's handles go first (sharding.NativeExchange registers itself here); the library also
+        # detaches any lane that outlives its handle (opd_detr_destroy), so the order is a courtesy, not a requirement
+        for ex in list(getattr(self, "_exchanges", [])):
+            ex.close()
+        self._exchanges = []
         if self._lib is not None:
             for h in self._handles:
                 self._lib.opd_detr_destroy(C.c_void_p(h))

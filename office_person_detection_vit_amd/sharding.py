@@ -71,11 +71,36 @@ class NativeExchange:
     go from the post-process kernel into the communicator's send buffer, ``ncclAllGather`` runs on the handle's stream, and ``wait``
     returns every rank's records from page-locked host memory."""
 
+    SETUP_TIMEOUT_S = 120.0   # ncclCommInitRank blocks until every rank has arrived: a rank whose peers never do must not hang forever
+
     def __init__(self, detector, rank: int, world: int, unique_id: bytes):
+        import os
+        import sys
+        import threading
+
         self._lib = _capi.load_library()
         self.detector, self.rank, self.world = detector, rank, world
         self._comm = C.c_void_p()
-        _capi.check(self._lib.opd_comm_create(unique_id, rank, world, C.c_void_p(detector.model), C.byref(self._comm)), "opd_comm_create")
+
+        def stalled():   # (a collective initialisation cannot be cancelled from outside: the process is the unit that fails)
+            print(f"NativeExchange: rank {rank}: communicator set-up did not finish within {self.SETUP_TIMEOUT_S:.0f} s", file=sys.stderr, flush=True)
+            os._exit(3)
+
+        dog = threading.Timer(float(os.environ.get("OPD_COMM_TIMEOUT", self.SETUP_TIMEOUT_S)), stalled)
+        dog.daemon = True
+        dog.start()
+        try:
+            _capi.check(self._lib.opd_comm_create(unique_id, rank, world, C.c_void_p(detector.model), C.byref(self._comm)), "opd_comm_create")
+        finally:
+            dog.cancel()
+        if not hasattr(detector, "_exchanges"):
+            detector._exchanges = []
+        detector._exchanges.append(self)   # HipDetrDetector.close() closes its exchanges before it destroys the handles
+
+    @staticmethod
+    def available() -> bool:
+        """librccl can be resolved in this process (every rank asks, and the ranks agree, BEFORE any of them enters the collective set-up)."""
+        return _capi.load_library().opd_comm_available() == 0
 
     @staticmethod
     def unique_id() -> bytes:
@@ -87,22 +112,40 @@ class NativeExchange:
         """-> (records int32 [world][per][Q][8], counts int32 [world][per]) of all ranks; ``per`` frame slots per rank."""
         det, lib = self.detector, self._lib
         Q = det.num_queries
+        # Failure symmetry: the all-gather is a collective -- a rank that raised between begin and exchange would leave its peers blocked in
+        # it.  So (1) everything that can be checked about the local frames is checked BEFORE the exchange is begun; (2) once begun, the
+        # exchange is ALWAYS issued and waited for, whatever happens locally: slots this rank could not fill keep the count -1 that
+        # opd_comm_begin wrote, the peers return, and the local error is raised afterwards.
+        if len(local_frames) > per:
+            raise ValueError(f"{len(local_frames)} local frames do not fit {per} slots per rank")
+        for f in local_frames:
+            if not isinstance(f, np.ndarray) or f.ndim != 3 or f.shape[2] != 3 or f.dtype != np.uint8:
+                raise ValueError("frames must be HxWx3 uint8 BGR arrays")
         _capi.check(lib.opd_comm_begin(self._comm, per), "opd_comm_begin")
-        for s0 in range(0, len(local_frames), det.max_batch):   # the handle's workspace holds max_batch frames
-            rec, cnt = C.c_void_p(), C.c_void_p()
-            _capi.check(lib.opd_comm_buffers(self._comm, s0, C.byref(rec), C.byref(cnt)), "opd_comm_buffers")
-            det.detect_records_at(list(local_frames[s0:s0 + det.max_batch]), rec.value, cnt.value)
+        failure = None
+        try:
+            for s0 in range(0, len(local_frames), det.max_batch):   # the handle's workspace holds max_batch frames
+                rec, cnt = C.c_void_p(), C.c_void_p()
+                _capi.check(lib.opd_comm_buffers(self._comm, s0, C.byref(rec), C.byref(cnt)), "opd_comm_buffers")
+                det.detect_records_at(list(local_frames[s0:s0 + det.max_batch]), rec.value, cnt.value)
+        except Exception as e:   # noqa: BLE001 -- re-raised below, after the collective every rank takes part in
+            failure = e
         _capi.check(lib.opd_comm_exchange(self._comm), "opd_comm_exchange")
         recs = np.empty((self.world, per, Q, 8), np.int32)
         counts = np.empty((self.world, per), np.int32)
         _capi.check(lib.opd_comm_wait(self._comm, recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), counts.ctypes.data_as(C.POINTER(C.c_int32))),
                     "opd_comm_wait")
+        if failure is not None:
+            raise failure
         return recs, counts
 
     def close(self) -> None:
         if self._comm:
             self._lib.opd_comm_destroy(self._comm)
             self._comm = C.c_void_p()
+        ex = getattr(self.detector, "_exchanges", None)
+        if ex is not None and self in ex:
+            ex.remove(self)
 
 
 class ShardedDetector:
@@ -127,6 +170,15 @@ class ShardedDetector:
         if self._native is None:
             import torch.distributed as dist
             rank, world = dist.get_rank(), dist.get_world_size()
+            # every rank or none: agree on availability before any rank enters ncclCommInitRank (a rank without librccl would otherwise
+            # raise here while its peers block in the collective)
+            flags = [None] * world
+            if world > 1:
+                dist.all_gather_object(flags, bool(NativeExchange.available()))
+            else:
+                flags = [bool(NativeExchange.available())]
+            if not all(flags):
+                raise RuntimeError(f"native exchange unavailable: librccl could not be resolved on rank(s) {[r for r, ok in enumerate(flags) if not ok]}")
             box = [NativeExchange.unique_id() if rank == 0 else None]
             if world > 1:
                 dist.broadcast_object_list(box, src=0)   # (set-up only: 128 bytes)

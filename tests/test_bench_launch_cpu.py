@@ -28,6 +28,19 @@ def test_self_launch_two_ranks_prints_one_json_line():
     assert out["detections_last_step"] == 0   # both ranks' (empty) records reached rank 0 and went through the NMS tail
 
 
+def test_self_launch_eight_ranks_rehearsal():
+    """The shape the driver's scaling run has (N = 8) as far as a CPU can take it: eight fresh rank processes, gloo rendezvous on 127.0.0.1,
+    the pipelined step loop with its all-gather, max-over-ranks timing, rank 0's NMS tail over 8 x 8 frame slots, the final barrier."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "7", "--warmup", "2", "--cpu-rehearsal"],
+                       env=_clean_env(), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, p.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["steps"] == 7 and out["config"]["global_batch"] == 64 and out["config"]["parallelism"] == "frame-sharded dp8"
+    assert out["exchange"] == "torch.distributed" and out["detections_last_step"] == 0 and out["sustained"] is None
+
+
 def test_launcher_fails_when_a_rank_fails(tmp_path):
     sys.path.insert(0, ROOT)
     import bench

@@ -112,6 +112,60 @@ def test_conv_gemm_matches_torch(lib, gemm_variant, case):
     np.testing.assert_allclose(got, want, atol=1.5e-3 * scale, rtol=1e-3)
 
 
+W8_CASES = [
+    # (B, H, W, Cin, N, k, stride, relu, residual)
+    (1, 9, 11, 64, 256, 3, 1, True, False),       # one ragged row tile, the shortest ring (9 k-steps)
+    (2, 13, 17, 128, 512, 3, 1, True, False),     # two column tiles, ragged rows
+    (2, 14, 15, 128, 256, 3, 2, True, False),     # stride 2 (first block of a stage)
+    (1, 25, 42, 512, 512, 3, 1, True, False),     # stage 4's 3x3 on one frame (1050 pixels: 9 row tiles, the last ragged; 72 k-steps)
+    (1, 16, 24, 192, 256, 1, 1, False, False),    # 1x1, exactly 3 k-steps (the minimum)
+    (2, 10, 21, 512, 1024, 1, 1, True, True),     # 1x1 expand + residual + ReLU
+    (1, 25, 42, 2048, 512, 1, 1, True, False),    # stage 4's reduce (32 k-steps)
+]
+
+
+@pytest.mark.parametrize("case", W8_CASES)
+def test_conv_w8_equals_four_wave_kernel_bit_for_bit(lib, case):
+    """kernels_w8.hip (128 x 256 tiles, eight waves, three-stage ring, staggered wave groups) against kernels_gemm.hip on the same operands:
+    per accumulator element the k order and the MFMA order are the same, so the outputs must be IDENTICAL -- which kernel runs a layer is a
+    speed choice only.  Plus the torch reference at the usual tolerance."""
+    B, H, W, Cin, N, k, stride, relu, use_res = case
+    rng = np.random.default_rng(hash(case) % (2 ** 32))
+    x, _ = _h(rng.standard_normal((B, H, W, Cin)))
+    w, _ = _h(rng.standard_normal((N, Cin, k, k)) * np.sqrt(2.0 / (Cin * k * k)))
+    bias = rng.standard_normal(N).astype(np.float32) * 0.1
+    pad = k // 2
+    OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    res = _h(rng.standard_normal((B, OH, OW, N)))[0] if use_res else None
+    lib.opd_test_set_conv_flags(0)
+    base = run_conv(lib, x, w, bias, stride, pad, relu, res)
+    lib.opd_test_set_conv_flags(1 << 12)
+    try:
+        got = run_conv(lib, x, w, bias, stride, pad, relu, res)
+    finally:
+        lib.opd_test_set_conv_flags(0)
+    want = ref_conv(x, w, bias, stride, pad, relu, res)
+    scale = float(np.abs(want).max())
+    np.testing.assert_allclose(got, want, atol=1.5e-3 * scale, rtol=1e-3)
+    assert np.array_equal(got.view(np.uint32), base.view(np.uint32)), f"max |diff| {np.abs(got - base).max()}"
+
+
+def test_conv_w8_repeated_launches_are_bit_identical(lib):
+    """Race screen for the ring's counted waits and raw barriers: 30 launches of stage 4's 3x3 shape must agree bit for bit."""
+    rng = np.random.default_rng(11)
+    x, _ = _h(rng.standard_normal((2, 25, 42, 512)))
+    w, _ = _h(rng.standard_normal((512, 512, 3, 3)) * np.sqrt(2.0 / (512 * 9)))
+    bias = rng.standard_normal(512).astype(np.float32) * 0.1
+    lib.opd_test_set_conv_flags(1 << 12)
+    try:
+        first = run_conv(lib, x, w, bias, 1, 1, True)
+        for _ in range(30):
+            again = run_conv(lib, x, w, bias, 1, 1, True)
+            assert np.array_equal(first.view(np.uint32), again.view(np.uint32))
+    finally:
+        lib.opd_test_set_conv_flags(0)
+
+
 def test_conv_gemm_integer_exact(lib, gemm_variant):
     """Small-integer operands: every product and sum is exact in fp16/fp32 -> bit-exact; asymmetric weights catch a
     transposed fragment map (cdna_hip_programming.md §3: 'A=I-check with ASYMMETRIC B')."""

@@ -9,8 +9,12 @@ configs[4]: 8 4K frames -> 32 overlapping 1080p tiles through ``TiledDetector(Sh
 """
 
 import ctypes as C
+import json
 import os
 import socket
+import subprocess
+import sys
+import time
 
 import numpy as np
 import pytest
@@ -336,6 +340,185 @@ def test_native_exchange_world_size_1(mild_path):
             dist.destroy_process_group()
     finally:
         det.close()
+
+
+def test_communicator_lanes_share_one_communicator_and_survive_their_handles(mild_path):
+    """Round 5: ONE RCCL communicator per rank with a LANE per detector handle (opd_comm_attach): own buffers and events, all all-gathers on
+    the communicator's own stream in submission order.  (a) three lanes (handle + two clones), exchanges submitted on all three before any
+    is waited for, waited in another order: every lane delivers exactly what opd_detr_detect gives for ITS frames; (b) a lane refuses a second
+    begin while its exchange is outstanding, the others do not care; (c) lifetime: destroying a handle detaches its lanes -- they
+    answer OPD_ESTATE from then on and opd_comm_destroy still frees them; lanes may be destroyed in any order, the parent first."""
+    from office_person_detection_vit_amd.sharding import NativeExchange
+    lib = _capi.load_library()
+    det = HipDetrDetector(model_path=mild_path, max_batch=2, max_size=(256, 320), resize=False)
+    det.load_model()
+    Q = det.num_queries
+    hw = np.asarray([[256, 320]] * 2, np.int32)
+    DetP, I32P = C.POINTER(_capi.OpdDet), C.POINTER(C.c_int32)
+    handles = [C.c_void_p(det.model)]
+    for _ in range(2):
+        hx = C.c_void_p()
+        _capi.check(lib.opd_detr_clone(handles[0], C.byref(hx)), "opd_detr_clone")
+        handles.append(hx)
+    batches = [np.stack(structured_frames(2, 256, 320, seed=300 + k)) for k in range(3)]
+    want = []
+    for k in range(3):
+        r = np.zeros((2, Q, 8), np.int32); c = np.zeros(2, np.int32)
+        _capi.check(lib.opd_detr_detect(handles[k], batches[k].ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320, 0.5,
+                                        hw.ctypes.data_as(C.c_void_p), r.ctypes.data_as(DetP), c.ctypes.data_as(I32P)), "opd_detr_detect")
+        want.append((r, c))
+    assert lib.opd_comm_available() == 0
+    lanes = [C.c_void_p()]
+    _capi.check(lib.opd_comm_create(NativeExchange.unique_id(), 0, 1, handles[0], C.byref(lanes[0])), "opd_comm_create")
+    for k in (1, 2):
+        lx = C.c_void_p()
+        _capi.check(lib.opd_comm_attach(lanes[0], handles[k], C.byref(lx)), "opd_comm_attach")
+        lanes.append(lx)
+    try:
+        for rnd in range(3):
+            for k in range(3):
+                _capi.check(lib.opd_comm_begin(lanes[k], 2), "opd_comm_begin")
+                _capi.check(lib.opd_comm_detect(lanes[k], 0, batches[k].ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320, 0.5,
+                                                hw.ctypes.data_as(C.c_void_p)), "opd_comm_detect")
+                _capi.check(lib.opd_comm_exchange(lanes[k]), "opd_comm_exchange")
+            assert lib.opd_comm_begin(lanes[1], 2) == _capi.OPD_ESTATE
+            for k in ((2, 0, 1), (0, 1, 2), (1, 2, 0))[rnd]:
+                got = np.zeros((1, 2, Q, 8), np.int32); got_c = np.zeros((1, 2), np.int32)
+                _capi.check(lib.opd_comm_wait(lanes[k], got.ctypes.data_as(DetP), got_c.ctypes.data_as(I32P)), "opd_comm_wait")
+                assert got_c[0].tolist() == want[k][1].tolist()
+                for f in range(2):
+                    np.testing.assert_array_equal(got[0, f, :want[k][1][f]], want[k][0][f, :want[k][1][f]])
+        # (c) handle 2 goes first: its lane is detached, not dangling
+        lib.opd_detr_destroy(handles[2])
+        assert lib.opd_comm_begin(lanes[2], 2) == _capi.OPD_ESTATE and b"destroyed" in lib.opd_last_error()
+        lib.opd_comm_destroy(lanes[2])
+        lib.opd_comm_destroy(lanes[0])   # the parent lane before its sibling: the communicator lives on in lane 1
+        _capi.check(lib.opd_comm_begin(lanes[1], 2), "opd_comm_begin")
+        _capi.check(lib.opd_comm_detect(lanes[1], 0, batches[1].ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320, 0.5,
+                                        hw.ctypes.data_as(C.c_void_p)), "opd_comm_detect")
+        _capi.check(lib.opd_comm_exchange(lanes[1]), "opd_comm_exchange")
+        got = np.zeros((1, 2, Q, 8), np.int32); got_c = np.zeros((1, 2), np.int32)
+        _capi.check(lib.opd_comm_wait(lanes[1], got.ctypes.data_as(DetP), got_c.ctypes.data_as(I32P)), "opd_comm_wait")
+        assert got_c[0].tolist() == want[1][1].tolist()
+        lib.opd_comm_destroy(lanes[1])
+        lib.opd_detr_destroy(handles[1])
+    finally:
+        det.close()
+
+
+def test_bench_pipelined_loop_through_a_one_rank_communicator():
+    """with the native exchange bench.py's pipelined loop submitted step i on a communicator whose step i - NS was still
+    outstanding -- OPD_ESTATE at step NS on every rank, and nothing ever ran that path (communicators existed only for world > 1).  The test
+    switch OPD_BENCH_FORCE_COMM=1 drives the same loop over a ONE-rank communicator with three lanes: more than 2 NS steps, warm-up included,
+    then the sustained leg; the line must say which exchange ran and report detections."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "OPD_TEST_HOOKS")}
+    env.update({"OPD_BENCH_FORCE_COMM": "1", "OPD_BENCH_SUSTAINED": "0"})
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for comms in ("shared", "per-handle"):
+        env["OPD_BENCH_COMMS"] = comms
+        p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "11", "--warmup", "4", "--batch", "2", "--height", "256", "--width", "320",
+                            "--no-cpu-baseline", "--serial-steps", "0"], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-3000:]
+        out = json.loads([l for l in p.stdout.splitlines() if l.strip()][-1])
+        assert out["exchange"].startswith("native") and ("ONE communicator" in out["exchange"]) == (comms == "shared"), out["exchange"]
+        assert out["steps"] == 11 and out["value"] > 0 and out["detections_last_step"] is not None
+
+
+def test_measurement_abi_modes_are_consistent(mild_path):
+    """opd_detr_set_profiling / stage_times / kernel_times / kernel_table had no test.  (a) outputs are bit-identical under
+    modes 0, 1 and 2; (b) mode 2: every stage mark > 0 and their sum <= the wall time of the call; (c) mode 1: flops4 sums to the
+    architecture's algorithmic FLOPs within 1 %, the kernel table accounts for every launch and every millisecond of kernel_times and its
+    rows carry real kernel names; (d) switching modes back and forth on one handle re-captures cleanly (the `invalid resource handle` seen in
+    round 4 at opd_model.cpp:660 was exactly this path)."""
+    lib = _capi.load_library()
+    H, W, B = 256, 320, 2
+    cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
+    h = C.c_void_p()
+    _capi.check(lib.opd_detr_create(C.byref(cfg), mild_path.encode(), 0, C.byref(h)), "opd_detr_create")
+    try:
+        frames = np.stack(structured_frames(B, H, W, seed=77))
+        logits = np.zeros((B, 100, 92), np.float32); boxes = np.zeros((B, 100, 4), np.float32)
+        F32P = C.POINTER(C.c_float)
+
+        def fwd():
+            t0 = time.perf_counter()
+            _capi.check(lib.opd_detr_forward(h, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,
+                                             logits.ctypes.data_as(F32P), boxes.ctypes.data_as(F32P), None), "opd_detr_forward")
+            return 1e3 * (time.perf_counter() - t0), logits.copy(), boxes.copy()
+
+        hw = np.asarray([[H, W]] * B, np.int32)
+        recs = np.zeros((B, 100, 8), np.int32); cnts = np.zeros(B, np.int32)
+
+        def det():   # (the stage / kernel times are those of the last DETECT call: forward + post-process)
+            t0 = time.perf_counter()
+            _capi.check(lib.opd_detr_detect(h, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W, 0.5,
+                                            hw.ctypes.data_as(C.c_void_p), recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), cnts.ctypes.data_as(C.POINTER(C.c_int32))),
+                        "opd_detr_detect")
+            return 1e3 * (time.perf_counter() - t0), recs.copy(), cnts.copy()
+
+        ref = ref_det = None
+        for mode in (0, 2, 1, 0, 1, 2, 2, 0):   # back and forth; each mode runs eager / capture / replay
+            _capi.check(lib.opd_detr_set_profiling(h, mode), "opd_detr_set_profiling")
+            for it in range(3):
+                _, lg, bx = fwd()
+                if ref is None:
+                    ref = (lg, bx)
+                np.testing.assert_array_equal(lg, ref[0])
+                np.testing.assert_array_equal(bx, ref[1])
+            for it in range(3):
+                wall_ms, rr, cc = det()
+                if ref_det is None:
+                    ref_det = (rr, cc)
+                    assert cc.sum() > 0
+                np.testing.assert_array_equal(cc, ref_det[1])
+                for f in range(B):
+                    np.testing.assert_array_equal(rr[f, :cc[f]], ref_det[0][f, :cc[f]])
+                s8 = (C.c_float * 8)()
+                _capi.check(lib.opd_detr_stage_times(h, s8), "opd_detr_stage_times")
+                st = np.asarray(list(s8))
+                if mode == 2 and it == 2:      # a replay with the marks inside the graph
+                    assert (st[:7] > 0).all(), st
+                    assert st.sum() <= wall_ms, (st.sum(), wall_ms)
+                if mode == 1:
+                    ms4, l4, f4 = (C.c_float * 4)(), (C.c_int32 * 4)(), (C.c_double * 4)()
+                    _capi.check(lib.opd_detr_kernel_times(h, ms4, l4, f4), "opd_detr_kernel_times")
+                    # algorithmic FLOPs of the architecture at this size: the oracle's layer list is the independent count
+                    from tools_flops import detr_r50_flops
+                    want = detr_r50_flops(H, W) * B
+                    assert abs(sum(f4) - want) <= 0.01 * want, (sum(f4), want)
+                    tab = (_capi.OpdKernelStat * 64)(); n = C.c_int(0)
+                    _capi.check(lib.opd_detr_kernel_table(h, tab, 64, C.byref(n)), "opd_detr_kernel_table")
+                    rows = [(tab[i].name.decode(), tab[i].launches, tab[i].ms, tab[i].flops) for i in range(n.value)]
+                    assert sum(r[1] for r in rows) == sum(l4) and abs(sum(r[2] for r in rows) - sum(ms4)) <= 1e-3 * sum(ms4) + 1e-4
+                    assert abs(sum(r[3] for r in rows) - sum(f4)) <= 1e-6 * sum(f4)
+                    names = " ".join(r[0] for r in rows)
+                    assert "conv_gemm_dma_kernel<" in names and "attention_kernel<" in names and "stem_pool2_kernel<true>" in names, names
+                    assert all(rows[i][2] >= rows[i + 1][2] for i in range(len(rows) - 1))   # longest first
+    finally:
+        lib.opd_detr_destroy(h)
+
+
+def test_stage1_residual_rebuild_is_invisible_end_to_end(mild_path):
+    """OPD_TAIL_RC / OPD_Y_STRIDE2 (round 5: stage 1's first tail stores a1 instead of its output, the second rebuilds it, the last stores its
+    output only where the next stage reads it): logits, boxes and the encoder map of a batch are bit-identical with the switches on and off,
+    eager, captured and replayed, also for a ragged last tile (203 x 333) and through a clone (the switches travel with opd_detr_clone)."""
+    for (H, W, B) in ((256, 320, 3), (203, 333, 2)):
+        frames = structured_frames(B, H, W, seed=515)
+        outs = {}
+        for flag in ("1", "0"):
+            os.environ["OPD_TAIL_RC"] = flag; os.environ["OPD_Y_STRIDE2"] = flag
+            try:
+                det = HipDetrDetector(model_path=mild_path, max_batch=B, max_size=(H, W), resize=False, streams=2)
+                det.load_model()
+            finally:
+                del os.environ["OPD_TAIL_RC"], os.environ["OPD_Y_STRIDE2"]
+            try:
+                outs[flag] = [det.forward_raw(frames) for _ in range(3)]
+            finally:
+                det.close()
+        for call in range(3):
+            for x, y in zip(outs["1"][call], outs["0"][call]):
+                np.testing.assert_array_equal(x, y)
 
 
 def test_multi_stream_plan_matches_live_oracle_at_batch8(mild_path, parity_log):

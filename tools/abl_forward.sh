@@ -6,7 +6,7 @@ O=${1:?outdir}; K=${2:-600}
 mkdir -p $O
 run() {   # name, env...
   local n=$1; shift
-  env "$@" python bench.py --steps $K --no-cpu-baseline --serial-steps 10 > $O/$n.json 2> $O/$n.err
+  env OPD_BENCH_SUSTAINED=0 "$@" python bench.py --steps $K --no-cpu-baseline --serial-steps 10 > $O/$n.json 2> $O/$n.err
   python - <<P
 import json
 d=json.load(open("$O/$n.json")); print("%-28s %8.1f frames/s  %.3f ms/step  serial %.3f ms  stage_ms %s" % ("$n", d["value"], d["ms_per_step"], d["serial"]["ms_per_step"], d.get("stage_ms")), flush=True)
