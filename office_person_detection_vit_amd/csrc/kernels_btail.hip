@@ -571,6 +571,289 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Third block of stage 1 with BOTH previous block outputs rebuilt (BtailParams::rc == 2; round 5).  With rc == 1 the second tail still stores
+// its output y1 (274 MB at batch 8) for this tail to read back as its residual.  Here the second tail stores its a1 instead (68 MB), and this
+// kernel rebuilds, per 32-channel half chunk,
+//     y0 = relu(b0 + W2_0 . a1_0 + Wsc . xs)      (block 0's tail arithmetic)
+//     y1 = relu(b1 + W2_1 . a1_1 + y0)            (block 1's)
+//     y2 = relu(b2 + W2_2 . a1   + y1)            (its own; a1 from its own 3x3), z += W3 . y2
+// from the three 64-channel tensors a1_0, a1_1, xs of its 32 pixels per wave (48 B-operand registers), each product in the order its own tail
+// runs it, each y rounded to fp16 where that tail rounds it: same bits (tests/test_kernels_gpu.py: chain test, route 2).  Stage 1 then reads and
+// writes 64-channel tensors only, plus the quarter of y2 that the next stage's stride-2 shortcut reads.
+// Half chunks: a 64-channel chunk would need 48 KiB of operands per step (four 64 x 64 slices + the 128 x 64 slice of W3), twice that double
+// buffered: one workgroup per CU.  A step therefore covers 32 channels: four [32][64] slices (16 KiB, double buffered in the two 3x3 stage
+// buffers) while the W3 slice of a chunk (16 KiB) lives for two steps in a double buffer of its own: 80 KiB per workgroup, two per CU.
+template <int C3>
+__global__ __launch_bounds__(256, 2) void btail_rc2_kernel(BtailParams p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    constexpr int C1 = 64, C2 = 256, NT1 = 4, KK1 = 2, NT3 = C3 / 16;
+    constexpr int A_BYTES = 128 * ROW_BYTES, STAGE_BYTES = A_BYTES + C1 * ROW_BYTES;   // 24 KiB
+    constexpr int QBUF0 = STAGE_BYTES, QBUF1 = 0;                                      // quads of even / odd steps: inside stage 1 / stage 0
+    constexpr int W3BUF = 2 * STAGE_BYTES;                                             // + (chunk & 1) * 16 KiB
+    static_assert(C3 == 128, "the W3 double buffer is laid out for 128 reduce channels");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int g = lane >> 4, li = lane & 15;
+    const int m_base = (p.rev ? xcd_logical_block_rev(blockIdx.x, gridDim.x) : xcd_logical_block(blockIdx.x, gridDim.x)) * 128;
+    const int wm0 = m_base + wave * 32;
+
+    const int lrow = lane >> 3;
+    const int lchunk = (lane & 7) ^ lrow;
+    const unsigned backoff = (unsigned)(p.W + 1) * (unsigned)C1 * 2u;
+    const __amdgpu_buffer_rsrc_t rsrc_a = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<char*>(reinterpret_cast<const char*>(p.x1)) - backoff, 0, (unsigned)((size_t)p.B * p.H * p.W * C1 * 2) + backoff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w1), 0, (unsigned)(C1 * 9 * C1 * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrc_w3 = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(p.w3p), 0, (unsigned)(C3 * C2 * 2), 0x00020000);
+    // this wave's [32][64] slice of every step: wave 0 block 0's expand, 1 block 0's shortcut, 2 block 1's expand, 3 this block's expand
+    const f16_t* const qsrc = wave == 0 ? p.rc_w2[1] : wave == 1 ? p.rc_wsc : wave == 2 ? p.rc_w2[0] : p.w2p;
+    const __amdgpu_buffer_rsrc_t rsrc_q = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(qsrc), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
+    unsigned rowoff[4], rowmask[4], woff1[2], woffq[4], woff3[4];
+    {
+        const int ohw = p.OH * p.OW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m_base + (wave * 4 + i) * 8 + lrow;
+            const bool okm = m < p.M;
+            const int mm = okm ? m : 0;
+            const int b = fdiv(mm, p.fd_ohw);
+            const int r = mm - b * ohw;
+            const int oh = fdiv(r, p.fd_ow);
+            const int ow = r - oh * p.OW;
+            rowoff[i] = (unsigned)(((b * p.H + oh) * p.W + ow) * C1) * 2u + (unsigned)lchunk * 16u;
+            unsigned kwmask = 0, mask = 0;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw)
+                if ((unsigned)(ow - 1 + kw) < (unsigned)p.W) kwmask |= 1u << kw;
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+                if ((unsigned)(oh - 1 + kh) < (unsigned)p.H) mask |= kwmask << (kh * 3);
+            rowmask[i] = okm ? mask : 0u;
+            // quad piece i: LDS rows 8 i + lrow of the 32-row block <- channel own_row(.) of the block (the block's base travels as the scalar offset)
+            woffq[i] = (unsigned)(own_row(i * 8 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;
+            woff3[i] = (unsigned)(own_row((wave * 4 + i) * 8 + lrow) * C2) * 2u + (unsigned)lchunk * 16u;
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i) woff1[i] = (unsigned)(own_row((wave * 2 + i) * 8 + lrow) * (9 * C1)) * 2u + (unsigned)lchunk * 16u;
+    }
+    constexpr int nk = 9;
+    int tap_kh = 0, tap_kw = 0;
+    auto issue_main = [&](int ks, int buf) {
+        unsigned char* As = smem + buf * STAGE_BYTES;
+        unsigned char* Ws = As + A_BYTES;
+        const int tap = tap_kh * 3 + tap_kw;
+        const int soff_a = ((tap_kh * p.W + tap_kw) * C1) * 2;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const unsigned vo = ((rowmask[i] >> tap) & 1u) ? rowoff[i] : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_a, (__attribute__((address_space(3))) void*)(As + (wave * 4 + i) * 1024), 16, vo, soff_a, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w1, (__attribute__((address_space(3))) void*)(Ws + (wave * 2 + i) * 1024), 16, woff1[i], ks * 128, 0, 0);
+        if (++tap_kw == 3) { tap_kw = 0; ++tap_kh; }
+    };
+    auto issue_quads = [&](int h) {   // step h = (chunk h >> 1, half h & 1): rows 32 h .. 32 h + 31 of the four [256][64] matrices
+        unsigned char* dst = smem + ((h & 1) ? QBUF1 : QBUF0) + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_q, (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, woffq[i], h * (32 * 64 * 2), 0, 0);
+    };
+    auto issue_w3 = [&](int j) {
+        unsigned char* dst = smem + W3BUF + (j & 1) * 16384;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_w3, (__attribute__((address_space(3))) void*)(dst + (wave * 4 + i) * 1024), 16, woff3[i], j * 128, 0, 0);
+    };
+    const bool pr_ok[2] = {wm0 + li < p.M, wm0 + 16 + li < p.M};
+    const size_t pr_row[2] = {(size_t)(wm0 + li) * C2 + g * 8, (size_t)(wm0 + 16 + li) * C2 + g * 8};
+    bool y_ok[2] = {pr_ok[0] && p.y != nullptr, pr_ok[1] && p.y != nullptr};
+    if (p.y_stride2) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = wm0 + mt * 16 + li;
+            const int r = m - fdiv(m, p.fd_ohw) * (p.OH * p.OW);
+            const int oh = fdiv(r, p.fd_ow), ow = r - oh * p.OW;
+            y_ok[mt] = y_ok[mt] && !((oh | ow) & 1);
+        }
+    }
+    // the three 64-channel inputs of the rebuild for this wave's 32 pixels, as B fragments (natural k order); loaded in front of everything else
+    half8 xs[2][2], a10[2][2], a11[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = wm0 + mt * 16 + li;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 v = {}, u0 = {}, u1 = {};
+            if (m < p.M) {
+                v = *reinterpret_cast<const half8*>(p.rc_xs + (size_t)m * 64 + kk * 32 + g * 8);
+                u0 = *reinterpret_cast<const half8*>(p.rc_a1[1] + (size_t)m * 64 + kk * 32 + g * 8);
+                u1 = *reinterpret_cast<const half8*>(p.rc_a1[0] + (size_t)m * 64 + kk * 32 + g * 8);
+            }
+            xs[mt][kk] = v; a10[mt][kk] = u0; a11[mt][kk] = u1;
+        }
+    }
+    issue_main(0, 0);
+    float4v acc1[NT1][2];
+#pragma unroll
+    for (int nt = 0; nt < NT1; ++nt) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.b1 + own_ch(nt, g));
+        acc1[nt][0] = b;
+        acc1[nt][1] = b;
+    }
+    OPD_DMA_BARRIER();
+    auto compute_main = [&](int buf) {
+        const unsigned char* As = smem + buf * STAGE_BYTES;
+        const unsigned char* Ws = As + A_BYTES;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 xf[2], wf[NT1];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) xf[mt] = *reinterpret_cast<const half8*>(As + swz(wave * 32 + mt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt) wf[nt] = *reinterpret_cast<const half8*>(Ws + swz(nt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < NT1; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc1[nt][mt] = OPD_MFMA_16x16x32(wf[nt], xf[mt], acc1[nt][mt]);
+        }
+    };
+#pragma unroll 1
+    for (int ks = 0; ks + 1 < nk; ++ks) {
+        issue_main(ks + 1, (ks + 1) & 1);
+        compute_main(ks & 1);
+        __syncthreads();
+    }
+    // last k-step (stage 0): stage 1 is free -> the quads of step 0; the W3 buffers lie behind both stages
+    issue_quads(0);
+    issue_w3(0);
+    compiler_fence();
+    compute_main((nk - 1) & 1);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+
+    half8 a1[2][KK1];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int kk = 0; kk < KK1; ++kk) {
+            float4v u = acc1[2 * kk][mt], v = acc1[2 * kk + 1][mt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                u[r] = u[r] > 0.f ? u[r] : 0.f;
+                v[r] = v[r] > 0.f ? v[r] : 0.f;
+            }
+            a1[mt][kk] = as_half8(pack2h(u[0], u[1]), pack2h(u[2], u[3]), pack2h(v[0], v[1]), pack2h(v[2], v[3]));
+        }
+    float4v accz[NT3][2];
+#pragma unroll
+    for (int nt = 0; nt < NT3; ++nt) {
+        const float4v b = *reinterpret_cast<const float4v*>(p.b3 + own_ch(nt, g));
+        accz[nt][0] = b;
+        accz[nt][1] = b;
+    }
+    // one [32][64] slice times a 64-channel B operand into two accumulator tiles per pixel half
+    auto mma_slice = [&](const unsigned char* W, const half8 (&bop)[2][2], float4v (&acc)[2][2]) {
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            half8 wf[2];
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) wf[nt] = *reinterpret_cast<const half8*>(W + swz(nt * 16 + li, kk * 4 + g));
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = OPD_MFMA_16x16x32(wf[nt], bop[mt][kk], acc[nt][mt]);
+        }
+    };
+    auto init_bias = [&](const float* bias, const int ch0, float4v (&acc)[2][2]) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            const float4v b = *reinterpret_cast<const float4v*>(bias + ch0 + g * 8 + nt * 4);
+            acc[nt][0] = b;
+            acc[nt][1] = b;
+        }
+    };
+    // + residual (the previous block's rounded output, 8 consecutive channels per lane), ReLU, fp16
+    auto finish = [&](float4v (&acc)[2][2], const uint4 (*res)[2], uint4 (&out)[2]) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float4v v0 = acc[0][mt], v1 = acc[1][mt];
+            if (res) {
+                const uint4 r = (*res)[mt];
+                float a, b;
+                unpack2h(r.x, a, b); v0[0] += a; v0[1] += b;
+                unpack2h(r.y, a, b); v0[2] += a; v0[3] += b;
+                unpack2h(r.z, a, b); v1[0] += a; v1[1] += b;
+                unpack2h(r.w, a, b); v1[2] += a; v1[3] += b;
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
+                v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+            }
+            out[mt] = make_uint4(pack2h(v0[0], v0[1]), pack2h(v0[2], v0[3]), pack2h(v1[0], v1[1]), pack2h(v1[2], v1[3]));
+        }
+    };
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const int j = h >> 1, q = h & 1, ch0 = h * 32;
+        if (h + 1 < 8) {
+            issue_quads(h + 1);
+            if (q == 1) issue_w3(j + 1);   // (its buffer was last read two steps ago)
+        }
+        compiler_fence();
+        const unsigned char* Q = smem + (q ? QBUF1 : QBUF0);
+        float4v acc[2][2];
+        uint4 r0[2], r1[2], y2[2];
+        init_bias(p.rc_b[1], ch0, acc);            // block 0: bias (expand + shortcut), W2_0 . a1_0, Wsc . xs
+        mma_slice(Q, a10, acc);
+        mma_slice(Q + 4096, xs, acc);
+        finish(acc, nullptr, r0);
+        init_bias(p.rc_b[0], ch0, acc);            // block 1: bias, W2_1 . a1_1, + y0
+        mma_slice(Q + 8192, a11, acc);
+        finish(acc, &r0, r1);
+        init_bias(p.b2, ch0, acc);                 // this block: bias, W2_2 . a1, + y1
+        mma_slice(Q + 12288, a1, acc);
+        finish(acc, &r1, y2);
+        half8 yf[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) yf[mt] = as_half8(y2[mt].x, y2[mt].y, y2[mt].z, y2[mt].w);
+        {   // z += W3[:, 64 j + 32 q ..] . y2: k-block q of the chunk's slice
+            const unsigned char* W3s = smem + W3BUF + (j & 1) * 16384;
+#pragma unroll
+            for (int nt = 0; nt < NT3; ++nt) {
+                const half8 wf = *reinterpret_cast<const half8*>(W3s + swz(nt * 16 + li, q * 4 + g));
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) accz[nt][mt] = OPD_MFMA_16x16x32(wf, yf[mt], accz[nt][mt]);
+            }
+        }
+        if (h + 1 < 8) {
+            wait_vmcnt<0>();   // the next step's operands (requested at the top) have landed; the y stores of this step go out behind the wait
+            __builtin_amdgcn_s_barrier();
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+            if (y_ok[mt]) *reinterpret_cast<half8*>(p.y + pr_row[mt] + ch0) = yf[mt];
+    }
+#pragma unroll
+    for (int qz = 0; qz < NT3 / 2; ++qz)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            float4v v0 = accz[2 * qz][mt], v1 = accz[2 * qz + 1][mt];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                v0[r] = v0[r] > 0.f ? v0[r] : 0.f;
+                v1[r] = v1[r] > 0.f ? v1[r] : 0.f;
+            }
+            if (pr_ok[mt])
+                *reinterpret_cast<uint4*>(p.z + (size_t)(wm0 + mt * 16 + li) * C3 + qz * 32 + g * 8) =
+                    make_uint4(pack2h(v0[0], v0[1]), pack2h(v0[2], v0[3]), pack2h(v1[0], v1[1]), pack2h(v1[2], v1[3]));
+        }
+#endif
+}
+
 template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false, int RC = 0>
 hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
     constexpr int MAIN = (128 + C1) * ROW_BYTES, CHUNK = 64 * C1 * 2 + C3 * ROW_BYTES + (SC ? 64 * ROW_BYTES : 0) + (RC ? 2 * 64 * ROW_BYTES : 0);
@@ -601,6 +884,15 @@ hipError_t OPD_SYM(opd_launch_btail)(const BtailParams& p_in, hipStream_t stream
     if (p.C1 == 256) return OPD_SYM(opd_launch_btail256)(p, stream);   // stage 3: kernels_btail3.hip
     if (p.y_stride2 && (p.stride != 1 || p.C3 == 0)) return hipErrorInvalidValue;   // (only next to a fused reduce: nobody else may need y)
     if (!p.y && !p.a1_out) return hipErrorInvalidValue;   // an output nobody could rebuild
+    if (p.rc == 2) {   // third block of stage 1: both previous outputs rebuilt (btail_rc2_kernel)
+        if (p.C1 != 64 || p.C3 != 128 || p.stride != 1 || p.res || p.xs || !p.rc_a1[0] || !p.rc_a1[1] || !p.rc_xs || !p.rc_w2[0] || !p.rc_w2[1] || !p.rc_wsc ||
+            !p.rc_b[0] || !p.rc_b[1] || !p.w3p || !p.z || p.trace || p.dbg || (size_t)p.M * 64 * 2 >= 0x7fffff00ull)
+            return hipErrorInvalidValue;
+        constexpr int LDS = 2 * (128 + 64) * ROW_BYTES + 2 * 16384;
+        OPD_SET_MAX_LDS_ONCE(btail_rc2_kernel<128>, LDS);
+        OPD_LAUNCH(btail_rc2_kernel<128>, dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
+        return hipGetLastError();
+    }
     if (p.rc) {   // residual rebuilt from the previous block's a1 and shortcut input (second block of stage 1)
         if (p.rc != 1 || p.C1 != 64 || p.C3 != 64 || p.stride != 1 || p.res || p.xs || !p.rc_a1[0] || !p.rc_xs || !p.rc_w2[0] || !p.rc_wsc || !p.rc_b[0] ||
             p.trace || (size_t)p.M * 64 * 2 >= 0x7fffff00ull)

@@ -135,8 +135,10 @@ struct BtailParams {
     // tail can rebuild the y it needs as its residual from the 64-channel tensors that made it instead of reading 274 MB back:
     //   y == null      -> y is not stored at all (the consumer recomputes it);
     //   a1_out         -> [M][C1] fp16: this block's a1 = relu(3x3), stored for that consumer (natural channel order);
-    //   rc = 1         -> residual = relu(rc_b0 + rc_w2[0] . rc_a1[0] + rc_wsc . rc_xs), the previous block's output rebuilt per 64-channel
+    //   rc = 1         -> residual = relu(rc_b[0] + rc_w2[0] . rc_a1[0] + rc_wsc . rc_xs), the previous block's output rebuilt per 64-channel
     //                     chunk with that block's own instruction order (bit-identical to what its tail would have stored); res must be null;
+    //   rc = 2         -> two levels: index [1] = the block before the previous one (the one with the shortcut: rc_b[1] = its b2 + bsc), index [0] = the
+    //                     previous block; residual = relu(rc_b[0] + rc_w2[0] . rc_a1[0] + relu(rc_b[1] + rc_w2[1] . rc_a1[1] + rc_wsc . rc_xs)); C3 = 128;
     //   y_stride2 = 1  -> y is stored only at pixels with even (oh, ow): the only ones a stride-2 1x1 shortcut of the next stage reads
     //                     (valid when the next block's reduce is fused as z, i.e. nobody else reads y).
     f16_t* a1_out;

@@ -760,7 +760,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
     // ones touch (per-frame sizes shrink from stage to stage).
     struct TrunkState { int cur_id; int ch, cw; int z_id; };   // cur_id 0 = pool, 1 = t0, 2 = t1; z_id -1 / 0 = m0 / 1 = m1
     int tail_no = 0;   // consecutive fused tails walk the tiles in alternating directions (tail_rev)
-    int rc_prev = -1;            // block whose tail stored a1 instead of y (its successor rebuilds the residual: BtailParams::rc)
+    int rc_prev = -1, rc_prev2 = -1;   // blocks whose tails stored a1 instead of y (their successors rebuild the residual: BtailParams::rc)
     const f16_t* rc_xs = nullptr;
     auto run_blocks = [&](int s_begin, int s_end, int b0, int nb, TrunkState& st, int l_begin = 0, int l_end = 1 << 30) -> int {
         auto trunk = [&](int id, size_t per_frame) { return (id == 0 ? m->d_pool : id == 1 ? m->d_t0 : m->d_t1) + (size_t)b0 * per_frame; };
@@ -829,12 +829,23 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     // that output chunk by chunk from a1 and the pooled map (the shortcut's input) as its residual.  Bit-identical results
                     // (tests/test_kernels_gpu.py, OPD_TAIL_RC=0/1 end to end); 344 MB less HBM traffic per forward at batch 8.  The a1 tensor lives in
                     // the shortcut buffer, which a fused shortcut leaves unused.
-                    const bool rc_ok = m->tail_rc && s == 0 && C1 == 64 && C3 == 64 && a.depths[0] >= 2 && !m->taps;
-                    f16_t* a1_keep = m->d_sc + (size_t)b0 * oh * ow * 64;
-                    if (rc_ok && sc_in_tail && l == 0) { p.y = nullptr; p.a1_out = a1_keep; rc_prev = bi; rc_xs = cur; }
-                    else if (rc_ok && l == 1 && rc_prev == bi - 1 && !b.has_sc) {
+                    // tail_rc == 2 (NOT the default: measured slower, opd_model.h) goes one block further: block 1 stores ITS a1 as well and block 2 (the last of stage 1, C3 = 128)
+                    // rebuilds both outputs (btail_rc2_kernel): stage 1 then moves 64-channel tensors only, plus the quarter of its last output
+                    // that the next stage's shortcut reads -- another 276 MB less per forward.
+                    const bool rc_ok = m->tail_rc && s == 0 && C1 == 64 && a.depths[0] >= 2 && !m->taps;
+                    const bool rc2_ok = rc_ok && m->tail_rc >= 2 && a.depths[0] == 3;
+                    f16_t* const a1_keep0 = m->d_sc + (size_t)b0 * oh * ow * 64;                                          // block 0's a1
+                    f16_t* const a1_keep1 = m->d_sc + (size_t)m->cfg.max_batch * oh * ow * 64 + (size_t)b0 * oh * ow * 64;   // block 1's a1 (behind the whole batch's block-0 tensor)
+                    if (rc_ok && C3 == 64 && sc_in_tail && l == 0) { p.y = nullptr; p.a1_out = a1_keep0; rc_prev = bi; rc_xs = cur; }
+                    else if (rc_ok && C3 == 64 && l == 1 && rc_prev == bi - 1 && !b.has_sc) {
                         const Block& pb = m->blocks[bi - 1];
-                        p.res = nullptr; p.rc = 1; p.rc_a1[0] = a1_keep; p.rc_xs = rc_xs; p.rc_w2[0] = pb.c2.w; p.rc_wsc = pb.sc.w; p.rc_b[0] = pb.bias2sc;
+                        p.res = nullptr; p.rc = 1; p.rc_a1[0] = a1_keep0; p.rc_xs = rc_xs; p.rc_w2[0] = pb.c2.w; p.rc_wsc = pb.sc.w; p.rc_b[0] = pb.bias2sc;
+                        if (rc2_ok && nbk && !nbk->has_sc && nbk->c1.Cin == 64) { p.y = nullptr; p.a1_out = a1_keep1; rc_prev2 = bi; }
+                    } else if (rc2_ok && C3 == 128 && l == 2 && rc_prev2 == bi - 1 && rc_prev == bi - 2 && !b.has_sc) {
+                        const Block &p1 = m->blocks[bi - 1], &p0 = m->blocks[bi - 2];
+                        p.res = nullptr; p.rc = 2; p.rc_xs = rc_xs; p.rc_wsc = p0.sc.w;
+                        p.rc_a1[0] = a1_keep1; p.rc_w2[0] = p1.c2.w; p.rc_b[0] = p1.c2.bias;
+                        p.rc_a1[1] = a1_keep0; p.rc_w2[1] = p0.c2.w; p.rc_b[1] = p0.bias2sc;
                     }
                     // The last block of stage 1 hands the next stage its reduce output z (fused above); the block output itself is then read
                     // by that stage's stride-2 shortcut only, i.e. at even (oh, ow): the other three quarters of its 274 MB are not stored.

@@ -213,7 +213,9 @@ struct opd_detr {
     int tail_rev = 1;        // consecutive fused tails walk their tiles in opposite directions (Infinity Cache reuse of the block output)
     int tail3 = 1;           // stage 3 (256-channel blocks) through the eight-wave fused tail (kernels_btail3.hip) where it pays (see run_blocks);
                              // 0: never (three launches per block), 2: always
-    int tail_rc = 1;         // stage 1: block 0 stores a1 instead of y, block 1 rebuilds y as its residual (kernels_btail.hip, RC; env OPD_TAIL_RC)
+    int tail_rc = 1;         // stage 1: block 0 (and, at 2, block 1) stores a1 instead of y; the successor rebuilds y as its residual (kernels_btail.hip, RC; env OPD_TAIL_RC:
+                             // 0 / 1 / 2).  2 is bit-identical too but measured SLOWER (stage 1 0.555 -> 0.575 ms, three streams 3020 -> 2950 frames/s, A/B x 2 on one box):
+                             // eight half-chunk steps with three GEMMs each cost more than the 276 MB they save)
     int y_stride2 = 1;       // last tail of stage 1: y stored only where the next stage's stride-2 shortcut reads it (env OPD_Y_STRIDE2)
     int wprefetch = 3;       // L2 warm-up of a launch's weights by its own workgroups: bit 0 implicit GEMM, bit 1 the encoder's FFN launch (env OPD_WPREFETCH)
     int w8 = 0;              // wide stage-4 layers through the eight-wave GEMM (kernels_w8.hip): bit 0 3x3, bit 1 1x1 K >= 1024, bit 2 1x1 K = 512 (env OPD_W8)
@@ -316,9 +318,19 @@ extern std::shared_mutex g_api_mu;
 // while A still owned it, or a dropped replay, below this library (every address baked into A's graph belongs to A or to A's weight
 // set; neither is freed while A lives; red zones and poison runs rule out this library's kernels writing outside their buffers).  Nothing
 // the capture code does wrong was found: launch errors inside a capture surface as the call's error (enqueue_forward's return code), and
-// since round 4 a refused capture / instantiation does too instead of falling back to eager launches silently.  Cause: UNKNOWN, below the
-// HIP API; the guard is LOAD-BEARING until a ROCm release is shown not to need it.  The regression
-// test is test_graph_replay_survives_foreign_allocations_and_handle_churn, which runs with the guard OFF.
+// since round 4 a refused capture / instantiation does too instead of falling back to eager launches silently.
+// Round 5 connected the log to round 4's own finding (counted waits that let register loads fly in front of LDS-DMA data prove nothing on this
+// hardware): tools/scan_dma_waits.py over the ISA of the revision that produced the bad log (f889722; profiles/r05_scan_dma_waits_round2_revision.txt)
+// finds 14 of its 20 barriers with LDS-DMA data in flight UNSOUND -- the first barrier of every fused-tail instantiation (six requests, then four
+// or eight bias loads, `vmcnt(4)` / `vmcnt(8)`), gemm_ln256_kernel, gemm_ln256_os_kernel, three of the FFN kernel -- all on the path of that
+// forward, and the one reproduction was the first GPU process of a freshly acquired box, i.e. cold requests, exactly when a request loses the
+// race against a younger load.  So that binary COULD compute on LDS bytes that had not landed; HEAD cannot (0 of 157 such barriers, both element
+// types, no kernel exempted; tests/test_isa_cpu.py).  What the scan does not explain is the VALUE: the same wrong number on two replays, equal to
+// handle B's result within fp16 noise -- stale LDS bytes would have to be B's tiles, left in the CUs' LDS by B's forward just before, which is
+// possible (LDS is not cleared between workgroups) but not shown.  Verdict: a sufficient mechanism existed at that revision and is gone; the
+// "below the HIP API" reading is no longer needed to explain the log, nor excluded by it.  The guard stays ON (it costs one re-capture per
+// handle creation / destruction, nothing per forward) and is no longer called load-bearing: the regression test
+// test_graph_replay_survives_foreign_allocations_and_handle_churn runs with the guard OFF at HEAD and passes (round-5 GPU suite).
 extern std::atomic<unsigned> g_handle_epoch;
 extern std::atomic<int> g_graph_guard;   // opd_test_set_graph_guard(0): leave stale-epoch graphs alone (diagnosis only)
 extern thread_local std::shared_lock<std::shared_mutex>* tl_api_lock;

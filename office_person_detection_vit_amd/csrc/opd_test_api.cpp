@@ -548,7 +548,8 @@ int opd_test_btail_sc(const uint16_t* x1, const uint16_t* w1, const float* b1, c
 //   old: tail a stores y_a -> tail b reads it back as its residual -> tail c stores all of y_c;
 //   new: tail a stores a1 only -> tail b REBUILDS y_a (rc = 1) -> tail c stores y_c at even (oh, ow) only (y_stride2; the buffer is pre-filled
 //        with `fill` so the caller sees what was not written).
-// Outputs: yb / zb [M][256] / [M][64], yc / zc [M][256] / [M][128], once per route (index 0 old, 1 new).
+//   new2: as new, but tail b stores its a1 too (no y_b at all) and tail c rebuilds BOTH previous outputs (rc = 2, btail_rc2_kernel).
+// Outputs: yb / zb [M][256] / [M][64], yc / zc [M][256] / [M][128], once per route (index 0 old, 1 new, 2 new2; yb[2] is left untouched).
 int opd_test_btail_chain(const uint16_t* x1, const uint16_t* xs, const uint16_t* const* w1, const float* const* b1, const uint16_t* const* w2,
                          const float* const* b2, const uint16_t* wsc, const uint16_t* const* w3, const float* const* b3, uint16_t* const* yb,
                          uint16_t* const* zb, uint16_t* const* yc, uint16_t* const* zc, int B, int H, int W, int fill) {
@@ -569,12 +570,13 @@ int opd_test_btail_chain(const uint16_t* x1, const uint16_t* xs, const uint16_t*
     uint16_t* ya = dm.up<uint16_t>(nullptr, M * 256);
     uint16_t* za = dm.up<uint16_t>(nullptr, M * 64);
     uint16_t* a1a = dm.up<uint16_t>(nullptr, M * 64);
+    uint16_t* a1b = dm.up<uint16_t>(nullptr, M * 64);
     uint16_t* d_yb = dm.up<uint16_t>(nullptr, M * 256);
     uint16_t* d_zb = dm.up<uint16_t>(nullptr, M * 64);
     uint16_t* d_yc = dm.up<uint16_t>(nullptr, M * 256);
     uint16_t* d_zc = dm.up<uint16_t>(nullptr, M * 128);
-    if (!d_x1 || !d_xs || !d_wsc || !ya || !za || !a1a || !d_yb || !d_zb || !d_yc || !d_zc) return tfail(OPD_ENOMEM, "test alloc failed");
-    for (int route = 0; route < 2; ++route) {
+    if (!d_x1 || !d_xs || !d_wsc || !ya || !za || !a1a || !a1b || !d_yb || !d_zb || !d_yc || !d_zc) return tfail(OPD_ENOMEM, "test alloc failed");
+    for (int route = 0; route < 3; ++route) {
         TCHK(hipMemset(ya, 0xEE, M * 256 * 2));
         TCHK(hipMemset(d_yc, fill, M * 256 * 2));
         auto base = [&](int i, const uint16_t* in, uint16_t* y, uint16_t* z, int c3) {
@@ -590,12 +592,20 @@ int opd_test_btail_chain(const uint16_t* x1, const uint16_t* xs, const uint16_t*
         BtailParams pb = base(1, za, d_yb, d_zb, 64);
         if (route) { pb.rc = 1; pb.rc_a1[0] = a1a; pb.rc_xs = d_xs; pb.rc_w2[0] = d_w2[0]; pb.rc_wsc = d_wsc; pb.rc_b[0] = d_b2[0]; }
         else pb.res = ya;
+        if (route == 2) { pb.y = nullptr; pb.a1_out = a1b; }
         TCHK(opd_launch_btail(pb, nullptr));
         BtailParams pc = base(2, d_zb, d_yc, d_zc, 128);
-        pc.res = d_yb; pc.y_stride2 = route;
+        pc.y_stride2 = route ? 1 : 0;
+        if (route == 2) {
+            pc.rc = 2; pc.rc_xs = d_xs; pc.rc_wsc = d_wsc;
+            pc.rc_a1[0] = a1b; pc.rc_w2[0] = d_w2[1]; pc.rc_b[0] = d_b2[1];
+            pc.rc_a1[1] = a1a; pc.rc_w2[1] = d_w2[0]; pc.rc_b[1] = d_b2[0];
+        } else {
+            pc.res = d_yb;
+        }
         TCHK(opd_launch_btail(pc, nullptr));
         TCHK(hipDeviceSynchronize());
-        TCHK(hipMemcpy(yb[route], d_yb, M * 256 * 2, hipMemcpyDeviceToHost));
+        if (route < 2) TCHK(hipMemcpy(yb[route], d_yb, M * 256 * 2, hipMemcpyDeviceToHost));
         TCHK(hipMemcpy(zb[route], d_zb, M * 64 * 2, hipMemcpyDeviceToHost));
         TCHK(hipMemcpy(yc[route], d_yc, M * 256 * 2, hipMemcpyDeviceToHost));
         TCHK(hipMemcpy(zc[route], d_zc, M * 128 * 2, hipMemcpyDeviceToHost));

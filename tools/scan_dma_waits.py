@@ -16,7 +16,7 @@ usage: scan_dma_waits.py [kernels_*.hip ...]   (default: every kernel file; exit
 import os, re, subprocess, sys, tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-CSRC = os.path.join(ROOT, "office_person_detection_vit_amd", "csrc")
+CSRC = os.environ.get("OPD_SCAN_CSRC") or os.path.join(ROOT, "office_person_detection_vit_amd", "csrc")   # (another revision's sources: a worktree's csrc)
 sys.path.insert(0, ROOT)
 from office_person_detection_vit_amd.csrc import build as B   # noqa: E402
 
@@ -25,7 +25,7 @@ bad = checked = 0
 for f in files:
     path = f if os.path.isabs(f) else os.path.join(CSRC, f)
     base = os.path.basename(path)
-    variants = [("f16", [])] + ([("bf16", B.BF16_FLAGS)] if base in B.ELEM_SOURCES else [])
+    variants = [("f16", [])] + ([("bf16", B.BF16_FLAGS)] if base in B.ELEM_SOURCES and os.path.exists(os.path.join(CSRC, "opd_elem.h")) else [])
     for tag, vflags in variants:
         with tempfile.NamedTemporaryFile(suffix=".s") as tmp:
             cmd = [B.hipcc_path()] + B.COMMON_FLAGS + B.EXTRA_FLAGS.get(base, []) + vflags + ["-S", "--cuda-device-only", "-I" + CSRC, path, "-o", tmp.name]
