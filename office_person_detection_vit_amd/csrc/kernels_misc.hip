@@ -640,6 +640,28 @@ hipError_t OPD_SYM(opd_launch_reduce_ln_pos)(const float* partials, int nsplit, 
     return hipGetLastError();
 }
 
+// Split-K reduction of a convolution: fp32 slabs summed in slice order (deterministic; slab 0 carries the bias), ReLU, one rounding to the
+// 16-bit operand type.  8 elements per thread (two 16-byte loads per slab, one 16-byte store).
+static __global__ __launch_bounds__(256) void reduce_act16_kernel(const float* __restrict__ partials, int nsplit, size_t slab_stride, f16_t* __restrict__ out,
+                                                           size_t n8, int relu) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n8) return;
+    const size_t o = i * 8;
+    float4v a = *reinterpret_cast<const float4v*>(partials + o), b = *reinterpret_cast<const float4v*>(partials + o + 4);
+    for (int z = 1; z < nsplit; ++z) {
+        a += *reinterpret_cast<const float4v*>(partials + z * slab_stride + o);
+        b += *reinterpret_cast<const float4v*>(partials + z * slab_stride + o + 4);
+    }
+    typedef elem_t half8v __attribute__((ext_vector_type(8)));
+    half8v h;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        h[r] = (elem_t)(relu && a[r] < 0.f ? 0.f : a[r]);
+        h[4 + r] = (elem_t)(relu && b[r] < 0.f ? 0.f : b[r]);
+    }
+    *reinterpret_cast<half8v*>(reinterpret_cast<elem_t*>(out) + o) = h;
+}
+
 // Diagnostic tap (opd_test_set_taps): position-weighted 64-bit sum of a buffer's 32-bit words, one partial per block.
 static __global__ void checksum_kernel(const uint32_t* __restrict__ buf, size_t nwords, unsigned long long* __restrict__ slots) {
     __shared__ unsigned long long part[256];
@@ -661,6 +683,12 @@ hipError_t opd_launch_checksum(const void* buf, size_t bytes, unsigned long long
     return hipGetLastError();
 }
 #endif
+
+hipError_t OPD_SYM(opd_launch_reduce_act16)(const float* partials, int nsplit, size_t slab_stride, f16_t* out, size_t n, int relu, hipStream_t stream) {
+    if (nsplit < 1 || n == 0 || (n % 8) != 0 || (slab_stride % 4) != 0) return hipErrorInvalidValue;
+    OPD_LAUNCH(reduce_act16_kernel, dim3((unsigned)((n / 8 + 255) / 256)), dim3(256), 0, stream, partials, nsplit, slab_stride, out, n / 8, relu);
+    return hipGetLastError();
+}
 
 hipError_t OPD_SYM(opd_launch_cast_f16)(const float* x, f16_t* y, size_t n, hipStream_t stream) {
     OPD_LAUNCH(cast_f16_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, stream, x, y, n);

@@ -49,3 +49,6 @@ hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t sl
     return OPD_PICK(opd_launch_reduce_ln_pos, dtype, partials, nsplit, slab_stride, residual, gamma, beta, y, y16, rows, pos, pos_ptrs, period, yp16, s);
 }
 hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t s, int dtype) { return OPD_PICK(opd_launch_cast_f16, dtype, x, y, n, s); }
+hipError_t opd_launch_reduce_act16(const float* partials, int nsplit, size_t slab_stride, f16_t* out, size_t n, int relu, hipStream_t s, int dtype) {
+    return OPD_PICK(opd_launch_reduce_act16, dtype, partials, nsplit, slab_stride, out, n, relu, s);
+}

@@ -264,6 +264,8 @@ hipError_t opd_launch_reduce_ln_pos(const float* partials, int nsplit, size_t sl
 hipError_t opd_launch_broadcast_rows(const float* c, float* y, f16_t* y16, int rows, hipStream_t stream, int dtype = 0);
 // fp32 -> fp16 cast of n elements (n % 8 == 0 not required).
 hipError_t opd_launch_cast_f16(const float* x, f16_t* y, size_t n, hipStream_t stream, int dtype = 0);
+// split-K convolution: out[i] = act(sum_z partials[z * slab_stride + i]) rounded once to the operand type (n % 8 == 0)
+hipError_t opd_launch_reduce_act16(const float* partials, int nsplit, size_t slab_stride, f16_t* out, size_t n, int relu, hipStream_t stream, int dtype = 0);
 // diagnostic tap: position-weighted 64-bit sums of `bytes / 4` words, OPD_TAP_BLOCKS partials written to slots[0 .. OPD_TAP_BLOCKS)
 #define OPD_TAP_BLOCKS 64
 hipError_t opd_launch_checksum(const void* buf, size_t bytes, unsigned long long* slots, hipStream_t stream);
@@ -426,3 +428,4 @@ OPD_DECL_ELEM(opd_launch_reduce_ln, const float* partials, int nsplit, size_t sl
 OPD_DECL_ELEM(opd_launch_reduce_ln_pos, const float* partials, int nsplit, size_t slab_stride, const float* residual, const float* gamma, const float* beta,
               float* y, f16_t* y16, int rows, const float* pos, const float* const* pos_ptrs, int period, f16_t* yp16, hipStream_t stream)
 OPD_DECL_ELEM(opd_launch_cast_f16, const float* x, f16_t* y, size_t n, hipStream_t stream)
+OPD_DECL_ELEM(opd_launch_reduce_act16, const float* partials, int nsplit, size_t slab_stride, f16_t* out, size_t n, int relu, hipStream_t stream)

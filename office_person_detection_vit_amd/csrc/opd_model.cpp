@@ -368,6 +368,7 @@ int fill_qc0(opd_detr* m) {
     return OPD_OK;
 }
 
+static int conv_splits(const opd_detr* m, const Conv& c, int stage);   // (below, with run_conv)
 static int build_workspace(opd_detr* m) {
     const Arch& a = m->arch;
     // Frames may come in either orientation (the HF size rule maps a portrait camera frame to about 1333 x 750): the handle
@@ -402,7 +403,19 @@ static int build_workspace(opd_detr* m) {
     const size_t D = a.d_model, Md = B * a.queries;
     RCCHK(dalloc(m, &m->d_x32, M * D, false));
     RCCHK(dalloc(m, &m->d_y32, M * D, false));
-    RCCHK(dalloc(m, &m->d_slab, std::max(M * D * 4, Md * D * 8), false));
+    for (int s = 0; s < 4; ++s) m->stage_px[s] = lvl[2 + s];
+    m->slab_floats = std::max(M * D * 4, Md * D * 8);
+    for (size_t bi = 0; bi < m->blocks.size(); ++bi) {   // split-K plans of small handles (conv_splits): room for their fp32 slabs
+        int s = 0;
+        while (s + 1 < 4 && (int)bi >= m->stage_first[s + 1]) ++s;
+        const Block& b = m->blocks[bi];
+        const bool first = (int)bi == m->stage_first[s];
+        // c0 runs at the stage's INPUT resolution in its first block, c1 / c2 at the output resolution
+        const int s_c0 = first && s > 0 ? s - 1 : s;
+        m->slab_floats = std::max(m->slab_floats, (size_t)conv_splits(m, b.c0, s_c0) * B * m->stage_px[s_c0] * b.c0.Cout);
+        m->slab_floats = std::max(m->slab_floats, (size_t)conv_splits(m, b.c1, s) * B * m->stage_px[s] * b.c1.Cout);
+    }
+    RCCHK(dalloc(m, &m->d_slab, m->slab_floats, false));
     RCCHK(dalloc(m, &m->d_x16, M * D, false));
     RCCHK(dalloc(m, &m->d_xp16, M * D, false));
     RCCHK(dalloc(m, &m->d_qkv16, M * 3 * D, false));
@@ -543,14 +556,42 @@ static int tap(opd_detr* m, const char* name, const void* p, size_t bytes) {
     return OPD_OK;
 }
 
+// Split-K plan of a deep convolution for SMALL handles (round 5).  A max_batch = 1 handle at 800 x 1333 runs stage 4's 3x3 as 72 workgroups
+// that each walk 72 k-steps (50 us: the launch lasts one workgroup's life, 184 CUs idle); cut eight ways it is 576 workgroups of 9 k-steps
+// plus a 3-us reduction.  The split follows the handle's CONFIGURATION (max_batch, the frame-size bounds, the layer), never the batch or frame
+// at hand -- a frame's low-order bits must not depend on the call it travels in -- and applies only where the unsplit launch would leave most
+// CUs without a workgroup.  Returns 1 (no split) or a divisor of the k-step count.
+static int conv_splits(const opd_detr* m, const Conv& c, int stage) {
+    if (!m->small_splitk || stage < 0 || stage > 3 || c.stem || c.K % 64 != 0 || c.Cout % 64 != 0) return 1;
+    const long long px = (long long)m->cfg.max_batch * (long long)m->stage_px[stage];
+    const long long tiles = ((px + 127) / 128) * (c.Cout / 64);
+    const int nk = c.K / 64;
+    if (tiles > 160 || nk < 24) return 1;
+    int best = 1;
+    for (int s : {2, 3, 4, 6, 8})
+        if (nk % s == 0 && nk / s >= 6 && tiles * s <= 640) best = s;
+    return best;
+}
+
 static int run_conv(opd_detr* m, const Conv& c, const f16_t* x, int B, int H, int W, int OH, int OW, void* out, bool relu,
-                    const f16_t* res16) {
+                    const f16_t* res16, int stage = -1) {
     ConvGemmParams p{}; p.dtype = m->dtype;
     p.x = x; p.w = c.w; p.bias = c.bias; p.res16 = res16; p.res32 = nullptr; p.out = out; p.out16_aux = nullptr; p.zero16 = m->zero_bias;
     p.B = B; p.H = H; p.W = W; p.Cin = c.Cin; p.OH = OH; p.OW = OW; p.N = c.Cout; p.KH = c.KH; p.KW = c.KW;
     p.stride = c.stride; p.pad = c.pad; p.M = B * OH * OW; p.K = c.K; p.relu = relu ? 1 : 0; p.bias_period = 0;
     p.out_f32 = 0; p.stem = c.stem ? 1 : 0; p.dbg = m->dbg_gemm; p.wprefetch = m->wprefetch & 1;
     // algorithmic FLOPs (2 x MAC over the real taps/channels; the stem's zero padding is not counted)
+    if (const int splits = res16 ? 1 : conv_splits(m, c, stage); splits > 1 && (size_t)splits * p.M * c.Cout <= m->slab_floats) {
+        p.out = m->d_slab; p.out_f32 = 1; p.relu = 0; p.split_k = splits;
+        RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)c.Cout * c.KH * c.KW * c.Cin));
+        HIPCHK(opd_launch_conv_gemm(p, m->stream));
+        RCCHK(timed_end(m));
+        RCCHK(timed_begin(m, CLS_OTHER, 0.0));
+        HIPCHK(opd_launch_reduce_act16(m->d_slab, splits, (size_t)p.M * c.Cout, reinterpret_cast<f16_t*>(out), (size_t)p.M * c.Cout, relu ? 1 : 0, m->stream, m->dtype));
+        RCCHK(timed_end(m));
+        RCCHK(tap(m, c.KH == 3 ? "conv3x3" : "conv1x1", out, (size_t)p.M * c.Cout * 2));
+        return OPD_OK;
+    }
     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * (double)c.Cout * c.KH * c.KW * c.Cin));
     // Wide layers with few row tiles (stage 4) through the eight-wave kernel (kernels_w8.hip; identical bits).  The choice follows the handle's
     // CONFIGURATION (max_batch and the layer), never the batch at hand.  OPD_W8: bit 0 = 3x3, bit 1 = 1x1 with K >= 1024, bit 2 = 1x1 with K = 512.
@@ -811,7 +852,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                 } else {
                     x1_id = 0;
                     f16_t* c0out = mid(0, (size_t)ch * cw * b.c0.Cout);
-                    RCCHK(run_conv(m, b.c0, cur, nb, ch, cw, ch, cw, c0out, true, nullptr));
+                    RCCHK(run_conv(m, b.c0, cur, nb, ch, cw, ch, cw, c0out, true, nullptr, (l == 0 && s > 0) ? s - 1 : s));
                     x1 = c0out;
                 }
                 st.z_id = -1;
@@ -863,7 +904,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     if (C3) st.z_id = 1 - x1_id;
                 } else {
                     f16_t* a1 = mid(1 - x1_id, (size_t)oh * ow * C1);
-                    RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr));
+                    RCCHK(run_conv(m, b.c1, x1, nb, ch, cw, oh, ow, a1, true, nullptr, s));
                     if (sc_in_expand) {
                         ConvGemmParams p{}; p.dtype = m->dtype;
                         p.x = a1; p.w = b.w2sc; p.bias = b.bias2sc; p.out = out; p.zero16 = m->zero_bias;
@@ -1430,6 +1471,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_TAIL_RC")) m->tail_rc = atoi(v);
     if (const char* v = getenv("OPD_WPREFETCH")) m->wprefetch = atoi(v);
     if (const char* v = getenv("OPD_W8")) m->w8 = atoi(v);
+    if (const char* v = getenv("OPD_SMALL_SPLITK")) m->small_splitk = atoi(v);
     if (const char* v = getenv("OPD_Y_STRIDE2")) m->y_stride2 = atoi(v);
     if (const char* v = getenv("OPD_TAIL3_SPLIT")) m->tail3_split = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
@@ -1489,7 +1531,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
-    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8;
+    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8; m->small_splitk = src->small_splitk;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());

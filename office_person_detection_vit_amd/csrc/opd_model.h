@@ -219,6 +219,10 @@ struct opd_detr {
     int y_stride2 = 1;       // last tail of stage 1: y stored only where the next stage's stride-2 shortcut reads it (env OPD_Y_STRIDE2)
     int wprefetch = 3;       // L2 warm-up of a launch's weights by its own workgroups: bit 0 implicit GEMM, bit 1 the encoder's FFN launch (env OPD_WPREFETCH)
     int w8 = 0;              // wide stage-4 layers through the eight-wave GEMM (kernels_w8.hip): bit 0 3x3, bit 1 1x1 K >= 1024, bit 2 1x1 K = 512 (env OPD_W8)
+    int small_splitk = 1;    // handles whose deep convolutions would fill a fraction of the CUs (small max_batch x frame): split their reduction over
+                             // workgroups, fp32 slabs + reduce_act16_kernel (run_conv; env OPD_SMALL_SPLITK)
+    size_t slab_floats = 0;  // capacity of d_slab
+    size_t stage_px[4] = {}; // per-frame pixel bound of the four stages' OUTPUT maps (build_workspace): what configuration-level plans count tiles with
     int num_cus = 256;
     int tail3_split = 1;     // stage 3: frames beyond whole rounds of the fused tail run as a second chain on `stream2` (0: one launch per tail)
     int dual_over_tail = 1;  // first block of stage 2: 3x3 + dual-source expand instead of shortcut launch + fused tail (-17 us)
