@@ -38,5 +38,9 @@ timeout -k 10 200 python tools/bench_dec.py > $O/bench_dec.txt 2>&1 &&
 timeout -k 10 120 tools/microbench/vmorder > $O/microbench_vmorder.txt 2>&1 &&
 timeout -k 10 300 python tools/host_rate_ref_pattern.py > $O/host_rate_ref_pattern.txt 2>&1 &&
 timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline --steps 300 > $O/bench_bf16.json 2> $O/bench_bf16.err &&
+timeout -k 10 120 tools/microbench/mfma_peak > $O/microbench_mfma_peak.txt 2>&1 &&
+OPD_BENCH_FORCE_COMM=1 timeout -k 10 300 python bench.py --steps 300 --no-cpu-baseline --serial-steps 0 > $O/bench_forced_comm_1rank.json 2> $O/bench_forced_comm.err &&
+OPD_BENCH_SUSTAINED=0 timeout -k 10 300 python bench.py --batch 1 --streams 1 --steps 400 --no-cpu-baseline > $O/bench_batch1.json 2> $O/bench_batch1.err &&
+timeout -k 10 400 tools/abl_forward.sh $O/abl 400 > $O/abl_forward.txt 2>&1 &&
 du -sh $O
 fi
