@@ -404,7 +404,7 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_x32, M * D, false));
     RCCHK(dalloc(m, &m->d_y32, M * D, false));
     for (int s = 0; s < 4; ++s) m->stage_px[s] = lvl[2 + s];
-    m->slab_floats = std::max(M * D * 4, Md * D * 8);
+    m->slab_floats = std::max(M * D * 8, Md * D * 8);   // (split-K slabs of the encoder side: 4 slices, 8 for small handles)
     for (size_t bi = 0; bi < m->blocks.size(); ++bi) {   // split-K plans of small handles (conv_splits): room for their fp32 slabs
         int s = 0;
         while (s + 1 < 4 && (int)bi >= m->stage_first[s + 1]) ++s;
@@ -1013,11 +1013,17 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         (void)lin;
         return OPD_OK;
     };
-    const bool deep_ok = m->deep_fc2 && D == 256;
+    // Small handles (round 5): the row-owner launches of the encoder side own 48 / 64 rows per workgroup and stream a whole weight matrix through
+    // each -- at max_batch = 1 that is 22 workgroups walking 2.2 MB apiece (42 us per layer, 27 us for the input projection).  Where the handle's
+    // CONFIGURATION bounds the token count below ~1400 the same linears run as tiled GEMMs with the reduction split eight ways over workgroups
+    // and the fixed-order reduce + LayerNorm kernel (the round-1 path): encoder stage 0.41 -> 0.32 ms at batch 1.  Never per batch.
+    const bool small_enc = m->small_enc && (size_t)m->cfg.max_batch * m->stage_px[3] <= 1400;
+    const int enc_splits = small_enc ? 8 : 4;
+    const bool deep_ok = m->deep_fc2 && D == 256 && !small_enc;
     if (deep_ok && m->proj.K % 64 == 0 && (size_t)M * m->proj.K * 2 < 0x7fffff00ull)
         RCCHK(run_deep(cur, nullptr, m->proj.w, m->proj.bias, m->proj.K, nullptr, nullptr, CLS_CONV));
     else
-        RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV, ps));
+        RCCHK(run_gemm_splitk_ln(m, cur, m->proj.w, m->proj.bias, M, D, m->proj.K, (m->proj.K / 64) % enc_splits == 0 ? enc_splits : 4, nullptr, nullptr, m->d_x32, m->d_x16, CLS_CONV, ps));
     bool qkv_done = false, kv_done = false;
     const int Q = a.queries, Md = B * Q, NKV = a.dec_layers * 2 * D;
     for (int i = 0; i < a.enc_layers; ++i) {
@@ -1028,7 +1034,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
         else
             RCCHK(run_gemm(m, m->d_x16, L.wqkv, plan->rb_enc[i], hw, M, 3 * D, D, m->d_qkv16, false, false, nullptr, enc_bias_ptrs[i], 3 * D, 2 * D));   // (pos enters q and k only)
         RCCHK(run_attn(m, m->d_qkv16, 3 * D, m->d_qkv16 + D, 3 * D, m->d_qkv16 + 2 * D, 3 * D, m->d_attn16, D, B, hw, hw, d_keyv, cw));
-        const bool ffn_fused = m->fused_enc_ffn && m->fuse_gemm_ln && L.ffn_pack && D == 256;
+        const bool ffn_fused = m->fused_enc_ffn && m->fuse_gemm_ln && L.ffn_pack && D == 256 && !small_enc;
         const bool front = ffn_fused && L.front && m->enc_front;   // the output projection + LayerNorm run inside the FFN launch
         if (front) {
         } else if (m->fuse_gemm_ln && D == 256) {
@@ -1068,7 +1074,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
             if (deep_ok && F % 64 == 0 && (size_t)M * F * 2 < 0x7fffff00ull) {
                 RCCHK(run_deep(m->d_ffn16, nullptr, L.fc2.w, L.fc2.b, F, m->d_x32, &L.ln2, CLS_GEMM));
             } else {
-                RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM, ps));
+                RCCHK(run_gemm_splitk_ln(m, m->d_ffn16, L.fc2.w, L.fc2.b, M, D, F, (F / 64) % enc_splits == 0 ? enc_splits : 4, m->d_x32, &L.ln2, m->d_x32, m->d_x16, CLS_GEMM, ps));
             }
         }
     }
@@ -1472,6 +1478,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_WPREFETCH")) m->wprefetch = atoi(v);
     if (const char* v = getenv("OPD_W8")) m->w8 = atoi(v);
     if (const char* v = getenv("OPD_SMALL_SPLITK")) m->small_splitk = atoi(v);
+    if (const char* v = getenv("OPD_SMALL_ENC")) m->small_enc = atoi(v);
     if (const char* v = getenv("OPD_Y_STRIDE2")) m->y_stride2 = atoi(v);
     if (const char* v = getenv("OPD_TAIL3_SPLIT")) m->tail3_split = atoi(v);
     if (const char* v = getenv("OPD_FUSE_PREP")) m->fuse_prep = atoi(v);
@@ -1531,7 +1538,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
-    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8; m->small_splitk = src->small_splitk;
+    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8; m->small_splitk = src->small_splitk; m->small_enc = src->small_enc;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());

@@ -221,6 +221,8 @@ struct opd_detr {
     int w8 = 0;              // wide stage-4 layers through the eight-wave GEMM (kernels_w8.hip): bit 0 3x3, bit 1 1x1 K >= 1024, bit 2 1x1 K = 512 (env OPD_W8)
     int small_splitk = 1;    // handles whose deep convolutions would fill a fraction of the CUs (small max_batch x frame): split their reduction over
                              // workgroups, fp32 slabs + reduce_act16_kernel (run_conv; env OPD_SMALL_SPLITK)
+    int small_enc = 1;       // handles bounded to <= 1400 tokens: the encoder side's deep linears as split-K GEMMs + reduce / LayerNorm instead of the
+                             // row-owner launches (enqueue_forward; env OPD_SMALL_ENC)
     size_t slab_floats = 0;  // capacity of d_slab
     size_t stage_px[4] = {}; // per-frame pixel bound of the four stages' OUTPUT maps (build_workspace): what configuration-level plans count tiles with
     int num_cus = 256;

@@ -1,17 +1,15 @@
 #!/bin/bash
-# Copy the summaries of tools/final_artifacts.sh (gpurun_out/final/) into profiles/ under this round's names.
-# usage: tools/collect_profiles.sh r03
+# Copy the summaries of tools/final_artifacts.sh (gpurun_out/final/: made on the GPU box, the raw traces stay there) into profiles/ under this
+# round's names.   usage: tools/collect_profiles.sh r05
 set -e
-R=${1:?round tag, e.g. r03}
+R=${1:?round tag, e.g. r05}
 O=gpurun_out/final
 P=profiles
 tail -n 1 $O/bench.json > $P/${R}_bench_default_k1000.json
 tail -n 1 $O/bench_k20.json > $P/${R}_bench_default_k20.json
-cp $(ls -t $O/prof_default/*/*_kernel_stats.csv | head -n 1) $P/${R}_bench_default_kernel_stats.csv
-cp $(ls -t $O/prof_streams1/*/*_kernel_stats.csv | head -n 1) $P/${R}_bench_streams1_kernel_stats.csv
-python tools/timeline.py $(ls -t $O/prof_streams1/*/*_kernel_trace.csv | head -n 1) --all > $P/${R}_bench_streams1_timeline.txt
-python tools/pmc_traffic.py $(ls -t $O/pmc_fetch/*/*_counter_collection.csv | head -n 1) $(ls -t $O/pmc_write/*/*_counter_collection.csv | head -n 1) $P/${R}_pmc_traffic.json
-python tools/pmc_mfma.py $(ls -t $O/pmc_sq/*/*_counter_collection.csv | head -n 1) $P/${R}_pmc_sq.json > $P/${R}_pmc_sq_per_kernel.txt
+for f in bench_default_kernel_stats.csv bench_streams1_kernel_stats.csv bench_streams1_timeline.txt overlap_three_streams.txt pmc_traffic.json pmc_sq.json pmc_sq_per_kernel.txt parity_table.json; do
+  [ -f $O/$f ] && cp $O/$f $P/${R}_$f
+done
 for f in bench_gloo2:bench_gloo2_selflaunch_rehearsal bench_r101_1066x1920:bench_r101_1066x1920 bench_r50_tile1080p_b4:bench_r50_tile1080p_b4 bench_bf16:bench_bf16 bench_forced_comm_1rank:bench_forced_comm_1rank bench_batch1:bench_batch1_streams1; do
   [ -f $O/${f%%:*}.json ] && tail -n 1 $O/${f%%:*}.json > $P/${R}_${f##*:}.json
 done
@@ -19,5 +17,4 @@ for f in host_rate:host_boundary_rate trace_gemm:trace_gemm bench_layers:bench_l
   [ -f $O/${f%%:*}.txt ] && cp $O/${f%%:*}.txt $P/${R}_${f##*:}.txt
 done
 cp $O/smoke.log $P/${R}_smoke_parity.txt
-cp gpurun_out/parity_table.json $P/${R}_parity_table.json
 ls -la $P | grep ${R}_

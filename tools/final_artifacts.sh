@@ -21,7 +21,16 @@ timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/pro
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 --serial-steps 0 > $O/pmc_fetch.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --streams 1 --serial-steps 0 > $O/pmc_write.log 2>&1 &&
 timeout -k 10 300 rocprofv3 --pmc SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE --kernel-trace --output-format csv -d $O/pmc_sq -- python3 $R/bench.py --steps 2 --warmup 1 --streams 1 --no-cpu-baseline --serial-steps 0 > $O/pmc_sq.log 2>&1 &&
-cd $R && find $O -name "*.csv" | head -30 && du -sh $O
+cd $R &&
+# summaries are made HERE: the raw traces exceed what a gpurun call copies back (64 MiB)
+python tools/timeline.py $(ls -t $O/prof_streams1/*/*_kernel_trace.csv | head -n 1) --all > $O/bench_streams1_timeline.txt &&
+python tools/overlap.py $(ls -t $O/prof_default/*/*_kernel_trace.csv | head -n 1) > $O/overlap_three_streams.txt &&
+python tools/pmc_traffic.py $(ls -t $O/pmc_fetch/*/*_counter_collection.csv | head -n 1) $(ls -t $O/pmc_write/*/*_counter_collection.csv | head -n 1) $O/pmc_traffic.json &&
+python tools/pmc_mfma.py $(ls -t $O/pmc_sq/*/*_counter_collection.csv | head -n 1) $O/pmc_sq.json > $O/pmc_sq_per_kernel.txt &&
+cp $(ls -t $O/prof_default/*/*_kernel_stats.csv | head -n 1) $O/bench_default_kernel_stats.csv &&
+cp $(ls -t $O/prof_streams1/*/*_kernel_stats.csv | head -n 1) $O/bench_streams1_kernel_stats.csv &&
+cp gpurun_out/parity_table.json $O/parity_table.json &&
+rm -rf $O/prof_default $O/prof_streams1 $O/pmc_fetch $O/pmc_write $O/pmc_sq && du -sh $O
 else
 OPD_BENCH_BACKEND=gloo timeout -k 10 300 python bench.py --gpus 2 --steps 5 --warmup 2 --no-cpu-baseline > $O/bench_gloo2.json 2> $O/bench_gloo2.err && tail -1 $O/bench_gloo2.json | cut -c1-300 &&
 timeout -k 10 300 python tools/host_rate.py 96 > $O/host_rate.txt 2>&1 && timeout -k 10 300 python tools/host_rate.py 96 720 1280 >> $O/host_rate.txt 2>&1 && cat $O/host_rate.txt &&
