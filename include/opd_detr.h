@@ -222,10 +222,15 @@ OPD_API int opd_detr_attention_map(opd_detr* m, int frame, int layer, const int3
  * The reference has no distributed mode; the port it reserves for batched detectors is `DetectorPort.detect(frames: Sequence[FrameDTO])`
  * (`src/core/interfaces.py:30-34`, home `src/adapters/__init__.py:1`).  Frames are independent, so the path shards by frame: one process
  * per GPU, each with its own detector handle, and ONE RCCL all-gather of fixed-size records per exchange (opd_det x num_queries per frame
- * slot + one int32 count per slot; count -1 = the slot holds no frame).  A communicator is bound to one handle and works on that
- * handle's stream: forward -> post-process (writes the send buffer) -> ncclAllGather -> copy to page-locked host memory, one host wait
- * (opd_comm_wait).  RCCL is resolved at run time (librccl.so.1); single-GPU callers never load it.  The 128-byte unique id travels from
- * rank 0 to the other ranks by whatever launched them (file, socket, MPI, a torch.distributed store): the library does no rendezvous. */
+ * slot + one int32 count per slot; count -1 = the slot holds no frame).  An `opd_comm` is a LANE: one detector handle's send / receive
+ * buffers and events on a communicator that all lanes of the rank share (opd_comm_create makes the communicator and its first lane,
+ * opd_comm_attach further lanes for further handles).  A step: forward -> post-process (writes the lane's send buffer) on the HANDLE's stream;
+ * ncclAllGather -> copy to page-locked host memory on the COMMUNICATOR's own stream, which waits for the handle's stream through an event;
+ * one host wait (opd_comm_wait).  All all-gathers of a rank are enqueued on that one stream in the order opd_comm_exchange was called: every
+ * rank must call it in the same order across its lanes.  RCCL is resolved at run time (librccl.so.1); single-GPU callers never load it.
+ * The 128-byte unique id travels from rank 0 to the other ranks by whatever launched them (file, socket, MPI, a torch.distributed store):
+ * the library does no rendezvous.  ncclCommInitRank blocks until every rank has arrived: callers check opd_comm_available() on every rank
+ * and agree on it first, and bound the set-up with a watchdog of their own (sharding.py, bench.py). */
 typedef struct opd_comm opd_comm;
 #define OPD_COMM_ID_BYTES 128
 OPD_API int opd_comm_available(void);          /* OPD_OK when librccl could be resolved in this process: every rank checks BEFORE any rank enters the collective set-up */
