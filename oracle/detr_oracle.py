@@ -267,8 +267,25 @@ class _SiteQuant:
         return t.to(self.dt).to(torch.float32) if self.on(site) else t
 
 
-def _quantizer(mode: Optional[str], sites=None):
-    return None if mode is None else _SiteQuant(mode, sites)
+class _MixedQuant:
+    """fp16 storage everywhere, bf16 at the sites whose name starts with one of `bf16_sites` (tools/mixed_bf16_probe.py: what a mixed
+    operand mode would cost in box drift).  Same interface as _SiteQuant."""
+
+    def __init__(self, bf16_sites):
+        self.bf16_sites = tuple(bf16_sites)
+
+    def on(self, site: Optional[str]) -> bool:
+        return True
+
+    def __call__(self, t, site: Optional[str] = None):
+        dt = torch.bfloat16 if (site is not None and any(site.startswith(p) for p in self.bf16_sites)) else torch.float16
+        return t.to(dt).to(torch.float32)
+
+
+def _quantizer(mode, sites=None):
+    if mode is None or isinstance(mode, str):
+        return None if mode is None else _SiteQuant(mode, sites)
+    return mode   # a quantizer object (_MixedQuant)
 
 
 def _weight_site(k: str) -> Optional[str]:
