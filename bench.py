@@ -364,20 +364,18 @@ def main() -> int:
                     detect_blocking(handles[0], d_flats[0])
                 out = collect(d_flats[0], 0)
             return out
-        # NS steps stay submitted ahead (one per handle).  Plain handles: step i - NS is collected right after step i has been submitted
-        # (rotating output buffers: 2 NS of them).  Native exchange: a communicator lane owns ONE send / receive buffer set, so step i - NS
-        # is collected BEFORE step i is submitted on the same lane (opd_comm_begin refuses a lane whose exchange has not been waited for).
+        # NS steps stay submitted ahead (one per handle); step i - NS is collected right after step i has been submitted.  Plain handles
+        # rotate 2 NS output buffers; a communicator lane owns TWO send / receive buffer sets (csrc/opd_comm.cpp: LaneSet), so step i fills
+        # one while step i - NS travels in the other -- the same loop either way.  (Round 4's lanes had one set, and this loop raised
+        # OPD_ESTATE at step NS: ADVICE r4.)
         tickets = {}
         for i in range(n + NS):
-            j = i - NS
-            if comms and j >= 0:
-                tickets.pop(j)
-                out = collect(None, j)
             if i < n:
                 tickets[i] = submit(i)
-            if not comms and j >= 0:
+            j = i - NS
+            if j >= 0:
                 t = tickets.pop(j)
-                if not rehearsal:
+                if not rehearsal and not comms:
                     _capi.check(lib.opd_detr_wait(handles[j % NS], t), "opd_detr_wait")
                 out = collect(d_flats[j % (2 * NS)], j)
         return out

@@ -245,7 +245,9 @@ OPD_API int opd_comm_attach(opd_comm* parent, opd_detr* m, opd_comm** out);
  * then return OPD_ESTATE from every call and only opd_comm_destroy remains valid on them. */
 OPD_API void opd_comm_destroy(opd_comm* c);
 OPD_API int opd_comm_info(const opd_comm* c, int* rank, int* world);
-/* One exchange = begin(slots) ; detect(slot0, frames ...) once or several times (a shard larger than max_batch goes in chunks) ; exchange ;
+/* A lane holds up to TWO exchanges: while one travels (issued, not yet waited for) the next may be begun, filled and issued; opd_comm_wait
+ * delivers them oldest first; a third opd_comm_begin returns OPD_ESTATE.
+ * One exchange = begin(slots) ; detect(slot0, frames ...) once or several times (a shard larger than max_batch goes in chunks) ; exchange ;
  * wait.  `slots` = frame slots per rank, the same number on every rank (an uneven shard leaves trailing slots at count -1).
  * opd_comm_detect = opd_detr_detect_async into the send buffer at slot0 (arguments as there); nothing synchronises before opd_comm_wait,
  * which delivers every rank's records: out_all [world][slots][num_queries], counts_all [world][slots] (host). */

@@ -89,30 +89,51 @@ struct CommShared {
     }
 };
 
-struct opd_comm {
-    std::shared_ptr<CommShared> sh;
-    opd_detr* m = nullptr;      // the handle this lane is bound to (its stream produces the records); null once that handle has been destroyed
-    int slots = 0;              // frame slots per rank of the current exchange
+// One exchange's buffers and events.  A lane owns TWO of them, used in turn: while exchange k travels (its all-gather and copy on the
+// communicator's stream), the handle's next forward fills the send buffer of exchange k + 1 -- the same depth the plain asynchronous path has
+// with its rotating output buffers, so the bench's pipelined loop (submit step i, then collect step i - NS) is the same with and without the
+// exchange.  (With one set the loop had to collect before it submitted: -3 % on one GPU, profiles/r05_ab_runs.txt.)
+struct LaneSet {
     int32_t* d_send = nullptr;  // [slots * Q * 8 record words][slots counts]
     int32_t* d_recv = nullptr;  // [world] x the same
     int32_t* h_recv = nullptr;  // page-locked copy of d_recv
     size_t cap_words = 0;       // words per rank the buffers hold
-    hipEvent_t ready = nullptr; // recorded on the handle's stream behind the post-process kernel(s) of an exchange
+    int slots = 0;              // frame slots per rank of this exchange
+    hipEvent_t ready = nullptr; // recorded on the handle's stream behind the post-process kernel(s) of the exchange
     hipEvent_t done = nullptr;  // recorded on the communicator's stream behind the copy to h_recv
-    bool pending = false;
+    int state = 0;              // 0 idle, 1 begun (being filled), 2 exchanged (travelling / arrived, not yet waited for)
+};
+
+struct opd_comm {
+    std::shared_ptr<CommShared> sh;
+    opd_detr* m = nullptr;      // the handle this lane is bound to (its stream produces the records); null once that handle has been destroyed
+    LaneSet set[2];
+    unsigned n_begun = 0, n_waited = 0;   // exchanges begun / waited for: exchange k lives in set[k & 1]
 };
 
 namespace {
 std::mutex g_lanes_mu;   // guards opd_detr::comms (the lanes bound to a handle)
 
+void free_set(LaneSet& s) {
+    if (s.d_send) (void)hipFree(s.d_send);
+    if (s.d_recv) (void)hipFree(s.d_recv);
+    if (s.h_recv) (void)hipHostFree(s.h_recv);
+    s.d_send = s.d_recv = s.h_recv = nullptr;
+    s.cap_words = 0;
+}
+
 int make_lane(std::shared_ptr<CommShared> sh, opd_detr* m, opd_comm** out) {
     std::unique_ptr<opd_comm> c(new (std::nothrow) opd_comm());
     if (!c) return fail(OPD_ENOMEM, "opd_comm: out of host memory");
     c->sh = std::move(sh); c->m = m;
-    if (hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->done, hipEventDisableTiming) != hipSuccess) {
-        if (c->ready) (void)hipEventDestroy(c->ready);
-        return fail(OPD_EHIP, "opd_comm: hipEventCreate failed");
-    }
+    for (LaneSet& s : c->set)
+        if (hipEventCreateWithFlags(&s.ready, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess) {
+            for (LaneSet& t : c->set) {
+                if (t.ready) (void)hipEventDestroy(t.ready);
+                if (t.done) (void)hipEventDestroy(t.done);
+            }
+            return fail(OPD_EHIP, "opd_comm: hipEventCreate failed");
+        }
     {
         std::lock_guard<std::mutex> lk(g_lanes_mu);
         m->comms.push_back(c.get());
@@ -124,6 +145,8 @@ int make_lane(std::shared_ptr<CommShared> sh, opd_detr* m, opd_comm** out) {
     do {                                                                                                                         \
         if (!(c)->m) return fail(OPD_ESTATE, what ": the detector handle this communicator lane was bound to has been destroyed"); \
     } while (0)
+// the exchange being filled (begun, not yet exchanged), or null
+LaneSet* open_set(opd_comm* c) { return c->n_begun > 0 && c->set[(c->n_begun - 1) & 1].state == 1 ? &c->set[(c->n_begun - 1) & 1] : nullptr; }
 }  // namespace
 
 // opd_detr_destroy: the handle's stream is about to go.  Its lanes stay valid objects (opd_comm_destroy still frees them) but refuse work.
@@ -132,7 +155,7 @@ void opd::comm_detach_all(opd_detr* m) {
     for (opd_comm* c : m->comms) {
         if (c->sh && c->sh->xstream) (void)hipStreamSynchronize(c->sh->xstream);   // (an exchange still in flight reads this handle's records)
         c->m = nullptr;
-        c->pending = false;
+        for (LaneSet& s : c->set) s.state = 0;
     }
     m->comms.clear();
 }
@@ -188,7 +211,7 @@ void opd_comm_destroy(opd_comm* c) {
     ApiScope api_scope;
     if (!c) return;
     (void)hipSetDevice(c->sh->device);
-    (void)hipStreamSynchronize(c->sh->xstream);   // this lane's exchange, if any, is over
+    (void)hipStreamSynchronize(c->sh->xstream);   // this lane's exchanges, if any, are over
     if (c->m) {
         (void)hipStreamSynchronize(c->m->stream);
         std::lock_guard<std::mutex> lk(g_lanes_mu);
@@ -196,11 +219,11 @@ void opd_comm_destroy(opd_comm* c) {
         for (size_t i = 0; i < v.size(); ++i)
             if (v[i] == c) { v.erase(v.begin() + i); break; }
     }
-    if (c->d_send) (void)hipFree(c->d_send);
-    if (c->d_recv) (void)hipFree(c->d_recv);
-    if (c->h_recv) (void)hipHostFree(c->h_recv);
-    if (c->ready) (void)hipEventDestroy(c->ready);
-    if (c->done) (void)hipEventDestroy(c->done);
+    for (LaneSet& s : c->set) {
+        free_set(s);
+        if (s.ready) (void)hipEventDestroy(s.ready);
+        if (s.done) (void)hipEventDestroy(s.done);
+    }
     delete c;   // (the communicator and its stream go with the last lane: ~CommShared)
 }
 
@@ -208,17 +231,14 @@ int opd_comm_begin(opd_comm* c, int slots) {
     ApiScope api_scope;
     if (!c || slots < 1) return fail(OPD_EINVAL, "opd_comm_begin: bad argument");
     LANE_ALIVE(c, "opd_comm_begin");
-    if (c->pending) return fail(OPD_ESTATE, "opd_comm_begin: the previous exchange has not been waited for");
+    if (open_set(c)) return fail(OPD_ESTATE, "opd_comm_begin: the exchange begun before has not been issued (opd_comm_exchange)");
+    LaneSet& s = c->set[c->n_begun & 1];
+    if (s.state != 0) return fail(OPD_ESTATE, "opd_comm_begin: two exchanges of this lane are outstanding (opd_comm_wait the older one first)");
     opd_detr* m = c->m;
     HIPCHK(hipSetDevice(m->device));
     const size_t Q = (size_t)m->arch.queries, words = (size_t)slots * Q * 8 + (size_t)slots;
-    if (words > c->cap_words) {   // (grow only; not on the steady-state path)
-        HIPCHK(hipStreamSynchronize(m->stream));
-        HIPCHK(hipStreamSynchronize(c->sh->xstream));
-        if (c->d_send) (void)hipFree(c->d_send);
-        if (c->d_recv) (void)hipFree(c->d_recv);
-        if (c->h_recv) (void)hipHostFree(c->h_recv);
-        c->d_send = c->d_recv = c->h_recv = nullptr; c->cap_words = 0;
+    if (words > s.cap_words) {   // (grow only; not on the steady-state path.  The set is idle: nothing in flight reads or writes it)
+        free_set(s);
         void *a = nullptr, *b = nullptr, *h = nullptr;
         if (hipMalloc(&a, words * 4) != hipSuccess || hipMalloc(&b, words * 4 * c->sh->world) != hipSuccess ||
             hipHostMalloc(&h, words * 4 * c->sh->world, hipHostMallocDefault) != hipSuccess) {
@@ -226,12 +246,14 @@ int opd_comm_begin(opd_comm* c, int slots) {
             if (b) (void)hipFree(b);
             return fail(OPD_ENOMEM, "opd_comm_begin: exchange buffers");
         }
-        c->d_send = static_cast<int32_t*>(a); c->d_recv = static_cast<int32_t*>(b); c->h_recv = static_cast<int32_t*>(h);
-        c->cap_words = words;
+        s.d_send = static_cast<int32_t*>(a); s.d_recv = static_cast<int32_t*>(b); s.h_recv = static_cast<int32_t*>(h);
+        s.cap_words = words;
     }
-    c->slots = slots;
+    s.slots = slots;
     // every slot starts as "no frame" (count -1): a rank with fewer frames than slots leaves the rest that way
-    HIPCHK(hipMemsetAsync(c->d_send + (size_t)slots * Q * 8, 0xFF, (size_t)slots * 4, m->stream));
+    HIPCHK(hipMemsetAsync(s.d_send + (size_t)slots * Q * 8, 0xFF, (size_t)slots * 4, m->stream));
+    s.state = 1;
+    ++c->n_begun;
     return OPD_OK;
 }
 
@@ -242,46 +264,49 @@ int opd_comm_detect(opd_comm* c, int slot0, const void* pixels, int pixel_format
     LANE_ALIVE(c, "opd_comm_detect");
     opd_detr* m = c->m;
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
-    if (c->slots < 1 || slot0 < 0 || slot0 + B > c->slots) return fail(OPD_EINVAL, "opd_comm_detect: frames do not fit the slots of opd_comm_begin");
+    LaneSet* s = open_set(c);
+    if (!s || slot0 < 0 || slot0 + B > s->slots) return fail(OPD_EINVAL, "opd_comm_detect: frames do not fit the slots of opd_comm_begin");
     if (m->profiling) return fail(OPD_ESTATE, "opd_comm_detect is not available in profiling mode");
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
     RCCHK(run_forward(m, d_pixels, pixel_format, B, H, W, nullptr));
     const size_t Q = (size_t)m->arch.queries;
-    opd_det* recs = reinterpret_cast<opd_det*>(c->d_send) + (size_t)slot0 * Q;
-    int32_t* counts = c->d_send + (size_t)c->slots * Q * 8 + slot0;
+    opd_det* recs = reinterpret_cast<opd_det*>(s->d_send) + (size_t)slot0 * Q;
+    int32_t* counts = s->d_send + (size_t)s->slots * Q * 8 + slot0;
     return enqueue_postprocess(m, threshold, orig_hw, recs, counts);
 }
 
 int opd_comm_buffers(opd_comm* c, int slot0, void** records, void** counts) {
     if (!c || !records || !counts) return fail(OPD_EINVAL, "opd_comm_buffers: null argument");
     LANE_ALIVE(c, "opd_comm_buffers");
-    if (c->slots < 1 || slot0 < 0 || slot0 >= c->slots) return fail(OPD_EINVAL, "opd_comm_buffers: slot outside the exchange begun");
+    LaneSet* s = open_set(c);
+    if (!s || slot0 < 0 || slot0 >= s->slots) return fail(OPD_EINVAL, "opd_comm_buffers: slot outside the exchange begun");
     const size_t Q = (size_t)c->m->arch.queries;
-    *records = reinterpret_cast<opd_det*>(c->d_send) + (size_t)slot0 * Q;
-    *counts = c->d_send + (size_t)c->slots * Q * 8 + slot0;
+    *records = reinterpret_cast<opd_det*>(s->d_send) + (size_t)slot0 * Q;
+    *counts = s->d_send + (size_t)s->slots * Q * 8 + slot0;
     return OPD_OK;
 }
 
 int opd_comm_exchange(opd_comm* c) {
     ApiScope api_scope;
-    if (!c || c->slots < 1) return fail(OPD_EINVAL, "opd_comm_exchange: no exchange begun");
+    if (!c) return fail(OPD_EINVAL, "opd_comm_exchange: null communicator");
     LANE_ALIVE(c, "opd_comm_exchange");
-    if (c->pending) return fail(OPD_ESTATE, "opd_comm_exchange: the previous exchange has not been waited for");
+    LaneSet* s = open_set(c);
+    if (!s) return fail(OPD_EINVAL, "opd_comm_exchange: no exchange begun");
     opd_detr* m = c->m;
     CommShared& sh = *c->sh;
     HIPCHK(hipSetDevice(m->device));
-    const size_t words = (size_t)c->slots * m->arch.queries * 8 + (size_t)c->slots;
-    HIPCHK(hipEventRecord(c->ready, m->stream));   // behind the post-process kernel(s) that filled the send buffer
+    const size_t words = (size_t)s->slots * m->arch.queries * 8 + (size_t)s->slots;
+    HIPCHK(hipEventRecord(s->ready, m->stream));   // behind the post-process kernel(s) that filled the send buffer
     {
         std::lock_guard<std::mutex> lk(sh.mu);     // the rank's collectives in ONE order: the order the exchanges were submitted in
-        HIPCHK(hipStreamWaitEvent(sh.xstream, c->ready, 0));
-        NCCLCHK(rccl().AllGather(c->d_send, c->d_recv, words, ncclInt32, sh.comm, sh.xstream));
-        HIPCHK(hipMemcpyAsync(c->h_recv, c->d_recv, words * 4 * sh.world, hipMemcpyDeviceToHost, sh.xstream));
-        HIPCHK(hipEventRecord(c->done, sh.xstream));
+        HIPCHK(hipStreamWaitEvent(sh.xstream, s->ready, 0));
+        NCCLCHK(rccl().AllGather(s->d_send, s->d_recv, words, ncclInt32, sh.comm, sh.xstream));
+        HIPCHK(hipMemcpyAsync(s->h_recv, s->d_recv, words * 4 * sh.world, hipMemcpyDeviceToHost, sh.xstream));
+        HIPCHK(hipEventRecord(s->done, sh.xstream));
     }
-    c->pending = true;
+    s->state = 2;
     return OPD_OK;
 }
 
@@ -289,18 +314,20 @@ int opd_comm_wait(opd_comm* c, opd_det* out_all, int32_t* counts_all) {
     ApiScope api_scope;
     if (!c || !out_all || !counts_all) return fail(OPD_EINVAL, "opd_comm_wait: null argument");
     LANE_ALIVE(c, "opd_comm_wait");
-    if (!c->pending) return fail(OPD_ESTATE, "opd_comm_wait: no exchange outstanding");
+    LaneSet& s = c->set[c->n_waited & 1];   // the OLDEST exchange not yet waited for
+    if (c->n_waited == c->n_begun || s.state != 2) return fail(OPD_ESTATE, "opd_comm_wait: no exchange outstanding");
     HIPCHK(hipSetDevice(c->m->device));
     {
         ApiUnlocked unlocked;   // the step's ONE host wait -- for the remote ranks too: another thread's graph capture must not queue behind it
-        HIPCHK(hipEventSynchronize(c->done));
+        HIPCHK(hipEventSynchronize(s.done));
     }
-    const size_t Q = (size_t)c->m->arch.queries, nrec = (size_t)c->slots * Q * 8, words = nrec + c->slots;
+    const size_t Q = (size_t)c->m->arch.queries, nrec = (size_t)s.slots * Q * 8, words = nrec + s.slots;
     for (int r = 0; r < c->sh->world; ++r) {
-        memcpy(out_all + (size_t)r * c->slots * Q, c->h_recv + (size_t)r * words, nrec * 4);
-        memcpy(counts_all + (size_t)r * c->slots, c->h_recv + (size_t)r * words + nrec, (size_t)c->slots * 4);
+        memcpy(out_all + (size_t)r * s.slots * Q, s.h_recv + (size_t)r * words, nrec * 4);
+        memcpy(counts_all + (size_t)r * s.slots, s.h_recv + (size_t)r * words + nrec, (size_t)s.slots * 4);
     }
-    c->pending = false;
+    s.state = 0;
+    ++c->n_waited;
     return OPD_OK;
 }
 

@@ -315,12 +315,22 @@ def test_native_exchange_world_size_1(mild_path):
                 _capi.check(lib.opd_comm_detect(comm, 0, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 3, 256, 320, 0.5,
                                                 hw.ctypes.data_as(C.c_void_p)), "opd_comm_detect")
                 _capi.check(lib.opd_comm_exchange(comm), "opd_comm_exchange")
-                assert lib.opd_comm_begin(comm, 4) != 0            # an exchange is outstanding
+                # a lane holds TWO exchanges (round 5): the next one may be begun and issued while this one travels; a third is refused
+                _capi.check(lib.opd_comm_begin(comm, 4), "opd_comm_begin")
+                assert lib.opd_comm_begin(comm, 4) == _capi.OPD_ESTATE          # the one just begun has not been issued
+                _capi.check(lib.opd_comm_detect(comm, 1, frames[:2].ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320, 0.5,
+                                                hw.ctypes.data_as(C.c_void_p)), "opd_comm_detect")
+                _capi.check(lib.opd_comm_exchange(comm), "opd_comm_exchange")
+                assert lib.opd_comm_begin(comm, 4) == _capi.OPD_ESTATE          # two outstanding
                 got = np.zeros((1, 4, Q, 8), np.int32); got_c = np.zeros((1, 4), np.int32)
                 _capi.check(lib.opd_comm_wait(comm, got.ctypes.data_as(C.POINTER(_capi.OpdDet)), got_c.ctypes.data_as(C.POINTER(C.c_int32))), "opd_comm_wait")
-                assert got_c[0].tolist() == want_c.tolist() + [-1]
+                assert got_c[0].tolist() == want_c.tolist() + [-1]              # the OLDER exchange comes first
                 for f in range(3):
                     np.testing.assert_array_equal(got[0, f, :want_c[f]], want[f, :want_c[f]])
+                _capi.check(lib.opd_comm_wait(comm, got.ctypes.data_as(C.POINTER(_capi.OpdDet)), got_c.ctypes.data_as(C.POINTER(C.c_int32))), "opd_comm_wait")
+                assert got_c[0].tolist() == [-1] + want_c[:2].tolist() + [-1]   # frames 0, 1 in slots 1, 2
+                for f in range(2):
+                    np.testing.assert_array_equal(got[0, 1 + f, :want_c[f]], want[f, :want_c[f]])
             assert lib.opd_comm_wait(comm, got.ctypes.data_as(C.POINTER(_capi.OpdDet)), got_c.ctypes.data_as(C.POINTER(C.c_int32))) != 0   # nothing outstanding
             assert lib.opd_comm_detect(comm, 2, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 3, 256, 320, 0.5,
                                        hw.ctypes.data_as(C.c_void_p)) != 0                                                                  # slots 2..4 of 4
@@ -345,8 +355,8 @@ def test_native_exchange_world_size_1(mild_path):
 def test_communicator_lanes_share_one_communicator_and_survive_their_handles(mild_path):
     """Round 5: ONE RCCL communicator per rank with a LANE per detector handle (opd_comm_attach): own buffers and events, all all-gathers on
     the communicator's own stream in submission order.  (a) three lanes (handle + two clones), exchanges submitted on all three before any
-    is waited for, waited in another order: every lane delivers exactly what opd_detr_detect gives for ITS frames; (b) a lane refuses a second
-    begin while its exchange is outstanding, the others do not care; (c) lifetime: destroying a handle detaches its lanes -- they
+    is waited for, waited in another order: every lane delivers exactly what opd_detr_detect gives for ITS frames; (b) (a lane's own depth of two
+    exchanges: test_native_exchange_world_size_1); (c) lifetime: destroying a handle detaches its lanes -- they
     answer OPD_ESTATE from then on and opd_comm_destroy still frees them; lanes may be destroyed in any order, the parent first."""
     from office_person_detection_vit_amd.sharding import NativeExchange
     lib = _capi.load_library()
@@ -381,7 +391,6 @@ def test_communicator_lanes_share_one_communicator_and_survive_their_handles(mil
                 _capi.check(lib.opd_comm_detect(lanes[k], 0, batches[k].ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, 2, 256, 320, 0.5,
                                                 hw.ctypes.data_as(C.c_void_p)), "opd_comm_detect")
                 _capi.check(lib.opd_comm_exchange(lanes[k]), "opd_comm_exchange")
-            assert lib.opd_comm_begin(lanes[1], 2) == _capi.OPD_ESTATE
             for k in ((2, 0, 1), (0, 1, 2), (1, 2, 0))[rnd]:
                 got = np.zeros((1, 2, Q, 8), np.int32); got_c = np.zeros((1, 2), np.int32)
                 _capi.check(lib.opd_comm_wait(lanes[k], got.ctypes.data_as(DetP), got_c.ctypes.data_as(I32P)), "opd_comm_wait")
