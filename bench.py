@@ -591,12 +591,13 @@ def main() -> int:
             out["cpu_baseline"] = cpu_baseline(path, H, W)
             out["speedup_vs_cpu_baseline"] = round(fps / out["cpu_baseline"]["value"], 1)
         print(json.dumps(out), file=json_out, flush=True)
+    if world > 1:
+        dist.barrier()   # every rank leaves together: rank 0's local legs above are over, and no rank tears its communicator down while a peer is still at work
     for cx in comms:
         lib.opd_comm_destroy(cx)
     for hx in handles:
         lib.opd_detr_destroy(hx)
     if world > 1:
-        dist.barrier()   # every rank leaves together: rank 0's local legs above are over
         dist.destroy_process_group()
     return 0
 

@@ -14,6 +14,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 thread_local const char* opd_last_kernel_name = nullptr;
+thread_local int opd_dbg_skip_launch = 0;
 const char* opd_kernel_name(const char* fmt, ...) {
     char buf[160];
     va_list ap;

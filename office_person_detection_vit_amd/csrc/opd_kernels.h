@@ -24,11 +24,12 @@ enum { OPD_DT_F16 = 0, OPD_DT_BF16 = 1 };   // operand type of a launch: every k
 // Every launch notes the kernel's name for the per-kernel timing table (opd_detr_kernel_table: profiling mode 1).  Templates whose arguments are
 // template parameters of the launcher format the instantiation's name the way rocprofv3 prints it (opd_kernel_name).
 extern thread_local const char* opd_last_kernel_name;          // opd_host.cpp
+extern thread_local int opd_dbg_skip_launch;                   // timing ablation (OPD_DBG_SKIP, tools/abl_forward.sh): launches are noted, not made
 const char* opd_kernel_name(const char* fmt, ...);             // a process-lifetime string (call once per instantiation: function-local static)
 #define OPD_LAUNCH(kernel, ...)                       \
     do {                                              \
         opd_last_kernel_name = #kernel;               \
-        hipLaunchKernelGGL(kernel, __VA_ARGS__);      \
+        if (!opd_dbg_skip_launch) hipLaunchKernelGGL(kernel, __VA_ARGS__); \
     } while (0)
 #define OPD_BOOLSTR(b) ((b) ? "true" : "false")
 

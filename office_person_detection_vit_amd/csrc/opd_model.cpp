@@ -702,6 +702,7 @@ static int run_attn(opd_detr* m, const f16_t* q, int ldq, const f16_t* k, int ld
 #define MARK(i)                                                   \
     do {                                                          \
         if (m->profiling) HIPCHK(hipEventRecord(m->ev[i], m->stream)); \
+        opd_dbg_skip_launch = (m->dbg_skip >> (i)) & 1;           \
     } while (0)
 
 // Enqueues the whole forward on m->stream.  `pixels` must already be on the device.
@@ -1492,6 +1493,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_HEADS2")) m->heads2 = atoi(v);
     if (const char* v = getenv("OPD_DBG_DEC_LAYERS")) m->dbg_dec_layers = atoi(v);   // timing ablation (tools/dec_cost.sh): results are wrong
     if (const char* v = getenv("OPD_DBG_BTAIL")) m->dbg_btail = atoi(v);             // timing ablations of the whole forward: BtailParams::dbg / ConvGemmParams::dbg
+    if (const char* v = getenv("OPD_DBG_SKIP")) m->dbg_skip = atoi(v);               // bit i: no kernel launches in segment i of stage_ms (stem, stages 1-4, encoder, decoder, post-process)
     if (const char* v = getenv("OPD_DBG_GEMM")) m->dbg_gemm = atoi(v);               // of every fused tail / implicit-GEMM launch (results are wrong)
     m->device = device_ordinal;
     int ndev = 0;
@@ -1537,7 +1539,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->h_enc_cat_w = src->h_enc_cat_w; m->h_enc_cat_b = src->h_enc_cat_b; m->h_kv_cat_w = src->h_kv_cat_w; m->h_kv_cat_b = src->h_kv_cat_b;
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
-    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers;
+    m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers; m->dbg_skip = src->dbg_skip;
     m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8; m->small_splitk = src->small_splitk; m->small_enc = src->small_enc;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);

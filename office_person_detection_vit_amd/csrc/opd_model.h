@@ -149,6 +149,7 @@ struct opd_detr {
     int dec_splits = 3;        // key ranges of the fused decoder's cross-attention
     int dbg_btail = 0, dbg_gemm = 0;   // timing ablations only (OPD_DBG_BTAIL / OPD_DBG_GEMM): the kernels' dbg bits for every launch of the forward
     int dbg_dec_layers = 1 << 20;   // timing ablation only (OPD_DBG_DEC_LAYERS): run this many decoder layers
+    int dbg_skip = 0;               // timing ablation only (OPD_DBG_SKIP): bit i = segment i of stage_ms launches nothing
     LNp dec_ln;
     float *wc = nullptr, *bc = nullptr, *w1 = nullptr, *b1 = nullptr, *w2 = nullptr, *b2 = nullptr, *w3 = nullptr, *b3 = nullptr;
     f16_t *wc_f = nullptr, *w1_f = nullptr, *w2_f = nullptr;   // the heads' 256-wide layers as split fp16 pairs in fragment order (heads2_kernel)

@@ -1,6 +1,7 @@
 #!/bin/bash
 # Timing ablations of the WHOLE forward under the multi-stream bench (results are wrong; the question is which resource the headline rate
-# is sensitive to): OPD_DBG_BTAIL / OPD_DBG_GEMM set the kernels' dbg bits for every fused tail / implicit-GEMM launch.
+# is sensitive to): OPD_DBG_BTAIL / OPD_DBG_GEMM set the kernels' dbg bits for every fused tail / implicit-GEMM launch; OPD_DBG_SKIP
+# (bit i = segment i of stage_ms: stem, stages 1-4, encoder, decoder, post-process) leaves whole segments' launches out.
 #   usage: tools/abl_forward.sh <outdir> [steps]
 O=${1:?outdir}; K=${2:-600}
 mkdir -p $O
@@ -21,4 +22,10 @@ run btail_no3x3 OPD_DBG_BTAIL=1
 run gemm_nostore OPD_DBG_GEMM=64
 run gemm_nomfma OPD_DBG_GEMM=1
 run gemm_nodma OPD_DBG_GEMM=2
+run no_stage12 OPD_DBG_SKIP=6
+run no_stage34 OPD_DBG_SKIP=24
+run no_enc_dec OPD_DBG_SKIP=96
+run only_stage12 OPD_DBG_SKIP=120
+run only_stage34 OPD_DBG_SKIP=102
+run only_enc_dec OPD_DBG_SKIP=30
 run base2 X=0
