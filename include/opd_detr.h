@@ -171,6 +171,19 @@ OPD_API int opd_detr_wait(opd_detr* m, int ticket);
  * camera frame size (h, w). */
 OPD_API int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int H, int W,
                             float threshold, opd_det* out, int32_t* counts);
+/* The same for a LIST of host frames, one pointer per frame (what the reference hands a detector: detect_batch(frames: List[np.ndarray]),
+ * deleted vit_detector.py:508; DetectorPort.detect(frames: Sequence[FrameDTO]), src/core/interfaces.py:30-34): frames[b] = [h][w][3] uint8
+ * BGR, all of one size, each uploaded from where it lies -- no stacked copy of the batch on the host (25.6 MB at batch 8: 0.75 ms of a
+ * 3.4-ms step).  (h, w) == (H, W): no resize.  mem_kind: OPD_MEM_HOST or OPD_MEM_HOST_PIXELS_DEVICE_OUT (the frames are host memory). */
+OPD_API int opd_detr_detect_frames(opd_detr* m, const uint8_t* const* frames, int mem_kind, int B, int h, int w, int H, int W,
+                                   float threshold, opd_det* out, int32_t* counts);
+/* `detect_with_features(frame)` in ONE call (yolov8_detector.py:134-159: detect, then pool the encoder map under every detection's box,
+ * src/tracking/feature_extractor.py:39-88): opd_detr_detect_frames on host frames + the appearance feature of every record of class `label`
+ * (ROI mean-pool + L2 norm exactly as opd_detr_roi_features computes it for the record's box), pooled while the records are still on the
+ * device -- one host wait instead of two.  features: [B][num_queries][d_model] fp32 (host), row = the record's query_index; rows of queries
+ * without a record of that class are NOT written (whatever the buffer held).  Suppression (opd_person_nms) happens afterwards on the host: a suppressed record's row is simply unused. */
+OPD_API int opd_detr_detect_frames_features(opd_detr* m, const uint8_t* const* frames, int B, int h, int w, int H, int W, float threshold,
+                                            int label, opd_det* out, int32_t* counts, float* features);
 /* Ragged-batch form (see opd_detr_forward_ragged); `valid_hw` and `orig_hw` are host arrays. */
 OPD_API int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W,
                            const int32_t* valid_hw, float threshold, const int32_t* orig_hw, opd_det* out, int32_t* counts);

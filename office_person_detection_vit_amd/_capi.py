@@ -61,6 +61,9 @@ API = {
     "opd_detr_forward_resized": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_void_p] * 3),
     "opd_detr_resize_u8": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 5 + [C.c_void_p]),
     "opd_detr_detect_resized": (C.c_int, [C.c_void_p, C.c_void_p] + [C.c_int] * 6 + [C.c_float, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
+    "opd_detr_detect_frames": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)] + [C.c_int] * 6 + [C.c_float, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
+    "opd_detr_detect_frames_features": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)] + [C.c_int] * 5 + [C.c_float, C.c_int, C.POINTER(OpdDet), C.POINTER(C.c_int32),
+                                                   C.POINTER(C.c_float)]),
     "opd_detr_postprocess": (C.c_int, [C.c_void_p, C.c_float, C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),
     "opd_detr_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   C.c_void_p, C.POINTER(OpdDet), C.POINTER(C.c_int32)]),

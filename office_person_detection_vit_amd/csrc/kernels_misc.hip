@@ -484,22 +484,64 @@ __global__ __launch_bounds__(1024) void postprocess_kernel(PostParams p) {
     if (q == 127) p.counts[b] = pos + keep;
 }
 
-// One block (256 threads = channels) per ROI: mean over the ROI window of the [h][w][256] map, then L2 normalise.
-__global__ __launch_bounds__(256) void roi_features_kernel(const float* __restrict__ enc, const int32_t* __restrict__ rois,
-                                                           float* __restrict__ out, int h, int w) {
+// One block per ROI: mean over the ROI window of the [h][w][256] map, then L2 normalise.  1024 threads = 16 groups of 64 lanes; a lane owns 4
+// channels (one 16-byte load per position), group g takes the window positions g, g + 16, ... in row-major order, and the 16 partial sums of
+// a channel are added in group order: a fixed summation order whatever the window.  (The first form -- 256 threads, one channel each, a serial
+// loop over the whole window -- took ~90 us for a large box: up to 1050 dependent-latency iterations on one CU.)
+__device__ __forceinline__ void roi_pool_l2(const float* __restrict__ enc, float* __restrict__ out_row, const int x0, const int y0, const int x1,
+                                            const int y1, const int w, float (&part)[16][256], float (&red)[4]) {
+    const int t = threadIdx.x, g = t >> 6, l = t & 63;
+    const int bw = x1 - x0, n = (y1 - y0) * bw;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int p = g; p < n; p += 16) {
+        const int dy = p / bw, dx = p - dy * bw;
+        const float4 v = *reinterpret_cast<const float4*>(enc + ((size_t)(y0 + dy) * w + (x0 + dx)) * 256 + 4 * l);
+        acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+    *reinterpret_cast<float4*>(&part[g][4 * l]) = acc;
+    __syncthreads();
+    if (t < 256) {
+        float sum = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) sum += part[k][t];
+        const float mean = sum / (float)n;
+        const float ss = wave_sum(mean * mean);
+        if ((t & 63) == 0) red[t >> 6] = ss;
+        part[0][t] = mean;   // (row 0 has been read by this thread only)
+    }
+    __syncthreads();
+    if (t < 256) {
+        const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
+        out_row[t] = part[0][t] / (norm + 1e-8f);
+    }
+}
+__global__ __launch_bounds__(1024) void roi_features_kernel(const float* __restrict__ enc, const int32_t* __restrict__ rois,
+                                                            float* __restrict__ out, int h, int w) {
+    __shared__ float part[16][256];
     __shared__ float red[4];
     const int r = blockIdx.x;
-    const int c = threadIdx.x;
-    const int x0 = rois[r * 4], y0 = rois[r * 4 + 1], x1 = rois[r * 4 + 2], y1 = rois[r * 4 + 3];
-    float acc = 0.f;
-    for (int y = y0; y < y1; ++y)
-        for (int x = x0; x < x1; ++x) acc += enc[((size_t)y * w + x) * 256 + c];
-    const float mean = acc / (float)((y1 - y0) * (x1 - x0));
-    const float ss = wave_sum(mean * mean);
-    if ((c & 63) == 0) red[c >> 6] = ss;
-    __syncthreads();
-    const float norm = sqrtf(red[0] + red[1] + red[2] + red[3]);
-    out[(size_t)r * 256 + c] = mean / (norm + 1e-8f);
+    roi_pool_l2(enc, out + (size_t)r * 256, rois[r * 4], rois[r * 4 + 1], rois[r * 4 + 2], rois[r * 4 + 3], w, part, red);
+}
+// The same for the RECORDS the post-process kernel left on the device (opd_detr_detect_frames_features): block (i, b) takes record i of frame
+// b; a record of class `label` gets its feature in row `query_index` of out[b] (other rows are not written).  Box -> map window as
+// opd_detr_roi_features computes it on the host from the (x, y, w, h) float32 box of a `Detection` (feature_extractor.py:68-78): the width is
+// the float32 difference, the scaling runs in double, the casts truncate.
+__global__ __launch_bounds__(1024) void roi_features_rec_kernel(const float* __restrict__ enc, const DetRec* __restrict__ recs,
+                                                               const int32_t* __restrict__ counts, const int32_t* __restrict__ orig_hw, int label,
+                                                               float* __restrict__ out, int Q, int h, int w) {
+    __shared__ float part[16][256];
+    __shared__ float red[4];
+    const int i = blockIdx.x, b = blockIdx.y;
+    if (i >= counts[b]) return;
+    const DetRec r = recs[(size_t)b * Q + i];
+    if (r.label != label) return;
+    const double oh = (double)orig_hw[2 * b], ow = (double)orig_hw[2 * b + 1];
+    const double x = (double)r.x1, y = (double)r.y1, bw = (double)(r.x2 - r.x1), bh = (double)(r.y2 - r.y1);
+    int x0 = (int)((x / ow) * w), y0 = (int)((y / oh) * h);
+    int x1 = (int)(((x + bw) / ow) * w), y1 = (int)(((y + bh) / oh) * h);
+    x0 = max(0, min(x0, w - 1)); y0 = max(0, min(y0, h - 1));
+    x1 = max(x0 + 1, min(x1, w)); y1 = max(y0 + 1, min(y1, h));
+    roi_pool_l2(enc + (size_t)b * h * w * 256, out + ((size_t)b * Q + r.query_index) * 256, x0, y0, x1, y1, w, part, red);
 }
 
 // Cross-attention map (get_attention_map): mean over heads and over the selected queries of softmax(q . k^T * scale) for ONE frame and
@@ -789,7 +831,13 @@ hipError_t opd_launch_similarity_matrix(const float* f1, const float* b1, const 
 hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois, float* out, int n, int h, int w,
                                    hipStream_t stream) {
     if (n <= 0) return hipErrorInvalidValue;
-    OPD_LAUNCH(roi_features_kernel, dim3(n), dim3(256), 0, stream, enc, rois, out, h, w);
+    OPD_LAUNCH(roi_features_kernel, dim3(n), dim3(1024), 0, stream, enc, rois, out, h, w);
+    return hipGetLastError();
+}
+hipError_t opd_launch_roi_features_records(const float* enc, const void* records, const int32_t* counts, const int32_t* orig_hw, int label,
+                                           float* out, int B, int Q, int h, int w, hipStream_t stream) {
+    if (B <= 0 || Q <= 0 || h <= 0 || w <= 0 || !enc || !records || !counts || !orig_hw || !out) return hipErrorInvalidValue;
+    OPD_LAUNCH(roi_features_rec_kernel, dim3(Q, B), dim3(1024), 0, stream, enc, reinterpret_cast<const DetRec*>(records), counts, orig_hw, label, out, Q, h, w);
     return hipGetLastError();
 }
 #endif

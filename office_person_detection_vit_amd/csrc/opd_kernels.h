@@ -306,6 +306,10 @@ hipError_t opd_launch_postprocess(const PostParams& p, hipStream_t stream);
 // ROI mean-pool + L2 normalise on the encoder map [h][w][256] of one frame.
 hipError_t opd_launch_roi_features(const float* enc, const int32_t* rois /*[n][4] x0,y0,x1,y1 map coords*/, float* out,
                                    int n, int h, int w, hipStream_t stream);
+// the same for the device records of a batch (opd_det [B][Q], counts [B], orig_hw [B][2]): out [B][Q][256], row = query_index, rows the kernel
+// does not visit (other classes, other queries) keep what they held
+hipError_t opd_launch_roi_features_records(const float* enc, const void* records, const int32_t* counts, const int32_t* orig_hw, int label,
+                                           float* out, int B, int Q, int h, int w, hipStream_t stream);
 
 // cross-attention map of one frame and one decoder layer: mean over heads and the `nsel` selected queries of the softmax rows, fp32;
 // q rows [query][ldq] (this frame's), k rows [key][ldk] (this frame's, this layer's), stat: >= nsel * heads * 8 bytes of scratch,

@@ -443,8 +443,11 @@ static int build_workspace(opd_detr* m) {
     RCCHK(dalloc(m, &m->d_logits, Md * a.ncls, false));
     RCCHK(dalloc(m, &m->d_boxes, Md * 4, false));
     // records of max_batch frames, the per-frame counts right behind them: ONE device-to-host copy fetches both
-    RCCHK(dalloc(m, &m->d_records, Md + ((size_t)B * 4 + sizeof(opd_det) - 1) / sizeof(opd_det), false));
+    // (and behind the counts, 32-byte aligned, room for one feature row per record: opd_detr_detect_frames_features fetches all three at once)
+    const size_t cnt_units = ((size_t)B * 4 + sizeof(opd_det) - 1) / sizeof(opd_det);
+    RCCHK(dalloc(m, &m->d_records, Md + cnt_units + Md * D * 4 / sizeof(opd_det), false));
     m->d_counts = reinterpret_cast<int32_t*>(m->d_records + Md);
+    m->d_feat_all = reinterpret_cast<float*>(m->d_records + Md + cnt_units);
     RCCHK(dalloc(m, &m->d_orig_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_valid_hw, B * 2, false));
     RCCHK(dalloc(m, &m->d_key_valid, B * 2, false));
@@ -1286,12 +1289,29 @@ int run_forward(opd_detr* m, const void* d_pixels, int pixel_format, int B, int 
 static inline bool pixels_on_device(int mem_kind) { return mem_kind == OPD_MEM_DEVICE; }
 static inline bool outputs_on_device(int mem_kind) { return mem_kind != OPD_MEM_HOST; }
 
+// A pointer that kernels will dereference must be memory the HIP runtime knows as device-accessible (device, page-locked host or managed):
+// an ordinary host pointer handed over with a DEVICE mem_kind would make a kernel fault the GPU -- for every process on it -- instead of
+// returning an error (hipPointerGetAttributes: 0.06 us per call).
+static bool device_accessible(const void* p) {
+    hipPointerAttribute_t a{};
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeHost || a.type == hipMemoryTypeManaged;
+}
+static int check_device_outputs(int mem_kind, const void* out, const void* counts, const char* who) {
+    if (!outputs_on_device(mem_kind)) return OPD_OK;
+    if (!device_accessible(out) || !device_accessible(counts))
+        return fail(OPD_EINVAL, std::string(who) + ": this mem_kind takes DEVICE output pointers; the ones given are not device-accessible memory");
+    return OPD_OK;
+}
+
 int check_shape(opd_detr* m, const void* pixels, int pixel_format, int mem_kind, int B, int H, int W) {
     if (!m) return fail(OPD_EINVAL, "null model handle");
     if (!pixels) return fail(OPD_EINVAL, "null pixel buffer");
     if (pixel_format != OPD_PIXELS_U8_BGR_HWC && pixel_format != OPD_PIXELS_F32_NCHW) return fail(OPD_EINVAL, "unknown pixel_format");
     if (mem_kind != OPD_MEM_HOST && mem_kind != OPD_MEM_DEVICE && mem_kind != OPD_MEM_HOST_PIXELS_DEVICE_OUT)
         return fail(OPD_EINVAL, "unknown mem_kind");
+    if (pixels_on_device(mem_kind) && !device_accessible(pixels))
+        return fail(OPD_EINVAL, "OPD_MEM_DEVICE: the pixel pointer is not device-accessible memory");
     const int edge = std::max(m->cfg.max_height, m->cfg.max_width);   // either orientation: see build_workspace
     if (B < 1 || B > m->cfg.max_batch || H < 32 || W < 32 || H > edge || W > edge ||
         (size_t)H * W > (size_t)m->cfg.max_height * m->cfg.max_width)
@@ -1315,7 +1335,8 @@ int stage_pixels(opd_detr* m, const void* pixels, int pixel_format, int mem_kind
 }
 
 // Frames at camera resolution -> m->d_u8 at model resolution (Pillow-exact bilinear, kernels_misc.hip).
-static int enqueue_resize(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int oh, int ow) {
+// (`list` != null: one host pointer per frame instead of the contiguous block `frames`)
+static int enqueue_resize(opd_detr* m, const uint8_t* frames, int mem_kind, int B, int h, int w, int oh, int ow, const uint8_t* const* list = nullptr) {
     if (h < 1 || w < 1 || (size_t)h * w > (size_t)1 << 26) return fail(OPD_EINVAL, "source frame size out of range");
     const size_t need = (size_t)B * h * w * 3;
     const uint8_t* d_in = frames;
@@ -1329,7 +1350,11 @@ static int enqueue_resize(opd_detr* m, const uint8_t* frames, int mem_kind, int 
             m->d_src = reinterpret_cast<uint8_t*>(q);
             m->src_bytes = need;
         }
-        HIPCHK(hipMemcpyAsync(m->d_src, frames, need, hipMemcpyHostToDevice, m->stream));
+        if (list) {
+            for (int b = 0; b < B; ++b) HIPCHK(hipMemcpyAsync(m->d_src + (size_t)b * h * w * 3, list[b], (size_t)h * w * 3, hipMemcpyHostToDevice, m->stream));
+        } else {
+            HIPCHK(hipMemcpyAsync(m->d_src, frames, need, hipMemcpyHostToDevice, m->stream));
+        }
         d_in = m->d_src;
     }
     const opd_detr::ResizeTab* tab = nullptr;
@@ -1379,17 +1404,21 @@ int enqueue_postprocess(opd_detr* m, float threshold, const int32_t* orig_hw, op
     return OPD_OK;
 }
 
-static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kind) {
+// (`features` != null: the [B][Q][d_model] feature rows behind the counts travel in the same copy)
+static int fetch_records(opd_detr* m, opd_det* out, int32_t* counts, int mem_kind, float* features = nullptr) {
     const int B = m->last_B, Q = m->arch.queries;
     if (!outputs_on_device(mem_kind)) {   // (device callers had the post-process kernel write into their buffers)
-        // one copy of [records of max_batch frames | counts] into page-locked memory (a copy into the caller's pageable arrays is staged by
-        // the runtime anyway, once per call), handed over after the wait
+        // one copy of [records of max_batch frames | counts (| features)] into page-locked memory (a copy into the caller's pageable arrays is
+        // staged by the runtime anyway, once per call), handed over after the wait
         const size_t rec_bytes = (size_t)m->cfg.max_batch * Q * sizeof(opd_det);
-        if (!m->sync_pinned) HIPCHK(hipHostMalloc(&m->sync_pinned, rec_bytes + (size_t)m->cfg.max_batch * 4, hipHostMallocDefault));
-        HIPCHK(hipMemcpyAsync(m->sync_pinned, m->d_records, rec_bytes + (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
+        const size_t feat_off = reinterpret_cast<const char*>(m->d_feat_all) - reinterpret_cast<const char*>(m->d_records);
+        const size_t feat_row = (size_t)Q * m->arch.d_model * 4;
+        if (!m->sync_pinned) HIPCHK(hipHostMalloc(&m->sync_pinned, feat_off + (size_t)m->cfg.max_batch * feat_row, hipHostMallocDefault));
+        HIPCHK(hipMemcpyAsync(m->sync_pinned, m->d_records, features ? feat_off + (size_t)B * feat_row : rec_bytes + (size_t)B * 4, hipMemcpyDeviceToHost, m->stream));
         HIPCHK(hipStreamSynchronize(m->stream));
         memcpy(out, m->sync_pinned, (size_t)B * Q * sizeof(opd_det));
         memcpy(counts, static_cast<char*>(m->sync_pinned) + rec_bytes, (size_t)B * 4);
+        if (features) memcpy(features, static_cast<char*>(m->sync_pinned) + feat_off, (size_t)B * feat_row);
     }
     HIPCHK(hipStreamSynchronize(m->stream));
     if (m->profiling) {
@@ -1663,6 +1692,7 @@ int opd_detr_detect_ragged(opd_detr* m, const void* pixels, int pixel_format, in
     ApiScope api_scope;
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect: null output buffer");
+    RCCHK(check_device_outputs(mem_kind, out, counts, "opd_detr_detect"));
     HIPCHK(hipSetDevice(m->device));
     const void* d_pixels = nullptr;
     RCCHK(stage_pixels(m, pixels, pixel_format, mem_kind, B, H, W, &d_pixels));
@@ -1676,6 +1706,7 @@ int opd_detr_detect_async(opd_detr* m, const void* pixels, int pixel_format, int
     ApiScope api_scope;
     RCCHK(check_shape(m, pixels, pixel_format, mem_kind, B, H, W));
     if (!out || !counts || !ticket) return fail(OPD_EINVAL, "opd_detr_detect_async: null argument");
+    RCCHK(check_device_outputs(mem_kind, out, counts, "opd_detr_detect_async"));
     if (m->profiling) return fail(OPD_ESTATE, "opd_detr_detect_async is not available in profiling mode");
     HIPCHK(hipSetDevice(m->device));
     const unsigned t = m->async_next & 3u;
@@ -1726,6 +1757,7 @@ int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, in
     if (!m) return fail(OPD_EINVAL, "null model handle");
     RCCHK(check_shape(m, frames, OPD_PIXELS_U8_BGR_HWC, mem_kind, B, H, W));
     if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect_resized: null output buffer");
+    RCCHK(check_device_outputs(mem_kind, out, counts, "opd_detr_detect_resized"));
     HIPCHK(hipSetDevice(m->device));
     RCCHK(enqueue_resize(m, frames, mem_kind, B, h, w, H, W));
     RCCHK(run_forward(m, m->d_u8, OPD_PIXELS_U8_BGR_HWC, B, H, W, nullptr));
@@ -1734,6 +1766,56 @@ int opd_detr_detect_resized(opd_detr* m, const uint8_t* frames, int mem_kind, in
     const bool dev = outputs_on_device(mem_kind);
     RCCHK(enqueue_postprocess(m, threshold, orig.data(), dev ? out : nullptr, dev ? counts : nullptr));
     return fetch_records(m, out, counts, mem_kind);
+}
+
+int opd_detr_detect_frames(opd_detr* m, const uint8_t* const* frames, int mem_kind, int B, int h, int w, int H, int W, float threshold,
+                           opd_det* out, int32_t* counts) {
+    ApiScope api_scope;
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    if (mem_kind != OPD_MEM_HOST && mem_kind != OPD_MEM_HOST_PIXELS_DEVICE_OUT) return fail(OPD_EINVAL, "opd_detr_detect_frames takes host frames");
+    RCCHK(check_shape(m, frames, OPD_PIXELS_U8_BGR_HWC, mem_kind, B, H, W));
+    for (int b = 0; b < B; ++b)
+        if (!frames[b]) return fail(OPD_EINVAL, "opd_detr_detect_frames: null frame pointer");
+    if (!out || !counts) return fail(OPD_EINVAL, "opd_detr_detect_frames: null output buffer");
+    RCCHK(check_device_outputs(mem_kind, out, counts, "opd_detr_detect_frames"));
+    HIPCHK(hipSetDevice(m->device));
+    if (h == H && w == W) {
+        const size_t n1 = (size_t)H * W * 3;
+        for (int b = 0; b < B; ++b) HIPCHK(hipMemcpyAsync(m->d_u8 + b * n1, frames[b], n1, hipMemcpyHostToDevice, m->stream));
+    } else {
+        RCCHK(enqueue_resize(m, nullptr, mem_kind, B, h, w, H, W, frames));
+    }
+    RCCHK(run_forward(m, m->d_u8, OPD_PIXELS_U8_BGR_HWC, B, H, W, nullptr));
+    std::vector<int32_t> orig((size_t)2 * B);
+    for (int b = 0; b < B; ++b) { orig[2 * b] = h; orig[2 * b + 1] = w; }
+    const bool dev = outputs_on_device(mem_kind);
+    RCCHK(enqueue_postprocess(m, threshold, orig.data(), dev ? out : nullptr, dev ? counts : nullptr));
+    return fetch_records(m, out, counts, mem_kind);
+}
+
+int opd_detr_detect_frames_features(opd_detr* m, const uint8_t* const* frames, int B, int h, int w, int H, int W, float threshold, int label,
+                                    opd_det* out, int32_t* counts, float* features) {
+    ApiScope api_scope;
+    if (!m) return fail(OPD_EINVAL, "null model handle");
+    RCCHK(check_shape(m, frames, OPD_PIXELS_U8_BGR_HWC, OPD_MEM_HOST, B, H, W));
+    for (int b = 0; b < B; ++b)
+        if (!frames[b]) return fail(OPD_EINVAL, "opd_detr_detect_frames_features: null frame pointer");
+    if (!out || !counts || !features) return fail(OPD_EINVAL, "opd_detr_detect_frames_features: null output buffer");
+    if (m->arch.d_model != 256) return fail(OPD_EINVAL, "opd_detr_detect_frames_features: the pooling kernel is built for d_model = 256");
+    HIPCHK(hipSetDevice(m->device));
+    const int Q = m->arch.queries;
+    if (h == H && w == W) {
+        const size_t n1 = (size_t)H * W * 3;
+        for (int b = 0; b < B; ++b) HIPCHK(hipMemcpyAsync(m->d_u8 + b * n1, frames[b], n1, hipMemcpyHostToDevice, m->stream));
+    } else {
+        RCCHK(enqueue_resize(m, nullptr, OPD_MEM_HOST, B, h, w, H, W, frames));
+    }
+    RCCHK(run_forward(m, m->d_u8, OPD_PIXELS_U8_BGR_HWC, B, H, W, nullptr));
+    std::vector<int32_t> orig((size_t)2 * B);
+    for (int b = 0; b < B; ++b) { orig[2 * b] = h; orig[2 * b + 1] = w; }
+    RCCHK(enqueue_postprocess(m, threshold, orig.data()));
+    HIPCHK(opd_launch_roi_features_records(m->d_x32, m->d_records, m->d_counts, m->d_orig_hw, label, m->d_feat_all, B, Q, m->last_fh, m->last_fw, m->stream));
+    return fetch_records(m, out, counts, OPD_MEM_HOST, features);   // records, counts and feature rows: one copy, one wait
 }
 
 int opd_host_alloc(size_t bytes, void** out) {

@@ -189,6 +189,7 @@ struct opd_detr {
     struct AsyncHost { void* pinned = nullptr; opd_det* out = nullptr; int32_t* counts = nullptr; int B = 0; };
     AsyncHost async_host[4];
     void* sync_pinned = nullptr;   // page-locked staging of the blocking entry points: [records of max_batch frames | counts]
+    float* d_feat_all = nullptr;   // [max_batch][queries][d_model] behind the counts in the d_records allocation: features of a batch's records (opd_detr_detect_frames_features)
     // device-side resize (camera resolution -> model resolution): source staging (grown on demand) and coefficient tables
     uint8_t* d_src = nullptr;
     size_t src_bytes = 0;

@@ -79,6 +79,7 @@ class HipDetrDetector:
         streams: int = 1,
         pinned_staging: bool = True,
         dtype: str = "fp16",
+        frame_lists: bool = True,
     ):
         """
         Args mirror ``config.yaml.disabled:33-44`` (``model_name``, ``confidence_threshold``, ``nms_threshold``,
@@ -95,6 +96,8 @@ class HipDetrDetector:
         (``OPD_FLAG_BF16``: the type the DETR-era config's deployment target names; same speed, 8 mantissa bits: boxes drift ~4x more).
         ``pinned_staging``: stack the caller's frames into page-locked memory (``opd_host_alloc``) so that the upload is
         one DMA; False stacks into ordinary numpy memory.
+        ``frame_lists``: hand a chunk of same-sized contiguous frames to the library as a list of pointers
+        (``opd_detr_detect_frames``: each frame is uploaded from where it lies) instead of stacking it first; False always stacks.
         """
         self.model_name = model_name
         self.model_path = model_path
@@ -116,6 +119,7 @@ class HipDetrDetector:
         self.model: Optional[int] = None  # opaque opd_detr* once loaded (handle 0)
         self._handles: List[int] = []  # all handles, handle 0 first
         self.pinned_staging = bool(pinned_staging)
+        self.frame_lists = bool(frame_lists)
         self._staging: dict = {}  # handle slot -> (pinned pointer, capacity in bytes)
         self.feature_extractor = FeatureExtractor()
         self._lib = None
@@ -308,9 +312,34 @@ class HipDetrDetector:
         self._detect_into(frames, model, C.addressof(recs), C.addressof(counts), on_device=False)
         return recs, counts, Q
 
+    def _frame_list_target(self, frames: Sequence[np.ndarray]) -> Optional[Tuple[int, int]]:
+        """(H, W) of the model input when the chunk can go down as a LIST of frame pointers (``opd_detr_detect_frames``: every frame
+        uploaded from where it lies, no stacked copy): contiguous uint8 [h, w, 3] frames of ONE size, model size reached on the device."""
+        f0 = frames[0]
+        for f in frames:
+            if not isinstance(f, np.ndarray) or f.dtype != np.uint8 or f.ndim != 3 or f.shape != f0.shape or f.shape[2] != 3 or not f.flags.c_contiguous:
+                return None
+        h, w = int(f0.shape[0]), int(f0.shape[1])
+        if not self.resize:
+            return (h, w)
+        th, tw = model_input_size(h, w, self.max_size[0], self.max_size[1])
+        return (th, tw) if ((th, tw) == (h, w) or self.device_resize) else None
+
     def _detect_into(self, frames: Sequence[np.ndarray], model: int, rec_ptr: int, cnt_ptr: int, on_device: bool) -> None:
         """One ``max_batch`` chunk of host frames -> ``[B][Q]`` ``opd_det`` records at ``rec_ptr`` and ``[B]`` counts at
         ``cnt_ptr``; ``on_device``: both are HIP device pointers on this detector's GPU (``OPD_MEM_HOST_PIXELS_DEVICE_OUT``)."""
+        if len(frames) == 0:
+            raise ValueError("empty frame batch")
+        target = self._frame_list_target(frames) if self.frame_lists else None
+        if target is not None:
+            kind = _capi.OPD_MEM_HOST_PIXELS_DEVICE_OUT if on_device else _capi.OPD_MEM_HOST
+            recs, counts = C.cast(C.c_void_p(rec_ptr), C.POINTER(_capi.OpdDet)), C.cast(C.c_void_p(cnt_ptr), C.POINTER(C.c_int32))
+            ptrs = (C.c_void_p * len(frames))(*[f.ctypes.data for f in frames])
+            rc = self._lib.opd_detr_detect_frames(C.c_void_p(model), ptrs, kind, len(frames), int(frames[0].shape[0]), int(frames[0].shape[1]),
+                                                  target[0], target[1], float(self.confidence_threshold), recs, counts)
+            _capi.check(rc, "opd_detr_detect_frames")
+            self._last_orig = [(int(f.shape[0]), int(f.shape[1])) for f in frames]
+            return
         batch, orig, valid, target = self._preprocess_batch(frames, self._handles.index(model))
         B, H, W, _ = batch.shape
         kind = _capi.OPD_MEM_HOST_PIXELS_DEVICE_OUT if on_device else _capi.OPD_MEM_HOST
@@ -425,6 +454,24 @@ class HipDetrDetector:
     def detect_with_features(self, frame: np.ndarray) -> Tuple[List[Detection], np.ndarray]:
         """Detection + (N, 256) appearance features pooled from the DETR encoder map; assigns ``det.features``
         (``yolov8_detector.py:134-159``; deleted vit_detector.py 148-171, 224-273)."""
+        self._require_model()
+        target = self._frame_list_target([frame]) if (self.frame_lists and isinstance(frame, np.ndarray)) else None
+        if target is not None and self._info.d_model == 256:
+            # one C-ABI call: the records and the pooled feature of every person record come back behind one host wait
+            Q, D = self._info.num_queries, self._info.d_model
+            recs, counts = (_capi.OpdDet * Q)(), (C.c_int32 * 1)()
+            feats = np.empty((1, Q, D), np.float32)
+            ptrs = (C.c_void_p * 1)(frame.ctypes.data)
+            rc = self._lib.opd_detr_detect_frames_features(C.c_void_p(self.model), ptrs, 1, int(frame.shape[0]), int(frame.shape[1]), target[0], target[1],
+                                                           float(self.confidence_threshold), PERSON_LABEL, recs, counts,
+                                                           feats.ctypes.data_as(C.POINTER(C.c_float)))
+            _capi.check(rc, "opd_detr_detect_frames_features")
+            self._last_orig = [(int(frame.shape[0]), int(frame.shape[1]))]
+            detections = self._postprocess_batch(recs, counts, Q)[0]
+            features = feats[0, [d.query_index for d in detections]] if detections else np.array([])
+            for i, det in enumerate(detections):
+                det.features = features[i]
+            return detections, features
         detections = self.detect(frame)
         features = self.extract_features(frame, detections)
         for i, det in enumerate(detections):

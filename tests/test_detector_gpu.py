@@ -227,6 +227,56 @@ def test_camera_resolution_frames_device_resize_equals_host_resize(weight_cache)
             assert 0 < d.bbox[2] <= 2 * 320 and 0 < d.bbox[3] <= 2 * 180 and -320 <= d.bbox[0] <= 320 and -180 <= d.bbox[1] <= 180
 
 
+def test_frame_list_entry_equals_the_stacked_batch(weight_cache):
+    """opd_detr_detect_frames (a LIST of frame pointers, each uploaded from where it lies -- what detect_batch / detect use for same-sized
+    contiguous frames) returns exactly what the stacked-block entries return: at model resolution, with the device resize, for a single
+    frame, and a non-contiguous frame still goes the stacked way."""
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    sig = lambda res: [[(d.query_index, d.bbox, d.confidence) for d in dets] for dets in res]
+    for (h, w), msz in (((288, 512), (288, 512)), ((180, 320), (288, 512))):
+        frames = structured_frames(3, h, w, seed=41)
+        outs = {}
+        for lists in (True, False):
+            det = HipDetrDetector(model_path=path, max_batch=2, max_size=msz, resize=True, frame_lists=lists)
+            det.load_model()
+            outs[lists] = (sig(det.detect_batch(frames)), sig([det.detect(frames[0])]))          # (3 frames = chunks of 2 + 1)
+            if lists:
+                wide = np.ascontiguousarray(np.concatenate([frames[1], frames[1]], axis=1))
+                view = wide[:, :w]                                                                # same pixels, not contiguous
+                assert not view.flags.c_contiguous and det._frame_list_target([view]) is None
+                assert sig([det.detect(view)]) == sig([det.detect(frames[1])])
+            det.close()
+        assert outs[True] == outs[False] and any(len(d) for d in outs[True][0])
+
+
+def test_detect_with_features_in_one_call_equals_the_two_call_form(weight_cache):
+    """opd_detr_detect_frames_features (records + the pooled feature of every person record behind ONE host wait: what detect_with_features
+    uses for a contiguous frame) against detect + opd_detr_roi_features on the surviving boxes: same detections, bit-identical features --
+    at model resolution and through the device resize, with a low threshold so that suppression has something to drop."""
+    path = ensure_weight_file(weight_cache, DetrArch(), 0, 1.0, "r50")
+    for (h, w) in ((288, 512), (180, 320)):
+        frames = structured_frames(4, h, w, seed=41)
+        outs = {}
+        for lists in (True, False):
+            det = HipDetrDetector(model_path=path, max_batch=1, max_size=(288, 512), resize=True, frame_lists=lists, confidence_threshold=0.05)
+            det.load_model()
+            res = []
+            for frame in frames + frames[:1]:                              # (the last call replays the graph on re-used buffers)
+                dets, feats = det.detect_with_features(frame)
+                assert len(feats) == len(dets) and all(np.array_equal(d.features, feats[i]) for i, d in enumerate(dets))
+                res.append(([(d.query_index, d.bbox, d.confidence) for d in dets], np.asarray(feats)))
+            assert res[0][0] == res[-1][0] and np.array_equal(res[0][1], res[-1][1])
+            outs[lists] = res
+            det.close()
+        n = sum(len(r[0]) for r in outs[True])
+        assert n >= 2, f"the test frames give {n} person detections at threshold 0.05: nothing to compare"
+        for (da, fa), (db, fb) in zip(outs[True], outs[False]):
+            assert da == db
+            np.testing.assert_array_equal(fa, fb)
+            if len(da):
+                assert np.allclose(np.linalg.norm(fa, axis=1), 1.0, atol=1e-4)
+
+
 def test_ragged_batch_matches_hf_golden(detectors, golden_dir):
     """Frames of different sizes in one batch (HF pads to the batch maximum and applies the pixel mask: nearest mask
     down-sampling, mask-dependent position embedding, key masks in encoder self-attention and decoder cross-attention).

@@ -507,6 +507,46 @@ def test_measurement_abi_modes_are_consistent(mild_path):
         lib.opd_detr_destroy(h)
 
 
+def test_device_mem_kinds_refuse_pointers_that_are_not_device_memory(mild_path):
+    """A host pointer handed over under OPD_MEM_DEVICE / OPD_MEM_HOST_PIXELS_DEVICE_OUT would make a kernel fault the GPU (for every process
+    on it); the C-ABI returns OPD_EINVAL instead, and the handle keeps working.  (Found by doing it: tools/host_b1_probe.py, round 5.)"""
+    lib = _capi.load_library()
+    H, W, B = 256, 320, 1
+    cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W, flags=0)
+    h = C.c_void_p()
+    _capi.check(lib.opd_detr_create(C.byref(cfg), mild_path.encode(), 0, C.byref(h)), "opd_detr_create")
+    try:
+        frames = np.stack(structured_frames(B, H, W, seed=5))
+        d_frames = torch.from_numpy(frames).cuda()
+        hw = np.asarray([[H, W]] * B, np.int32)
+        recs = np.zeros((B, 100, 8), np.int32); cnts = np.zeros(B, np.int32)
+        d_out = torch.zeros((B * 100 * 8 + B,), dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        DetP, I32P = C.POINTER(_capi.OpdDet), C.POINTER(C.c_int32)
+        h_recs, h_cnts = recs.ctypes.data_as(DetP), cnts.ctypes.data_as(I32P)
+        d_recs, d_cnts = C.cast(C.c_void_p(d_out.data_ptr()), DetP), C.cast(C.c_void_p(d_out[B * 800:].data_ptr()), I32P)
+
+        def detect(pix, kind, r, c):
+            return lib.opd_detr_detect(h, pix, _capi.OPD_PIXELS_U8_BGR_HWC, kind, B, H, W, 0.5, hw.ctypes.data_as(C.c_void_p), r, c)
+
+        host_pix, dev_pix = frames.ctypes.data_as(C.c_void_p), C.c_void_p(d_frames.data_ptr())
+        assert detect(host_pix, _capi.OPD_MEM_DEVICE, d_recs, d_cnts) == _capi.OPD_EINVAL          # host pixels as device pixels
+        assert b"not device-accessible" in lib.opd_last_error()
+        assert detect(dev_pix, _capi.OPD_MEM_DEVICE, h_recs, h_cnts) == _capi.OPD_EINVAL          # host outputs as device outputs
+        assert detect(host_pix, _capi.OPD_MEM_HOST_PIXELS_DEVICE_OUT, h_recs, h_cnts) == _capi.OPD_EINVAL
+        t = C.c_int()
+        assert lib.opd_detr_detect_async(h, dev_pix, _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_DEVICE, B, H, W, 0.5, hw.ctypes.data_as(C.c_void_p),
+                                         h_recs, h_cnts, C.byref(t)) == _capi.OPD_EINVAL
+        # the right pointers: both memory kinds give the same records
+        assert detect(host_pix, _capi.OPD_MEM_HOST, h_recs, h_cnts) == 0
+        assert detect(dev_pix, _capi.OPD_MEM_DEVICE, d_recs, d_cnts) == 0
+        got = d_out.cpu().numpy()
+        n = max(int(cnts[0]), 0)
+        assert np.array_equal(got[:B * 800].reshape(B, 100, 8)[0, :n], recs[0, :n]) and got[B * 800] == cnts[0]
+    finally:
+        lib.opd_detr_destroy(h)
+
+
 def test_stage1_residual_rebuild_is_invisible_end_to_end(mild_path):
     """OPD_TAIL_RC / OPD_Y_STRIDE2 (round 5: stage 1's first tail stores a1 instead of its output, the second rebuilds it, the last stores its
     output only where the next stage reads it): logits, boxes and the encoder map of a batch are bit-identical with the switches on and off,

@@ -13,8 +13,9 @@ H, W = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (800, 1333
 path = ensure_weight_file(os.environ.get("OPD_WEIGHT_CACHE", "/tmp/opd_weights"), DetrArch.resnet50(), 0, 1.0, "r50")
 base = [structured_frame(H, W, 1234 + i) for i in range(8)]
 frames = [base[i % 8] for i in range(n)]
-for streams, pinned in ((1, False), (1, True), (3, False), (3, True)):
-    det = HipDetrDetector(model_path=path, max_batch=8, max_size=(800, 1333), resize=True, streams=streams, pinned_staging=pinned)
+# (lists: the chunk goes down as a list of frame pointers, opd_detr_detect_frames; otherwise it is stacked first, into page-locked or ordinary memory)
+for streams, pinned, lists in ((1, False, True), (1, True, False), (1, False, False), (3, False, True), (3, True, False), (3, False, False)):
+    det = HipDetrDetector(model_path=path, max_batch=8, max_size=(800, 1333), resize=True, streams=streams, pinned_staging=pinned, frame_lists=lists)
     det.load_model()
     det.detect_batch(frames[:8 * streams])   # warm-up: graph capture per handle
     best = 1e9
@@ -22,6 +23,6 @@ for streams, pinned in ((1, False), (1, True), (3, False), (3, True)):
         t0 = time.perf_counter()
         out = det.detect_batch(frames)
         best = min(best, time.perf_counter() - t0)
-    print(f"{H}x{W} host frames, streams={streams}, pinned={int(pinned)}: {n / best:8.1f} frames/s  ({1e3 * best / (n / 8):.2f} ms per batch of 8, "
+    print(f"{H}x{W} host frames, streams={streams}, {'frame list' if lists else 'stacked, pinned' if pinned else 'stacked, pageable'}: {n / best:8.1f} frames/s  ({1e3 * best / (n / 8):.2f} ms per batch of 8, "
           f"{sum(len(d) for d in out)} detections)", flush=True)
     det.close()
