@@ -46,6 +46,7 @@ timeout -k 10 200 python tools/bench_enc_ffn.py --ablate > $O/bench_enc_ffn.txt 
 timeout -k 10 200 python tools/bench_dec.py > $O/bench_dec.txt 2>&1 &&
 timeout -k 10 120 tools/microbench/vmorder > $O/microbench_vmorder.txt 2>&1 &&
 timeout -k 10 300 python tools/host_rate_ref_pattern.py > $O/host_rate_ref_pattern.txt 2>&1 &&
+timeout -k 10 200 python tools/host_b1_probe.py 64 > $O/host_b1_probe.txt 2>&1 &&
 timeout -k 10 300 python bench.py --dtype bf16 --no-cpu-baseline --steps 300 > $O/bench_bf16.json 2> $O/bench_bf16.err &&
 timeout -k 10 120 tools/microbench/mfma_peak > $O/microbench_mfma_peak.txt 2>&1 &&
 OPD_BENCH_FORCE_COMM=1 timeout -k 10 300 python bench.py --steps 300 --no-cpu-baseline --serial-steps 0 > $O/bench_forced_comm_1rank.json 2> $O/bench_forced_comm.err &&
