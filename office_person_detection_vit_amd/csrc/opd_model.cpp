@@ -1507,6 +1507,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_TAIL_RC")) m->tail_rc = atoi(v);
     if (const char* v = getenv("OPD_WPREFETCH")) m->wprefetch = atoi(v);
     if (const char* v = getenv("OPD_W8")) m->w8 = atoi(v);
+    if (m->w8 < 0) m->w8 = (cfg->flags & OPD_FLAG_MULTI_STREAM) ? 1 : 0;
     if (const char* v = getenv("OPD_SMALL_SPLITK")) m->small_splitk = atoi(v);
     if (const char* v = getenv("OPD_SMALL_ENC")) m->small_enc = atoi(v);
     if (const char* v = getenv("OPD_Y_STRIDE2")) m->y_stride2 = atoi(v);

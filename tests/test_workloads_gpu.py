@@ -570,6 +570,48 @@ def test_stage1_residual_rebuild_is_invisible_end_to_end(mild_path):
                 np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("flag_bf16", [0, 1])
+def test_multi_stream_eight_wave_3x3_is_invisible_end_to_end(mild_path, monkeypatch, flag_bf16):
+    """OPD_FLAG_MULTI_STREAM handles run stage 4's 3x3 convolutions through the eight-wave kernel (kernels_w8.hip; OPD_W8 = -1 = by the flags):
+    a speed choice only -- logits, boxes and the encoder map are bit-identical with OPD_W8=0, for fp16 and for the bf16 instantiation."""
+    lib = _capi.load_library()
+    H, W, B = 384, 512, 2
+    frames = np.stack(structured_frames(B, H, W, seed=19))
+    monkeypatch.setenv("OPD_SMALL_SPLITK", "0")   # (a handle this small would split the reduction of its deep convolutions instead: another plan)
+    outs = []
+    for w8 in ("0", None):
+        if w8 is None:
+            monkeypatch.delenv("OPD_W8", raising=False)
+        else:
+            monkeypatch.setenv("OPD_W8", w8)
+        cfg = _capi.OpdConfig(struct_size=C.sizeof(_capi.OpdConfig), max_batch=B, max_height=H, max_width=W,
+                              flags=_capi.OPD_FLAG_MULTI_STREAM | (_capi.OPD_FLAG_BF16 if flag_bf16 else 0))
+        h = C.c_void_p()
+        _capi.check(lib.opd_detr_create(C.byref(cfg), mild_path.encode(), 0, C.byref(h)), "opd_detr_create")
+        try:
+            logits = np.zeros((B, 100, 92), np.float32); boxes = np.zeros((B, 100, 4), np.float32); enc = np.zeros((B, 12 * 16, 256), np.float32)
+            F32P = C.POINTER(C.c_float)
+            _capi.check(lib.opd_detr_set_profiling(h, 1), "opd_detr_set_profiling")      # (the kernel table tells which kernels ran)
+            hw = np.asarray([[H, W]] * B, np.int32)
+            recs = np.zeros((B, 100, 8), np.int32); cnts = np.zeros(B, np.int32)
+            _capi.check(lib.opd_detr_detect(h, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W, 0.5,
+                                            hw.ctypes.data_as(C.c_void_p), recs.ctypes.data_as(C.POINTER(_capi.OpdDet)), cnts.ctypes.data_as(C.POINTER(C.c_int32))),
+                        "opd_detr_detect")
+            ktab = (_capi.OpdKernelStat * 64)(); kc = C.c_int(0)
+            _capi.check(lib.opd_detr_kernel_table(h, ktab, 64, C.byref(kc)), "opd_detr_kernel_table")
+            names = [ktab[i].name.decode() for i in range(kc.value)]
+            _capi.check(lib.opd_detr_set_profiling(h, 0), "opd_detr_set_profiling")
+            for _ in range(3):
+                _capi.check(lib.opd_detr_forward(h, frames.ctypes.data_as(C.c_void_p), _capi.OPD_PIXELS_U8_BGR_HWC, _capi.OPD_MEM_HOST, B, H, W,
+                                                 logits.ctypes.data_as(F32P), boxes.ctypes.data_as(F32P), enc.ctypes.data_as(F32P)), "opd_detr_forward")
+            outs.append((logits.copy(), boxes.copy(), enc.copy(), names))
+        finally:
+            lib.opd_detr_destroy(h)
+    assert not any("conv_w8" in n for n in outs[0][3]) and any("conv_w8" in n for n in outs[1][3]), outs[1][3]
+    for a, b in zip(outs[0][:3], outs[1][:3]):
+        assert np.array_equal(a.view(np.uint32), b.view(np.uint32))
+
+
 def test_small_handle_split_k_plan(mild_path, parity_log):
     """Round 5: a max_batch = 1 handle splits the reduction of its deep convolutions over workgroups (csrc/opd_model.cpp::conv_splits: stage 3 / 4's
     3x3 and stage 4's 2048 -> 512 reduce become split-K launches + reduce_act16_kernel) because unsplit they occupy a quarter of the CUs for
