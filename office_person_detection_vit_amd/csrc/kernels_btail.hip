@@ -118,8 +118,12 @@ __device__ __forceinline__ void compiler_fence() { asm volatile("" ::: "memory")
 // wave as B fragments (32 KiB per workgroup instead of the 64-KiB residual), streams the 64 x 64 slices of W2' and Wsc with its own chunk
 // operands and runs the previous tail's chunk arithmetic -- same operands, same MFMA order, same fp16 rounding -- so the residual it adds has
 // the bits that tail would have stored.  The previous tail then stores a1' (68 MB at batch 8) instead of y' (274 MB), and nobody reads y'.
-template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false, int RC = 0>
-__global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
+// NW: waves per workgroup = 32-pixel row groups per tile.  4: 128-pixel tiles, two workgroups per CU; 8: 256-pixel tiles, one workgroup per CU -- the
+// same eight waves on a CU, but one set of weight tiles staged for 256 pixels instead of two sets for 128 each (round 5: the SQ counters of a
+// stage-2 tail read SQ_VMEM_TA_CMD_FIFO_FULL for 80 % of the busy cycles -- the CU's vector-memory path is what the tails wait for, and
+// 40 % of what they push through it are weight tiles).  A wave's arithmetic does not depend on NW: identical bits.
+template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false, int RC = 0, int NW = 4>
+__global__ __launch_bounds__(64 * NW, 8 / NW) void btail_kernel(BtailParams p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     unsigned long long tstamp[16] = {};
     auto stamp = [&](const int i) {
@@ -134,13 +138,17 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     constexpr int C2 = 4 * C1;
     constexpr int NT1 = C1 / 16;               // c1 accumulator tiles per wave (all C1 channels)
     constexpr int KK1 = C1 / 32;               // 32-channel k-blocks of a1
-    constexpr int A_BYTES = 128 * ROW_BYTES;   // 128 pixels x 64 halfs
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    constexpr int BM = 32 * NW;                // pixels per tile
+    constexpr int A_BYTES = BM * ROW_BYTES;    // BM pixels x 64 halfs
     constexpr int RC_BYTES = RC ? 2 * 64 * ROW_BYTES : 0;    // chunks of the previous block's W2 and Wsc: [64 rows][64 halfs] each
-    constexpr int W1_PIECES = C1 / 32;         // 1-KiB pieces of the W1 tile per wave
+    constexpr int W1_PIECES = C1 / (8 * NW);   // 1-KiB pieces of the W1 tile per wave
     constexpr int NCH = C2 / 64;               // 64-channel chunks of y
     constexpr int W2C_BYTES = 64 * C1 * 2;     // chunk of W2: C1/64 sub-tiles of [64 rows][64 halfs]
-    constexpr int W2_PIECES = W2C_BYTES / 4096;
-    constexpr int W3_PIECES = C3 / 32;         // slice of W3: [C3 rows][64 halfs]
+    constexpr int W2_PIECES = W2C_BYTES / (1024 * NW);
+    constexpr int W3_PIECES = C3 / (8 * NW);   // slice of W3: [C3 rows][64 halfs]
+    constexpr int SC_PIECES = 8 / NW;          // a [64 rows][64 halfs] slice (Wsc; RC: the previous block's W2 and Wsc): pieces per wave
+    static_assert(W1_PIECES >= 1 && W2_PIECES >= 1 && (C3 == 0 || W3_PIECES >= 1), "every wave stages at least one piece of every operand");
     constexpr int NT3 = C3 / 16;
     constexpr int WSC_BYTES = SC ? 64 * ROW_BYTES : 0;   // chunk of Wsc: [64 rows][64 halfs]
     constexpr int CHUNK_BYTES = W2C_BYTES + C3 * ROW_BYTES + WSC_BYTES + RC_BYTES;
@@ -153,7 +161,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const int g = lane >> 4, li = lane & 15;
     // p.rev: every XCD walks its range of tiles backwards, so that a kernel starts on the rows its predecessor wrote LAST (the ones still
     // in the 256-MiB Infinity Cache; a 274-MB tensor written and re-read in the same order never hits)
-    const int m_base = (p.rev ? xcd_logical_block_rev(blockIdx.x, gridDim.x) : xcd_logical_block(blockIdx.x, gridDim.x)) * 128;
+    const int m_base = (p.rev ? xcd_logical_block_rev(blockIdx.x, gridDim.x) : xcd_logical_block(blockIdx.x, gridDim.x)) * BM;
     const int wm0 = m_base + wave * 32;        // this wave's 32 pixels
 
     // ---- staging coordinates (see conv_gemm_dma_kernel): piece = 8 tile rows x 128 B, lane -> (row lane>>3, slot lane&7)
@@ -168,8 +176,9 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     const __amdgpu_buffer_rsrc_t rsrc_sc = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(SC ? p.wsc : RC ? p.rc_wsc : p.w2p), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrc_rw = __builtin_amdgcn_make_buffer_rsrc(const_cast<f16_t*>(RC ? p.rc_w2[0] : p.w2p), 0, (unsigned)(C2 * 64 * 2), 0x00020000);
     unsigned rowoff[4], rowmask[4], woff1[W1_PIECES], woff2[W2_PIECES], woff3[W3_PIECES ? W3_PIECES : 1], woffsc[2];
-    woffsc[0] = (unsigned)(own_row(wave * 16 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;        // rows 8 (2 wave) + lrow of the 64-row chunk
-    woffsc[1] = (unsigned)(own_row(wave * 16 + 8 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)   // rows 8 (SC_PIECES wave + i) + lrow of the 64-row chunk (entry 1 is unused with eight waves)
+        woffsc[i] = (unsigned)(own_row(((wave * SC_PIECES + i) & 7) * 8 + lrow) * 64) * 2u + (unsigned)lchunk * 16u;
     {
         const int ohw = p.OH * p.OW;
 #pragma unroll
@@ -243,17 +252,17 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
         if constexpr (SC) {
             unsigned char* Wscs = W2s + W2C_BYTES + C3 * ROW_BYTES;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, (__attribute__((address_space(3))) void*)(Wscs + (wave * 2 + i) * 1024), 16,
+            for (int i = 0; i < SC_PIECES; ++i)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, (__attribute__((address_space(3))) void*)(Wscs + (wave * SC_PIECES + i) * 1024), 16,
                                                          woffsc[i], j * (64 * 64 * 2), 0, 0);
         }
         if constexpr (RC) {   // the previous block's expand and shortcut slices: [64 rows][64 k] each, rows in this kernel's ownership order
             unsigned char* Wr = W2s + W2C_BYTES + C3 * ROW_BYTES;
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_rw, (__attribute__((address_space(3))) void*)(Wr + (wave * 2 + i) * 1024), 16,
+            for (int i = 0; i < SC_PIECES; ++i) {
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_rw, (__attribute__((address_space(3))) void*)(Wr + (wave * SC_PIECES + i) * 1024), 16,
                                                          woffsc[i], j * (64 * 64 * 2), 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, (__attribute__((address_space(3))) void*)(Wr + 8192 + (wave * 2 + i) * 1024), 16,
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_sc, (__attribute__((address_space(3))) void*)(Wr + 8192 + (wave * SC_PIECES + i) * 1024), 16,
                                                          woffsc[i], j * (64 * 64 * 2), 0, 0);
             }
         }
@@ -273,14 +282,15 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
     }
     const size_t pr_row[2] = {(size_t)(wm0 + li) * C2 + g * 8, (size_t)(wm0 + 16 + li) * C2 + g * 8};
     // RDMA: wave-private residual staging: rows of this wave, whole 128-byte rows, swizzled like every other tile
-    unsigned char* const res_lds = smem + 2 * STAGE_BYTES + wave * 4096;   // + (j & 1) * 16384 for chunk j
+    constexpr int RES_BUF = NW * 4096;
+    unsigned char* const res_lds = smem + 2 * STAGE_BYTES + wave * 4096;   // + (j & 1) * RES_BUF for chunk j
     const __amdgpu_buffer_rsrc_t rsrc_r = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<f16_t*>(p.res ? p.res : p.x1), 0, p.res ? (unsigned)((size_t)p.M * C2 * 2) : 0u, 0x00020000);   // rows >= M: zeros
     const unsigned res_voff = (unsigned)((wm0 + lrow) * C2) * 2u + (unsigned)lchunk * 16u;
     auto issue_res = [&](int j) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (__attribute__((address_space(3))) void*)(res_lds + (j & 1) * 16384 + i * 1024), 16,
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc_r, (__attribute__((address_space(3))) void*)(res_lds + (j & 1) * RES_BUF + i * 1024), 16,
                                                      res_voff + (unsigned)(i * 8 * C2 * 2), j * 128, 0, 0);
     };
     const bool has_res = RC ? true : (!SC && p.res != nullptr && !(p.dbg & 4));
@@ -417,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void btail_kernel(BtailParams p) {
             if (has_res) {   // paired layout out of this wave's rows of the staged chunk; then the buffer is free for chunk j+2
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    res_cur[i] = *reinterpret_cast<const uint4*>(res_lds + (j & 1) * 16384 + swz((i & 1) * 16 + li, (i >> 1) * 4 + g));
+                    res_cur[i] = *reinterpret_cast<const uint4*>(res_lds + (j & 1) * RES_BUF + swz((i & 1) * 16 + li, (i >> 1) * 4 + g));
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (j + 2 < NCH) issue_res(j + 2);
             }
@@ -854,13 +864,15 @@ __global__ __launch_bounds__(256, 2) void btail_rc2_kernel(BtailParams p) {
 #endif
 }
 
-template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false, int RC = 0>
+template <int C1, int C3, bool RDMA, bool SC = false, bool TRACE = false, int RC = 0, int NW = 4>
 hipError_t launch_btail_t(const BtailParams& p, hipStream_t stream) {
-    constexpr int MAIN = (128 + C1) * ROW_BYTES, CHUNK = 64 * C1 * 2 + C3 * ROW_BYTES + (SC ? 64 * ROW_BYTES : 0) + (RC ? 2 * 64 * ROW_BYTES : 0);
-    constexpr int LDS = 2 * (MAIN > CHUNK ? MAIN : CHUNK) + (RDMA ? 2 * 16384 : 0);
-    OPD_SET_MAX_LDS_ONCE((btail_kernel<C1, C3, RDMA, SC, TRACE, RC>), LDS);
-    OPD_LAUNCH((btail_kernel<C1, C3, RDMA, SC, TRACE, RC>), dim3((p.M + 127) / 128), dim3(256), LDS, stream, p);
-    static const char* const kname = opd_kernel_name("btail_kernel<%d, %d, %s, %s, %s, %d>", C1, C3, OPD_BOOLSTR(RDMA), OPD_BOOLSTR(SC), OPD_BOOLSTR(TRACE), RC);
+    constexpr int BM = 32 * NW;
+    constexpr int MAIN = (BM + C1) * ROW_BYTES, CHUNK = 64 * C1 * 2 + C3 * ROW_BYTES + (SC ? 64 * ROW_BYTES : 0) + (RC ? 2 * 64 * ROW_BYTES : 0);
+    constexpr int LDS = 2 * (MAIN > CHUNK ? MAIN : CHUNK) + (RDMA ? 2 * NW * 4096 : 0);
+    static_assert(LDS <= 160 * 1024, "LDS per workgroup");
+    OPD_SET_MAX_LDS_ONCE((btail_kernel<C1, C3, RDMA, SC, TRACE, RC, NW>), LDS);
+    OPD_LAUNCH((btail_kernel<C1, C3, RDMA, SC, TRACE, RC, NW>), dim3((p.M + BM - 1) / BM), dim3(64 * NW), LDS, stream, p);
+    static const char* const kname = opd_kernel_name("btail_kernel<%d, %d, %s, %s, %s, %d, %d>", C1, C3, OPD_BOOLSTR(RDMA), OPD_BOOLSTR(SC), OPD_BOOLSTR(TRACE), RC, NW);
     opd_last_kernel_name = kname;
     return hipGetLastError();
 }
@@ -884,6 +896,8 @@ hipError_t OPD_SYM(opd_launch_btail)(const BtailParams& p_in, hipStream_t stream
     if (p.C1 == 256) return OPD_SYM(opd_launch_btail256)(p, stream);   // stage 3: kernels_btail3.hip
     if (p.y_stride2 && (p.stride != 1 || p.C3 == 0)) return hipErrorInvalidValue;   // (only next to a fused reduce: nobody else may need y)
     if (!p.y && !p.a1_out) return hipErrorInvalidValue;   // an output nobody could rebuild
+    if (p.nw != 0 && p.nw != 4 && p.nw != 8) return hipErrorInvalidValue;
+    if (p.nw == 8 && (p.trace || p.rc == 2)) return hipErrorInvalidValue;   // (the traced and the two-level instantiations exist with four waves only)
     if (p.rc == 2) {   // third block of stage 1: both previous outputs rebuilt (btail_rc2_kernel)
         if (p.C1 != 64 || p.C3 != 128 || p.stride != 1 || p.res || p.xs || !p.rc_a1[0] || !p.rc_a1[1] || !p.rc_xs || !p.rc_w2[0] || !p.rc_w2[1] || !p.rc_wsc ||
             !p.rc_b[0] || !p.rc_b[1] || !p.w3p || !p.z || p.trace || p.dbg || (size_t)p.M * 64 * 2 >= 0x7fffff00ull)
@@ -897,11 +911,11 @@ hipError_t OPD_SYM(opd_launch_btail)(const BtailParams& p_in, hipStream_t stream
         if (p.rc != 1 || p.C1 != 64 || p.C3 != 64 || p.stride != 1 || p.res || p.xs || !p.rc_a1[0] || !p.rc_xs || !p.rc_w2[0] || !p.rc_wsc || !p.rc_b[0] ||
             p.trace || (size_t)p.M * 64 * 2 >= 0x7fffff00ull)
             return hipErrorInvalidValue;
-        return launch_btail_t<64, 64, false, false, false, 1>(p, stream);
+        return p.nw == 8 ? launch_btail_t<64, 64, false, false, false, 1, 8>(p, stream) : launch_btail_t<64, 64, false, false, false, 1>(p, stream);
     }
     if (p.xs) {   // fused shortcut convolution: stride 1, 64 -> 256 channels next to a 64-channel 3x3 (first block of stage 1)
         if (p.C1 != 64 || p.C3 != 64 || p.stride != 1 || !p.wsc || p.res || (size_t)p.M * 64 * 2 >= 0x7fffff00ull) return hipErrorInvalidValue;
-        return launch_btail_t<64, 64, false, true>(p, stream);
+        return p.nw == 8 ? launch_btail_t<64, 64, false, true, false, 0, 8>(p, stream) : launch_btail_t<64, 64, false, true>(p, stream);
     }
     if (p.trace) {   // tools/trace_btail.py: the two shapes that dominate stages 1 and 2
         if (p.C1 == 64 && p.C3 == 64 && (p.dbg & 16)) return launch_btail_t<64, 64, false, false, true>(p, stream);
@@ -911,10 +925,16 @@ hipError_t OPD_SYM(opd_launch_btail)(const BtailParams& p_in, hipStream_t stream
     }
     if (p.C1 == 64) {
         const bool rdma = !(p.dbg & 16);   // dbg 16: residual through VGPR loads (the first form: cross-check / timing)
+        if (rdma && p.nw == 8) {           // 256-pixel tiles, eight waves (BtailParams::nw)
+            if (p.C3 == 0) return launch_btail_t<64, 0, true, false, false, 0, 8>(p, stream);
+            if (p.C3 == 64) return launch_btail_t<64, 64, true, false, false, 0, 8>(p, stream);
+            return launch_btail_t<64, 128, true, false, false, 0, 8>(p, stream);
+        }
         if (p.C3 == 0) return rdma ? launch_btail_t<64, 0, true>(p, stream) : launch_btail_t<64, 0, false>(p, stream);
         if (p.C3 == 64) return rdma ? launch_btail_t<64, 64, true>(p, stream) : launch_btail_t<64, 64, false>(p, stream);
         return rdma ? launch_btail_t<64, 128, true>(p, stream) : launch_btail_t<64, 128, false>(p, stream);
     }
+    if (p.nw == 8) return p.C3 == 0 ? launch_btail_t<128, 0, false, false, false, 0, 8>(p, stream) : launch_btail_t<128, 128, false, false, false, 0, 8>(p, stream);
     if (p.C3 == 0) return launch_btail_t<128, 0, false>(p, stream);
     return launch_btail_t<128, 128, false>(p, stream);
 }

@@ -150,6 +150,7 @@ struct BtailParams {
     const float* rc_b[2];
     int rc;
     int y_stride2;
+    int nw;   // waves per workgroup of the C1 = 64 / 128 kernels: 0 / 4 = 128-pixel tiles, two workgroups per CU; 8 = 256-pixel tiles, one per CU (identical bits)
 };
 bool opd_btail_supported(int C1, int C3);
 hipError_t opd_launch_btail(const BtailParams& p, hipStream_t stream);

@@ -900,6 +900,7 @@ static int enqueue_forward(opd_detr* m, const void* d_pixels, int pixel_format, 
                     p.B = nb; p.H = ch; p.W = cw; p.OH = oh; p.OW = ow; p.stride = b.c1.stride; p.M = nb * oh * ow; p.C1 = C1; p.C3 = C3;
                     p.rev = m->tail_rev ? (tail_no++ & 1) : 0;
                     p.dbg = m->dbg_btail;
+                    p.nw = (C1 == 256 || p.rc == 2) ? 0 : m->tail_nw;
                     RCCHK(timed_begin(m, CLS_CONV, 2.0 * p.M * ((double)C1 * 9 * C1 + 4.0 * C1 * C1 + 4.0 * C1 * C3 + (sc_in_tail ? 64.0 * 256 : 0.0))));
                     HIPCHK(opd_launch_btail(p, m->stream));
                     RCCHK(timed_end(m));
@@ -1506,6 +1507,7 @@ static int create_impl(const opd_config* cfg, const char* weights_path, int devi
     if (const char* v = getenv("OPD_TAIL3")) m->tail3 = atoi(v);
     if (const char* v = getenv("OPD_TAIL_RC")) m->tail_rc = atoi(v);
     if (const char* v = getenv("OPD_WPREFETCH")) m->wprefetch = atoi(v);
+    if (const char* v = getenv("OPD_TAIL_NW")) m->tail_nw = atoi(v) == 8 ? 8 : 4;
     if (const char* v = getenv("OPD_W8")) m->w8 = atoi(v);
     if (m->w8 < 0) m->w8 = (cfg->flags & OPD_FLAG_MULTI_STREAM) ? 1 : 0;
     if (const char* v = getenv("OPD_SMALL_SPLITK")) m->small_splitk = atoi(v);
@@ -1570,7 +1572,7 @@ static int clone_impl(const opd_detr* src, opd_detr** out) {
     m->small_m_gemm = src->small_m_gemm; m->fuse_gemm_ln = src->fuse_gemm_ln; m->deep_fc2 = src->deep_fc2;
     m->fuse_btail = src->fuse_btail; m->fuse_shortcut = src->fuse_shortcut; m->fuse_stem_pool = src->fuse_stem_pool; m->fuse_prep = src->fuse_prep; m->pos_shadow = src->pos_shadow; m->trunk_subbatch = src->trunk_subbatch; m->dual_over_tail = src->dual_over_tail; m->tail_rev = src->tail_rev; m->tail3 = src->tail3; m->num_cus = src->num_cus; m->tail3_split = src->tail3_split;
     m->dec0_h = src->dec0_h; m->fuse_dec0 = src->fuse_dec0; m->qc0 = src->qc0; m->fused_dec = src->fused_dec; m->fused_enc_ffn = src->fused_enc_ffn; m->enc_tail = src->enc_tail; m->enc_front = src->enc_front; m->dec_splits = src->dec_splits; m->wround = src->wround; m->dbg_dec_layers = src->dbg_dec_layers; m->dbg_skip = src->dbg_skip;
-    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8; m->small_splitk = src->small_splitk; m->small_enc = src->small_enc;
+    m->tail_rc = src->tail_rc; m->y_stride2 = src->y_stride2; m->dbg_btail = src->dbg_btail; m->dbg_gemm = src->dbg_gemm; m->wprefetch = src->wprefetch; m->w8 = src->w8; m->tail_nw = src->tail_nw; m->small_splitk = src->small_splitk; m->small_enc = src->small_enc;
     auto cleanup = [&](int code) {
         for (void* p : m->allocs) (void)hipFree(p);
         drop_streams(m.get());

@@ -220,6 +220,7 @@ struct opd_detr {
                              // eight half-chunk steps with three GEMMs each cost more than the 276 MB they save)
     int y_stride2 = 1;       // last tail of stage 1: y stored only where the next stage's stride-2 shortcut reads it (env OPD_Y_STRIDE2)
     int wprefetch = 3;       // L2 warm-up of a launch's weights by its own workgroups: bit 0 implicit GEMM, bit 1 the encoder's FFN launch (env OPD_WPREFETCH)
+    int tail_nw = 4;         // waves per workgroup of the stage 1-2 fused tails (BtailParams::nw; env OPD_TAIL_NW)
     int w8 = -1;             // wide stage-4 layers through the eight-wave GEMM (kernels_w8.hip; identical bits): bit 0 3x3, bit 1 1x1 K >= 1024, bit 2 1x1 K = 512
                              // (env OPD_W8).  -1 = by the handle's flags: the 3x3 for OPD_FLAG_MULTI_STREAM handles (132 one-per-CU workgroups cost 22 % less
                              // CU time than 424 four-wave ones and leave the other CUs to the other streams: +1.1 %, 8 of 8 interleaved pairs), nothing for a

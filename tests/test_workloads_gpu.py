@@ -570,6 +570,30 @@ def test_stage1_residual_rebuild_is_invisible_end_to_end(mild_path):
                 np.testing.assert_array_equal(x, y)
 
 
+@pytest.mark.parametrize("dtype", ["fp16", "bf16"])
+def test_tail_workgroup_shape_is_invisible_end_to_end(mild_path, monkeypatch, dtype):
+    """OPD_TAIL_NW = 8 (the stage 1-2 fused tails as eight-wave workgroups on 256-pixel tiles: one set of weight tiles staged per 256 pixels)
+    against the four-wave form: a wave's arithmetic is the same, so logits, boxes and the encoder map are bit-identical -- with the
+    residual rebuild on and off (all tail variants), ragged last tiles (203 x 333: 4 250 / 1 092 pixels at stage 1 / 2 are not multiples of 256),
+    eager, captured and replayed."""
+    for (H, W, B) in ((256, 320, 3), (203, 333, 2)):
+        frames = structured_frames(B, H, W, seed=616)
+        for rc in ("1", "0"):
+            monkeypatch.setenv("OPD_TAIL_RC", rc)
+            outs = {}
+            for nw in ("4", "8"):
+                monkeypatch.setenv("OPD_TAIL_NW", nw)
+                det = HipDetrDetector(model_path=mild_path, max_batch=B, max_size=(H, W), resize=False, dtype=dtype)
+                det.load_model()
+                try:
+                    outs[nw] = [det.forward_raw(frames) for _ in range(3)]
+                finally:
+                    det.close()
+            for call in range(3):
+                for x, y in zip(outs["4"][call], outs["8"][call]):
+                    np.testing.assert_array_equal(x, y)
+
+
 @pytest.mark.parametrize("flag_bf16", [0, 1])
 def test_multi_stream_eight_wave_3x3_is_invisible_end_to_end(mild_path, monkeypatch, flag_bf16):
     """OPD_FLAG_MULTI_STREAM handles run stage 4's 3x3 convolutions through the eight-wave kernel (kernels_w8.hip; OPD_W8 = -1 = by the flags):
