@@ -162,6 +162,9 @@ def main() -> int:
     args = parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         return launch_ranks(args.gpus, sys.argv[1:])
+    # (ranks started by torch.distributed.run inherit their launcher's environment; this driver supports dmabuf IPC only, and RCCL / device-memory
+    #  sharing across processes fails without the switch -- set before anything loads the HIP runtime)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     # stdout carries the ONE JSON line and nothing else: libraries that print to fd 1 (gloo's connection banner, a chatty
     # runtime) are redirected to stderr for the rest of the process
